@@ -1,0 +1,164 @@
+/*
+ * mpstime_hip.h - C ABI of libmpstime_hip.so, the MI355X (gfx950) sweep engine
+ * for MPSTime.jl's DMRG-style training sweep.
+ *
+ * The reference (hugopstackhouse/MPSTime.jl) has no FFI: the seam this library
+ * replaces is the Julia method
+ *     fitMPS(W::MPS, training_states_meta, testing_states_meta, opts)
+ *     src/Training/RealRealHighDimension.jl:587-890
+ * selected at :556-560 / :578-582 (where `use_legacy_ITensor` already switches
+ * engines).  Each entry point below cites the reference lines it stands in for.
+ * INTEGRATION.md shows the Julia `ccall` shim that binds them.
+ *
+ * Conventions
+ *   - plain C, no C++ types or exceptions cross the boundary;
+ *   - every call returns 0 (MPST_OK) or a negative mpst_status; the message of
+ *     the last failure on a context is available from mpst_last_error();
+ *   - sites, classes and samples are 0-based here (the Julia shim converts);
+ *   - the caller owns every host buffer, which only has to stay valid for the
+ *     duration of the call; the library owns all device memory;
+ *   - one caller thread per context; calls block until the device work is done
+ *     unless stated otherwise.
+ *
+ * Data layouts at the boundary
+ *   - encoded series  phi[N][T][d]   (d fastest, i.e. a Julia Array of size (d,T,N));
+ *     series sorted by class (asserted, RealRealHighDimension.jl:621-625);
+ *   - label_idx[N]    0-based class slot, non-decreasing;
+ *   - site tensor j   column-major array of size (d, chi[j], chi[j+1]) and, on the
+ *     label site, (d, chi[j], chi[j+1], C): element (s,l,r,c) at
+ *     s + d*(l + chi[j]*(r + chi[j+1]*c)).  chi[0] = chi[T] = 1.
+ */
+#ifndef MPSTIME_HIP_H
+#define MPSTIME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPST_ABI_VERSION 1
+
+typedef enum {
+    MPST_OK = 0,
+    MPST_ERR_INVALID = -1,      /* bad argument / call order (Julia: ArgumentError) */
+    MPST_ERR_UNSUPPORTED = -2,  /* option combination the engine lacks (Julia: ErrorException, cf. loss_functions.jl:166-170) */
+    MPST_ERR_DEVICE = -3,       /* HIP / RCCL runtime failure */
+    MPST_ERR_SVD = -4,          /* bond-tensor decomposition failed / non-finite spectrum; the
+                                   class of failure tune() retries on (hyperparameters/tuning.jl:73-86) */
+    MPST_ERR_NOMEM = -5
+} mpst_status;
+
+enum { MPST_LOSS_KLD = 0, MPST_LOSS_MSE = 1 };   /* src/Structs/options.jl:318-327 */
+enum { MPST_OPT_TSGO = 0, MPST_OPT_GD = 1 };     /* src/Structs/options.jl:298-311 */
+enum { MPST_F64 = 0, MPST_F32 = 1, MPST_C128 = 2, MPST_C64 = 3 };
+enum { MPST_SVD_DEFAULT = 0, MPST_SVD_JACOBI = 1 };  /* opts.svd_alg, RealRealHighDimension.jl:756,798 */
+enum { MPST_TRAIN = 0, MPST_TEST = 1 };
+
+/* The MPSOptions fields the sweep consumes
+ * (src/Structs/options.jl:106-143; RealRealHighDimension.jl:591-592,606,716-722). */
+typedef struct {
+    int32_t chi_max;            /* opts.chi_max  (:720) */
+    int32_t update_iters;       /* opts.update_iters (:716) */
+    int32_t loss;               /* MPST_LOSS_*  <- opts.loss_grad */
+    int32_t optimiser;          /* MPST_OPT_*   <- opts.bbopt */
+    int32_t rescale_before;     /* opts.rescale[1]  (loss_functions.jl:109) */
+    int32_t rescale_after;      /* opts.rescale[2]  (loss_functions.jl:177) */
+    int32_t train_classes_separately;  /* TrainSeparate{B} (:606) */
+    int32_t svd_alg;            /* MPST_SVD_* */
+    int32_t rebuild_caches;     /* 1: redo both full cache rebuilds per sweep as the reference does
+                                   (:770,:804); 0: skip them (bit-identical results) */
+    int32_t reserved0;
+    double  eta;                /* opts.eta (:719) */
+    double  cutoff;             /* opts.cutoff (:722) */
+} mpst_options;
+
+/* Per-sweep result of mpst_sweep (RealRealHighDimension.jl:727,806-808). */
+typedef struct {
+    double  seconds;            /* device time of the sweep (HIP events) */
+    int32_t svd_status;         /* 0 or MPST_ERR_SVD */
+    int32_t max_chi;            /* largest bond dimension after the sweep */
+    int32_t eig_sweeps_total;   /* diagnostic: Jacobi sweeps summed over bonds */
+    int32_t reserved;
+} mpst_sweep_stats;
+
+/* Test hook output of mpst_bond_step: gauge-invariant per-bond quantities. */
+#define MPST_MAX_SPECTRUM 512
+typedef struct {
+    double  loss;               /* loss before the (first) step, loss_functions.jl:371 */
+    double  grad_norm;          /* ||grad||_F of the first iteration (:79) */
+    double  bt_norm;            /* ||bt_new||_F before the rescale (:177) */
+    int32_t chi_new;            /* kept bond dimension after truncation */
+    int32_t n_spectrum;         /* number of entries valid in spectrum[] */
+    int32_t eig_sweeps;
+    int32_t reserved;
+    double  spectrum[MPST_MAX_SPECTRUM];  /* all singular values of the (rescaled) bond tensor, descending */
+} mpst_bond_debug;
+
+int         mpst_version(void);
+const char* mpst_last_error(void* ctx);           /* never freed by the caller; NULL ctx -> creation errors */
+
+/* One context per GPU (one process per GPU).  Replaces nothing in the reference:
+ * device selection is new. */
+int  mpst_create(void** ctx, int device_id);
+void mpst_destroy(void* ctx);
+
+/* Batch sharding over GPUs (new design): every rank holds N/G series;
+ * the bond gradient + loss are all-reduced with RCCL once per optimiser step.
+ * `unique_id` is the 128-byte ncclUniqueId produced on rank 0 and distributed by the host. */
+int  mpst_comm_unique_id(uint8_t out_id[128]);
+int  mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank);
+
+/* EncodedTimeSeriesSet -> device (src/Structs/structs.jl:12-33).  `n_global_per_class`
+ * may be NULL on a single GPU; with sharding it carries the global class counts that
+ * the loss normalisation uses (loss_functions.jl:367,371,423-424). */
+int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* label_idx,
+                      int64_t N, int32_t T, int32_t d, int32_t C, int32_t dtype,
+                      const int64_t* n_global_per_class);
+
+int  mpst_set_options(void* ctx, const mpst_options* o);
+
+/* MPS in / out (the W::MPS argument and the TrainedMPS.mps result). `site[j]` points at
+ * site tensor j in the boundary layout above; `label_site` is where the "f(x)" index
+ * lives (utils.jl:342-354); training requires T-1 on entry (:19-29). */
+int  mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_t T, int32_t label_site);
+int  mpst_get_chi(void* ctx, int32_t* chi_out /*[T+1]*/, int32_t* label_site);
+int  mpst_get_mps(void* ctx, void* const* site_out /* T buffers sized from mpst_get_chi */);
+
+/* construct_caches(W, training_states; going_left=true), RealRealHighDimension.jl:631. */
+int  mpst_build_caches(void* ctx);
+
+/* One full sweep = RealRealHighDimension.jl:727-808. */
+int  mpst_sweep(void* ctx, mpst_sweep_stats* out);
+
+/* One bond update (:733-762 going left, :777-801 going right) - test hook. */
+int  mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* dbg);
+
+/* MSE_loss_acc / MSE_loss_acc_conf, src/summary.jl:33-114.  conf is C*C row-major
+ * [truth][prediction] (may be NULL). */
+int  mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64_t* conf);
+
+/* classify(mps, states), src/summary.jl:116-136: predicted class slot per series,
+ * and optionally the raw overlaps yhat[N][C]. */
+int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[N][C] or NULL*/);
+
+/* normalize!(W), RealRealHighDimension.jl:852. */
+int  mpst_normalize(void* ctx);
+
+/* Diagnostics used by bench.py / tests (no reference counterpart). */
+int  mpst_selftest_mfma(void* ctx, const double* A /*16xK row-major*/, const double* B /*Kx16*/,
+                        int32_t K, double* C_out /*16x16*/);
+int  mpst_selftest_eig(void* ctx, const double* G /*n*n symmetric*/, int32_t n, int32_t alg,
+                       double* lambda_out /*n*/, double* E_out /*n*n row-major [i][k]*/, int32_t* sweeps);
+/* Per-kernel timing with HIP events recorded on the engine's own stream around every launch
+ * of the selected kernel classes during mpst_sweep / mpst_bond_step (bit k of kernel_mask):
+ * 0 yhat, 1 grad, 2 grad_reduce+update, 3 gram, 4 eig, 5 split, 6 env, 7 bt_assemble, 8 all-reduce.
+ * mpst_set_profile also resets the accumulators; mpst_get_profile returns the summed device
+ * microseconds and the launch count per class (arrays of 16). */
+int  mpst_set_profile(void* ctx, uint32_t kernel_mask);
+int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPSTIME_HIP_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of libmpstime_hip.so (include/mpstime_hip.h).
+
+The HIP library is the product path: if it is missing or fails to load this
+module raises - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpstime_hip.so")
+
+MPST_OK, MPST_ERR_INVALID, MPST_ERR_UNSUPPORTED, MPST_ERR_DEVICE, MPST_ERR_SVD, MPST_ERR_NOMEM = 0, -1, -2, -3, -4, -5
+LOSS = {"KLD": 0, "MSE": 1}
+OPT = {"TSGO": 0, "GD": 1}
+F64 = 0
+MAX_SPECTRUM = 512
+KERNEL_CLASSES = ("yhat", "grad", "grad_reduce+update", "gram", "eig", "split", "env", "bt_assemble", "allreduce")
+
+
+class mpst_options(C.Structure):
+    _fields_ = [("chi_max", C.c_int32), ("update_iters", C.c_int32), ("loss", C.c_int32), ("optimiser", C.c_int32),
+                ("rescale_before", C.c_int32), ("rescale_after", C.c_int32), ("train_classes_separately", C.c_int32),
+                ("svd_alg", C.c_int32), ("rebuild_caches", C.c_int32), ("reserved0", C.c_int32),
+                ("eta", C.c_double), ("cutoff", C.c_double)]
+
+
+class mpst_sweep_stats(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("svd_status", C.c_int32), ("max_chi", C.c_int32),
+                ("eig_sweeps_total", C.c_int32), ("reserved", C.c_int32)]
+
+
+class mpst_bond_debug(C.Structure):
+    _fields_ = [("loss", C.c_double), ("grad_norm", C.c_double), ("bt_norm", C.c_double), ("chi_new", C.c_int32),
+                ("n_spectrum", C.c_int32), ("eig_sweeps", C.c_int32), ("reserved", C.c_int32),
+                ("spectrum", C.c_double * MAX_SPECTRUM)]
+
+
+# every symbol include/mpstime_hip.h declares: name -> (restype, argtypes)
+_vp, _i32, _i64, _dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
+SYMBOLS = {
+    "mpst_version": (C.c_int, []),
+    "mpst_last_error": (C.c_char_p, [_vp]),
+    "mpst_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "mpst_destroy": (None, [_vp]),
+    "mpst_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "mpst_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "mpst_set_dataset": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i32), _i64, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
+    "mpst_set_options": (C.c_int, [_vp, C.POINTER(mpst_options)]),
+    "mpst_set_mps": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32), _i32, _i32]),
+    "mpst_get_chi": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "mpst_get_mps": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "mpst_build_caches": (C.c_int, [_vp]),
+    "mpst_sweep": (C.c_int, [_vp, C.POINTER(mpst_sweep_stats)]),
+    "mpst_bond_step": (C.c_int, [_vp, _i32, _i32, C.POINTER(mpst_bond_debug)]),
+    "mpst_eval": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.POINTER(_i64)]),
+    "mpst_classify": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _dp]),
+    "mpst_normalize": (C.c_int, [_vp]),
+    "mpst_selftest_mfma": (C.c_int, [_vp, _dp, _dp, _i32, _dp]),
+    "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
+    "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),
+    "mpst_get_profile": (C.c_int, [_vp, _dp, C.POINTER(_i64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmpstime_hip.so and bind every declared symbol.  Raises if the
+    library has not been built (``python -c 'import __graft_entry__ as g; g.build()'``
+    or ``make -C mpstime.jl_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP sweep engine has not been built "
+                           "(make -C mpstime.jl_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MPSTError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[mpst {code}] {msg}")
+        self.code = code
+
+
+class SVDError(MPSTError):
+    """Bond-tensor decomposition failed - the failure class `tune` retries on
+    (src/Training/hyperparameters/tuning.jl:73-86)."""

@@ -1,0 +1,704 @@
+// C ABI of libmpstime_hip.so (include/mpstime_hip.h): context management, host<->device
+// marshalling, the sweep driver (src/Training/RealRealHighDimension.jl:724-851 restated as a
+// stream of kernel launches with no host read-back inside a sweep) and the RCCL plumbing.
+#include <rccl/rccl.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "mpst_internal.h"
+
+using namespace mpst;
+
+namespace {
+
+thread_local std::string g_err;  // errors raised without a context (mpst_create)
+
+enum KClass { K_YHAT = 0, K_GRAD, K_UPDATE, K_GRAM, K_EIG, K_SPLIT, K_ENV, K_BT, K_ALLREDUCE, K_NCLASS };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    mpst_options opt{};
+    bool have_opt = false;
+    int T = 0, d = 0, C = 0;
+    int cap = 0;              // capacity bond dimension of all device buffers
+    DataSet ds[2];
+    // MPS
+    bool have_mps = false;
+    double* sites = nullptr;
+    int64_t site_stride = 0;
+    int32_t* chi = nullptr;         // device [T+1]
+    int32_t* label_site = nullptr;  // device
+    // caches + workspaces (train set)
+    double *LE = nullptr, *RE = nullptr;
+    int64_t cache_elems = 0;
+    double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
+    double *gram = nullptr, *lam = nullptr, *E = nullptr;
+    int64_t partial_elems = 0;
+    DevScalars* sc = nullptr;
+    // eval scratch
+    double *chainL[2] = {nullptr, nullptr}, *chainR[2] = {nullptr, nullptr}, *yeval = nullptr, *out3 = nullptr;
+    int64_t* conf = nullptr;
+    int32_t* pred = nullptr;
+    int64_t eval_N = 0;
+    double* norm2 = nullptr;
+    bool ws_ready = false;
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    // profiling
+    unsigned prof_mask = 0;
+    std::vector<hipEvent_t> ev_pool;
+    struct Rec { int k; size_t e0, e1; };
+    std::vector<Rec> recs;
+    size_t ev_used = 0;
+    double prof_us[16] = {0};
+    int64_t prof_cnt[16] = {0};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+};
+
+int fail(Ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_err = buf;
+    return code;
+}
+
+#define HIPC(c, call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail((c), MPST_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+template <typename T>
+int dalloc(Ctx* c, T** p, int64_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n <= 0) n = 1;
+    hipError_t e = hipMalloc((void**)p, (size_t)n * sizeof(T));
+    if (e != hipSuccess) return fail(c, MPST_ERR_NOMEM, "hipMalloc of %lld bytes failed: %s", (long long)(n * sizeof(T)), hipGetErrorString(e));
+    return 0;
+}
+template <typename T>
+void dfree(T** p) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+}
+
+void free_dataset(DataSet& s) {
+    dfree(&s.phi); dfree(&s.label); dfree(&s.tiles); dfree(&s.chunks); dfree(&s.cls_chunk_off); dfree(&s.inv_count);
+    s = DataSet();
+}
+
+View make_view(Ctx* c, int which) {
+    View v{};
+    const DataSet& s = c->ds[which];
+    v.T = c->T; v.d = c->d; v.C = c->C; v.chi_max = c->opt.chi_max; v.cap = c->cap;
+    v.N = s.N;
+    v.invN = s.Nglobal > 0 ? 1.0 / (double)s.Nglobal : 0.0;
+    v.phi = s.phi; v.label = s.label; v.tiles = s.tiles; v.chunks = s.chunks;
+    v.cls_chunk_off = s.cls_chunk_off; v.inv_count = s.inv_count;
+    v.ntiles = s.ntiles; v.nchunks = s.nchunks;
+    v.chi = c->chi; v.label_site = c->label_site; v.sites = c->sites; v.site_stride = c->site_stride;
+    v.LE = c->LE; v.RE = c->RE; v.bt = c->bt; v.yhat = c->yhat; v.tile_loss = c->tile_loss;
+    v.partial = c->partial; v.gradbuf = c->gradbuf; v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.sc = c->sc;
+    v.loss = c->opt.loss; v.optimiser = c->opt.optimiser; v.rescale_before = c->opt.rescale_before;
+    v.rescale_after = c->opt.rescale_after; v.train_sep = c->opt.train_classes_separately; v.svd_alg = c->opt.svd_alg;
+    v.eta = c->opt.eta; v.cutoff = c->opt.cutoff;
+    return v;
+}
+
+// (re)allocate everything whose size depends on (dataset, options, capacity)
+int ensure_workspace(Ctx* c) {
+    if (c->ws_ready) return 0;
+    if (!c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options must be called first");
+    if (!c->have_mps) return fail(c, MPST_ERR_INVALID, "mpst_set_mps must be called first");
+    const DataSet& tr = c->ds[MPST_TRAIN];
+    if (tr.N <= 0) return fail(c, MPST_ERR_INVALID, "no training data set (mpst_set_dataset)");
+    const int dm = c->d * c->cap;
+    if (dm > MAX_DIM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "d*chi_max = %d exceeds the %d supported by the LDS-resident eigensolver", dm, MAX_DIM);
+    if (c->C > MAX_C) return fail(c, MPST_ERR_UNSUPPORTED, "more than %d classes unsupported", MAX_C);
+    const int64_t Lmax = (int64_t)dm * dm;
+    int rc;
+    c->cache_elems = (int64_t)c->T * tr.N * c->cap;
+    if ((rc = dalloc(c, &c->LE, c->cache_elems))) return rc;
+    if ((rc = dalloc(c, &c->RE, c->cache_elems))) return rc;
+    if ((rc = dalloc(c, &c->bt, c->C * Lmax))) return rc;
+    if ((rc = dalloc(c, &c->yhat, (int64_t)c->C * tr.N))) return rc;
+    if ((rc = dalloc(c, &c->tile_loss, (int64_t)c->C * tr.ntiles))) return rc;
+    c->partial_elems = (int64_t)(c->opt.loss == MPST_LOSS_MSE ? c->C : 1) * tr.nchunks * Lmax;
+    if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
+    if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax))) return rc;
+    HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax) * sizeof(double)));
+    if ((rc = dalloc(c, &c->gram, (int64_t)MAX_DIM * MAX_DIM))) return rc;
+    if ((rc = dalloc(c, &c->lam, MAX_DIM + 2))) return rc;
+    if ((rc = dalloc(c, &c->E, (int64_t)MAX_DIM * c->cap))) return rc;
+    if ((rc = dalloc(c, &c->sc, 1))) return rc;
+    HIPC(c, hipMemset(c->sc, 0, sizeof(DevScalars)));
+    if ((rc = dalloc(c, &c->norm2, 1))) return rc;
+    int64_t en = std::max(c->ds[0].N, c->ds[1].N);
+    c->eval_N = en;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dalloc(c, &c->chainL[k], en * c->cap))) return rc;
+        if ((rc = dalloc(c, &c->chainR[k], en * c->cap))) return rc;
+    }
+    if ((rc = dalloc(c, &c->yeval, en * c->C))) return rc;
+    if ((rc = dalloc(c, &c->out3, 4))) return rc;
+    if ((rc = dalloc(c, &c->conf, (int64_t)MAX_C * MAX_C))) return rc;
+    if ((rc = dalloc(c, &c->pred, en))) return rc;
+    init_kernel_attrs();
+    c->ws_ready = true;
+    return 0;
+}
+
+// ---- profiling helpers: HIP events on the stream the kernels are launched on -------------
+hipEvent_t pool_event(Ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+struct ProfScope {
+    Ctx* c; int k; bool on; size_t e0 = 0;
+    ProfScope(Ctx* c_, int k_) : c(c_), k(k_), on((c_->prof_mask >> k_) & 1u) {
+        if (on) { e0 = c->ev_used; (void)hipEventRecord(pool_event(c), c->stream); }
+    }
+    ~ProfScope() {
+        if (on) { size_t e1 = c->ev_used; (void)hipEventRecord(pool_event(c), c->stream); c->recs.push_back({k, e0, e1}); }
+    }
+};
+void prof_collect(Ctx* c) {
+    for (auto& r : c->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e1]) == hipSuccess) {
+            c->prof_us[r.k] += 1e3 * ms;
+            c->prof_cnt[r.k] += 1;
+        }
+    }
+    c->recs.clear();
+    c->ev_used = 0;
+}
+
+// ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
+int enqueue_bond(Ctx* c, const View& v, int lid, int going_left) {
+    hipStream_t s = c->stream;
+    const int rid = lid + 1;
+    { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }                    // flatten_bt :733/:777
+    if (v.rescale_before) launch_bt_prescale(v, lid, s);                        // loss_functions.jl:109
+    for (int it = 0; it < c->opt.update_iters; ++it) {                          // TSGO/custGD :44,:75
+        { ProfScope p(c, K_YHAT); launch_yhat(v, lid, s); }
+        { ProfScope p(c, K_GRAD); launch_grad(v, lid, s); }
+        { ProfScope p(c, K_UPDATE); launch_grad_reduce(v, lid, s); }
+        if (c->comm) {
+            ProfScope p(c, K_ALLREDUCE);
+            const size_t cnt = 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap;
+            ncclResult_t r = ncclAllReduce(c->gradbuf, c->gradbuf, cnt, ncclDouble, ncclSum, c->comm, s);
+            if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+        }
+        { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
+    }
+    { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
+    { ProfScope p(c, K_EIG); launch_eig(v, lid, going_left, s); }
+    { ProfScope p(c, K_SPLIT); launch_split(v, lid, going_left, s); }
+    {
+        ProfScope p(c, K_ENV);                                                  // update_caches! :759/:799
+        const int64_t cs = (int64_t)v.N * v.cap;
+        if (going_left)
+            launch_env(v, rid, 0, rid < c->T - 1 ? c->RE + (int64_t)(rid + 1) * cs : nullptr, rid + 1, ENV_M_E, rid,
+                       c->RE + (int64_t)rid * cs, s);
+        else
+            launch_env(v, lid, 1, lid > 0 ? c->LE + (int64_t)(lid - 1) * cs : nullptr, lid, ENV_M_E, lid + 1,
+                       c->LE + (int64_t)lid * cs, s);
+    }
+    return 0;
+}
+
+// construct_caches (RealRealHighDimension.jl:45-103)
+void enqueue_caches(Ctx* c, const View& v, int going_left) {
+    const int64_t cs = (int64_t)v.N * v.cap;
+    ProfScope p(c, K_ENV);
+    if (going_left) {
+        for (int j = 0; j <= c->T - 2; ++j)
+            launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1,
+                       c->LE + (int64_t)j * cs, c->stream);
+    } else {
+        for (int j = c->T - 1; j >= 1; --j)
+            launch_env(v, j, 0, j < c->T - 1 ? c->RE + (int64_t)(j + 1) * cs : nullptr, j + 1, ENV_M_SITE_T, j,
+                       c->RE + (int64_t)j * cs, c->stream);
+    }
+}
+
+int check_ready(Ctx* c) {
+    if (!c) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    return ensure_workspace(c);
+}
+
+int host_chi(Ctx* c, std::vector<int32_t>& chi, int32_t* ls) {
+    chi.resize(c->T + 1);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(chi.data(), c->chi, (size_t)(c->T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(ls, c->label_site, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// evaluation chain into scratch: returns yhat on device in c->yeval ([N][C])
+int enqueue_eval(Ctx* c, int which) {
+    View v = make_view(c, which);
+    if (v.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
+    std::vector<int32_t> chi; int32_t p;
+    int rc = host_chi(c, chi, &p);
+    if (rc) return rc;
+    const double* Lc = nullptr; const double* Rc = nullptr;
+    int pp = 0;
+    for (int j = 0; j < p; ++j) {
+        launch_env(v, j, 1, j > 0 ? c->chainL[pp ^ 1] : nullptr, j, ENV_M_SITE, j + 1, c->chainL[pp], c->stream);
+        Lc = c->chainL[pp]; pp ^= 1;
+    }
+    pp = 0;
+    for (int j = c->T - 1; j > p; --j) {
+        launch_env(v, j, 0, j < c->T - 1 ? c->chainR[pp ^ 1] : nullptr, j + 1, ENV_M_SITE_T, j, c->chainR[pp], c->stream);
+        Rc = c->chainR[pp]; pp ^= 1;
+    }
+    launch_eval_final(v, Lc, Rc, c->yeval, c->stream);
+    return 0;
+}
+
+}  // namespace
+
+// ===========================================================================================
+extern "C" {
+
+int mpst_version(void) { return MPST_ABI_VERSION; }
+
+const char* mpst_last_error(void* ctx) { return ctx ? ((Ctx*)ctx)->err.c_str() : g_err.c_str(); }
+
+int mpst_create(void** ctx, int device_id) {
+    if (!ctx) return fail(nullptr, MPST_ERR_INVALID, "ctx is NULL");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, MPST_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, MPST_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
+    Ctx* c = new Ctx();
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return fail(nullptr, MPST_ERR_DEVICE, "cannot initialise device %d", device_id);
+    }
+    (void)hipEventCreate(&c->ev_start);
+    (void)hipEventCreate(&c->ev_stop);
+    *ctx = c;
+    return 0;
+}
+
+void mpst_destroy(void* ctx) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    free_dataset(c->ds[0]); free_dataset(c->ds[1]);
+    dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
+    dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
+    dfree(&c->E); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
+    for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mpst_comm_unique_id(uint8_t out_id[128]) {
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId size");
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MPST_ERR_DEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memcpy(out_id, &id, 128);
+    return 0;
+}
+
+int mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MPST_ERR_INVALID, "bad communicator arguments");
+    HIPC(c, hipSetDevice(c->device));
+    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->nranks = nranks; c->rank = rank;
+    if (nranks == 1) return 0;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, MPST_ERR_DEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    return 0;
+}
+
+int mpst_set_options(void* ctx, const mpst_options* o) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !o) return fail(c, MPST_ERR_INVALID, "NULL argument");
+    if (o->chi_max < 1) return fail(c, MPST_ERR_INVALID, "chi_max must be >= 1");
+    if (o->update_iters < 1) return fail(c, MPST_ERR_INVALID, "update_iters must be >= 1");
+    if (o->loss != MPST_LOSS_KLD && o->loss != MPST_LOSS_MSE)
+        return fail(c, MPST_ERR_UNSUPPORTED, "loss_grad must be KLD or MSE (Mixed exists only in the legacy ITensor path)");
+    if (o->optimiser != MPST_OPT_TSGO && o->optimiser != MPST_OPT_GD)
+        return fail(c, MPST_ERR_UNSUPPORTED, "Optim/OptimKit based solvers currently unimplemented for this version, set 'use_legacy_ITensor=true' in MPSOptions to enable");
+    if (o->loss == MPST_LOSS_MSE && o->train_classes_separately)
+        return fail(c, MPST_ERR_UNSUPPORTED, "no Loss_Grad_MSE method for TrainSeparate{true} (loss_functions.jl:561)");
+    if (c->have_mps && o->chi_max > c->cap)
+        return fail(c, MPST_ERR_INVALID, "chi_max %d exceeds the capacity %d fixed when the MPS was set; call mpst_set_options before mpst_set_mps", o->chi_max, c->cap);
+    const bool resize = !c->have_opt || o->loss != c->opt.loss;
+    c->opt = *o;
+    c->have_opt = true;
+    if (resize) c->ws_ready = false;
+    return 0;
+}
+
+int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
+                     int32_t C, int32_t dtype, const int64_t* n_global_per_class) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 (train) or 1 (test)");
+    if (dtype != MPST_F64)
+        return fail(c, MPST_ERR_UNSUPPORTED, "only Float64 encodings are supported by the array sweep (complex encodings need use_legacy_ITensor, loss_functions.jl:203-217)");
+    if (N < 0 || T < 2 || d < 1 || C < 1) return fail(c, MPST_ERR_INVALID, "bad data set dimensions");
+    if ((c->T && c->T != T) || (c->d && c->d != d) || (c->C && c->C != C)) {
+        if (c->have_mps || c->ds[which ^ 1].N > 0)
+            return fail(c, MPST_ERR_INVALID, "data set dimensions (T=%d,d=%d,C=%d) disagree with the context (T=%d,d=%d,C=%d)", T, d, C, c->T, c->d, c->C);
+    }
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->T = T; c->d = d; c->C = C;
+    DataSet& s = c->ds[which];
+    free_dataset(s);
+    c->ws_ready = false;
+    s.N = N;
+    s.counts.assign(C, 0);
+    if (N == 0) return 0;
+    if (!phi_ || !label_idx) return fail(c, MPST_ERR_INVALID, "NULL data pointer");
+    for (int64_t i = 0; i < N; ++i) {
+        const int32_t l = label_idx[i];
+        if (l < 0 || l >= C) return fail(c, MPST_ERR_INVALID, "label_idx[%lld] = %d out of range", (long long)i, l);
+        if (i && l < label_idx[i - 1]) return fail(c, MPST_ERR_INVALID, "Training data must be sorted by class!");  // :624
+        s.counts[l]++;
+    }
+    s.gcounts.assign(C, 0);
+    s.Nglobal = 0;
+    for (int k = 0; k < C; ++k) {
+        s.gcounts[k] = n_global_per_class ? n_global_per_class[k] : s.counts[k];
+        s.Nglobal += s.gcounts[k];
+    }
+    // site-major copy [T][N][d]
+    const double* phi = (const double*)phi_;
+    std::vector<double> tmp((size_t)N * T * d);
+    for (int64_t i = 0; i < N; ++i)
+        for (int t = 0; t < T; ++t)
+            memcpy(&tmp[((size_t)t * N + i) * d], &phi[((size_t)i * T + t) * d], (size_t)d * sizeof(double));
+    int rc;
+    if ((rc = dalloc(c, &s.phi, (int64_t)tmp.size()))) return rc;
+    HIPC(c, hipMemcpy(s.phi, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = dalloc(c, &s.label, N))) return rc;
+    HIPC(c, hipMemcpy(s.label, label_idx, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
+    // class-pure spans
+    std::vector<Span> tiles, chunks;
+    std::vector<int32_t> coff(C + 1, 0);
+    int64_t start = 0;
+    for (int k = 0; k < C; ++k) {
+        coff[k] = (int32_t)chunks.size();
+        for (int64_t o = 0; o < s.counts[k]; o += TILE_S)
+            tiles.push_back({(int32_t)(start + o), (int32_t)std::min<int64_t>(TILE_S, s.counts[k] - o), k, 0});
+        for (int64_t o = 0; o < s.counts[k]; o += CHUNK_S)
+            chunks.push_back({(int32_t)(start + o), (int32_t)std::min<int64_t>(CHUNK_S, s.counts[k] - o), k, 0});
+        start += s.counts[k];
+    }
+    coff[C] = (int32_t)chunks.size();
+    s.ntiles = (int32_t)tiles.size();
+    s.nchunks = (int32_t)chunks.size();
+    if ((rc = dalloc(c, &s.tiles, (int64_t)tiles.size()))) return rc;
+    HIPC(c, hipMemcpy(s.tiles, tiles.data(), tiles.size() * sizeof(Span), hipMemcpyHostToDevice));
+    if ((rc = dalloc(c, &s.chunks, (int64_t)chunks.size()))) return rc;
+    HIPC(c, hipMemcpy(s.chunks, chunks.data(), chunks.size() * sizeof(Span), hipMemcpyHostToDevice));
+    if ((rc = dalloc(c, &s.cls_chunk_off, C + 1))) return rc;
+    HIPC(c, hipMemcpy(s.cls_chunk_off, coff.data(), (size_t)(C + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    std::vector<double> inv(C);
+    for (int k = 0; k < C; ++k) inv[k] = s.gcounts[k] > 0 ? 1.0 / (double)s.gcounts[k] : 0.0;
+    if ((rc = dalloc(c, &s.inv_count, C))) return rc;
+    HIPC(c, hipMemcpy(s.inv_count, inv.data(), (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_t T, int32_t label_site) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !site || !chi) return fail(c, MPST_ERR_INVALID, "NULL argument");
+    if (!c->have_opt) return fail(c, MPST_ERR_INVALID, "call mpst_set_options before mpst_set_mps");
+    if (c->T == 0) return fail(c, MPST_ERR_INVALID, "call mpst_set_dataset before mpst_set_mps");
+    if (T != c->T) return fail(c, MPST_ERR_INVALID, "MPS has %d sites, data has %d", T, c->T);
+    if (label_site < 0 || label_site >= T) return fail(c, MPST_ERR_INVALID, "label_site out of range");
+    if (chi[0] != 1 || chi[T] != 1) return fail(c, MPST_ERR_INVALID, "chi[0] and chi[T] must be 1");
+    int cap = c->opt.chi_max;
+    for (int j = 0; j <= T; ++j) {
+        if (chi[j] < 1) return fail(c, MPST_ERR_INVALID, "chi[%d] < 1", j);
+        cap = std::max(cap, (int)chi[j]);
+    }
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const int d = c->d, C = c->C;
+    if (cap != c->cap || !c->sites) {
+        c->cap = cap;
+        c->site_stride = (int64_t)C * cap * d * cap;
+        int rc;
+        if ((rc = dalloc(c, &c->sites, c->site_stride * T))) return rc;
+        if ((rc = dalloc(c, &c->chi, T + 1))) return rc;
+        if ((rc = dalloc(c, &c->label_site, 1))) return rc;
+        c->ws_ready = false;
+    }
+    // boundary layout (s, l, r[, c]) column-major  ->  internal [c][l][s][r]
+    std::vector<double> buf((size_t)c->site_stride * T, 0.0);
+    for (int j = 0; j < T; ++j) {
+        const int Dl = chi[j], Dr = chi[j + 1], Cj = (j == label_site) ? C : 1;
+        const double* src = (const double*)site[j];
+        if (!src) return fail(c, MPST_ERR_INVALID, "site[%d] is NULL", j);
+        double* dst = &buf[(size_t)j * c->site_stride];
+        for (int cc = 0; cc < Cj; ++cc)
+            for (int r = 0; r < Dr; ++r)
+                for (int l = 0; l < Dl; ++l)
+                    for (int s = 0; s < d; ++s)
+                        dst[(((size_t)cc * Dl + l) * d + s) * Dr + r] = src[s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))];
+    }
+    HIPC(c, hipMemcpy(c->sites, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->chi, chi, (size_t)(T + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->label_site, &label_site, sizeof(int32_t), hipMemcpyHostToDevice));
+    c->have_mps = true;
+    return 0;
+}
+
+int mpst_get_chi(void* ctx, int32_t* chi_out, int32_t* label_site) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->have_mps) return fail(c, MPST_ERR_INVALID, "no MPS set");
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<int32_t> chi; int32_t ls;
+    int rc = host_chi(c, chi, &ls);
+    if (rc) return rc;
+    if (chi_out) memcpy(chi_out, chi.data(), chi.size() * sizeof(int32_t));
+    if (label_site) *label_site = ls;
+    return 0;
+}
+
+int mpst_get_mps(void* ctx, void* const* site_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->have_mps || !site_out) return fail(c, MPST_ERR_INVALID, "no MPS set / NULL argument");
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<int32_t> chi; int32_t ls;
+    int rc = host_chi(c, chi, &ls);
+    if (rc) return rc;
+    std::vector<double> buf((size_t)c->site_stride * c->T);
+    HIPC(c, hipMemcpy(buf.data(), c->sites, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int d = c->d;
+    for (int j = 0; j < c->T; ++j) {
+        const int Dl = chi[j], Dr = chi[j + 1], Cj = (j == ls) ? c->C : 1;
+        double* dst = (double*)site_out[j];
+        if (!dst) return fail(c, MPST_ERR_INVALID, "site_out[%d] is NULL", j);
+        const double* src = &buf[(size_t)j * c->site_stride];
+        for (int cc = 0; cc < Cj; ++cc)
+            for (int r = 0; r < Dr; ++r)
+                for (int l = 0; l < Dl; ++l)
+                    for (int s = 0; s < d; ++s)
+                        dst[s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))] = src[(((size_t)cc * Dl + l) * d + s) * Dr + r];
+    }
+    return 0;
+}
+
+int mpst_build_caches(void* ctx) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    int32_t ls;
+    HIPC(c, hipMemcpy(&ls, c->label_site, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (ls != c->T - 1) return fail(c, MPST_ERR_INVALID, "the label index must sit on the last site before training (found site %d)", ls);
+    View v = make_view(c, MPST_TRAIN);
+    enqueue_caches(c, v, 1);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    return 0;
+}
+
+int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    View v = make_view(c, MPST_TRAIN);
+    HIPC(c, hipEventRecord(c->ev_start, c->stream));
+    for (int j = c->T - 2; j >= 0; --j)                                        // :731
+        if ((rc = enqueue_bond(c, v, j, 1))) return rc;
+    if (c->opt.rebuild_caches) enqueue_caches(c, v, 0);                         // :770
+    for (int j = 0; j <= c->T - 2; ++j)                                        // :776
+        if ((rc = enqueue_bond(c, v, j, 0))) return rc;
+    if (c->opt.rebuild_caches) enqueue_caches(c, v, 1);                         // :804
+    HIPC(c, hipEventRecord(c->ev_stop, c->stream));
+    HIPC(c, hipEventSynchronize(c->ev_stop));
+    float ms = 0.f;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    prof_collect(c);
+    DevScalars sc;
+    HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    std::vector<int32_t> chi(c->T + 1);
+    HIPC(c, hipMemcpy(chi.data(), c->chi, chi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out) {
+        out->seconds = 1e-3 * ms;
+        out->svd_status = sc.status;
+        out->max_chi = *std::max_element(chi.begin(), chi.end());
+        out->eig_sweeps_total = sc.eig_sweeps_total;
+        out->reserved = 0;
+    }
+    if (sc.status) return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
+    return 0;
+}
+
+int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* dbg) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (lid < 0 || lid > c->T - 2) return fail(c, MPST_ERR_INVALID, "lid out of range");
+    View v = make_view(c, MPST_TRAIN);
+    if ((rc = enqueue_bond(c, v, lid, going_left ? 1 : 0))) return rc;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    DevScalars sc;
+    HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    if (dbg) {
+        double lam[MAX_DIM + 2];
+        HIPC(c, hipMemcpy(lam, c->lam, sizeof lam, hipMemcpyDeviceToHost));
+        dbg->loss = sc.loss;
+        dbg->grad_norm = sc.grad_norm;
+        dbg->bt_norm = std::sqrt(sc.bt_norm2);
+        dbg->chi_new = sc.n_keep;
+        dbg->n_spectrum = sc.n_spec;
+        dbg->eig_sweeps = sc.eig_sweeps;
+        dbg->reserved = 0;
+        for (int i = 0; i < sc.n_spec && i < MPST_MAX_SPECTRUM; ++i) dbg->spectrum[i] = std::sqrt(std::max(lam[i], 0.0)) * sc.inv_norm;
+    }
+    if (sc.status) return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed at bond %d", lid);
+    return 0;
+}
+
+int mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64_t* conf) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (which != 0 && which != 1) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
+    if ((rc = enqueue_eval(c, which))) return rc;
+    View v = make_view(c, which);
+    launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    double o[3];
+    HIPC(c, hipMemcpy(o, c->out3, sizeof o, hipMemcpyDeviceToHost));
+    // multi-GPU: sums over shards
+    double tot[4] = {o[0], o[1], o[2], (double)v.N};
+    std::vector<int64_t> cf((size_t)c->C * c->C);
+    HIPC(c, hipMemcpy(cf.data(), c->conf, cf.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (c->comm) {
+        double* dtmp = c->out3;
+        HIPC(c, hipMemcpy(dtmp, tot, sizeof tot, hipMemcpyHostToDevice));
+        if (ncclAllReduce(dtmp, dtmp, 4, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess ||
+            ncclAllReduce(c->conf, c->conf, cf.size(), ncclInt64, ncclSum, c->comm, c->stream) != ncclSuccess)
+            return fail(c, MPST_ERR_DEVICE, "ncclAllReduce (eval) failed");
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpy(tot, dtmp, sizeof tot, hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(cf.data(), c->conf, cf.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    if (mse) *mse = tot[0] / tot[3];
+    if (kld) *kld = tot[1] / tot[3];
+    if (acc) *acc = tot[2] / tot[3];
+    if (conf) memcpy(conf, cf.data(), cf.size() * sizeof(int64_t));
+    return 0;
+}
+
+int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (which != 0 && which != 1) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
+    if ((rc = enqueue_eval(c, which))) return rc;
+    View v = make_view(c, which);
+    launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (pred) HIPC(c, hipMemcpy(pred, c->pred, (size_t)v.N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (yhat) HIPC(c, hipMemcpy(yhat, c->yeval, (size_t)v.N * c->C * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mpst_normalize(void* ctx) {
+    Ctx* c = (Ctx*)ctx;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    View v = make_view(c, MPST_TRAIN);
+    launch_norm2(v, c->norm2, c->stream);
+    launch_scale_sites(v, c->norm2, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int mpst_set_profile(void* ctx, uint32_t kernel_mask) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    c->prof_mask = kernel_mask;
+    for (int i = 0; i < 16; ++i) { c->prof_us[i] = 0; c->prof_cnt[i] = 0; }
+    return 0;
+}
+
+int mpst_get_profile(void* ctx, double* total_us, int64_t* count) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    for (int i = 0; i < 16; ++i) {
+        if (total_us) total_us[i] = c->prof_us[i];
+        if (count) count[i] = c->prof_cnt[i];
+    }
+    return 0;
+}
+
+int mpst_selftest_mfma(void* ctx, const double* A, const double* B, int32_t K, double* C_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    int rc;
+    if ((rc = dalloc(c, &dA, 16 * K)) || (rc = dalloc(c, &dB, 16 * K)) || (rc = dalloc(c, &dC, 256))) return rc;
+    HIPC(c, hipMemcpy(dA, A, (size_t)16 * K * sizeof(double), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(dB, B, (size_t)16 * K * sizeof(double), hipMemcpyHostToDevice));
+    launch_selftest_mfma(dA, dB, K, dC, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(C_out, dC, 256 * sizeof(double), hipMemcpyDeviceToHost));
+    dfree(&dA); dfree(&dB); dfree(&dC);
+    return 0;
+}
+
+int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double* lambda_out, double* E_out, int32_t* sweeps) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (n < 1 || n > MAX_DIM) return fail(c, MPST_ERR_INVALID, "n must be in 1..%d", MAX_DIM);
+    HIPC(c, hipSetDevice(c->device));
+    double *dG = nullptr, *dl = nullptr, *dE = nullptr;
+    int32_t* ds = nullptr;
+    int rc;
+    if ((rc = dalloc(c, &dG, n * n)) || (rc = dalloc(c, &dl, n)) || (rc = dalloc(c, &dE, n * n)) || (rc = dalloc(c, &ds, 1))) return rc;
+    HIPC(c, hipMemcpy(dG, G, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
+    launch_eig_raw(dG, n, alg, dl, dE, ds, c->stream);
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipMemcpy(lambda_out, dl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIPC(c, hipMemcpy(E_out, dE, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
+    if (sweeps) HIPC(c, hipMemcpy(sweeps, ds, sizeof(int32_t), hipMemcpyDeviceToHost));
+    dfree(&dG); dfree(&dl); dfree(&dE); dfree(&ds);
+    return 0;
+}
+
+}  // extern "C"

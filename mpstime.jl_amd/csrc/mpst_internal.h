@@ -1,0 +1,124 @@
+// Internal declarations shared by the translation units of libmpstime_hip.so.
+// gfx950 only; fp64 real path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mpstime_hip.h"
+
+namespace mpst {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) * B(4x16).
+// lane l supplies A[l&15][l>>4] and B[l>>4][l&15]; it owns D[(l>>4) + 4*r][l&15], r = 0..3.
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// A class-pure run of consecutive series (<= 16 for tiles, <= 64 for chunks).
+struct Span {
+    int32_t start;
+    int32_t count;
+    int32_t cls;
+    int32_t pad;
+};
+
+constexpr int TILE_S = 16;    // series per yhat/env tile (one MFMA M-tile)
+constexpr int CHUNK_S = 64;   // series per gradient chunk (the GEMM K extent of one partial)
+constexpr int GB = 64;        // gradient output block edge per workgroup
+constexpr int MAX_DIM = 128;  // d*chi_max limit of the LDS-resident eigensolver
+constexpr int MAX_C = 16;
+
+// Device-resident scalars of the running sweep (never read by the host inside a sweep).
+struct DevScalars {
+    double loss;        // loss of the first update iteration of the last bond
+    double grad_norm;
+    double bt_norm2;    // trace of the Gram matrix = ||bt_new||_F^2
+    double inv_norm;    // 1/||bt_new|| when rescale_after else 1
+    int32_t n_keep;
+    int32_t n_spec;
+    int32_t eig_sweeps;
+    int32_t status;     // sticky error flag (non-finite spectrum ...)
+    int32_t eig_sweeps_total;
+    int32_t pad[3];
+};
+
+// One encoded data set on the device.
+struct DataSet {
+    int64_t N = 0;
+    double* phi = nullptr;       // [T][N][d] site-major
+    int32_t* label = nullptr;    // [N]
+    Span* tiles = nullptr;       // class-pure tiles of <= TILE_S series
+    int32_t ntiles = 0;
+    Span* chunks = nullptr;      // class-pure chunks of <= CHUNK_S series
+    int32_t nchunks = 0;
+    int32_t* cls_chunk_off = nullptr;  // [C+1] first chunk of each class
+    double* inv_count = nullptr;       // [C] 1 / (global series count of the class)
+    std::vector<int64_t> counts;       // local per-class counts
+    std::vector<int64_t> gcounts;      // global per-class counts
+    int64_t Nglobal = 0;
+};
+
+// Everything a kernel needs, passed by value.
+struct View {
+    int32_t T, d, C, chi_max;  // chi_max = truncation maxdim
+    int32_t cap;               // capacity bond dimension: row stride of LE/RE/E, slot sizing
+    int64_t N;          // series of the data set the launch works on
+    double invN;        // 1 / global N
+    const double* phi;
+    const int32_t* label;
+    const Span* tiles;
+    const Span* chunks;
+    const int32_t* cls_chunk_off;
+    const double* inv_count;
+    int32_t ntiles, nchunks;
+    int32_t* chi;       // [T+1] device bond dimensions
+    int32_t* label_site;
+    double* sites;      // T slots of site_stride doubles, layout [c][l][s][r] compact
+    int64_t site_stride;
+    double* LE;         // [T][N][chi_max]
+    double* RE;
+    double* bt;         // [C][X][Y] compact
+    double* yhat;       // [C][N]
+    double* tile_loss;  // [C][ntiles]
+    double* partial;    // gradient partials
+    double* gradbuf;    // [2 + C*Lmax]: loss, pad, grad[c][x][y]
+    double* gram;       // [MAX_DIM*MAX_DIM]
+    double* lam;        // [MAX_DIM]
+    double* E;          // [MAX_DIM][ldE = cap] eigenvectors of the kept subspace
+    DevScalars* sc;
+    // options
+    int32_t loss, optimiser, rescale_before, rescale_after, train_sep, svd_alg;
+    double eta, cutoff;
+};
+
+// launchers (mpst_kernels.hip)
+void launch_bt_assemble(const View& v, int lid, hipStream_t s);
+void launch_bt_prescale(const View& v, int lid, hipStream_t s);
+void launch_yhat(const View& v, int lid, hipStream_t s);
+void launch_grad(const View& v, int lid, hipStream_t s);
+void launch_grad_reduce(const View& v, int lid, hipStream_t s);
+void launch_update(const View& v, int lid, int first_iter, hipStream_t s);
+void launch_gram(const View& v, int lid, int going_left, hipStream_t s);
+void launch_split(const View& v, int lid, int going_left, hipStream_t s);
+// env step: out[i][k] = sum_z Z_i[z] M[z][k], Z = (prev (x) phi_site) on the left
+// (z = a*d + s) or (phi_site (x) prev) on the right (z = s*D + b).
+// mode 0: M = kept eigenvectors v.E;  mode 1: M = site tensor as [(a,s)][k];
+// mode 2: M = site tensor transposed, M[(s,b)][k] = W[k][(s,b)].
+enum { ENV_M_E = 0, ENV_M_SITE = 1, ENV_M_SITE_T = 2 };
+void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond,
+                int mode, int out_bond, double* out, hipStream_t s);
+void init_kernel_attrs();
+void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);
+void launch_eval_reduce(const View& v, const double* yhat_in, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
+void launch_norm2(const View& v, double* out_norm2, hipStream_t s);
+void launch_scale_sites(const View& v, const double* norm2, hipStream_t s);
+void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s);
+
+// mpst_eig.hip
+void launch_eig(const View& v, int lid, int going_left, hipStream_t s);
+void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* sweeps, hipStream_t s);
+
+}  // namespace mpst

@@ -1,0 +1,739 @@
+// Hot-path kernels of the sweep engine (gfx950, fp64).
+//
+// Per bond (lid, rid = lid+1) the reference runs, one series at a time,
+//   phi~_i = ps_i[lid] (x) LE_i (x) ps_i[rid] (x) RE_i,   yhat_i = <bt[:,c_i], phi~_i>,
+//   grad[:,c] += phi~_i / yhat_i          (src/Training/loss_functions.jl:248-262,322-379)
+// Here the same sums are three batched GEMMs over Khatri-Rao operands that are
+// never materialised in HBM:
+//   X_i[x] = LE_i[a] * ps_i[lid][s],   x = a*d + s      (dim X = chi_l * d)
+//   Y_i[y] = ps_i[rid][s] * RE_i[b],   y = s*chi_r + b  (dim Y = d * chi_r)
+//   yhat_i = X_i^T B_c Y_i,   G_c = sum_i w_i X_i Y_i^T,   env_new = Y E  /  X E.
+// X/Y tiles are formed in LDS from coalesced rows of LE/RE and the (d) site
+// vectors, and fed to v_mfma_f64_16x16x4_f64.
+#include "mpst_internal.h"
+
+namespace mpst {
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+struct BondDims {
+    int Dl, Dm, Dr, X, Y, L;
+};
+__device__ __forceinline__ BondDims bond_dims(const View& v, int lid) {
+    BondDims b;
+    b.Dl = v.chi[lid];
+    b.Dm = v.chi[lid + 1];
+    b.Dr = v.chi[lid + 2];
+    b.X = b.Dl * v.d;
+    b.Y = v.d * b.Dr;
+    b.L = b.X * b.Y;
+    return b;
+}
+
+// Deterministic block-wide sum (fixed tree), result broadcast to all threads.
+// `red` must hold blockDim.x/64 doubles.
+__device__ __forceinline__ double block_sum(double x, double* red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = x;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+// One wave computes a 16x16 tile  acc += sum_k A(m0+i, k) * B(k, n0+j)  with operands read
+// straight from global/L2 (the matrices here are <= 128 KB and MFMA f64 issues once per 64 cycles,
+// so operand delivery is not the limiter).
+__device__ __forceinline__ d4 wave_gemm_tile(const double* __restrict__ A, int64_t sam, int64_t sak, int M,
+                                             const double* __restrict__ B, int64_t sbk, int64_t sbn, int N,
+                                             int K, int m0, int n0, d4 acc) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m = m0 + i, n = n0 + i;
+    const bool mv = m < M, nv = n < N;
+    const double* ap = A + (int64_t)m * sam;
+    const double* bp = B + (int64_t)n * sbn;
+#pragma unroll 4
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const bool kv = k < K;
+        const double a = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
+        const double b = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
+        acc = mfma_f64(a, b, acc);
+    }
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// flatten_bt  (RealRealHighDimension.jl:221-238):  B_c = W[lid] * W[rid] per class
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bt_assemble(View v, int lid) {
+    const BondDims b = bond_dims(v, lid);
+    const int c = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tx = (b.X + 15) >> 4, ty = (b.Y + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tx * ty) return;
+    const int m0 = (tile / ty) * 16, n0 = (tile % ty) * 16;
+    const int ls = *v.label_site;
+    const int cl = (ls == lid) ? c : 0, cr = (ls == lid + 1) ? c : 0;
+    const double* Wl = v.sites + (int64_t)lid * v.site_stride + (int64_t)cl * b.X * b.Dm;
+    const double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride + (int64_t)cr * b.Dm * b.Y;
+    d4 acc = {0, 0, 0, 0};
+    acc = wave_gemm_tile(Wl, b.Dm, 1, b.X, Wr, b.Y, 1, b.Y, b.Dm, m0, n0, acc);
+    double* out = v.bt + (int64_t)c * b.L;
+    const int col = n0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (lane >> 4) + 4 * r;
+        if (row < b.X && col < b.Y) out[(int64_t)row * b.Y + col] = acc[r];
+    }
+}
+
+// normalize!(BT_init) when rescale[1] (loss_functions.jl:109-111): one workgroup, C*L <= 2*16384.
+__global__ __launch_bounds__(1024) void k_bt_prescale(View v, int lid) {
+    __shared__ double red[16];
+    const BondDims b = bond_dims(v, lid);
+    const int n = v.C * b.L;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += v.bt[i] * v.bt[i];
+    const double tot = block_sum(s, red);
+    const double inv = 1.0 / sqrt(tot);
+    for (int i = threadIdx.x; i < n; i += 1024) v.bt[i] *= inv;
+}
+
+// ---------------------------------------------------------------------------------------
+// yhat_i = X_i^T B_c Y_i for a tile of 16 series  (+ per-tile loss terms)
+//   KLD: own class only (loss_functions.jl:302-320);  MSE: every class (blockIdx.y) (:535-558)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const BondDims b = bond_dims(v, lid);
+    const int d = v.d, rid = lid + 1;
+    const Span tl = v.tiles[blockIdx.x];
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int c = mse ? (int)blockIdx.y : tl.cls;
+    const int XP = (b.X + 3) & ~3, XS = XP + 2;
+    const int YP = (b.Y + 15) & ~15, YS = YP + 2;
+    double* Xs = smem;                 // [16][XS]
+    double* Ys = Xs + 16 * XS;         // [16][YS]
+    double* red = Ys + 16 * YS;        // [4][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+
+    for (int idx = tid; idx < 16 * XS; idx += 256) {
+        const int i = idx / XS, x = idx - i * XS;
+        double val = 0.0;
+        if (i < tl.count && x < b.X) {
+            const int a = x / d, s = x - a * d;
+            const int64_t smp = tl.start + i;
+            const double le = LEp ? LEp[smp * v.cap + a] : 1.0;
+            val = le * phl[smp * d + s];
+        }
+        Xs[idx] = val;
+    }
+    for (int idx = tid; idx < 16 * YS; idx += 256) {
+        const int i = idx / YS, y = idx - i * YS;
+        double val = 0.0;
+        if (i < tl.count && y < b.Y) {
+            const int s = y / b.Dr, bb = y - s * b.Dr;
+            const int64_t smp = tl.start + i;
+            const double re = REn ? REn[smp * v.cap + bb] : 1.0;
+            val = phr[smp * d + s] * re;
+        }
+        Ys[idx] = val;
+    }
+    __syncthreads();
+
+    const double* Bc = v.bt + (int64_t)c * b.L;
+    const int i16 = lane & 15, kq = lane >> 4;
+    double p[4] = {0, 0, 0, 0};
+    const int nty = YP >> 4;
+    for (int nt = wave; nt < nty; nt += 4) {
+        d4 acc = {0, 0, 0, 0};
+        const int col = nt * 16 + i16;
+        const bool cv = col < b.Y;
+#pragma unroll 4
+        for (int k0 = 0; k0 < XP; k0 += 4) {
+            const int kx = k0 + kq;
+            const double a = Xs[i16 * XS + kx];
+            const double bv = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
+            acc = mfma_f64(a, bv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] += acc[r] * Ys[(kq + 4 * r) * YS + col];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double x = p[r];
+        x += __shfl_xor(x, 1, 64);
+        x += __shfl_xor(x, 2, 64);
+        x += __shfl_xor(x, 4, 64);
+        x += __shfl_xor(x, 8, 64);
+        if (i16 == 0) red[wave * 16 + kq + 4 * r] = x;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double term = 0.0;
+        if (tid < 16) {
+            const double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            if (tid < tl.count) {
+                v.yhat[(int64_t)c * v.N + tl.start + tid] = yh;
+                if (mse) {
+                    const double m = (tl.cls == c) ? 1.0 : 0.0;
+                    term = 0.5 * (yh - m) * (yh - m);          // MSE_iter! :554
+                } else {
+                    term = -log(yh * yh);                      // KLD_iter! :318
+                }
+            }
+        }
+        term += __shfl_xor(term, 1, 64);
+        term += __shfl_xor(term, 2, 64);
+        term += __shfl_xor(term, 4, 64);
+        term += __shfl_xor(term, 8, 64);
+        if (tid == 0) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + blockIdx.x] = term;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// gradient partials: P[chunk] (64x64 block) = sum_{i in chunk} w_i X_i Y_i^T
+//   KLD: w_i = 1/yhat_i                      (loss_functions.jl:258, :367)
+//   MSE: w_i = yhat_i^c - [label_i == c]     (:489, :608)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grad(View v, int lid) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int XS = GB + 16;  // row stride: lanes 16-31 land on the other half of the bank row
+    double* Xs = smem;           // [64 series][XS]
+    double* Ys = smem + CHUNK_S * XS;
+    const BondDims b = bond_dims(v, lid);
+    const int d = v.d, rid = lid + 1;
+    const int nby = (b.Y + GB - 1) / GB, nbx = (b.X + GB - 1) / GB;
+    const int blk = blockIdx.y;
+    if (blk >= nbx * nby) return;
+    const int bx = blk / nby, by = blk - bx * nby;
+    const Span ch = v.chunks[blockIdx.x];
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int c = mse ? (int)blockIdx.z : ch.cls;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+    const double* yh = v.yhat + (int64_t)c * v.N;
+
+    for (int idx = tid; idx < CHUNK_S * GB; idx += 256) {
+        const int i = idx / GB, xx = idx - i * GB;
+        const int x = bx * GB + xx;
+        double val = 0.0;
+        if (i < ch.count && x < b.X) {
+            const int a = x / d, s = x - a * d;
+            const int64_t smp = ch.start + i;
+            const double le = LEp ? LEp[smp * v.cap + a] : 1.0;
+            val = le * phl[smp * d + s];
+        }
+        Xs[i * XS + xx] = val;
+    }
+    for (int idx = tid; idx < CHUNK_S * GB; idx += 256) {
+        const int i = idx / GB, yy = idx - i * GB;
+        const int y = by * GB + yy;
+        double val = 0.0;
+        if (i < ch.count && y < b.Y) {
+            const int s = y / b.Dr, bb = y - s * b.Dr;
+            const int64_t smp = ch.start + i;
+            const double re = REn ? REn[smp * v.cap + bb] : 1.0;
+            const double w = mse ? (yh[smp] - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yh[smp];
+            val = w * phr[smp * d + s] * re;
+        }
+        Ys[i * XS + yy] = val;
+    }
+    __syncthreads();
+
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int mt = wave;  // 16 x-rows of the block per wave
+    d4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = d4{0, 0, 0, 0};
+    const int kmax = (ch.count + 3) & ~3;
+    if (bx * GB + mt * 16 < b.X) {
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+            const double a = Xs[(k0 + kq) * XS + mt * 16 + i16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const double bv = Ys[(k0 + kq) * XS + nt * 16 + i16];
+                acc[nt] = mfma_f64(a, bv, acc[nt]);
+            }
+        }
+    }
+    const int64_t pc = mse ? (int64_t)c * v.nchunks + blockIdx.x : blockIdx.x;
+    double* out = v.partial + pc * (int64_t)b.L;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = by * GB + nt * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = bx * GB + mt * 16 + kq + 4 * r;
+            if (row < b.X && col < b.Y) out[(int64_t)row * b.Y + col] = acc[nt][r];
+        }
+    }
+}
+
+// grad[c] = scale_c * sum_chunks P ; loss = scaled sum of the tile terms.
+// gradbuf = [loss, 0, grad[c][x][y] ...] is the buffer the multi-GPU all-reduce sums.
+__global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid) {
+    __shared__ double red[4];
+    const BondDims b = bond_dims(v, lid);
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int64_t total = (int64_t)v.C * b.L;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) {
+        const int c = (int)(idx / b.L);
+        const int64_t e = idx - (int64_t)c * b.L;
+        double s = 0.0;
+        if (mse) {
+            const double* p = v.partial + (int64_t)c * v.nchunks * b.L + e;
+            for (int k = 0; k < v.nchunks; ++k) s += p[(int64_t)k * b.L];
+            s *= v.invN;                                           // :608
+        } else {
+            const int k0 = v.cls_chunk_off[c], k1 = v.cls_chunk_off[c + 1];
+            const double* p = v.partial + e;
+            for (int k = k0; k < k1; ++k) s += p[(int64_t)k * b.L];
+            s *= -(v.train_sep ? v.inv_count[c] : v.invN);         // :367 / :424
+        }
+        v.gradbuf[2 + idx] = s;
+    }
+    if (blockIdx.x == 0) {
+        double s = 0.0;
+        if (mse) {
+            for (int i = threadIdx.x; i < v.C * v.ntiles; i += 256) s += v.tile_loss[i];
+            s *= v.invN;                                           // :612
+        } else {
+            for (int i = threadIdx.x; i < v.ntiles; i += 256) {
+                const double w = v.train_sep ? v.inv_count[v.tiles[i].cls] : v.invN;   // :423 / :371
+                s += v.tile_loss[i] * w;
+            }
+        }
+        const double tot = block_sum(s, red);
+        if (threadIdx.x == 0) {
+            v.gradbuf[0] = tot;
+            v.gradbuf[1] = 0.0;
+        }
+    }
+}
+
+// TSGO: bt -= eta * grad/||grad||  (loss_functions.jl:79);  GD: bt -= eta * grad (:49).
+// Every workgroup recomputes ||grad|| in the same fixed order, so all see the same bits.
+__global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter) {
+    __shared__ double red[4];
+    const BondDims b = bond_dims(v, lid);
+    const int n = v.C * b.L;
+    const double* g = v.gradbuf + 2;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    const double nrm2 = block_sum(s, red);
+    const double nrm = sqrt(nrm2);
+    const double step = (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v.bt[i] -= step * g[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && first_iter) {
+        v.sc->loss = v.gradbuf[0];
+        v.sc->grad_norm = nrm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Gram matrix of the bond tensor viewed as the matrix decomposeBT hands to svd
+// (RealRealHighDimension.jl:166-169 / :185-188):
+//   going left : rows (a, c, s_l), cols (s_r, b)  -> G = sum_c B_c^T B_c   (Y x Y)
+//   going right: rows (b, c, s_r), cols (s_l, a)  -> G = sum_c B_c B_c^T   (X x X)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gram(View v, int lid, int going_left) {
+    const BondDims b = bond_dims(v, lid);
+    const int n = going_left ? b.Y : b.X;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tn = (n + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tn * tn) return;
+    const int m0 = (tile / tn) * 16, n0 = (tile % tn) * 16;
+    d4 acc = {0, 0, 0, 0};
+    if (going_left) {
+        // k runs over (c, x) jointly: element (k, p) at k*Y + p
+        acc = wave_gemm_tile(v.bt, 1, b.Y, n, v.bt, b.Y, 1, n, v.C * b.X, m0, n0, acc);
+    } else {
+        for (int c = 0; c < v.C; ++c) {
+            const double* Bc = v.bt + (int64_t)c * b.L;
+            acc = wave_gemm_tile(Bc, b.Y, 1, n, Bc, 1, b.Y, n, b.Y, m0, n0, acc);
+        }
+    }
+    const int col = n0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (lane >> 4) + 4 * r;
+        if (row < n && col < n) v.gram[(int64_t)row * n + col] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// decomposeBT back-split (RealRealHighDimension.jl:172-176 / :190-194) from the kept
+// eigenvectors E (dim x n_keep):
+//   going left : W[rid] = E^T (right-orthonormal V),   W[lid][c] = B_c E * inv_norm  (= U*S, label)
+//   going right: W[lid] = E   (left-orthonormal  U),   W[rid][c] = E^T B_c * inv_norm (= V*S, label)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_split(View v, int lid, int going_left) {
+    const BondDims b = bond_dims(v, lid);
+    const int nk = v.sc->n_keep;
+    const int ldE = v.cap;
+    const double inv = v.sc->inv_norm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* Wl = v.sites + (int64_t)lid * v.site_stride;
+    double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
+    const int tk = (nk + 15) >> 4;
+    const int col = lane & 15, rq = lane >> 4;
+    if (going_left) {
+        const int tx = (b.X + 15) >> 4;
+        const int ntile = v.C * tx * tk;
+        for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+            const int c = tile / (tx * tk), rem = tile - c * tx * tk;
+            const int m0 = (rem / tk) * 16, n0 = (rem % tk) * 16;
+            const double* Bc = v.bt + (int64_t)c * b.L;
+            d4 acc = {0, 0, 0, 0};
+            acc = wave_gemm_tile(Bc, b.Y, 1, b.X, v.E, ldE, 1, nk, b.Y, m0, n0, acc);
+            double* out = Wl + (int64_t)c * b.X * nk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + rq + 4 * r;
+                if (row < b.X && n0 + col < nk) out[(int64_t)row * nk + n0 + col] = acc[r] * inv;
+            }
+        }
+        // W[rid][k][y] = E[y][k]
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nk * b.Y; i += gridDim.x * 256) {
+            const int k = i / b.Y, y = i - k * b.Y;
+            Wr[i] = v.E[(int64_t)y * ldE + k];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *v.label_site = lid;
+    } else {
+        const int ty = (b.Y + 15) >> 4;
+        const int ntile = v.C * tk * ty;
+        for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+            const int c = tile / (tk * ty), rem = tile - c * tk * ty;
+            const int m0 = (rem / ty) * 16, n0 = (rem % ty) * 16;
+            const double* Bc = v.bt + (int64_t)c * b.L;
+            d4 acc = {0, 0, 0, 0};
+            // (E^T B_c)[k][y] : A(m=k, kk=x) = E[x*ldE + k], B(kk=x, n=y) = Bc[x*Y + y]
+            acc = wave_gemm_tile(v.E, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0, acc);
+            double* out = Wr + (int64_t)c * nk * b.Y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + rq + 4 * r;
+                if (row < nk && n0 + col < b.Y) out[(int64_t)row * b.Y + n0 + col] = acc[r] * inv;
+            }
+        }
+        // W[lid][x][k] = E[x][k]
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < b.X * nk; i += gridDim.x * 256) {
+            const int x = i / nk, k = i - x * nk;
+            Wl[i] = v.E[(int64_t)x * ldE + k];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *v.label_site = lid + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// environment step (construct_caches :72-77,:90-98 and update_caches! :124-141):
+//   out[i][k] = sum_z Z_i[z] * M[z*sz + k*sk]
+// left side : Z_i[a*d+s] = prev_i[a] * phi_i[s]     (LE),  dimension Dp*d
+// right side: Z_i[s*Dp+b] = phi_i[s] * prev_i[b]    (RE)
+// prev == nullptr means the boundary (Dp = 1, value 1).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, const double* __restrict__ prev,
+                                             int prev_bond, int mode, int out_bond, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int d = v.d;
+    const int Dp = prev ? v.chi[prev_bond] : 1;
+    const int Dout = v.chi[out_bond];
+    const int Z = Dp * d;
+    const double* __restrict__ M;
+    int64_t sz, sk;
+    if (mode == ENV_M_E) {
+        M = v.E;
+        sz = v.cap;
+        sk = 1;
+    } else if (mode == ENV_M_SITE) {
+        M = v.sites + (int64_t)site * v.site_stride;   // [(a,s)][k], k = right bond
+        sz = v.chi[site + 1];
+        sk = 1;
+    } else {
+        M = v.sites + (int64_t)site * v.site_stride;   // [k][(s,b)], k = left bond
+        sz = 1;
+        sk = (int64_t)d * v.chi[site + 1];
+    }
+    const int ZP = (Z + 3) & ~3, ZS = ZP + 2;
+    const Span tl = v.tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* ph = v.phi + (int64_t)site * v.N * d;
+    for (int idx = tid; idx < 16 * ZS; idx += 256) {
+        const int i = idx / ZS, z = idx - i * ZS;
+        double val = 0.0;
+        if (i < tl.count && z < Z) {
+            const int64_t smp = tl.start + i;
+            int a, s;
+            if (left_side) {
+                a = z / d;
+                s = z - a * d;
+            } else {
+                s = z / Dp;
+                a = z - s * Dp;
+            }
+            const double pv = prev ? prev[smp * v.cap + a] : 1.0;
+            val = pv * ph[smp * d + s];
+        }
+        smem[idx] = val;
+    }
+    __syncthreads();
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int nt_out = (Dout + 15) >> 4;
+    for (int nt = wave; nt < nt_out; nt += 4) {
+        const int col = nt * 16 + i16;
+        const bool cv = col < Dout;
+        d4 acc = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < ZP; k0 += 4) {
+            const int z = k0 + kq;
+            const double a = smem[i16 * ZS + z];
+            const double bv = (cv && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
+            acc = mfma_f64(a, bv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = kq + 4 * r;
+            if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// evaluation (src/summary.jl:4-136): yhat_i[c] = sum_{a,s,b} L_i[a] phi_i[s] R_i[b] W_p[c][a][s][b]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_eval_final(View v, const double* __restrict__ Lc,
+                                                    const double* __restrict__ Rc, double* __restrict__ yout) {
+    const int p = *v.label_site;
+    const int Dl = v.chi[p], Dr = v.chi[p + 1], d = v.d;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= v.N) return;
+    const double* W = v.sites + (int64_t)p * v.site_stride;
+    const double* ph = v.phi + ((int64_t)p * v.N + i) * d;
+    const double* L = (p > 0) ? Lc + i * v.cap : nullptr;
+    const double* R = (p < v.T - 1) ? Rc + i * v.cap : nullptr;
+    for (int c = 0; c < v.C; ++c) {
+        const double* Wc = W + (int64_t)c * Dl * d * Dr;
+        double acc = 0.0;
+        for (int a = 0; a < Dl; ++a) {
+            const double la = L ? L[a] : 1.0;
+            for (int s = 0; s < d; ++s) {
+                const double ls = la * ph[s];
+                const double* w = Wc + ((int64_t)a * d + s) * Dr;
+                double t = 0.0;
+                for (int bb = 0; bb < Dr; ++bb) t += w[bb] * (R ? R[bb] : 1.0);
+                acc += ls * t;
+            }
+        }
+        yout[i * v.C + c] = acc;
+    }
+}
+
+// MSE_loss_acc_iter (summary.jl:33-58): one workgroup, fixed-order sums.
+// out3 = {mean mse, mean kld, accuracy}; conf[truth][pred]; pred[i] = argmax |yhat| (first max).
+__global__ __launch_bounds__(1024) void k_eval_reduce(View v, const double* __restrict__ yin, double* out3,
+                                                      int64_t* conf, int32_t* pred) {
+    __shared__ double red[16];
+    __shared__ int cm[MAX_C * MAX_C];
+    const int C = v.C;
+    for (int i = threadIdx.x; i < C * C; i += 1024) cm[i] = 0;
+    __syncthreads();
+    double mse = 0.0, kld = 0.0, acc = 0.0;
+    for (int64_t i = threadIdx.x; i < v.N; i += 1024) {
+        const double* y = yin + i * C;
+        const int lab = v.label[i];
+        double s = 0.0, best = -1.0;
+        int arg = 0;
+        for (int c = 0; c < C; ++c) {
+            const double t = y[c] - (c == lab ? 1.0 : 0.0);
+            s += t * t;
+            const double ab = fabs(y[c]);
+            if (ab > best) {
+                best = ab;
+                arg = c;
+            }
+        }
+        mse += 0.5 * s;
+        kld += -log(y[lab] * y[lab]);
+        acc += (arg == lab) ? 1.0 : 0.0;
+        if (pred) pred[i] = arg;
+        atomicAdd(&cm[lab * C + arg], 1);
+    }
+    const double tm = block_sum(mse, red);
+    const double tk = block_sum(kld, red);
+    const double ta = block_sum(acc, red);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out3[0] = tm;
+        out3[1] = tk;
+        out3[2] = ta;
+    }
+    if (conf)
+        for (int i = threadIdx.x; i < C * C; i += 1024) conf[i] = cm[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// normalize!(W) (RealRealHighDimension.jl:852; ITensors: every site / exp(lognorm/T)).
+// <W|W> by transfer matrices in one workgroup: E <- sum_{s(,c)} A_s^T E A_s.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_norm2(View v, double* out_norm2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int cm = v.cap;
+    double* E = smem;             // [cm][cm]
+    double* Tm = E + cm * cm;     // [cm][cm]  T = E * A_s
+    double* En = Tm + cm * cm;    // [cm][cm]
+    const int tid = threadIdx.x;
+    const int ls = *v.label_site;
+    for (int i = tid; i < cm * cm; i += 1024) E[i] = 0.0;
+    __syncthreads();
+    if (tid == 0) E[0] = 1.0;
+    __syncthreads();
+    for (int j = 0; j < v.T; ++j) {
+        const int Dl = v.chi[j], Dr = v.chi[j + 1], d = v.d;
+        const int Cj = (j == ls) ? v.C : 1;
+        const double* W = v.sites + (int64_t)j * v.site_stride;
+        for (int i = tid; i < Dr * Dr; i += 1024) En[(i / Dr) * cm + (i % Dr)] = 0.0;
+        __syncthreads();
+        for (int c = 0; c < Cj; ++c)
+            for (int s = 0; s < d; ++s) {
+                const double* A = W + (int64_t)c * Dl * d * Dr + (int64_t)s * Dr;  // A[a][r] at a*d*Dr + r
+                for (int i = tid; i < Dl * Dr; i += 1024) {
+                    const int a = i / Dr, r = i - a * Dr;
+                    double t = 0.0;
+                    for (int a2 = 0; a2 < Dl; ++a2) t += E[a * cm + a2] * A[(int64_t)a2 * d * Dr + r];
+                    Tm[a * cm + r] = t;
+                }
+                __syncthreads();
+                for (int i = tid; i < Dr * Dr; i += 1024) {
+                    const int r1 = i / Dr, r2 = i - r1 * Dr;
+                    double t = 0.0;
+                    for (int a = 0; a < Dl; ++a) t += A[(int64_t)a * d * Dr + r1] * Tm[a * cm + r2];
+                    En[r1 * cm + r2] += t;
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < Dr * Dr; i += 1024) {
+            const int r1 = i / Dr, r2 = i - r1 * Dr;
+            E[r1 * cm + r2] = En[r1 * cm + r2];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *out_norm2 = E[0];
+}
+
+__global__ __launch_bounds__(256) void k_scale_sites(View v, const double* norm2) {
+    const int j = blockIdx.x;
+    const int ls = *v.label_site;
+    const int n = ((j == ls) ? v.C : 1) * v.chi[j] * v.d * v.chi[j + 1];
+    const double z = exp(0.5 * log(*norm2) / (double)v.T);
+    double* W = v.sites + (int64_t)j * v.site_stride;
+    for (int i = threadIdx.x; i < n; i += 256) W[i] /= z;
+}
+
+__global__ void k_selftest_mfma(const double* A, const double* B, int K, double* C) {
+    const int lane = threadIdx.x & 63;
+    d4 acc = {0, 0, 0, 0};
+    acc = wave_gemm_tile(A, K, 1, 16, B, 16, 1, 16, K, 0, 0, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers.  Grids are sized for the maximum bond dimension; kernels read the live
+// dimensions from device memory and idle the surplus workgroups, so no launch depends on
+// a host read-back and a whole sweep can be enqueued (or graph-captured) at once.
+// ---------------------------------------------------------------------------------------
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+void launch_bt_assemble(const View& v, int lid, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int tiles = cdiv(dm, 16) * cdiv(dm, 16);
+    hipLaunchKernelGGL(k_bt_assemble, dim3(cdiv(tiles, 4), v.C), dim3(256), 0, s, v, lid);
+}
+void launch_bt_prescale(const View& v, int lid, hipStream_t s) {
+    hipLaunchKernelGGL(k_bt_prescale, dim3(1), dim3(1024), 0, s, v, lid);
+}
+void launch_yhat(const View& v, int lid, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * (((dm + 15) & ~15) + 2) + 64) * sizeof(double);
+    const int gy = v.loss == MPST_LOSS_MSE ? v.C : 1;
+    hipLaunchKernelGGL(k_yhat, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
+}
+void launch_grad(const View& v, int lid, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int nb = cdiv(dm, GB) * cdiv(dm, GB);
+    const size_t lds = (size_t)2 * CHUNK_S * (GB + 16) * sizeof(double);
+    const int gz = v.loss == MPST_LOSS_MSE ? v.C : 1;
+    hipLaunchKernelGGL(k_grad, dim3(v.nchunks, nb, gz), dim3(256), lds, s, v, lid);
+}
+void launch_grad_reduce(const View& v, int lid, hipStream_t s) {
+    const int64_t tot = (int64_t)v.C * v.d * v.cap * v.d * v.cap;
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, lid);
+}
+void launch_update(const View& v, int lid, int first_iter, hipStream_t s) {
+    hipLaunchKernelGGL(k_update, dim3(32), dim3(256), 0, s, v, lid, first_iter);
+}
+void launch_gram(const View& v, int lid, int going_left, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int tiles = cdiv(dm, 16) * cdiv(dm, 16);
+    hipLaunchKernelGGL(k_gram, dim3(cdiv(tiles, 4)), dim3(256), 0, s, v, lid, going_left);
+}
+void launch_split(const View& v, int lid, int going_left, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int tiles = v.C * cdiv(dm, 16) * cdiv(v.cap, 16);
+    hipLaunchKernelGGL(k_split, dim3(cdiv(tiles, 4)), dim3(256), 0, s, v, lid, going_left);
+}
+void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond, int mode,
+                int out_bond, double* out, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const size_t lds = (size_t)16 * (((dm + 3) & ~3) + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_env, dim3(v.ntiles), dim3(256), lds, s, v, site, left_side, prev, prev_bond, mode,
+                       out_bond, out);
+}
+void init_kernel_attrs() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(2 * CHUNK_S * (GB + 16) * sizeof(double)));
+    (void)hipFuncSetAttribute((const void*)k_yhat, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    done = true;
+}
+void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yout, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_final, dim3((unsigned)((v.N + 255) / 256)), dim3(256), 0, s, v, Lc, Rc, yout);
+}
+void launch_eval_reduce(const View& v, const double* yin, double* out3, int64_t* conf, int32_t* pred,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_eval_reduce, dim3(1), dim3(1024), 0, s, v, yin, out3, conf, pred);
+}
+void launch_norm2(const View& v, double* out_norm2, hipStream_t s) {
+    const size_t lds = (size_t)3 * v.cap * v.cap * sizeof(double);
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(1024), lds, s, v, out_norm2);
+}
+void launch_scale_sites(const View& v, const double* norm2, hipStream_t s) {
+    hipLaunchKernelGGL(k_scale_sites, dim3(v.T), dim3(256), 0, s, v, norm2);
+}
+void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, s, A, B, K, C);
+}
+
+}  // namespace mpst

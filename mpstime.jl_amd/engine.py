@@ -1,0 +1,176 @@
+"""SweepEngine: thin Python mirror of the C ABI (one context = one GPU).
+
+Arrays cross the boundary in the layouts of include/mpstime_hip.h.  On the
+Python side a site tensor is an ndarray (Dl, d, Dr) or (Dl, d, Dr, C) - the
+boundary layout is its Fortran-order (d, Dl, Dr[, C]) permutation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _site_to_abi(t):
+    t = np.asarray(t, dtype=np.float64)
+    if t.ndim == 3:
+        a = np.transpose(t, (1, 0, 2))          # (d, Dl, Dr)
+    else:
+        a = np.transpose(t, (1, 0, 2, 3))       # (d, Dl, Dr, C)
+    return np.asfortranarray(a)
+
+
+def _site_from_abi(buf, Dl, d, Dr, Cj):
+    shape = (d, Dl, Dr) + ((Cj,) if Cj else ())
+    a = np.reshape(buf, shape, order="F")
+    return np.ascontiguousarray(np.transpose(a, (1, 0, 2) + ((3,) if Cj else ())))
+
+
+class SweepEngine:
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        self.ctx = C.c_void_p()
+        rc = self.lib.mpst_create(C.byref(self.ctx), device)
+        if rc:
+            raise L.MPSTError(rc, (self.lib.mpst_last_error(None) or b"").decode())
+        self.T = self.d = self.C = 0
+        self.N = [0, 0]
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            msg = (self.lib.mpst_last_error(self.ctx) or b"").decode()
+            raise (L.SVDError if rc == L.MPST_ERR_SVD else L.MPSTError)(rc, msg)
+
+    def close(self):
+        if getattr(self, "ctx", None) and self.ctx.value:
+            self.lib.mpst_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ----------------------------------------------------------------
+    def set_options(self, chi_max, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO",
+                    rescale=(False, True), train_classes_separately=False, svd_alg=0, rebuild_caches=False):
+        if str(loss).upper() not in L.LOSS:
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"loss {loss!r} unsupported by the array sweep")
+        if str(bbopt).upper() not in L.OPT:
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED,
+                              "Optim/OptimKit based solvers currently unimplemented for this version, "
+                              "set 'use_legacy_ITensor=true' in MPSOptions to enable")
+        o = L.mpst_options(int(chi_max), int(update_iters), L.LOSS[str(loss).upper()], L.OPT[str(bbopt).upper()],
+                           int(bool(rescale[0])), int(bool(rescale[1])), int(bool(train_classes_separately)),
+                           int(svd_alg), int(bool(rebuild_caches)), 0, float(eta), float(cutoff))
+        self._chk(self.lib.mpst_set_options(self.ctx, C.byref(o)))
+
+    def set_dataset(self, which, phi, label_index, C_classes, global_counts=None):
+        phi = np.ascontiguousarray(phi, dtype=np.float64)
+        lab = np.ascontiguousarray(label_index, dtype=np.int32)
+        N, T, d = phi.shape if phi.ndim == 3 and phi.size else (0, self.T, self.d)
+        gc = None
+        if global_counts is not None:
+            gc = np.ascontiguousarray(global_counts, dtype=np.int64)
+        self._chk(self.lib.mpst_set_dataset(
+            self.ctx, which, phi.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.POINTER(C.c_int32)), N, T, d,
+            int(C_classes), L.F64, gc.ctypes.data_as(C.POINTER(C.c_int64)) if gc is not None else None))
+        self.T, self.d, self.C = T, d, int(C_classes)
+        self.N[which] = N
+
+    def set_mps(self, W, label_site=None):
+        T = len(W)
+        if label_site is None:
+            label_site = [j for j, t in enumerate(W) if np.ndim(t) == 4]
+            assert len(label_site) == 1, "exactly one site must carry the label index"
+            label_site = label_site[0]
+        chi = np.array([W[0].shape[0]] + [t.shape[2] for t in W], dtype=np.int32)
+        bufs = [_site_to_abi(t) for t in W]
+        ptrs = (C.c_void_p * T)(*[b.ctypes.data for b in bufs])
+        self._chk(self.lib.mpst_set_mps(self.ctx, ptrs, chi.ctypes.data_as(C.POINTER(C.c_int32)), T, int(label_site)))
+
+    def get_chi(self):
+        chi = np.zeros(self.T + 1, dtype=np.int32)
+        ls = C.c_int32()
+        self._chk(self.lib.mpst_get_chi(self.ctx, chi.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ls)))
+        return chi, ls.value
+
+    def get_mps(self):
+        chi, ls = self.get_chi()
+        bufs = []
+        for j in range(self.T):
+            n = self.d * chi[j] * chi[j + 1] * (self.C if j == ls else 1)
+            bufs.append(np.zeros(int(n), dtype=np.float64))
+        ptrs = (C.c_void_p * self.T)(*[b.ctypes.data for b in bufs])
+        self._chk(self.lib.mpst_get_mps(self.ctx, ptrs))
+        return [_site_from_abi(bufs[j], int(chi[j]), self.d, int(chi[j + 1]), self.C if j == ls else 0)
+                for j in range(self.T)]
+
+    # -- the path ---------------------------------------------------------------------
+    def build_caches(self):
+        self._chk(self.lib.mpst_build_caches(self.ctx))
+
+    def sweep(self):
+        st = L.mpst_sweep_stats()
+        self._chk(self.lib.mpst_sweep(self.ctx, C.byref(st)))
+        return {"seconds": st.seconds, "max_chi": st.max_chi, "eig_sweeps_total": st.eig_sweeps_total}
+
+    def bond_step(self, lid, going_left):
+        dbg = L.mpst_bond_debug()
+        self._chk(self.lib.mpst_bond_step(self.ctx, int(lid), int(bool(going_left)), C.byref(dbg)))
+        return {"loss": dbg.loss, "grad_norm": dbg.grad_norm, "bt_new_norm": dbg.bt_norm, "chi": dbg.chi_new,
+                "eig_sweeps": dbg.eig_sweeps, "S": np.array(dbg.spectrum[:dbg.n_spectrum])}
+
+    def eval(self, which=0):
+        mse, kld, acc = C.c_double(), C.c_double(), C.c_double()
+        conf = np.zeros((self.C, self.C), dtype=np.int64)
+        self._chk(self.lib.mpst_eval(self.ctx, which, C.byref(mse), C.byref(kld), C.byref(acc),
+                                     conf.ctypes.data_as(C.POINTER(C.c_int64))))
+        return mse.value, kld.value, acc.value, conf
+
+    def classify(self, which=1, return_overlaps=False):
+        N = self.N[which]
+        pred = np.zeros(N, dtype=np.int32)
+        yh = np.zeros((N, self.C), dtype=np.float64)
+        self._chk(self.lib.mpst_classify(self.ctx, which, pred.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         yh.ctypes.data_as(C.POINTER(C.c_double))))
+        return (pred, yh) if return_overlaps else pred
+
+    def normalize(self):
+        self._chk(self.lib.mpst_normalize(self.ctx))
+
+    # -- diagnostics ------------------------------------------------------------------
+    def set_profile(self, mask):
+        self._chk(self.lib.mpst_set_profile(self.ctx, int(mask)))
+
+    def get_profile(self):
+        us = np.zeros(16)
+        cnt = np.zeros(16, dtype=np.int64)
+        self._chk(self.lib.mpst_get_profile(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double)),
+                                            cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
+
+    def selftest_mfma(self, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        K = A.shape[1]
+        out = np.zeros((16, 16))
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mpst_selftest_mfma(self.ctx, A.ctypes.data_as(dp), B.ctypes.data_as(dp), K,
+                                              out.ctypes.data_as(dp)))
+        return out
+
+    def selftest_eig(self, G, alg=0):
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        n = G.shape[0]
+        lam = np.zeros(n)
+        E = np.zeros((n, n))
+        sw = C.c_int32()
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mpst_selftest_eig(self.ctx, G.ctypes.data_as(dp), n, alg, lam.ctypes.data_as(dp),
+                                             E.ctypes.data_as(dp), C.byref(sw)))
+        return lam, E, sw.value
