@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py - full sweeps/sec of the MI355X sweep engine on BASELINE.json's headline config.
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): synthetic two-class
+"noisy trendy sine" (docs/src/classification.md:20-43 of the reference), N=4096 series of
+length T=100, RobustSigmoid+MinMax preprocessing, Legendre d=4 encoding, chi_max=32, KLD loss,
+TSGO eta=0.01, update_iters=1, rescale=(false,true), cutoff=1e-10, fp64.  One "step" = one full
+sweep (src/Training/RealRealHighDimension.jl:727-808: 2(T-1) bond updates; the two cache
+rebuilds per sweep are redundant recomputation and are skipped unless --rebuild-caches).
+
+With --gpus N>1 (launched by torch.distributed.run) the N=4096 series are sharded over the
+ranks (strong scaling) and the bond gradient is all-reduced with RCCL once per optimiser step.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD spec)
+PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_inputs(N, T, d, seed=1):
+    import mpstime_jl_amd as mt
+    rng = np.random.default_rng(seed)
+    half = N // 2
+    X1, _ = mt.trendy_sine(T, half, period=(12.0, 15.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+    X2, _ = mt.trendy_sine(T, N - half, period=(16.0, 19.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+    X = np.concatenate([X1, X2])
+    y = np.concatenate([np.ones(half, dtype=np.int64), 2 * np.ones(N - half, dtype=np.int64)])
+    opts = mt.MPSOptions(d=d, encoding="Legendre", verbosity=-1)
+    enc = mt.model_encoding(opts.encoding)
+    Xs, _ = mt.transform_train_data(X, opts, enc.range)
+    return mt.encode_dataset(X, Xs, y, enc, d, {1: 0, 2: 1})
+
+
+def kernel_model(N, d, chi, C):
+    """Algorithmic flops / bytes per launch of each kernel class at steady state (all bulk bonds at
+    chi_max); formulas from SURVEY.md 8(d), stated again in DESIGN.md."""
+    X = Y = d * chi
+    m, n = chi * C * d, d * chi
+    return {
+        "yhat": ("mfma", 2.0 * N * X * Y),                 # Z = X B_c, rowdot with Y
+        "grad": ("mfma", 2.0 * N * X * Y),                 # G_c = X^T diag(w) Y
+        "eig": ("mfma", 4.0 * m * n * n + 8.0 * n ** 3),   # dense SVD of the (chi C d) x (d chi) bond matrix
+        "gram": ("mfma", 2.0 * m * n * n),
+        "split": ("mfma", 2.0 * m * n * chi),
+        "bt_assemble": ("mfma", 2.0 * C * X * chi * Y),
+        "env": ("hbm", 8.0 * N * (chi + d + chi)),         # read env row + site vector, write new env row
+        "grad_reduce+update": ("hbm", 8.0 * (N / 64.0 + 3.0) * C * X * Y),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--T", type=int, default=100)
+    ap.add_argument("--chi", type=int, default=32)
+    ap.add_argument("--d", type=int, default=4)
+    ap.add_argument("--rebuild-caches", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bonds", type=int, default=24)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import mpstime_jl_amd as mt
+    N, T, d, chi, C = args.N, args.T, args.d, args.chi, 2
+    full = make_inputs(N, T, d)
+    W0 = mt.generate_startingMPS(4, T, d, C, 1234)
+
+    eng = mt.SweepEngine(local_rank)
+    eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO",
+                    rescale=(False, True), rebuild_caches=args.rebuild_caches)
+    if world > 1:
+        sh = mt.Shard(rank, world)
+        local, gcounts = sh.split(full)
+        sh.attach(eng)
+        eng.set_dataset(0, local.phi, local.label_index, C, gcounts)
+    else:
+        eng.set_dataset(0, full.phi, full.label_index, C)
+    eng.set_mps(W0)
+    eng.build_caches()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # warmup: chi grows to chi_max during the first sweep; the last warmup sweep is profiled per
+    # kernel class to find the dominant kernel
+    for w in range(args.warmup):
+        if w == args.warmup - 1:
+            eng.set_profile(0x1FF)
+        eng.sweep()
+    breakdown = eng.get_profile() if args.warmup > 0 else {}
+    dominant = max(breakdown, key=lambda k: breakdown[k][0]) if breakdown else "eig"
+    kidx = list(mt._lib.KERNEL_CLASSES).index(dominant)
+    eng.set_profile(1 << kidx)          # HIP events on the engine's stream around the dominant kernel only
+
+    sync()
+    t0 = time.perf_counter()
+    dev_s = 0.0
+    for _ in range(args.steps):
+        dev_s += eng.sweep()["seconds"]
+    sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = eng.get_profile()
+    mse, kld, acc, _ = eng.eval(0)
+    chi_now, _ = eng.get_chi()
+
+    out = None
+    if rank == 0:
+        model = kernel_model(N / world, d, chi, C)
+        us_tot, cnt = prof[dominant]
+        avg_us = us_tot / max(cnt, 1)
+        bound, alg = model.get(dominant, ("mfma", 0.0))
+        if bound == "mfma":
+            achieved, peak, unit = alg / (avg_us * 1e-6) / 1e12, PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
+        else:
+            achieved, peak, unit = alg / (avg_us * 1e-6) / 1e9, PEAK_HBM_GBS, "GB/s"
+        kernels = {}
+        for k, (us, c) in breakdown.items():
+            if c == 0:
+                continue
+            b, a = model.get(k, ("mfma", 0.0))
+            per = us / c
+            kernels[k] = {"avg_us": round(per, 3), "launches_per_sweep": c, "share": round(us / max(sum(v[0] for v in breakdown.values()), 1e-9), 4),
+                          "bound": b, "achieved": round(a / (per * 1e-6) / (1e12 if b == "mfma" else 1e9), 4),
+                          "unit": "TFLOP/s" if b == "mfma" else "GB/s"}
+        out = {
+            "metric": "full sweeps/sec (N=4096,T=100,chi=32,d=4)", "value": args.steps / elapsed, "unit": "sweeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"DMRG training sweep, noisy trendy sine 2-class, N={N}, T={T}, chi_max={chi}, d={d} Legendre, "
+                                   f"KLD+TSGO eta=0.01, fp64; configs[2] of BASELINE.json",
+                       "N": N, "T": T, "chi_max": chi, "d": d, "C": C, "rebuild_caches": bool(args.rebuild_caches),
+                       "parallelism": f"batch-shard x{world}" if world > 1 else "single GPU",
+                       "bond_dims_max": int(chi_now.max())},
+            "device_ms_per_step": 1e3 * dev_s / args.steps,
+            "train_KL_div_after": kld, "train_acc_after": acc,
+            "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": None, "avg_launch_us": avg_us, "launches": cnt,
+                         "algorithmic_per_launch": alg},
+            "kernels": kernels,
+        }
+
+    # ---- CPU baseline: the C restatement of the reference loop structure, bounded sample --------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle.c_oracle import COracle
+            Wnow = eng.get_mps()                      # steady-state MPS (all bulk bonds at chi_max)
+            co = COracle(Wnow, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=True,
+                         native=True)
+            t_c0 = time.perf_counter()
+            co.build_caches()                         # construct_caches: one of the two rebuilds per sweep
+            t_cache = time.perf_counter() - t_c0
+            skip = 6                                  # leave the narrow edge bonds out of the per-bond average
+            co.sweep(max_bonds=skip, first_bond=0)
+            r = co.sweep(max_bonds=args.cpu_bonds, first_bond=skip)
+            per_bond = r["seconds"] / max(r["bonds"], 1)
+            sweep_s = per_bond * 2 * (T - 1) + 2 * t_cache
+            out["cpu_baseline"] = {
+                "value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/mps_oracle.c (-O3 -march=native -ffast-math, 1 thread for the per-series loops, SciPy "
+                          f"OpenBLAS dgesdd): {r['bonds']} steady-state bulk bond updates ({per_bond:.3f} s each) + one "
+                          f"construct_caches ({t_cache:.2f} s) timed on this host, extrapolated to 2(T-1)={2 * (T - 1)} bonds "
+                          f"+ 2 cache rebuilds; the Julia reference itself cannot run here",
+                "host_cpus": os.cpu_count(), "seconds_sampled": r["seconds"] + t_cache}
+        except Exception as e:      # the baseline is a reported extra, never a reason to lose the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,4 +1,17 @@
-"""mpstime.jl_amd - MI355X-native sweep engine behind MPSTime.jl's fitMPS API."""
+"""mpstime.jl_amd - MI355X-native sweep engine behind MPSTime.jl's fitMPS / MPSOptions /
+Encodings API.  The hot path lives in libmpstime_hip.so (csrc/); everything here is the
+host-side mirror of the reference's interface for that path."""
 from . import _lib
-from .engine import SweepEngine
 from ._lib import MPSTError, SVDError
+from .engine import SweepEngine
+from .options import MPSOptions, safe_options
+from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_encoding, symbolic_encoding,
+                        transform_data, transform_train_data, transform_test_data, legendre_encode,
+                        legendre_encode_no_norm, fourier_encode, get_fourier_freqs, angle_encode, sahand_encode,
+                        uniform_encode)
+from .training import TrainedMPS, fitMPS, fit_encoded, classify, generate_startingMPS, trendy_sine
+from .distributed import Shard, split_encoded
+
+__all__ = ["SweepEngine", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
+           "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
+           "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError"]
