@@ -124,7 +124,8 @@ def main():
     t0 = time.perf_counter()
     dev_s = 0.0
     for _ in range(args.steps):
-        dev_s += eng.sweep()["seconds"]
+        st = eng.sweep()
+        dev_s += st["seconds"]
     sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -166,6 +167,7 @@ def main():
                        "bond_dims_max": int(chi_now.max())},
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "train_KL_div_after": kld, "train_acc_after": acc,
+            "eig_fallbacks_total": st["eig_fallbacks"], "eig_phases_us_last_bond": eng.eig_phases(),
             "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": None, "avg_launch_us": avg_us, "launches": cnt,
                          "algorithmic_per_launch": alg},

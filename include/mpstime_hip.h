@@ -79,7 +79,8 @@ typedef struct {
     int32_t svd_status;         /* 0 or MPST_ERR_SVD */
     int32_t max_chi;            /* largest bond dimension after the sweep */
     int32_t eig_sweeps_total;   /* diagnostic: Jacobi sweeps summed over bonds */
-    int32_t reserved;
+    int32_t eig_fallbacks;      /* diagnostic: bonds (cumulative) on which the fast eigensolver's on-device
+                                   verification failed and the Jacobi path was used */
 } mpst_sweep_stats;
 
 /* Test hook output of mpst_bond_step: gauge-invariant per-bond quantities. */
@@ -157,6 +158,9 @@ int  mpst_selftest_eig(void* ctx, const double* G /*n*n symmetric*/, int32_t n, 
  * microseconds and the launch count per class (arrays of 16). */
 int  mpst_set_profile(void* ctx, uint32_t kernel_mask);
 int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16]*/);
+/* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
+ * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation */
+int  mpst_get_eig_phases(void* ctx, double* us /*[5]*/);
 
 #ifdef __cplusplus
 }

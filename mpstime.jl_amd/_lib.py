@@ -28,7 +28,7 @@ class mpst_options(C.Structure):
 
 class mpst_sweep_stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("svd_status", C.c_int32), ("max_chi", C.c_int32),
-                ("eig_sweeps_total", C.c_int32), ("reserved", C.c_int32)]
+                ("eig_sweeps_total", C.c_int32), ("eig_fallbacks", C.c_int32)]
 
 
 class mpst_bond_debug(C.Structure):
@@ -61,6 +61,7 @@ SYMBOLS = {
     "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),
     "mpst_get_profile": (C.c_int, [_vp, _dp, C.POINTER(_i64)]),
+    "mpst_get_eig_phases": (C.c_int, [_vp, _dp]),
 }
 
 _lib = None

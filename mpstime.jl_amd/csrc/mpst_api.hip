@@ -557,7 +557,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         out->svd_status = sc.status;
         out->max_chi = *std::max_element(chi.begin(), chi.end());
         out->eig_sweeps_total = sc.eig_sweeps_total;
-        out->reserved = 0;
+        out->eig_fallbacks = sc.eig_fallbacks;
     }
     if (sc.status) return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
     return 0;
@@ -662,6 +662,17 @@ int mpst_get_profile(void* ctx, double* total_us, int64_t* count) {
         if (total_us) total_us[i] = c->prof_us[i];
         if (count) count[i] = c->prof_cnt[i];
     }
+    return 0;
+}
+
+int mpst_get_eig_phases(void* ctx, double* us) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->sc || !us) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    DevScalars sc;
+    HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) us[i] = 0.01 * (double)(sc.eig_stamps[i + 1] - sc.eig_stamps[i]);   // 100 MHz ticks
     return 0;
 }
 

@@ -1,23 +1,38 @@
 // Symmetric eigensolver for the Gram matrix of the bond tensor (n = d*chi <= 128), and the
-// NDTensors truncation rule.  This is the device-side stand-in for ITensors.svd -> LAPACK gesdd
-// + truncate! in decomposeBT (src/Training/RealRealHighDimension.jl:166-169,185-188).
+// NDTensors truncation rule.  Device-side stand-in for ITensors.svd -> LAPACK gesdd + truncate!
+// in decomposeBT (src/Training/RealRealHighDimension.jl:166-169,185-188).
 //
-// With A the (chi*C*d) x (d*chi) matrix the reference decomposes, G = A^T A = V S^2 V^T, so the
-// right singular vectors are the eigenvectors of G, S = sqrt(lambda) and U*S = A V (k_split).
+// With A the (chi*C*d) x (d*chi) matrix the reference decomposes, G = A^T A = V S^2 V^T: the
+// right singular vectors are the eigenvectors of G, S = sqrt(lambda), and U*S = A V (k_split).
+// Only the chi_max largest eigenpairs and the trace are needed: the truncation rule discards the
+// rest, and the discarded weight is trace - sum(kept).
 //
-// Algorithm (MPST_SVD_JACOBI and, for now, the default): one-sided (Hestenes) Jacobi on the
-// columns of G held in LDS (128 KB for n = 128): rotating column pairs until all columns are
-// mutually orthogonal gives G J = V Lambda, i.e. column k converges to lambda_k v_k; the
-// eigenvector is the normalised column and lambda_k its norm.  Orthogonality of the output is
-// at the level of the (relative) rotation threshold, ~1e-15.  64 disjoint pairs are rotated
-// concurrently (round-robin tournament ordering), 16 lanes per pair.
+// One workgroup (the problem is a latency chain, not a throughput problem), two algorithms:
+//
+//  * default: Householder tridiagonalisation with the matrix held in registers (16 doubles per
+//    thread, thread (r, q) owns G[r][q + 8k]), 2 barriers per reflector; multisection Sturm
+//    bisection for the K largest eigenvalues (16 lanes per eigenvalue, 17-fold interval shrink
+//    per step, division-free recurrence); eigenvectors of the tridiagonal by twisted factorisation
+//    (one lane per eigenvalue); back-transformation through the stored reflectors (16 lanes per
+//    vector).  The result is verified on the device (residual in T, orthonormality of the output)
+//    and, if the check fails (clustered eigenvalues), the kernel falls through to
+//  * MPST_SVD_JACOBI: one-sided (Hestenes) Jacobi on the columns of G in LDS - slow (ms) but
+//    unconditionally robust; column k converges to lambda_k v_k.
 #include "mpst_internal.h"
 
 namespace mpst {
 
 constexpr int EIG_THREADS = 1024;
 constexpr int EIG_MAX_SWEEPS = 40;
+constexpr int TRI_KMAX = 32;      // eigenpairs the tridiagonal path can deliver
+constexpr int TRI_NSTEP = 14;     // 17^-14 = 6e-18 of the Gershgorin interval
+constexpr int EIG_LDS_DOUBLES = 17664;  // 138 KB: max over both algorithms
 
+__device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
+
+// =====================================================================================
+// Jacobi path
+// =====================================================================================
 struct EigShared {
     double* Gs;     // [np][np] column-major
     double* nrm;    // [np]
@@ -71,12 +86,9 @@ __device__ int jacobi_core(EigShared sh, int np) {
                     aqq += vq[m] * vq[m];
                     apq += vp[m] * vq[m];
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    app += __shfl_xor(app, o, 64);
-                    aqq += __shfl_xor(aqq, o, 64);
-                    apq += __shfl_xor(apq, o, 64);
-                }
+                app = sum16(app);
+                aqq = sum16(aqq);
+                apq = sum16(apq);
                 if (fabs(apq) > tol * sqrt(app * aqq) && app * aqq > 0.0) {
                     const double zeta = (aqq - app) / (2.0 * apq);
                     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -107,8 +119,7 @@ __device__ int jacobi_core(EigShared sh, int np) {
         const double* cp = sh.Gs + (size_t)col * np;
         double s = 0.0;
         for (int row = sub; row < np; row += 16) s += cp[row] * cp[row];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        s = sum16(s);
         if (sub == 0) sh.nrm[col] = sqrt(s);
     }
     __syncthreads();
@@ -134,96 +145,14 @@ __device__ __forceinline__ EigShared carve(double* smem, int np) {
     return sh;
 }
 
-// Engine kernel: eigen-decompose v.gram, apply the NDTensors truncation rule, publish
-// n_keep / chi / inv_norm / spectrum and the kept eigenvectors E[dim][ldE].
-__global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_left) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double red[16];
-    const int tid = threadIdx.x;
-    const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
-    const int X = Dl * v.d, Y = v.d * Dr;
-    const int n = going_left ? Y : X;
-    const int rows = v.C * (going_left ? X : Y);
-    const int np = (n + 1) & ~1;
-    EigShared sh = carve(smem, np);
-    for (int i = tid; i < np * np; i += EIG_THREADS) {
-        const int col = i / np, row = i - col * np;
-        sh.Gs[i] = (row < n && col < n) ? v.gram[(size_t)row * n + col] : 0.0;
-    }
-    __syncthreads();
-    // trace = ||bt_new||_F^2 (fixed order)
-    double tr = 0.0;
-    for (int i = tid; i < n; i += EIG_THREADS) tr += sh.Gs[(size_t)i * np + i];
-    {
-        // block_sum inline (deterministic)
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) tr += __shfl_xor(tr, o, 64);
-        if ((tid & 63) == 0) red[tid >> 6] = tr;
-        __syncthreads();
-        tr = 0.0;
-        for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
-        __syncthreads();
-    }
-    const int sweeps = jacobi_core(sh, np);
-
-    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
-    const int ldE = v.cap;
-    // eigenvalues in descending order
-    __shared__ double lam_s[MAX_DIM + 2];
-    if (tid < np) lam_s[sh.rank[tid]] = sh.nrm[tid];
-    __syncthreads();
-    if (tid < np) v.lam[tid] = lam_s[tid];
-    // truncation (NDTensors truncate!, relative cutoff) by one thread
-    if (tid == 0) {
-        int nspec = rows < n ? rows : n;
-        const double inv2 = inv * inv;
-        int nk = nspec;
-        double truncerr = 0.0, scale = 0.0;
-        bool bad = false;
-        for (int i = 0; i < nspec; ++i) {
-            const double P = lam_s[i] * inv2;
-            scale += P;
-            if (!(P == P) || P > 1e300) bad = true;
-        }
-        if (scale == 0.0) scale = 1.0;
-        if (nspec > 1) {
-            while (nk > v.chi_max) {
-                truncerr += lam_s[nk - 1] * inv2;
-                --nk;
-            }
-            while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= v.cutoff * scale) {
-                truncerr += lam_s[nk - 1] * inv2;
-                --nk;
-            }
-        }
-        if (nk > v.chi_max) nk = v.chi_max;
-        v.sc->n_keep = nk;
-        v.sc->n_spec = nspec;
-        v.sc->bt_norm2 = tr;
-        v.sc->inv_norm = inv;
-        v.sc->eig_sweeps = sweeps;
-        v.sc->eig_sweeps_total += sweeps;
-        if (bad || sweeps >= EIG_MAX_SWEEPS) v.sc->status = MPST_ERR_SVD;
-        v.chi[lid + 1] = nk;
-    }
-    // kept eigenvectors: E[row][rank] = col/||col||
-    for (int i = tid; i < np * np; i += EIG_THREADS) {
-        const int col = i / np, row = i - col * np;
-        const int rk = sh.rank[col];
-        if (rk < ldE && row < n) {
-            const double nr = sh.nrm[col];
-            v.E[(size_t)row * ldE + rk] = nr > 0.0 ? sh.Gs[i] / nr : 0.0;
-        }
-    }
-}
-
-// Raw variant for tests: full spectrum + all eigenvectors E[i][k] (n x n row-major).
-__global__ __launch_bounds__(EIG_THREADS) void k_eig_raw(const double* G, int n, double* lam, double* E,
-                                                         int32_t* sweeps_out) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+// Full Jacobi solve of G (global, n x n): lam_out[0..n) descending, eigenvectors
+// E[row*ldE + rank] for rank < kcols.  Returns sweeps.
+__device__ int jacobi_solve(const double* __restrict__ G, int n, double* smem, double* lam_out, double* E, int ldE,
+                            int kcols) {
     const int tid = threadIdx.x;
     const int np = (n + 1) & ~1;
     EigShared sh = carve(smem, np);
+    __syncthreads();
     for (int i = tid; i < np * np; i += EIG_THREADS) {
         const int col = i / np, row = i - col * np;
         sh.Gs[i] = (row < n && col < n) ? G[(size_t)row * n + col] : 0.0;
@@ -232,43 +161,511 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_raw(const double* G, int n,
     const int sweeps = jacobi_core(sh, np);
     if (tid < np) {
         const int rk = sh.rank[tid];
-        if (rk < n) lam[rk] = sh.nrm[tid];
+        if (rk < n) lam_out[rk] = sh.nrm[tid];
     }
     for (int i = tid; i < np * np; i += EIG_THREADS) {
         const int col = i / np, row = i - col * np;
         const int rk = sh.rank[col];
-        if (rk < n && row < n) {
+        if (rk < kcols && row < n) {
             const double nr = sh.nrm[col];
-            E[(size_t)row * n + rk] = nr > 0.0 ? sh.Gs[i] / nr : 0.0;
+            E[(size_t)row * ldE + rk] = nr > 0.0 ? sh.Gs[i] / nr : 0.0;
         }
     }
-    if (tid == 0) *sweeps_out = sweeps;
+    __syncthreads();
+    return sweeps;
 }
 
-static size_t eig_lds_bytes(int np) { return ((size_t)np * np + np) * sizeof(double) + (np + 4) * sizeof(int); }
+// =====================================================================================
+// Tridiagonal path
+// =====================================================================================
+struct TriShared {
+    double* Vs;    // packed Householder vectors: v_i[c], c > i, at voff(i) + c - i - 1   (<= 8128)
+    double* xs;    // [2][128]
+    double* ps;    // [2][128]
+    double* de;    // [128][2]: (d_j, e_{j-1}^2)
+    double* es;    // [128]
+    double* taus;  // [128]
+    double* lam;   // [32]
+    double* Z;     // [128][32]  eigenvectors of T, later of G
+    double* Ub;    // [128][32]
+    double* misc;  // [64] scalars + [128] raw row
+};
+__device__ __forceinline__ TriShared tri_carve(double* smem) {
+    TriShared t;
+    t.Vs = smem;
+    t.xs = t.Vs + 8128;
+    t.ps = t.xs + 256;
+    t.de = t.ps + 256;
+    t.es = t.de + 256;
+    t.taus = t.es + 128;
+    t.lam = t.taus + 128;
+    t.Z = t.lam + 32;
+    t.Ub = t.Z + 128 * TRI_KMAX;
+    t.misc = t.Ub + 128 * TRI_KMAX;   // total 17440 + 192 <= EIG_LDS_DOUBLES
+    return t;
+}
+__device__ __forceinline__ int voff(int i, int n) { return i * (n - 1) - (i * (i - 1)) / 2; }
+
+// reciprocal to full double precision from the hardware seed (2 Newton steps)
+__device__ __forceinline__ double frcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+
+// # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free with
+// power-of-two rescaling every 8 steps.
+__device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n, double x) {
+    double pp = 1.0, p = de[0] - x;
+    int cnt = ((unsigned)hi32(p)) >> 31;
+    for (int j = 1; j < n; ++j) {
+        const double t = de[2 * j] - x;
+        const double pn = fma(t, p, -de[2 * j + 1] * pp);
+        cnt += ((unsigned)(hi32(pn) ^ hi32(p))) >> 31;
+        pp = p;
+        p = pn;
+        if ((j & 7) == 0) {
+            int e = (hi32(p) >> 20) & 0x7ff;
+            if (e == 0) e = (hi32(pp) >> 20) & 0x7ff;
+            e = e < 2 ? 2 : (e > 2044 ? 2044 : e);
+            const double sc = __hiloint2double((2046 - e) << 20, 0);
+            p *= sc;
+            pp *= sc;
+        }
+    }
+    return cnt;
+}
+
+// Top-K eigenpairs of the symmetric G (global, n x n, 2 <= n <= 128, K <= 32).
+// Outputs: t.lam[0..K) descending (LDS); eigenvectors in t.Z[c*32 + k].  Returns true if the
+// on-device verification passed.
+__device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared t, unsigned long long* stamps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define TRI_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    TRI_STAMP(0);
+    const int r = tid >> 3, q = tid & 7;
+    // ---- load: thread (r, q) owns G[r][q + 8k] ---------------------------------------------
+    double A[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = q + 8 * k;
+        A[k] = (r < n && c < n) ? G[(size_t)r * n + c] : 0.0;
+    }
+    if (tid < 256) {
+        t.xs[tid] = 0.0;
+        t.ps[tid] = 0.0;
+    }
+    __syncthreads();
+    // ---- Householder tridiagonalisation (dsytd2, full storage) -----------------------------
+    // Step i: the 8 lanes that own row i build the reflector (norm, beta, tau) and publish v in LDS;
+    // every live wave then forms its rows of p = tau*A*v (barrier), the scalar v^T p, and applies
+    // the rank-2 update A -= v w^T + w v^T to its register block.  2 barriers per step.
+    for (int i = 0; i < n - 1; ++i) {
+        double* vb = t.xs + (i & 1) * 128;
+        double* p = t.ps + (i & 1) * 128;
+        if (wave == (i >> 3)) {
+            // the wave that owns row i: publish the raw row, then all 64 lanes build the reflector
+            double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
+            if (r == i) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) xr[q + 8 * k] = A[k];
+            }
+            const int c0 = lane, c1 = lane + 64;
+            const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
+            const double s = wave_sum((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
+            const double al = xr[i + 1], di = xr[i];
+            double beta = al, tau = 0.0, scale = 0.0;
+            if (s != 0.0) {
+                beta = -copysign(sqrt(al * al + s), al);
+                tau = (beta - al) * frcp(beta);
+                scale = frcp(al - beta);
+            }
+            const double v0 = (c0 == i + 1) ? 1.0 : (c0 > i + 1 ? x0 * scale : 0.0);
+            const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
+            vb[c0] = v0;
+            vb[c1] = v1;
+            const int off = voff(i, n) - i - 1;
+            if (c0 > i && c0 < n) t.Vs[off + c0] = v0;
+            if (c1 > i && c1 < n) t.Vs[off + c1] = v1;
+            if (lane == 0) {
+                t.de[2 * i] = di;
+                t.es[i] = beta;
+                t.taus[i] = tau;
+            }
+        }
+        __syncthreads();
+        const bool live = (wave * 8 + 7) > i;      // this wave still owns trailing rows
+        const double tau = t.taus[i];
+        if (live) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += A[k] * vb[q + 8 * k];
+            acc = sum8(acc);
+            if (q == 0) p[r] = (r > i) ? tau * acc : 0.0;
+        } else if (wave * 8 + 7 == i) {
+            // this wave's rows have just retired: clear their p entries in both buffers for good
+            if (q == 0) {
+                t.ps[r] = 0.0;
+                t.ps[128 + r] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const int c0 = lane, c1 = lane + 64;
+            const double dot = wave_sum(p[c0] * vb[c0] + p[c1] * vb[c1]);
+            const double a2 = -0.5 * tau * dot;
+            const double vr = vb[r];
+            const double wr = p[r] + a2 * vr;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int c = q + 8 * k;
+                const double vcv = vb[c];
+                const double wc = p[c] + a2 * vcv;
+                A[k] -= vr * wc + wr * vcv;
+            }
+        }
+    }
+    {   // last diagonal element
+        double* x = t.xs + ((n - 1) & 1) * 128;
+        __syncthreads();
+        if (r == n - 1) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[q + 8 * k] = A[k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            t.de[2 * (n - 1)] = x[n - 1];
+            t.es[n - 1] = 0.0;
+        }
+        __syncthreads();
+    }
+    TRI_STAMP(1);
+    // ---- e^2 and Gershgorin bounds ----------------------------------------------------------
+    if (tid < n) t.de[2 * tid + 1] = tid > 0 ? t.es[tid - 1] * t.es[tid - 1] : 0.0;
+    if (wave == 0) {
+        double gl = 1e300, gu = -1e300;
+        for (int j = lane; j < n; j += 64) {
+            const double a = j > 0 ? fabs(t.es[j - 1]) : 0.0, b = j < n - 1 ? fabs(t.es[j]) : 0.0;
+            const double dj = t.de[2 * j];
+            gl = fmin(gl, dj - a - b);
+            gu = fmax(gu, dj + a + b);
+        }
+        gl = -wave_max(-gl);
+        gu = wave_max(gu);
+        if (lane == 0) {
+            const double w = fmax(fabs(gl), fabs(gu));
+            const double pad = 2.0 * n * 2.3e-16 * w + 1e-300;
+            t.misc[0] = gl - pad;
+            t.misc[1] = gu + pad;
+            t.misc[2] = w;
+        }
+    }
+    __syncthreads();
+    // ---- multisection bisection for the K largest eigenvalues --------------------------------
+    {
+        const int grp = tid >> 4, sec = tid & 15;
+        if (grp < K) {
+            double lo = t.misc[0], hi = t.misc[1];
+            const int target = n - 1 - grp;   // ascending index of the grp-th largest
+            for (int it = 0; it < TRI_NSTEP; ++it) {
+                const double h = (hi - lo) * (1.0 / 17.0);
+                const double xq = lo + h * (sec + 1);
+                const int cnt = sturm_count(t.de, n, xq);
+                const unsigned long long b = __ballot(cnt <= target);
+                const int jj = __popc((unsigned)((b >> (lane & 48)) & 0xFFFFull));
+                const double nlo = jj > 0 ? lo + h * jj : lo;
+                const double nhi = jj < 16 ? lo + h * (jj + 1) : hi;
+                lo = nlo;
+                hi = nhi;
+            }
+            if (sec == 0) t.lam[grp] = 0.5 * (lo + hi);
+        }
+    }
+    __syncthreads();
+    TRI_STAMP(2);
+    // ---- eigenvectors of T: twisted factorisation, one lane per eigenvalue ------------------------
+    if (tid < K) {
+        const int k = tid;
+        const double lamk = t.lam[k];
+        const double pivmin = 1e-290 + 1e-30 * t.misc[2];
+        double* z = t.Z + k;     // stride 32
+        double* ub = t.Ub + k;
+        double dm = t.de[2 * (n - 1)] - lamk;
+        if (fabs(dm) < pivmin) dm = -pivmin;
+        z[(n - 1) * 32] = dm;                              // D^-_{n-1}
+        for (int i = n - 2; i >= 0; --i) {
+            const double e = t.es[i];
+            const double u = e * frcp(dm);                 // U_i = e_i / D^-_{i+1}
+            ub[i * 32] = u;
+            dm = (t.de[2 * i] - lamk) - u * e;
+            if (fabs(dm) < pivmin) dm = -pivmin;
+            z[i * 32] = dm;
+        }
+        double dp = t.de[0] - lamk;
+        if (fabs(dp) < pivmin) dp = -pivmin;
+        double gmin = fabs(z[0]);                          // gamma_0 = D^-_0
+        int rb = 0;
+        for (int i = 0; i < n - 1; ++i) {
+            const double e = t.es[i];
+            const double l = e * frcp(dp);                 // L_i = e_i / D_i
+            const double sh = t.de[2 * (i + 1)] - lamk;
+            double dn = sh - l * e;
+            if (fabs(dn) < pivmin) dn = -pivmin;
+            const double gam = dn + z[(i + 1) * 32] - sh;  // gamma_{i+1}
+            z[i * 32] = l;
+            if (fabs(gam) < gmin) {
+                gmin = fabs(gam);
+                rb = i + 1;
+            }
+            dp = dn;
+        }
+        z[rb * 32] = 1.0;
+        double nrm = 1.0;
+        for (int i = rb - 1; i >= 0; --i) {
+            const double zi = -z[i * 32] * z[(i + 1) * 32];
+            z[i * 32] = zi;
+            nrm += zi * zi;
+        }
+        for (int i = rb; i < n - 1; ++i) {
+            const double zi = -ub[i * 32] * z[i * 32];
+            z[(i + 1) * 32] = zi;
+            nrm += zi * zi;
+        }
+        const double sc = 1.0 / sqrt(nrm);
+        // normalise + residual ||T z - lam z||_inf (verification)
+        double res = 0.0, zprev = 0.0, zc = z[0] * sc;
+        for (int i = 0; i < n; ++i) {
+            const double zn = (i < n - 1) ? z[(i + 1) * 32] * sc : 0.0;
+            const double ri = (t.de[2 * i] - lamk) * zc + (i > 0 ? t.es[i - 1] * zprev : 0.0) +
+                              (i < n - 1 ? t.es[i] * zn : 0.0);
+            res = fmax(res, fabs(ri));
+            z[i * 32] = zc;
+            zprev = zc;
+            zc = zn;
+        }
+        t.misc[32 + k] = res;
+    }
+    __syncthreads();
+    TRI_STAMP(3);
+    // ---- back-transformation z <- H(0) H(1) ... H(n-2) z, 16 lanes per vector --------------------
+    {
+        const int k = tid >> 4, j = tid & 15;
+        if (k < K) {
+            double zz[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int c = j + 16 * m;
+                zz[m] = c < n ? t.Z[c * 32 + k] : 0.0;
+            }
+            for (int i = n - 2; i >= 0; --i) {
+                const double tau = t.taus[i];
+                const double* vi = t.Vs + voff(i, n) - i - 1;    // vi[c] valid for i < c < n
+                double vv[8];
+                double dot = 0.0;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int c = j + 16 * m;
+                    vv[m] = (c > i && c < n) ? vi[c] : 0.0;
+                    dot += vv[m] * zz[m];
+                }
+                dot = sum16(dot);
+                const double f = tau * dot;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) zz[m] -= f * vv[m];
+            }
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int c = j + 16 * m;
+                if (c < n) t.Z[c * 32 + k] = zz[m];
+            }
+        }
+    }
+    __syncthreads();
+    TRI_STAMP(4);
+    // ---- verification: residuals in T and deviation from orthonormality D = Z^T Z - I ---------
+    double* D = t.Ub;      // [32][32], Ub is free now
+    double err = 0.0;
+    {
+        const int a = tid >> 5, b = tid & 31;
+        double dv = 0.0;
+        if (a < K && b < K) {
+            double dot = 0.0;
+            for (int c = 0; c < n; ++c) dot += t.Z[c * 32 + a] * t.Z[c * 32 + b];
+            dv = dot - (a == b ? 1.0 : 0.0);
+            err = fabs(dv);
+        }
+        D[a * 32 + b] = dv;
+        // T-residual tolerated up to 1e-8 ||T|| (mapped onto the 1e-9 threshold below)
+        if (tid < K) err = fmax(err, t.misc[32 + tid] / (t.misc[2] > 0.0 ? t.misc[2] : 1.0) * 0.1);
+    }
+    err = wave_max(err);
+    __syncthreads();
+    if (lane == 0) t.misc[8 + wave] = err;
+    __syncthreads();
+    double emax = 0.0;
+    for (int w = 0; w < EIG_THREADS / 64; ++w) emax = fmax(emax, t.misc[8 + w]);
+    const bool ok = emax < 1e-9 && emax == emax;
+    // ---- first-order symmetric (Loewdin) re-orthonormalisation: Z <- Z (I - D/2); the residual
+    //      non-orthogonality drops from |D| to |D|^2 (< 1e-18) without leaving the subspace --------
+    if (ok) {
+        double zn[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = tid + m * EIG_THREADS;        // over [128][32]
+            const int c = idx >> 5, a = idx & 31;
+            double acc = 0.0;
+            if (c < n && a < K) {
+                for (int b = 0; b < K; ++b) acc += t.Z[c * 32 + b] * D[b * 32 + a];
+                acc = t.Z[c * 32 + a] - 0.5 * acc;
+            }
+            zn[m] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = tid + m * EIG_THREADS;
+            const int c = idx >> 5, a = idx & 31;
+            if (c < n && a < K) t.Z[idx] = zn[m];
+        }
+        __syncthreads();
+    }
+    TRI_STAMP(5);
+#undef TRI_STAMP
+    return ok;
+}
+
+// =====================================================================================
+// Engine kernel: eigen-decompose v.gram, apply the NDTensors truncation rule, publish
+// n_keep / chi / inv_norm / spectrum and the kept eigenvectors E[dim][ldE].
+// =====================================================================================
+__global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_left) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double lam_s[MAX_DIM + 2];
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
+    const int X = Dl * v.d, Y = v.d * Dr;
+    const int n = going_left ? Y : X;
+    const int rows = v.C * (going_left ? X : Y);
+    const int nspec = rows < n ? rows : n;                    // LAPACK's min(m, n)
+    const int K0 = nspec < v.chi_max ? nspec : v.chi_max;     // eigenpairs that can survive maxdim
+    const int ldE = v.cap;
+    // trace = ||bt_new||_F^2 (fixed order)
+    double tr = 0.0;
+    for (int i = tid; i < n; i += EIG_THREADS) tr += v.gram[(size_t)i * n + i];
+    tr = wave_sum(tr);
+    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    __syncthreads();
+    tr = 0.0;
+    for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
+    __syncthreads();
+
+    int sweeps = 0;
+    bool done = false;
+    if (v.svd_alg != MPST_SVD_JACOBI && K0 <= TRI_KMAX && n >= 2) {
+        TriShared t = tri_carve(smem);
+        done = tri_solve(v.gram, n, K0, t, v.sc->eig_stamps);
+        if (done) {
+            if (tid < K0) lam_s[tid] = t.lam[tid];
+            for (int i = tid; i < n * K0; i += EIG_THREADS) {
+                const int c = i / K0, k = i - c * K0;
+                v.E[(size_t)c * ldE + k] = t.Z[c * 32 + k];
+            }
+        }
+        __syncthreads();
+    }
+    const bool fell_back = !done && v.svd_alg != MPST_SVD_JACOBI && K0 <= TRI_KMAX && n >= 2;
+    if (!done) {
+        sweeps = jacobi_solve(v.gram, n, smem, lam_s, v.E, ldE, K0);
+        if (sweeps == 0) sweeps = 1;
+    }
+    __syncthreads();
+    if (tid < K0) v.lam[tid] = lam_s[tid];
+    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+    // truncation (NDTensors truncate!, relative cutoff).  The weight beyond the first
+    // K0 values is trace - sum(first K0).
+    if (tid == 0) {
+        const double inv2 = inv * inv;
+        const double scale0 = tr * inv2;
+        const double scale = scale0 == 0.0 ? 1.0 : scale0;
+        double kept = 0.0;
+        bool bad = !(tr == tr) || tr > 1e300;
+        for (int i = 0; i < K0; ++i) {
+            const double P = lam_s[i] * inv2;
+            kept += P;
+            if (!(P == P) || P > 1e300) bad = true;
+        }
+        int nk = K0;
+        double truncerr = scale0 - kept;
+        if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
+        if (nspec > 1) {
+            while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= v.cutoff * scale) {
+                truncerr += lam_s[nk - 1] * inv2;
+                --nk;
+            }
+        }
+        v.sc->n_keep = nk;
+        v.sc->n_spec = K0;
+        v.sc->bt_norm2 = tr;
+        v.sc->inv_norm = inv;
+        v.sc->eig_sweeps = sweeps;
+        v.sc->eig_sweeps_total += sweeps;
+        if (fell_back) v.sc->eig_fallbacks += 1;
+        if (bad || sweeps >= EIG_MAX_SWEEPS) v.sc->status = MPST_ERR_SVD;
+        v.chi[lid + 1] = nk;
+    }
+}
+
+// Raw variant for tests.  alg 1: Jacobi, full spectrum, *info = sweeps.  alg 0/2: tridiagonal
+// path, top K = min(n, 32) eigenpairs (the remaining outputs are zero), *info = -1; if the
+// device-side verification failed Jacobi is used instead and *info = 0.
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_raw(const double* G, int n, int alg, double* lam, double* E,
+                                                         int32_t* info) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double lam_s[MAX_DIM + 2];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += EIG_THREADS) E[i] = 0.0;
+    if (tid < n) lam[tid] = 0.0;
+    __syncthreads();
+    if (alg != MPST_SVD_JACOBI && n >= 2) {
+        const int K = n < TRI_KMAX ? n : TRI_KMAX;
+        TriShared t = tri_carve(smem);
+        const bool ok = tri_solve(G, n, K, t, nullptr);
+        if (ok) {
+            if (tid < K) lam[tid] = t.lam[tid];
+            for (int i = tid; i < n * K; i += EIG_THREADS) {
+                const int c = i / K, k = i - c * K;
+                E[(size_t)c * n + k] = t.Z[c * 32 + k];
+            }
+            if (tid == 0) *info = -1;
+            return;
+        }
+        __syncthreads();
+    }
+    const int sweeps = jacobi_solve(G, n, smem, lam_s, E, n, n);
+    if (tid < n) lam[tid] = lam_s[tid];
+    if (tid == 0) *info = (alg != MPST_SVD_JACOBI && n >= 2) ? 0 : sweeps;
+}
+
+static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double); }
 
 static bool g_attr_set = false;
 static void ensure_attrs() {
     if (g_attr_set) return;
-    const int maxb = (int)eig_lds_bytes(MAX_DIM);
-    (void)hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
-    (void)hipFuncSetAttribute((const void*)k_eig_raw, hipFuncAttributeMaxDynamicSharedMemorySize, maxb);
+    (void)hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_eig_raw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
     g_attr_set = true;
 }
 
 void launch_eig(const View& v, int lid, int going_left, hipStream_t s) {
     ensure_attrs();
-    int dm = v.d * v.cap;
-    if (dm > MAX_DIM) dm = MAX_DIM;
-    const int np = (dm + 1) & ~1;
-    hipLaunchKernelGGL(k_eig, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(np), s, v, lid, going_left);
+    hipLaunchKernelGGL(k_eig, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left);
 }
 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* sweeps, hipStream_t s) {
-    (void)alg;
     ensure_attrs();
-    const int np = (n + 1) & ~1;
-    hipLaunchKernelGGL(k_eig_raw, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(np), s, G, n, lam, E, sweeps);
+    hipLaunchKernelGGL(k_eig_raw, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, G, n, alg, lam, E, sweeps);
 }
 
 }  // namespace mpst

@@ -17,6 +17,59 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute ------------------------
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, >100 cycles of dependent latency
+// per step); the reductions here sit on the critical path of single-workgroup kernels, so they
+// use DPP row operations (a VALU modifier) and v_readlane for the cross-row step.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // reverse within each 8 lanes
+constexpr int DPP_MIRROR = 0x140;      // reverse within each 16 lanes
+// all-reduce (sum) over aligned groups of 4 / 8 / 16 lanes
+__device__ __forceinline__ double sum4(double x) {
+    x += dpp_mov<DPP_XOR1>(x);
+    x += dpp_mov<DPP_XOR2>(x);
+    return x;
+}
+__device__ __forceinline__ double sum8(double x) {
+    x = sum4(x);
+    x += dpp_mov<DPP_HALF_MIRROR>(x);
+    return x;
+}
+__device__ __forceinline__ double sum16(double x) {
+    x = sum8(x);
+    x += dpp_mov<DPP_MIRROR>(x);
+    return x;
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+// all-reduce over the 64 lanes of a wave (fixed order, wave-uniform result)
+__device__ __forceinline__ double wave_sum(double x) {
+    x = sum16(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+__device__ __forceinline__ double max16(double x) {
+    x = fmax(x, dpp_mov<DPP_XOR1>(x));
+    x = fmax(x, dpp_mov<DPP_XOR2>(x));
+    x = fmax(x, dpp_mov<DPP_HALF_MIRROR>(x));
+    x = fmax(x, dpp_mov<DPP_MIRROR>(x));
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+    x = max16(x);
+    return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+
 // A class-pure run of consecutive series (<= 16 for tiles, <= 64 for chunks).
 struct Span {
     int32_t start;
@@ -42,7 +95,9 @@ struct DevScalars {
     int32_t eig_sweeps;
     int32_t status;     // sticky error flag (non-finite spectrum ...)
     int32_t eig_sweeps_total;
-    int32_t pad[3];
+    int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
+    int32_t pad[2];
+    unsigned long long eig_stamps[8];   // s_memrealtime (100 MHz) at the phase boundaries of the last k_eig
 };
 
 // One encoded data set on the device.

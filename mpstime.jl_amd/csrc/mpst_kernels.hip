@@ -34,8 +34,7 @@ __device__ __forceinline__ BondDims bond_dims(const View& v, int lid) {
 // Deterministic block-wide sum (fixed tree), result broadcast to all threads.
 // `red` must hold blockDim.x/64 doubles.
 __device__ __forceinline__ double block_sum(double x, double* red) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+    x = wave_sum(x);
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[w] = x;
@@ -173,11 +172,7 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        double x = p[r];
-        x += __shfl_xor(x, 1, 64);
-        x += __shfl_xor(x, 2, 64);
-        x += __shfl_xor(x, 4, 64);
-        x += __shfl_xor(x, 8, 64);
+        const double x = sum16(p[r]);
         if (i16 == 0) red[wave * 16 + kq + 4 * r] = x;
     }
     __syncthreads();
@@ -195,10 +190,7 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
                 }
             }
         }
-        term += __shfl_xor(term, 1, 64);
-        term += __shfl_xor(term, 2, 64);
-        term += __shfl_xor(term, 4, 64);
-        term += __shfl_xor(term, 8, 64);
+        term = sum16(term);
         if (tid == 0) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + blockIdx.x] = term;
     }
 }

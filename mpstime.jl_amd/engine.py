@@ -117,7 +117,8 @@ class SweepEngine:
     def sweep(self):
         st = L.mpst_sweep_stats()
         self._chk(self.lib.mpst_sweep(self.ctx, C.byref(st)))
-        return {"seconds": st.seconds, "max_chi": st.max_chi, "eig_sweeps_total": st.eig_sweeps_total}
+        return {"seconds": st.seconds, "max_chi": st.max_chi, "eig_sweeps_total": st.eig_sweeps_total,
+                "eig_fallbacks": st.eig_fallbacks}
 
     def bond_step(self, lid, going_left):
         dbg = L.mpst_bond_debug()
@@ -153,6 +154,11 @@ class SweepEngine:
         self._chk(self.lib.mpst_get_profile(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double)),
                                             cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
+
+    def eig_phases(self):
+        us = np.zeros(5)
+        self._chk(self.lib.mpst_get_eig_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
+        return dict(zip(("tridiag", "bisect", "eigvec", "backtransform", "verify"), us.tolist()))
 
     def selftest_mfma(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)
