@@ -245,12 +245,16 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
 #define TRI_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TRI_STAMP(0);
     const int r = tid >> 3, q = tid & 7;
-    // ---- load: thread (r, q) owns G[r][q + 8k] ---------------------------------------------
+    // ---- load: thread (r, q) owns the column pairs c = 2q + 16k + {0,1}, k = 0..7 of row r -----
+    // (A[2k+h]); its LDS operands are then 16-byte reads that are conflict-free across q.
     double A[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = q + 8 * k;
-        A[k] = (r < n && c < n) ? G[(size_t)r * n + c] : 0.0;
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * q + 16 * k + h;
+            A[2 * k + h] = (r < n && c < n) ? G[(size_t)r * n + c] : 0.0;
+        }
     }
     if (tid < 256) {
         t.xs[tid] = 0.0;
@@ -269,7 +273,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
             double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
             if (r == i) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) xr[q + 8 * k] = A[k];
+                for (int k = 0; k < 8; ++k) *(double2*)&xr[2 * q + 16 * k] = make_double2(A[2 * k], A[2 * k + 1]);
             }
             const int c0 = lane, c1 = lane + 64;
             const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
@@ -300,7 +304,11 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         if (live) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc += A[k] * vb[q + 8 * k];
+            for (int k = 0; k < 8; ++k) {
+                const double2 vv = *(const double2*)&vb[2 * q + 16 * k];
+                acc += A[2 * k] * vv.x;
+                acc += A[2 * k + 1] * vv.y;
+            }
             acc = sum8(acc);
             if (q == 0) p[r] = (r > i) ? tau * acc : 0.0;
         } else if (wave * 8 + 7 == i) {
@@ -318,11 +326,12 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
             const double vr = vb[r];
             const double wr = p[r] + a2 * vr;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int c = q + 8 * k;
-                const double vcv = vb[c];
-                const double wc = p[c] + a2 * vcv;
-                A[k] -= vr * wc + wr * vcv;
+            for (int k = 0; k < 8; ++k) {
+                const double2 vv = *(const double2*)&vb[2 * q + 16 * k];
+                const double2 pv = *(const double2*)&p[2 * q + 16 * k];
+                const double w0 = pv.x + a2 * vv.x, w1 = pv.y + a2 * vv.y;
+                A[2 * k] -= vr * w0 + wr * vv.x;
+                A[2 * k + 1] -= vr * w1 + wr * vv.y;
             }
         }
     }
@@ -331,7 +340,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         __syncthreads();
         if (r == n - 1) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) x[q + 8 * k] = A[k];
+            for (int k = 0; k < 8; ++k) *(double2*)&x[2 * q + 16 * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
         __syncthreads();
         if (tid == 0) {

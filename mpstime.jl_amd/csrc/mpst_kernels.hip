@@ -49,22 +49,61 @@ __device__ __forceinline__ double block_sum(double x, double* red) {
 // so operand delivery is not the limiter).
 __device__ __forceinline__ d4 wave_gemm_tile(const double* __restrict__ A, int64_t sam, int64_t sak, int M,
                                              const double* __restrict__ B, int64_t sbk, int64_t sbn, int N,
-                                             int K, int m0, int n0, d4 acc) {
+                                             int K, int m0, int n0, d4 acc, int kbeg = 0, int kend = -1) {
     const int lane = threadIdx.x & 63;
     const int i = lane & 15, kq = lane >> 4;
     const int m = m0 + i, n = n0 + i;
     const bool mv = m < M, nv = n < N;
     const double* ap = A + (int64_t)m * sam;
     const double* bp = B + (int64_t)n * sbn;
-#pragma unroll 4
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kq;
-        const bool kv = k < K;
-        const double a = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
-        const double b = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
-        acc = mfma_f64(a, b, acc);
+    if (kend < 0) kend = K;
+    // 8 k-steps (32 columns of K) per batch: 16 independent loads are in flight before the MFMAs
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < kend;
+            a[u] = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
+            b[u] = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 4 * u < kend) acc = mfma_f64(a[u], b[u], acc);
     }
     return acc;
+}
+
+// Khatri-Rao tile of 16 series in LDS: Zs[i][z], z = a*d + s (left: prev_i[a]*phi_i[s]) or
+// z = s*Dp + a (right: phi_i[s]*prev_i[a]); columns [Z, ZS) are zeroed.  256 threads: 16 per series.
+// All global loads are issued before the first use (no per-element integer division).
+__device__ __forceinline__ void stage_tile16(double* __restrict__ Zs, int ZS, const Span tl,
+                                             const double* __restrict__ prev, int Dp, const double* __restrict__ ph,
+                                             int d, int cap, bool left) {
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    const bool valid = i < tl.count;
+    const int64_t smp = tl.start + (valid ? i : 0);
+    double pa[8], pp[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = j + 16 * m;
+        pa[m] = (valid && a < Dp) ? (prev ? prev[smp * cap + a] : 1.0) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) pp[s] = (valid && s < d) ? ph[smp * d + s] : 0.0;
+    double* row = Zs + i * ZS;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = j + 16 * m;
+        if (a < Dp) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < d) row[left ? a * d + s : s * Dp + a] = pa[m] * pp[s];
+            for (int s = 8; s < d; ++s)
+                row[left ? a * d + s : s * Dp + a] = valid ? pa[m] * ph[smp * d + s] : 0.0;
+        }
+    }
+    for (int z = Dp * d + j; z < ZS; z += 16) row[z] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -128,28 +167,8 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     const double* phl = v.phi + (int64_t)lid * v.N * d;
     const double* phr = v.phi + (int64_t)rid * v.N * d;
 
-    for (int idx = tid; idx < 16 * XS; idx += 256) {
-        const int i = idx / XS, x = idx - i * XS;
-        double val = 0.0;
-        if (i < tl.count && x < b.X) {
-            const int a = x / d, s = x - a * d;
-            const int64_t smp = tl.start + i;
-            const double le = LEp ? LEp[smp * v.cap + a] : 1.0;
-            val = le * phl[smp * d + s];
-        }
-        Xs[idx] = val;
-    }
-    for (int idx = tid; idx < 16 * YS; idx += 256) {
-        const int i = idx / YS, y = idx - i * YS;
-        double val = 0.0;
-        if (i < tl.count && y < b.Y) {
-            const int s = y / b.Dr, bb = y - s * b.Dr;
-            const int64_t smp = tl.start + i;
-            const double re = REn ? REn[smp * v.cap + bb] : 1.0;
-            val = phr[smp * d + s] * re;
-        }
-        Ys[idx] = val;
-    }
+    stage_tile16(Xs, XS, tl, LEp, b.Dl, phl, d, v.cap, true);
+    stage_tile16(Ys, YS, tl, REn, b.Dr, phr, d, v.cap, false);
     __syncthreads();
 
     const double* Bc = v.bt + (int64_t)c * b.L;
@@ -160,12 +179,20 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
         d4 acc = {0, 0, 0, 0};
         const int col = nt * 16 + i16;
         const bool cv = col < b.Y;
-#pragma unroll 4
-        for (int k0 = 0; k0 < XP; k0 += 4) {
-            const int kx = k0 + kq;
-            const double a = Xs[i16 * XS + kx];
-            const double bv = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
-            acc = mfma_f64(a, bv, acc);
+        // the whole B_c column slice this lane needs (<= 32 k-steps for d*chi <= 128) is requested
+        // from L2 up front; the MFMAs then run back to back with the A operand from LDS
+        for (int kb = 0; kb < XP; kb += 128) {
+            double bv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int kx = kb + 4 * u + kq;
+                bv[u] = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int k0 = kb + 4 * u;
+                if (k0 < XP) acc = mfma_f64(Xs[i16 * XS + k0 + kq], bv[u], acc);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] += acc[r] * Ys[(kq + 4 * r) * YS + col];
@@ -222,30 +249,44 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
     const double* phr = v.phi + (int64_t)rid * v.N * d;
     const double* yh = v.yhat + (int64_t)c * v.N;
 
-    for (int idx = tid; idx < CHUNK_S * GB; idx += 256) {
-        const int i = idx / GB, xx = idx - i * GB;
-        const int x = bx * GB + xx;
-        double val = 0.0;
-        if (i < ch.count && x < b.X) {
-            const int a = x / d, s = x - a * d;
-            const int64_t smp = ch.start + i;
-            const double le = LEp ? LEp[smp * v.cap + a] : 1.0;
-            val = le * phl[smp * d + s];
-        }
-        Xs[i * XS + xx] = val;
+    // index tables: one integer division per column of the block instead of one per element
+    __shared__ int xa_[GB], xs_[GB], yb_[GB], ys_[GB];
+    if (tid < GB) {
+        const int x = bx * GB + tid;
+        const int a = x / d;
+        xa_[tid] = x < b.X ? a : -1;
+        xs_[tid] = x - a * d;
+    } else if (tid < 2 * GB) {
+        const int y = by * GB + tid - GB;
+        const int sy = y / b.Dr;
+        yb_[tid - GB] = y < b.Y ? y - sy * b.Dr : -1;
+        ys_[tid - GB] = sy;
     }
-    for (int idx = tid; idx < CHUNK_S * GB; idx += 256) {
-        const int i = idx / GB, yy = idx - i * GB;
-        const int y = by * GB + yy;
-        double val = 0.0;
-        if (i < ch.count && y < b.Y) {
-            const int s = y / b.Dr, bb = y - s * b.Dr;
-            const int64_t smp = ch.start + i;
-            const double re = REn ? REn[smp * v.cap + bb] : 1.0;
-            const double w = mse ? (yh[smp] - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yh[smp];
-            val = w * phr[smp * d + s] * re;
+    __syncthreads();
+    {
+        // thread -> column xx = tid & 63 of the block, series i = (tid >> 6) + 4m; every load of
+        // the 16 series is issued before the first product is formed
+        const int xx = tid & 63, i0 = tid >> 6;
+        const int a = xa_[xx], sx = xs_[xx], bb = yb_[xx], sy = ys_[xx];
+        double le[16], pl[16], re[16], pr[16], w[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = i0 + 4 * m;
+            const bool ok = i < ch.count;
+            const int64_t smp = ch.start + (ok ? i : 0);
+            le[m] = (ok && a >= 0) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
+            pl[m] = (ok && a >= 0) ? phl[smp * d + sx] : 0.0;
+            re[m] = (ok && bb >= 0) ? (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
+            pr[m] = (ok && bb >= 0) ? phr[smp * d + sy] : 0.0;
+            const double yv = ok ? yh[smp] : 1.0;
+            w[m] = mse ? (yv - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yv;
         }
-        Ys[i * XS + yy] = val;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int i = i0 + 4 * m;
+            Xs[i * XS + xx] = le[m] * pl[m];
+            Ys[i * XS + xx] = w[m] * pr[m] * re[m];
+        }
     }
     __syncthreads();
 
@@ -289,17 +330,31 @@ __global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid) {
     if (idx < total) {
         const int c = (int)(idx / b.L);
         const int64_t e = idx - (int64_t)c * b.L;
-        double s = 0.0;
+        // fixed association order: 8 interleaved partial sums, then a fixed tree
+        const double* p;
+        int k0, k1;
+        double scale;
         if (mse) {
-            const double* p = v.partial + (int64_t)c * v.nchunks * b.L + e;
-            for (int k = 0; k < v.nchunks; ++k) s += p[(int64_t)k * b.L];
-            s *= v.invN;                                           // :608
+            p = v.partial + (int64_t)c * v.nchunks * b.L + e;
+            k0 = 0;
+            k1 = v.nchunks;
+            scale = v.invN;                                        // :608
         } else {
-            const int k0 = v.cls_chunk_off[c], k1 = v.cls_chunk_off[c + 1];
-            const double* p = v.partial + e;
-            for (int k = k0; k < k1; ++k) s += p[(int64_t)k * b.L];
-            s *= -(v.train_sep ? v.inv_count[c] : v.invN);         // :367 / :424
+            p = v.partial + e;
+            k0 = v.cls_chunk_off[c];
+            k1 = v.cls_chunk_off[c + 1];
+            scale = -(v.train_sep ? v.inv_count[c] : v.invN);      // :367 / :424
         }
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = k0; k < k1; k += 8) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (k + u < k1) ? p[(int64_t)(k + u) * b.L] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += t[u];
+        }
+        double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        s *= scale;
         v.gradbuf[2 + idx] = s;
     }
     if (blockIdx.x == 0) {
@@ -328,8 +383,18 @@ __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter)
     const BondDims b = bond_dims(v, lid);
     const int n = v.C * b.L;
     const double* g = v.gradbuf + 2;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    // ||grad||^2: every workgroup sums the whole (L2-resident) gradient in the same order
+    double s4[4] = {0, 0, 0, 0};
+    const int n4 = n & ~7;
+    for (int i = threadIdx.x * 2; i < n4; i += 2048) {
+        double2 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = (i + 512 * u < n4) ? *(const double2*)&g[i + 512 * u] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += t[u].x * t[u].x + t[u].y * t[u].y;
+    }
+    double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    for (int i = n4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
     const double nrm2 = block_sum(s, red);
     const double nrm = sqrt(nrm2);
     const double step = (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
@@ -347,28 +412,39 @@ __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter)
 //   going right: rows (b, c, s_r), cols (s_l, a)  -> G = sum_c B_c B_c^T   (X x X)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gram(View v, int lid, int going_left) {
+    __shared__ double part[4][256];
     const BondDims b = bond_dims(v, lid);
     const int n = going_left ? b.Y : b.X;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tn = (n + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x;          // one 16x16 tile per workgroup, K split over its 4 waves
     if (tile >= tn * tn) return;
     const int m0 = (tile / tn) * 16, n0 = (tile % tn) * 16;
     d4 acc = {0, 0, 0, 0};
     if (going_left) {
         // k runs over (c, x) jointly: element (k, p) at k*Y + p
-        acc = wave_gemm_tile(v.bt, 1, b.Y, n, v.bt, b.Y, 1, n, v.C * b.X, m0, n0, acc);
+        const int K = v.C * b.X;
+        const int kq4 = (((K + 3) >> 2) + 3) & ~3;
+        acc = wave_gemm_tile(v.bt, 1, b.Y, n, v.bt, b.Y, 1, n, K, m0, n0, acc, wave * kq4, min(K, (wave + 1) * kq4));
     } else {
+        const int K = b.Y;
+        const int kq4 = (((K + 3) >> 2) + 3) & ~3;
         for (int c = 0; c < v.C; ++c) {
             const double* Bc = v.bt + (int64_t)c * b.L;
-            acc = wave_gemm_tile(Bc, b.Y, 1, n, Bc, 1, b.Y, n, b.Y, m0, n0, acc);
+            acc = wave_gemm_tile(Bc, b.Y, 1, n, Bc, 1, b.Y, n, K, m0, n0, acc, wave * kq4, min(K, (wave + 1) * kq4));
         }
     }
-    const int col = n0 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (lane >> 4) + 4 * r;
-        if (row < n && col < n) v.gram[(int64_t)row * n + col] = acc[r];
+    for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        const int col = n0 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (lane >> 4) + 4 * r;
+            const double sum = (part[0][r * 64 + lane] + part[1][r * 64 + lane]) + (part[2][r * 64 + lane] + part[3][r * 64 + lane]);
+            if (row < n && col < n) v.gram[(int64_t)row * n + col] = sum;
+        }
     }
 }
 
@@ -469,24 +545,7 @@ __global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, co
     const Span tl = v.tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* ph = v.phi + (int64_t)site * v.N * d;
-    for (int idx = tid; idx < 16 * ZS; idx += 256) {
-        const int i = idx / ZS, z = idx - i * ZS;
-        double val = 0.0;
-        if (i < tl.count && z < Z) {
-            const int64_t smp = tl.start + i;
-            int a, s;
-            if (left_side) {
-                a = z / d;
-                s = z - a * d;
-            } else {
-                s = z / Dp;
-                a = z - s * Dp;
-            }
-            const double pv = prev ? prev[smp * v.cap + a] : 1.0;
-            val = pv * ph[smp * d + s];
-        }
-        smem[idx] = val;
-    }
+    stage_tile16(smem, ZS, tl, prev, Dp, ph, d, v.cap, left_side != 0);
     __syncthreads();
     const int i16 = lane & 15, kq = lane >> 4;
     const int nt_out = (Dout + 15) >> 4;
@@ -494,12 +553,18 @@ __global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, co
         const int col = nt * 16 + i16;
         const bool cv = col < Dout;
         d4 acc = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int k0 = 0; k0 < ZP; k0 += 4) {
-            const int z = k0 + kq;
-            const double a = smem[i16 * ZS + z];
-            const double bv = (cv && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
-            acc = mfma_f64(a, bv, acc);
+        for (int kb = 0; kb < ZP; kb += 128) {
+            double bv[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int z = kb + 4 * u + kq;
+                bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int k0 = kb + 4 * u;
+                if (k0 < ZP) acc = mfma_f64(smem[i16 * ZS + k0 + kq], bv[u], acc);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -686,7 +751,7 @@ void launch_update(const View& v, int lid, int first_iter, hipStream_t s) {
 void launch_gram(const View& v, int lid, int going_left, hipStream_t s) {
     const int dm = v.d * v.cap;
     const int tiles = cdiv(dm, 16) * cdiv(dm, 16);
-    hipLaunchKernelGGL(k_gram, dim3(cdiv(tiles, 4)), dim3(256), 0, s, v, lid, going_left);
+    hipLaunchKernelGGL(k_gram, dim3(tiles), dim3(256), 0, s, v, lid, going_left);
 }
 void launch_split(const View& v, int lid, int going_left, hipStream_t s) {
     const int dm = v.d * v.cap;
