@@ -159,8 +159,9 @@ int  mpst_selftest_eig(void* ctx, const double* G /*n*n symmetric*/, int32_t n, 
 int  mpst_set_profile(void* ctx, uint32_t kernel_mask);
 int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
- * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation */
-int  mpst_get_eig_phases(void* ctx, double* us /*[5]*/);
+ * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
+ * cycles (s_memtime) of the tridiagonalisation, for the effective clock */
+int  mpst_get_eig_phases(void* ctx, double* us /*[6]*/);
 
 #ifdef __cplusplus
 }

@@ -673,6 +673,7 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     DevScalars sc;
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
     for (int i = 0; i < 5; ++i) us[i] = 0.01 * (double)(sc.eig_stamps[i + 1] - sc.eig_stamps[i]);   // 100 MHz ticks
+    us[5] = (double)(sc.eig_stamps[7] - sc.eig_stamps[6]);   // shader cycles spent in the tridiagonalisation
     return 0;
 }
 

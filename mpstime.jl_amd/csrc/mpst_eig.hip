@@ -22,7 +22,7 @@
 
 namespace mpst {
 
-constexpr int EIG_THREADS = 1024;
+constexpr int EIG_THREADS = 512;   // 8 waves = 2 per SIMD: the phases are VALU-issue bound, fewer fatter waves win
 constexpr int EIG_MAX_SWEEPS = 40;
 constexpr int TRI_KMAX = 32;      // eigenpairs the tridiagonal path can deliver
 constexpr int TRI_NSTEP = 14;     // 17^-14 = 6e-18 of the Gershgorin interval
@@ -69,9 +69,9 @@ __device__ int jacobi_core(EigShared sh, int np) {
         __syncthreads();
         int rotated = 0;
         for (int r = 0; r < np - 1; ++r) {
-            if (k < npairs) {
+            for (int kk = k; kk < npairs; kk += EIG_THREADS >> 4) {
                 int p, q;
-                pair_of(r, k, np, p, q);
+                pair_of(r, kk, np, p, q);
                 double* cp = sh.Gs + (size_t)p * np;
                 double* cq = sh.Gs + (size_t)q * np;
                 double vp[8], vq[8];
@@ -244,15 +244,16 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define TRI_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TRI_STAMP(0);
-    const int r = tid >> 3, q = tid & 7;
-    // ---- load: thread (r, q) owns the column pairs c = 2q + 16k + {0,1}, k = 0..7 of row r -----
-    // (A[2k+h]); its LDS operands are then 16-byte reads that are conflict-free across q.
-    double A[16];
+    if (stamps && tid == 0) stamps[6] = __builtin_readcyclecounter();
+    const int r = tid >> 2, q = tid & 3;
+    // ---- load: thread (r, q) owns the column pairs c = 2q + 8k + {0,1}, k = 0..15 of row r ----
+    // (A[2k+h], 32 doubles); its LDS operands are 16-byte reads, broadcast across the 16 rows of a wave.
+    double A[32];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = 2 * q + 16 * k + h;
+            const int c = 2 * q + 8 * k + h;
             A[2 * k + h] = (r < n && c < n) ? G[(size_t)r * n + c] : 0.0;
         }
     }
@@ -262,56 +263,68 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
     }
     __syncthreads();
     // ---- Householder tridiagonalisation (dsytd2, full storage) -----------------------------
-    // Step i: the 8 lanes that own row i build the reflector (norm, beta, tau) and publish v in LDS;
-    // every live wave then forms its rows of p = tau*A*v (barrier), the scalar v^T p, and applies
-    // the rank-2 update A -= v w^T + w v^T to its register block.  2 barriers per step.
-    for (int i = 0; i < n - 1; ++i) {
-        double* vb = t.xs + (i & 1) * 128;
-        double* p = t.ps + (i & 1) * 128;
-        if (wave == (i >> 3)) {
-            // the wave that owns row i: publish the raw row, then all 64 lanes build the reflector
-            double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
-            if (r == i) {
+    // Step i: (a) every live wave forms its rows of p = tau*A*v from the published reflector v_i
+    // (barrier), (b) the scalar v^T p and the rank-2 update A -= v w^T + w v^T on its register
+    // block, with w = p + a2 v folded into two FMAs per element:
+    //     A[r][c] -= v_r p_c + (a2 v_r + w_r) v_c.
+    // (c) Look-ahead: the wave that owns row i+1 runs at raised priority, so it finishes its part of
+    // the update first and builds reflector i+1 (row -> LDS, norm, beta, tau, v) while the other
+    // waves are still updating.  2 barriers per step.
+    auto build_reflector = [&](int i) {
+        // executed by all 64 lanes of the wave that owns row i
+        double* vbn = t.xs + (i & 1) * 128;
+        double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
+        if (r == i) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) *(double2*)&xr[2 * q + 16 * k] = make_double2(A[2 * k], A[2 * k + 1]);
-            }
-            const int c0 = lane, c1 = lane + 64;
-            const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
-            const double s = wave_sum((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
-            const double al = xr[i + 1], di = xr[i];
-            double beta = al, tau = 0.0, scale = 0.0;
-            if (s != 0.0) {
-                beta = -copysign(sqrt(al * al + s), al);
-                tau = (beta - al) * frcp(beta);
-                scale = frcp(al - beta);
-            }
-            const double v0 = (c0 == i + 1) ? 1.0 : (c0 > i + 1 ? x0 * scale : 0.0);
-            const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
-            vb[c0] = v0;
-            vb[c1] = v1;
-            const int off = voff(i, n) - i - 1;
-            if (c0 > i && c0 < n) t.Vs[off + c0] = v0;
-            if (c1 > i && c1 < n) t.Vs[off + c1] = v1;
-            if (lane == 0) {
-                t.de[2 * i] = di;
-                t.es[i] = beta;
-                t.taus[i] = tau;
-            }
+            for (int k = 0; k < 16; ++k) *(double2*)&xr[2 * q + 8 * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
-        __syncthreads();
-        const bool live = (wave * 8 + 7) > i;      // this wave still owns trailing rows
+        const int c0 = lane, c1 = lane + 64;
+        const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
+        const double s = wave_sum((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
+        const double al = xr[i + 1], di = xr[i];
+        double beta = al, tau = 0.0, scale = 0.0;
+        if (s != 0.0) {
+            beta = -copysign(sqrt(al * al + s), al);
+            tau = (beta - al) * frcp(beta);
+            scale = frcp(al - beta);
+        }
+        const double v0 = (c0 == i + 1) ? 1.0 : (c0 > i + 1 ? x0 * scale : 0.0);
+        const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
+        vbn[c0] = v0;
+        vbn[c1] = v1;
+        const int off = voff(i, n) - i - 1;
+        if (c0 > i && c0 < n) t.Vs[off + c0] = v0;
+        if (c1 > i && c1 < n) t.Vs[off + c1] = v1;
+        if (lane == 0) {
+            t.de[2 * i] = di;
+            t.es[i] = beta;
+            t.taus[i] = tau;
+        }
+    };
+    if (wave == 0) build_reflector(0);
+    __syncthreads();
+    for (int i = 0; i < n - 1; ++i) {
+        const double* vb = t.xs + (i & 1) * 128;
+        double* p = t.ps + (i & 1) * 128;
+        const bool live = (wave * 16 + 15) > i;    // this wave still owns trailing rows
+        const bool next_owner = (i + 1 < n - 1) && wave == ((i + 1) >> 4);
         const double tau = t.taus[i];
+        double2 vv[16];
         if (live) {
-            double acc = 0.0;
+            if (next_owner) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double2 vv = *(const double2*)&vb[2 * q + 16 * k];
-                acc += A[2 * k] * vv.x;
-                acc += A[2 * k + 1] * vv.y;
+            for (int k = 0; k < 16; ++k) vv[k] = *(const double2*)&vb[2 * q + 8 * k];
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                acc0 = fma(A[2 * k], vv[k].x, acc0);
+                acc1 = fma(A[2 * k + 1], vv[k].y, acc1);
+                acc2 = fma(A[2 * k + 2], vv[k + 1].x, acc2);
+                acc3 = fma(A[2 * k + 3], vv[k + 1].y, acc3);
             }
-            acc = sum8(acc);
+            const double acc = sum4((acc0 + acc1) + (acc2 + acc3));
             if (q == 0) p[r] = (r > i) ? tau * acc : 0.0;
-        } else if (wave * 8 + 7 == i) {
+        } else if (wave * 16 + 15 == i) {
             // this wave's rows have just retired: clear their p entries in both buffers for good
             if (q == 0) {
                 t.ps[r] = 0.0;
@@ -321,26 +334,38 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         __syncthreads();
         if (live) {
             const int c0 = lane, c1 = lane + 64;
+            const double pr = p[r], vr = vb[r];
             const double dot = wave_sum(p[c0] * vb[c0] + p[c1] * vb[c1]);
             const double a2 = -0.5 * tau * dot;
-            const double vr = vb[r];
-            const double wr = p[r] + a2 * vr;
+            const double wr = pr + a2 * vr;
+            const double g = a2 * vr + wr;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const double2 vv = *(const double2*)&vb[2 * q + 16 * k];
-                const double2 pv = *(const double2*)&p[2 * q + 16 * k];
-                const double w0 = pv.x + a2 * vv.x, w1 = pv.y + a2 * vv.y;
-                A[2 * k] -= vr * w0 + wr * vv.x;
-                A[2 * k + 1] -= vr * w1 + wr * vv.y;
+            for (int kb = 0; kb < 16; kb += 8) {
+                double2 pv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] = *(const double2*)&p[2 * q + 8 * (kb + k)];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int kk = kb + k;
+                    A[2 * kk] = fma(-vr, pv[k].x, A[2 * kk]);
+                    A[2 * kk + 1] = fma(-vr, pv[k].y, A[2 * kk + 1]);
+                    A[2 * kk] = fma(-g, vv[kk].x, A[2 * kk]);
+                    A[2 * kk + 1] = fma(-g, vv[kk].y, A[2 * kk + 1]);
+                }
+            }
+            if (next_owner) {
+                build_reflector(i + 1);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
+        __syncthreads();
     }
     {   // last diagonal element
         double* x = t.xs + ((n - 1) & 1) * 128;
         __syncthreads();
         if (r == n - 1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) *(double2*)&x[2 * q + 16 * k] = make_double2(A[2 * k], A[2 * k + 1]);
+            for (int k = 0; k < 16; ++k) *(double2*)&x[2 * q + 8 * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
         __syncthreads();
         if (tid == 0) {
@@ -350,6 +375,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         __syncthreads();
     }
     TRI_STAMP(1);
+    if (stamps && tid == 0) stamps[7] = __builtin_readcyclecounter();
     // ---- e^2 and Gershgorin bounds ----------------------------------------------------------
     if (tid < n) t.de[2 * tid + 1] = tid > 0 ? t.es[tid - 1] * t.es[tid - 1] : 0.0;
     if (wave == 0) {
@@ -496,15 +522,17 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
     double* D = t.Ub;      // [32][32], Ub is free now
     double err = 0.0;
     {
-        const int a = tid >> 5, b = tid & 31;
-        double dv = 0.0;
-        if (a < K && b < K) {
-            double dot = 0.0;
-            for (int c = 0; c < n; ++c) dot += t.Z[c * 32 + a] * t.Z[c * 32 + b];
-            dv = dot - (a == b ? 1.0 : 0.0);
-            err = fabs(dv);
+        const int b = tid & 31;
+        for (int a = tid >> 5; a < 32; a += EIG_THREADS >> 5) {
+            double dv = 0.0;
+            if (a < K && b < K) {
+                double dot = 0.0;
+                for (int c = 0; c < n; ++c) dot += t.Z[c * 32 + a] * t.Z[c * 32 + b];
+                dv = dot - (a == b ? 1.0 : 0.0);
+                err = fmax(err, fabs(dv));
+            }
+            D[a * 32 + b] = dv;
         }
-        D[a * 32 + b] = dv;
         // T-residual tolerated up to 1e-8 ||T|| (mapped onto the 1e-9 threshold below)
         if (tid < K) err = fmax(err, t.misc[32 + tid] / (t.misc[2] > 0.0 ? t.misc[2] : 1.0) * 0.1);
     }
@@ -518,9 +546,10 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
     // ---- first-order symmetric (Loewdin) re-orthonormalisation: Z <- Z (I - D/2); the residual
     //      non-orthogonality drops from |D| to |D|^2 (< 1e-18) without leaving the subspace --------
     if (ok) {
-        double zn[4];
+        constexpr int NZ = 4096 / EIG_THREADS;
+        double zn[NZ];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NZ; ++m) {
             const int idx = tid + m * EIG_THREADS;        // over [128][32]
             const int c = idx >> 5, a = idx & 31;
             double acc = 0.0;
@@ -532,7 +561,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         }
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < NZ; ++m) {
             const int idx = tid + m * EIG_THREADS;
             const int c = idx >> 5, a = idx & 31;
             if (c < n && a < K) t.Z[idx] = zn[m];

@@ -156,9 +156,9 @@ class SweepEngine:
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
 
     def eig_phases(self):
-        us = np.zeros(5)
+        us = np.zeros(6)
         self._chk(self.lib.mpst_get_eig_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
-        return dict(zip(("tridiag", "bisect", "eigvec", "backtransform", "verify"), us.tolist()))
+        return dict(zip(("tridiag", "bisect", "eigvec", "backtransform", "verify", "tridiag_cycles"), us.tolist()))
 
     def selftest_mfma(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)
