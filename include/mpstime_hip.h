@@ -126,7 +126,9 @@ int  mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_
 int  mpst_get_chi(void* ctx, int32_t* chi_out /*[T+1]*/, int32_t* label_site);
 int  mpst_get_mps(void* ctx, void* const* site_out /* T buffers sized from mpst_get_chi */);
 
-/* construct_caches(W, training_states; going_left=true), RealRealHighDimension.jl:631. */
+/* construct_caches, RealRealHighDimension.jl:45-103,631: the left environments of every site left of
+ * the label site and the right environments of every site right of it.  With the label on the last
+ * site (the state training starts from) this is construct_caches(W, ...; going_left=true). */
 int  mpst_build_caches(void* ctx);
 
 /* One full sweep = RealRealHighDimension.jl:727-808. */

@@ -522,10 +522,21 @@ int mpst_build_caches(void* ctx) {
     int rc = check_ready(c);
     if (rc) return rc;
     int32_t ls;
+    HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipMemcpy(&ls, c->label_site, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (ls != c->T - 1) return fail(c, MPST_ERR_INVALID, "the label index must sit on the last site before training (found site %d)", ls);
+    // environments on both sides of the label site p: LE[0..p-1] and RE[T-1..p+1].  With the label
+    // on the last site (the state fitMPS starts from) this is construct_caches(W; going_left=true).
     View v = make_view(c, MPST_TRAIN);
-    enqueue_caches(c, v, 1);
+    const int64_t cs = (int64_t)v.N * v.cap;
+    {
+        ProfScope p(c, K_ENV);
+        for (int j = 0; j < ls && j <= c->T - 2; ++j)
+            launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1,
+                       c->LE + (int64_t)j * cs, c->stream);
+        for (int j = c->T - 1; j > ls && j >= 1; --j)
+            launch_env(v, j, 0, j < c->T - 1 ? c->RE + (int64_t)(j + 1) * cs : nullptr, j + 1, ENV_M_SITE_T, j,
+                       c->RE + (int64_t)j * cs, c->stream);
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     return 0;

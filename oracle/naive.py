@@ -60,4 +60,4 @@ def loss_and_grad(W, bt5, lid, phi, label_index, class_distribution, loss="KLD",
     else:
         raise ValueError(loss)
     val.backward()
-    return float(val), b.grad.numpy().copy(), yhat.detach().numpy()
+    return float(val.detach()), b.grad.numpy().copy(), yhat.detach().numpy()

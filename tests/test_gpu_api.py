@@ -1,0 +1,74 @@
+"""Public API on the GPU: fitMPS from raw data, classify, error paths of the C ABI
+(structural properties of test/classification.jl:22-24)."""
+import numpy as np
+import pytest
+
+import mpstime_jl_amd as mt
+
+pytestmark = pytest.mark.gpu
+
+
+def _toy(n=60, T=20, seed=3):
+    rng = np.random.default_rng(seed)
+    X1, _ = mt.trendy_sine(T, n // 2, period=(12.0, 15.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+    X2, _ = mt.trendy_sine(T, n // 2, period=(16.0, 19.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+    X = np.concatenate([X1, X2])
+    y = np.concatenate([np.zeros(n // 2, dtype=int), np.ones(n // 2, dtype=int)])
+    p = rng.permutation(n)
+    return X[p], y[p]
+
+
+def test_fitmps_classify_structural_properties():
+    Xtr, ytr = _toy(80, 20, 3)
+    Xte, yte = _toy(30, 20, 4)
+    opts = mt.MPSOptions(d=3, chi_max=8, nsweeps=3, eta=0.05, verbosity=-1)
+    mps, info, test_states = mt.fitMPS(Xtr, ytr, Xte, yte, opts)
+    mps2, info2, _ = mt.fitMPS(Xtr, ytr, opts=opts)
+    # (b) training is identical with or without test data (classification.jl:23)
+    assert mps == mps2 and info["train_KL_div"] == info2["train_KL_div"]
+    assert "test_acc" not in info2
+    # (a) classify(mps, test_states) == classify(mps, X_test)[sortperm(y_test)] (classification.jl:22)
+    p_states = mt.classify(mps, test_states)
+    p_raw = mt.classify(mps, Xte)
+    assert np.array_equal(p_states, p_raw[np.argsort(yte, kind="stable")])
+    assert np.mean(p_states == np.sort(yte)) == info["test_acc"][-1]
+    assert info["train_KL_div"][-2] < info["train_KL_div"][0]
+    # unsupervised overload: one class, label index of dimension 1 (RealRealHighDimension.jl:416)
+    mps1, info1, _ = mt.fitMPS(Xtr, opts=opts.set(nsweeps=1))
+    assert mps1.mps[-1].shape[3] == 1 and info1["train_acc"][-1] == 1.0
+
+
+def test_abi_error_paths(engine_cls):
+    e = engine_cls(0)
+    try:
+        with pytest.raises(mt.MPSTError, match="set_options"):
+            e.build_caches()
+        e.set_options(chi_max=4)
+        phi = np.random.default_rng(0).uniform(-1, 1, (8, 4, 2))
+        with pytest.raises(mt.MPSTError, match="sorted by class"):
+            e.set_dataset(0, phi, np.array([0, 1, 0, 1, 0, 1, 0, 1]), 2)
+        e.set_dataset(0, phi, np.array([0, 0, 0, 0, 1, 1, 1, 1]), 2)
+        W = mt.generate_startingMPS(2, 4, 2, 2, 0)
+        e.set_mps(W)
+        e.build_caches()
+        e.bond_step(2, True)
+        e.build_caches()                        # label now on site 2: environments on both sides of it
+        with pytest.raises(mt.MPSTError, match="no Loss_Grad_MSE method"):
+            e.set_options(chi_max=4, loss="MSE", train_classes_separately=True)
+        with pytest.raises(mt.MPSTError):
+            e.set_options(chi_max=64)           # exceeds the capacity fixed by set_mps
+    finally:
+        e.close()
+
+
+def test_dimension_limit_is_reported(engine_cls):
+    e = engine_cls(0)
+    try:
+        e.set_options(chi_max=40)
+        phi = np.random.default_rng(0).uniform(-1, 1, (8, 4, 4))
+        e.set_dataset(0, phi, np.zeros(8, dtype=int), 1)
+        e.set_mps(mt.generate_startingMPS(2, 4, 4, 1, 0))
+        with pytest.raises(mt.MPSTError, match="exceeds the 128"):
+            e.build_caches()
+    finally:
+        e.close()

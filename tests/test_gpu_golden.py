@@ -1,0 +1,207 @@
+"""HIP engine (through the C ABI and through the fitMPS mirror) against the committed golden
+fixtures, and against the C oracle at BASELINE.json's full size.
+
+Tolerances (fp64): per-bond loss 1e-7 and ||grad|| 1e-6 relative, kept singular values 1e-7 of the
+largest (differences accumulate along the 2(T-1) bonds of a sweep: every bond is conditioned on all
+previous truncations, and with KLD ~ 50 the overlaps are ~1e-11 so 1/yhat amplifies rounding), bond
+dimensions / predictions / accuracy exact, per-sweep train KLD 1e-6 relative (north_star's loss-curve
+tolerance), final overlaps 1e-6 of the largest.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import mpstime_jl_amd as mt
+from oracle import ref_numpy as R
+from tests.helpers import load_engine
+from tests.test_oracle import load_golden
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+FREE_RUNNING = [p for p in GOLDEN if "config1" not in p]
+
+
+def test_config1_teacher_forced_bond_by_bond(engine_cls):
+    """BASELINE.json configs[0] (N=200, T=50, chi=4, d=2, two-class trendy sine).  With a train KLD of
+    ~50 the overlaps are ~1e-11 and single series with yhat near zero dominate the gradient through
+    1/yhat (no clamping in the reference), so a free-running comparison amplifies rounding
+    by many orders of magnitude at some bonds.  Here every bond update starts from the oracle's
+    state (set_mps + build_caches), which isolates the parity of one update from that conditioning."""
+    g, ds, W0, opts = load_golden([p for p in GOLDEN if "config1" in p][0])
+    T = ds.phi.shape[1]
+    eng = engine_cls(0)
+    try:
+        load_engine(eng, ds, W0, opts)
+        W = [t.copy() for t in W0]
+        LE, RE = R.construct_caches(W, ds.phi, True)
+        k = 0
+        worst = [0.0, 0.0, 0.0, 0.0]
+        for going_left, order in ((True, range(T - 2, -1, -1)), (False, range(0, T - 1))):
+            if not going_left:
+                LE, RE = R.construct_caches(W, ds.phi, False)
+            for lid in order:
+                eng.set_mps(W)
+                eng.build_caches()
+                tr = eng.bond_step(lid, going_left)
+                tro = {}
+                R.bond_step(W, LE, RE, lid, ds, opts, going_left, tro)
+                assert tr["chi"] == tro["chi"] == int(g["bond_chi"][k])
+                worst[0] = max(worst[0], abs(tr["loss"] - tro["loss"]) / max(1.0, abs(tro["loss"])))
+                worst[1] = max(worst[1], abs(tr["grad_norm"] - tro["grad_norm"]) / tro["grad_norm"])
+                worst[2] = max(worst[2], np.abs(tr["S"][:tr["chi"]] - tro["S"]).max() / tro["S"][0])
+                yo, yg = R.contract_mps(W, ds.phi), R.contract_mps(eng.get_mps(), ds.phi)
+                worst[3] = max(worst[3], np.abs(yo - yg).max() / np.abs(yo).max())
+                k += 1
+        assert worst[0] < 1e-11 and worst[1] < 1e-8 and worst[2] < 1e-9 and worst[3] < 1e-8, worst
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("path", FREE_RUNNING, ids=[os.path.basename(p)[:-4] for p in FREE_RUNNING])
+def test_engine_reproduces_golden_bond_by_bond(engine_cls, path):
+    g, ds, W0, opts = load_golden(path)
+    T = ds.phi.shape[1]
+    eng = engine_cls(0)
+    try:
+        load_engine(eng, ds, W0, opts)
+        eng.build_caches()
+        curve = [eng.eval(0)]
+        k = 0
+        for _ in range(opts.nsweeps):
+            for going_left, order in ((True, range(T - 2, -1, -1)), (False, range(0, T - 1))):
+                for lid in order:
+                    tr = eng.bond_step(lid, going_left)
+                    assert int(g["bond_lid"][k]) == lid and bool(g["bond_left"][k]) == going_left
+                    assert tr["chi"] == int(g["bond_chi"][k])
+                    assert abs(tr["loss"] - g["bond_loss"][k]) <= 1e-7 * max(1.0, abs(g["bond_loss"][k]))
+                    assert abs(tr["grad_norm"] - g["bond_grad_norm"][k]) <= 1e-6 * g["bond_grad_norm"][k]
+                    So = g["bond_S"][k, :tr["chi"]]
+                    assert np.abs(tr["S"][:tr["chi"]] - So).max() <= 1e-7 * So[0]
+                    k += 1
+            curve.append(eng.eval(0))
+        eng.normalize()
+        curve.append(eng.eval(0))
+        for i, (mse, kld, acc, _) in enumerate(curve):
+            assert abs(kld - g["train_KL_div"][i]) <= 1e-6 * max(1.0, abs(g["train_KL_div"][i]))
+            assert abs(mse - g["train_loss"][i]) <= 1e-6
+            assert acc == g["train_acc"][i]
+        W = eng.get_mps()
+        assert np.abs(R.contract_mps(W, ds.phi) - g["overlaps"]).max() <= 1e-6 * np.abs(g["overlaps"]).max()
+        assert np.array_equal(R.classify(W, ds.phi), g["pred"])
+        chi, ls = eng.get_chi()
+        assert ls == T - 1 and np.array_equal(chi, g["final_chi"])
+    finally:
+        eng.close()
+
+
+def test_fit_encoded_training_information(capsys):
+    """The drop-in seam fitMPS(W, train_states, test_states, opts): keys, lengths and values of
+    training_information (RealRealHighDimension.jl:636-655,664,862)."""
+    g, ds, W0, opts = load_golden([p for p in GOLDEN if "kld_tsgo_c2" in p][0])
+    ets = mt.EncodedTimeSeriesSet(ds.phi, ds.label_index + 1, ds.label_index, np.zeros((len(ds.label_index), 0)),
+                                  ds.class_distribution)
+    mo = mt.MPSOptions(nsweeps=opts.nsweeps, chi_max=opts.chi_max, eta=opts.eta, d=ds.phi.shape[2], verbosity=-1)
+    trained, info, _ = mt.fit_encoded(W0, ets, ets, mo)
+    assert set(info) == {"train_loss", "train_acc", "test_loss", "test_acc", "time_taken", "train_KL_div",
+                         "test_KL_div", "test_conf"}
+    n = opts.nsweeps + 2
+    assert all(len(v) == n for v in info.values())
+    assert info["time_taken"][0] == 0.0 and np.isnan(info["time_taken"][-1])
+    assert np.allclose(info["train_KL_div"], g["train_KL_div"], rtol=1e-6)
+    assert np.allclose(info["test_KL_div"], info["train_KL_div"], rtol=1e-12)     # same set supplied as test data
+    assert info["test_conf"][-1].sum() == len(ds.label_index)
+    assert isinstance(trained, mt.TrainedMPS) and trained.opts == mo
+    # classify(mps, states) == classify(mps, X)[sortperm(y)] is exercised in test_gpu_api.py
+    assert np.array_equal(mt.classify(trained, ets) - 1, g["pred"])
+
+
+def _config3(N=4096, T=100, d=4):
+    import bench
+    full = bench.make_inputs(N, T, d)
+    W0 = mt.generate_startingMPS(4, T, d, 2, 1234)
+    return full, W0
+
+
+def test_full_size_config3_against_c_oracle(engine_cls):
+    """BASELINE.json configs[2] (N=4096, T=100, chi=32, d=4): every bond update of the first full
+    sweep against the C restatement, each starting from the oracle's state (set_mps + build_caches).
+
+    Free-running comparison is meaningless at this size: oracle/sensitivity_study.py shows the oracle
+    diverging from ITSELF by O(1) in per-bond loss within one sweep after a 1e-13 perturbation (the
+    first sweep starts from overlaps yhat ~ 0 and weights series by 1/yhat).  From a common
+    state one update is well conditioned, and that is what is compared; afterwards size-independent
+    properties are checked on the engine's own free-running sweep."""
+    from oracle.c_oracle import COracle
+    full, W0 = _config3()
+    T, chi = 100, 32
+    co = COracle(W0, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=False)
+    co.build_caches()
+    eng = engine_cls(0)
+    sub = slice(0, 4096, 32)
+    try:
+        eng.set_options(chi_max=chi, eta=0.01)
+        eng.set_dataset(0, full.phi, full.label_index, 2)
+        worst = dict(loss=0.0, grad=0.0, S=0.0, overlap=0.0)
+        chi_flips = 0
+        for q in range(2 * (T - 1)):
+            going_left = q < T - 1
+            lid = (T - 2 - q) if going_left else (q - (T - 1))
+            eng.set_mps(co.get_mps())
+            eng.build_caches()
+            ref = co.sweep(max_bonds=1, first_bond=q, record=True)["bonds_rec"][0]
+            tr = eng.bond_step(lid, going_left)
+            worst["loss"] = max(worst["loss"], abs(tr["loss"] - ref["loss"]) / max(1.0, abs(ref["loss"])))
+            worst["grad"] = max(worst["grad"], abs(tr["grad_norm"] - ref["grad_norm"]) / ref["grad_norm"])
+            nk = min(tr["chi"], ref["chi"])
+            worst["S"] = max(worst["S"], np.abs(tr["S"][:nk] - ref["S"][:nk]).max() / ref["S"][0])
+            if tr["chi"] != ref["chi"]:
+                # only a singular value sitting on the cutoff may be decided differently
+                P = ref["S"] ** 2 / np.sum(ref["S"] ** 2)
+                lo, hi = sorted((tr["chi"], ref["chi"]))
+                tail = P[lo:].sum()
+                assert hi - lo == 1 and abs(tail - 1e-10) < 1e-3 * 1e-10, (q, lid, tr["chi"], ref["chi"], tail)
+                chi_flips += 1
+            elif q % 9 == 0:
+                yo = R.contract_mps(co.get_mps(), full.phi[sub])
+                yg = R.contract_mps(eng.get_mps(), full.phi[sub])
+                worst["overlap"] = max(worst["overlap"], np.abs(yo - yg).max() / np.abs(yo).max())
+        assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, worst
+        assert chi_flips <= 2
+        # free-running sweep of the engine itself: properties
+        eng.set_mps(W0)
+        eng.build_caches()
+        kld0 = eng.eval(0)[1]
+        eng.sweep()
+        Wg = eng.get_mps()
+        assert abs(R.mps_norm(Wg) - 1.0) < 1e-10
+        for t in Wg[:-1]:
+            m = t.reshape(-1, t.shape[2])
+            assert np.abs(m.T @ m - np.eye(m.shape[1])).max() < 1e-10      # left-orthonormal after the forward half-sweep
+        mse, kld, acc, conf = eng.eval(0)
+        yall = R.contract_mps(Wg, full.phi)
+        assert abs(kld - np.mean(-np.log(yall[np.arange(4096), full.label_index] ** 2))) < 1e-9 * max(1, abs(kld))
+        assert conf.sum() == 4096 and acc == np.mean(np.argmax(np.abs(yall), 1) == full.label_index)
+        assert kld < kld0 - 10 and acc > 0.9          # it trains: same regime as the oracle (KLD -23.5, acc 0.96)
+    finally:
+        eng.close()
+
+
+def test_full_size_sweeps_are_deterministic(engine_cls):
+    """Fixed-order reductions everywhere: two runs of two sweeps give bit-identical tensors."""
+    full, W0 = _config3(N=1024)
+    outs = []
+    for _ in range(2):
+        eng = engine_cls(0)
+        eng.set_options(chi_max=32, eta=0.01)
+        eng.set_dataset(0, full.phi, full.label_index, 2)
+        eng.set_mps(W0)
+        eng.build_caches()
+        eng.sweep()
+        eng.sweep()
+        outs.append(eng.get_mps())
+        eng.close()
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))

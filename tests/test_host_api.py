@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference API: MPSOptions defaults and validation, encodings,
+preprocessing, data-set encoding, starting MPS, batch sharding (all CPU)."""
+import math
+
+import numpy as np
+import pytest
+
+import mpstime_jl_amd as mt
+from mpstime_jl_amd.options import engine_options
+
+
+def test_mpsoptions_defaults_match_reference():
+    # src/Structs/options.jl:106-143
+    o = mt.MPSOptions()
+    ref = dict(verbosity=1, nsweeps=10, chi_max=25, eta=0.01, d=5, encoding="Legendre_No_Norm", projected_basis=False,
+               aux_basis_dim=2, cutoff=1e-10, update_iters=1, dtype="Float64", loss_grad="KLD", bbopt="TSGO",
+               track_cost=False, rescale=(False, True), train_classes_separately=False,
+               encode_classes_separately=False, return_encoding_meta_info=False, minmax=True, exit_early=False,
+               sigmoid_transform=True, init_rng=1234, chi_init=4, log_level=3, data_bounds=(0.0, 1.0),
+               use_legacy_ITensor=False, svd_alg="divide_and_conquer")
+    assert o.asdict() == ref and len(ref) == 27
+    assert mt.MPSOptions(encoding=":Fourier").dtype == "ComplexF64"       # options.jl:117
+    assert mt.MPSOptions().set(chi_max=7).chi_max == 7                    # _set_options
+
+
+def test_engine_option_resolution_and_rejections():
+    e = engine_options(mt.MPSOptions(loss_grad=":MSE", bbopt=":GD"))
+    assert e["loss"] == "MSE" and e["bbopt"] == "GD"
+    with pytest.raises(RuntimeError, match="Optim/OptimKit based solvers currently unimplemented"):
+        engine_options(mt.MPSOptions(bbopt="Optim"))                      # loss_functions.jl:166-170
+    with pytest.raises(RuntimeError, match="legacy"):
+        engine_options(mt.MPSOptions(loss_grad="Mixed"))
+    with pytest.raises(RuntimeError, match="Float64-only"):
+        engine_options(mt.MPSOptions(encoding="Fourier"))
+    with pytest.raises(ValueError):
+        mt.MPSOptions(encoding="nonsense")
+
+
+@pytest.mark.parametrize("name", ["Legendre", "Legendre_No_Norm", "Legendre_Norm", "Fourier", "Stoudenmire", "Sahand",
+                                  "Uniform"])
+def test_model_symbolic_encoding_round_trip(name):
+    # test/basis_tests.jl:3-8
+    enc = mt.model_encoding(name)
+    assert mt.model_encoding(mt.symbolic_encoding(enc)).name == enc.name
+
+
+def test_legendre_basis_is_orthonormal_and_matches_closed_forms():
+    # bases.jl:77-92: phi_k = sqrt((2k+1)/2) P_k;  Gauss-Legendre quadrature is exact here
+    xs, ws = np.polynomial.legendre.leggauss(16)
+    phi = mt.legendre_encode_no_norm(xs, 6)
+    gram = (phi * ws[:, None]).T @ phi
+    assert np.allclose(gram, np.eye(6), atol=1e-13)
+    x = np.array([-0.7, 0.0, 0.3, 1.0])
+    assert np.allclose(mt.legendre_encode_no_norm(x, 3)[:, 2], math.sqrt(2.5) * 0.5 * (3 * x ** 2 - 1))
+    assert np.allclose(mt.legendre_encode(x, 4), mt.legendre_encode_no_norm(x, 4) / math.sqrt(math.sqrt(4.5) * 4))
+
+
+def test_fourier_basis():
+    assert mt.get_fourier_freqs(5) == [0, 1, -1, 2, -2] and mt.get_fourier_freqs(4) == [0, 1, -1, 2]
+    f = mt.fourier_encode(np.array([0.25]), 3)[0]
+    assert np.allclose(f, np.array([1, np.exp(0.25j * np.pi), np.exp(-0.25j * np.pi)]) / math.sqrt(3))
+    assert abs(np.vdot(f, f) - 1) < 1e-14
+
+
+def test_transform_data_ranges_and_out_of_bounds_rescale():
+    rng = np.random.default_rng(0)
+    Xtr = rng.normal(size=(30, 20))
+    Xte = np.concatenate([rng.normal(size=(5, 20)), 10 * rng.normal(size=(2, 20))])   # two series far out of range
+    opts = mt.MPSOptions()
+    enc = mt.model_encoding("Legendre")
+    a, b, norms, oob = mt.transform_data(Xtr, Xte, opts, enc.range)
+    assert a.min() == -1.0 and a.max() == 1.0                  # MinMax over the whole training matrix
+    assert b.min() >= -1.0 - 1e-12 and b.max() <= 1.0 + 1e-12  # utils.jl:243-266
+    assert len(oob) >= 1
+    med, iqr = norms.sigmoid
+    assert med == np.median(Xtr) and iqr > 0
+    # data_bounds shrink the interval (utils.jl:186-191)
+    a2, _, _, _ = mt.transform_data(Xtr, Xte[:0], mt.MPSOptions(data_bounds=(0.1, 0.9)), enc.range)
+    assert abs(a2.min() + 0.8) < 1e-12 and abs(a2.max() - 0.8) < 1e-12
+
+
+def test_encode_dataset_sorts_stably_and_counts_classes():
+    X = np.linspace(-1, 1, 6 * 4).reshape(6, 4)
+    y = np.array([3, 1, 3, 1, 2, 1])
+    enc = mt.model_encoding("Legendre")
+    ets = mt.encode_dataset(X, X, y, enc, 3, {1: 0, 2: 1, 3: 2})
+    assert list(ets.labels) == [1, 1, 1, 2, 3, 3]
+    assert np.array_equal(ets.original_data, X[[1, 3, 5, 4, 0, 2]])          # stable sortperm (encodings.jl:43)
+    assert list(ets.label_index) == [0, 0, 0, 1, 2, 2] and list(ets.class_distribution) == [3, 1, 2]
+    assert ets.phi.shape == (6, 4, 3)
+    with pytest.raises(ValueError, match="rescaled between"):
+        mt.encode_dataset(X * 2, X * 2, y, enc, 3, {1: 0, 2: 1, 3: 2})         # encodings.jl:115-119
+
+
+def test_starting_mps_is_normalised_and_left_canonical():
+    W = mt.generate_startingMPS(4, 9, 3, 2, init_rng=7)
+    # bond dimensions are capped by d^j near the ends, as ITensors.random_mps does
+    assert W[-1].shape == (3, 3, 1, 2) and W[0].shape == (1, 3, 3) and W[4].shape == (4, 3, 4)
+    for t in W[:-1]:
+        m = t.reshape(-1, t.shape[2])
+        assert np.allclose(m.T @ m, np.eye(m.shape[1]), atol=1e-13)
+    assert abs(np.linalg.norm(W[-1]) - 1) < 1e-14
+    W2 = mt.generate_startingMPS(4, 9, 3, 2, init_rng=7)
+    assert all(np.array_equal(a, b) for a, b in zip(W, W2))
+
+
+def test_batch_shards_partition_every_class():
+    X = np.random.default_rng(1).uniform(-1, 1, (23, 5))
+    y = np.array([0] * 9 + [1] * 3 + [2] * 11)
+    ets = mt.encode_dataset(X, X, y, mt.model_encoding("Legendre"), 2, {0: 0, 1: 1, 2: 2})
+    for world in (1, 2, 3, 8):
+        parts = [mt.split_encoded(ets, r, world) for r in range(world)]
+        assert all(np.array_equal(g, [9, 3, 11]) for _, g in parts)
+        assert sum(len(p) for p, _ in parts) == 23
+        assert np.array_equal(sum(p.class_distribution for p, _ in parts), [9, 3, 11])
+        for p, _ in parts:
+            assert np.all(np.diff(p.label_index) >= 0)                          # shards stay class-sorted
+        got = np.sort(np.concatenate([p.original_data[:, 0] for p, _ in parts]))
+        assert np.array_equal(got, np.sort(ets.original_data[:, 0]))
+
+
+def test_fitmps_input_validation_needs_no_gpu():
+    X = np.random.default_rng(2).normal(size=(10, 6))
+    with pytest.raises(AssertionError, match="training labels"):
+        mt.fitMPS(X, np.zeros(9, dtype=int))
+    with pytest.raises(ValueError, match="not present in the training set"):
+        mt.fitMPS(X, np.zeros(10, dtype=int), X[:2], np.array([0, 5]))
+    with pytest.raises(RuntimeError, match="complex valued encoding"):
+        mt.fitMPS(X, np.zeros(10, dtype=int), opts=mt.MPSOptions(encoding="Fourier", dtype="Float64"))
+    with pytest.raises(ValueError, match="Custom"):
+        mt.fitMPS(X, np.zeros(10, dtype=int), custom_encoding=mt.model_encoding("Legendre"))
