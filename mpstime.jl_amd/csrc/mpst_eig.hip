@@ -240,7 +240,13 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n,
 // Top-K eigenpairs of the symmetric G (global, n x n, 2 <= n <= 128, K <= 32).
 // Outputs: t.lam[0..K) descending (LDS); eigenvectors in t.Z[c*32 + k].  Returns true if the
 // on-device verification passed.
-__device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared t, unsigned long long* stamps) {
+// `select(lam, K)` is called (by every thread, after a barrier) once the K largest eigenvalues are in
+// t.lam and returns how many eigenvectors are wanted (<= K): eigenvectors of values the truncation
+// rule is going to discard are never formed - those are the clustered, noise-level ones that make
+// the twisted factorisation lose orthogonality.
+template <typename Select>
+__device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared t, unsigned long long* stamps,
+                          Select select) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #define TRI_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TRI_STAMP(0);
@@ -418,6 +424,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         }
     }
     __syncthreads();
+    K = select(t.lam, K);
     TRI_STAMP(2);
     // ---- eigenvectors of T: twisted factorisation, one lane per eigenvalue ------------------------
     if (tid < K) {
@@ -518,10 +525,25 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
     }
     __syncthreads();
     TRI_STAMP(4);
-    // ---- verification: residuals in T and deviation from orthonormality D = Z^T Z - I ---------
+    // ---- verification + symmetric (Loewdin) re-orthonormalisation ---------------------------------
+    // D = Z^T Z - I; Z <- Z (I - D/2) squares the deviation without leaving the subspace.  Up to two
+    // rounds: close (but separated) eigenvalues leave |D| ~ 1e-6, genuine clusters leave |D| ~ 1 and
+    // are handed to the Jacobi path, as is a residual ||T z - lambda z|| above 1e-8 ||T||.
     double* D = t.Ub;      // [32][32], Ub is free now
-    double err = 0.0;
+    bool ok = true;
     {
+        double rres = 0.0;
+        if (tid < K) rres = t.misc[32 + tid] / (t.misc[2] > 0.0 ? t.misc[2] : 1.0);
+        rres = wave_max(rres);
+        __syncthreads();
+        if (lane == 0) t.misc[8 + wave] = rres;
+        __syncthreads();
+        double rmax = 0.0;
+        for (int w = 0; w < EIG_THREADS / 64; ++w) rmax = fmax(rmax, t.misc[8 + w]);
+        ok = rmax < 1e-8 && rmax == rmax;
+    }
+    for (int round = 0; round < 2 && ok; ++round) {
+        double err = 0.0;
         const int b = tid & 31;
         for (int a = tid >> 5; a < 32; a += EIG_THREADS >> 5) {
             double dv = 0.0;
@@ -533,19 +555,17 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
             }
             D[a * 32 + b] = dv;
         }
-        // T-residual tolerated up to 1e-8 ||T|| (mapped onto the 1e-9 threshold below)
-        if (tid < K) err = fmax(err, t.misc[32 + tid] / (t.misc[2] > 0.0 ? t.misc[2] : 1.0) * 0.1);
-    }
-    err = wave_max(err);
-    __syncthreads();
-    if (lane == 0) t.misc[8 + wave] = err;
-    __syncthreads();
-    double emax = 0.0;
-    for (int w = 0; w < EIG_THREADS / 64; ++w) emax = fmax(emax, t.misc[8 + w]);
-    const bool ok = emax < 1e-9 && emax == emax;
-    // ---- first-order symmetric (Loewdin) re-orthonormalisation: Z <- Z (I - D/2); the residual
-    //      non-orthogonality drops from |D| to |D|^2 (< 1e-18) without leaving the subspace --------
-    if (ok) {
+        err = wave_max(err);
+        __syncthreads();
+        if (lane == 0) t.misc[8 + wave] = err;
+        __syncthreads();
+        double emax = 0.0;
+        for (int w = 0; w < EIG_THREADS / 64; ++w) emax = fmax(emax, t.misc[8 + w]);
+        if (!(emax < 1e-4)) {
+            ok = false;
+            break;
+        }
+        if (round == 1 && emax < 1e-13) break;       // already orthonormal to rounding
         constexpr int NZ = 4096 / EIG_THREADS;
         double zn[NZ];
 #pragma unroll
@@ -554,7 +574,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
             const int c = idx >> 5, a = idx & 31;
             double acc = 0.0;
             if (c < n && a < K) {
-                for (int b = 0; b < K; ++b) acc += t.Z[c * 32 + b] * D[b * 32 + a];
+                for (int bb = 0; bb < K; ++bb) acc += t.Z[c * 32 + bb] * D[bb * 32 + a];
                 acc = t.Z[c * 32 + a] - 0.5 * acc;
             }
             zn[m] = acc;
@@ -567,6 +587,7 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
             if (c < n && a < K) t.Z[idx] = zn[m];
         }
         __syncthreads();
+        if (emax < 1e-8) break;                       // one round suffices: residual |D|^2 < 1e-16
     }
     TRI_STAMP(5);
 #undef TRI_STAMP
@@ -599,15 +620,39 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_
     for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
     __syncthreads();
 
+    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+    // NDTensors truncate! (relative cutoff) on P = lambda*inv^2.  The weight beyond the
+    // first K0 values is trace - sum(first K0).  Evaluated redundantly by every thread.
+    auto truncate = [&](const double* lam, int K) -> int {
+        const double inv2 = inv * inv;
+        const double scale0 = tr * inv2;
+        const double scale = scale0 == 0.0 ? 1.0 : scale0;
+        double kept = 0.0;
+        for (int i = 0; i < K; ++i) kept += lam[i] * inv2;
+        int nk = K;
+        double truncerr = scale0 - kept;
+        if (truncerr < 0.0 || nspec <= K) truncerr = 0.0;
+        if (nspec > 1) {
+            while (nk > 1 && truncerr + lam[nk - 1] * inv2 <= v.cutoff * scale) {
+                truncerr += lam[nk - 1] * inv2;
+                --nk;
+            }
+        }
+        return nk;
+    };
     int sweeps = 0;
     bool done = false;
+    int nk = K0;
     if (v.svd_alg != MPST_SVD_JACOBI && K0 <= TRI_KMAX && n >= 2) {
         TriShared t = tri_carve(smem);
-        done = tri_solve(v.gram, n, K0, t, v.sc->eig_stamps);
+        done = tri_solve(v.gram, n, K0, t, v.sc->eig_stamps, [&](const double* lam, int K) {
+            nk = truncate(lam, K);
+            return nk;
+        });
         if (done) {
             if (tid < K0) lam_s[tid] = t.lam[tid];
-            for (int i = tid; i < n * K0; i += EIG_THREADS) {
-                const int c = i / K0, k = i - c * K0;
+            for (int i = tid; i < n * nk; i += EIG_THREADS) {
+                const int c = i / nk, k = i - c * nk;
                 v.E[(size_t)c * ldE + k] = t.Z[c * 32 + k];
             }
         }
@@ -617,31 +662,16 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_
     if (!done) {
         sweeps = jacobi_solve(v.gram, n, smem, lam_s, v.E, ldE, K0);
         if (sweeps == 0) sweeps = 1;
+        __syncthreads();
+        nk = truncate(lam_s, K0);
     }
     __syncthreads();
     if (tid < K0) v.lam[tid] = lam_s[tid];
-    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
-    // truncation (NDTensors truncate!, relative cutoff).  The weight beyond the first
-    // K0 values is trace - sum(first K0).
     if (tid == 0) {
-        const double inv2 = inv * inv;
-        const double scale0 = tr * inv2;
-        const double scale = scale0 == 0.0 ? 1.0 : scale0;
-        double kept = 0.0;
         bool bad = !(tr == tr) || tr > 1e300;
         for (int i = 0; i < K0; ++i) {
-            const double P = lam_s[i] * inv2;
-            kept += P;
+            const double P = lam_s[i] * inv * inv;
             if (!(P == P) || P > 1e300) bad = true;
-        }
-        int nk = K0;
-        double truncerr = scale0 - kept;
-        if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
-        if (nspec > 1) {
-            while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= v.cutoff * scale) {
-                truncerr += lam_s[nk - 1] * inv2;
-                --nk;
-            }
         }
         v.sc->n_keep = nk;
         v.sc->n_spec = K0;
@@ -669,7 +699,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_raw(const double* G, int n,
     if (alg != MPST_SVD_JACOBI && n >= 2) {
         const int K = n < TRI_KMAX ? n : TRI_KMAX;
         TriShared t = tri_carve(smem);
-        const bool ok = tri_solve(G, n, K, t, nullptr);
+        const bool ok = tri_solve(G, n, K, t, nullptr, [](const double*, int K_) { return K_; });
         if (ok) {
             if (tid < K) lam[tid] = t.lam[tid];
             for (int i = tid; i < n * K; i += EIG_THREADS) {
