@@ -1,0 +1,144 @@
+# MPSTimeHIP.jl - Julia shim that plugs libmpstime_hip.so in as the sweep engine of MPSTime.jl.
+#
+# The seam is the method the reference selects at src/Training/RealRealHighDimension.jl:556-560,
+#     fitMPS(W::MPS, training_states_meta, testing_states_meta, opts)        (:587-890)
+# next to the existing `use_legacy_ITensor` switch.  Everything above it (options, preprocessing,
+# encodings, generate_startingMPS) and below it (TrainedMPS, classify, imputation) stays Julia.
+#
+# Julia is not installed in the build container or on the GPU box (SURVEY.md fact 3), so this file
+# has been written to the C ABI in include/mpstime_hip.h but never executed; the Python mirror in
+# mpstime.jl_amd/ drives the identical ABI and is what the tests run.
+module MPSTimeHIP
+
+using ITensors, ITensorMPS
+import MPSTime: EncodedTimeSeriesSet, PState, AbstractMPSOptions, MPSOptions, Options, TrainedMPS,
+                safe_options, find_label, get_siteinds, KLDLoss, MSELoss, BBOpt
+
+const LIB = get(ENV, "MPSTIME_HIP_LIB", "libmpstime_hip.so")
+
+struct MpstOptions            # mpst_options, field for field
+    chi_max::Int32; update_iters::Int32; loss::Int32; optimiser::Int32
+    rescale_before::Int32; rescale_after::Int32; train_classes_separately::Int32
+    svd_alg::Int32; rebuild_caches::Int32; reserved0::Int32
+    eta::Float64; cutoff::Float64
+end
+struct MpstSweepStats
+    seconds::Float64; svd_status::Int32; max_chi::Int32; eig_sweeps_total::Int32; eig_fallbacks::Int32
+end
+
+const MPST_ERR_UNSUPPORTED = -2
+const MPST_ERR_SVD = -4
+
+function check(ctx, rc)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:mpst_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))
+    rc == MPST_ERR_SVD && throw(ArgumentError(msg))          # the class tune() retries on (tuning.jl:73-86)
+    rc == MPST_ERR_UNSUPPORTED && error(msg)                 # loss_functions.jl:166-170
+    error("mpstime_hip [$rc]: $msg")
+end
+
+"EncodedTimeSeriesSet -> (phi[d,T,N] Float64, label_idx 0-based Int32)"
+function pack_states(ets::EncodedTimeSeriesSet, d, T)
+    N = length(ets.timeseries)
+    phi = Array{Float64}(undef, d, T, N)
+    lab = Vector{Int32}(undef, N)
+    for (i, ps) in enumerate(ets.timeseries)
+        for t in 1:T
+            phi[:, t, i] .= ps.pstate[t]
+        end
+        lab[i] = Int32(ps.label_index) - 1
+    end
+    return phi, lab
+end
+
+"Site tensors in the boundary layout: column-major (s, l_left, l_right[, label])."
+function pack_mps(W::MPS)
+    T = length(W)
+    pos, label_idx = find_label(W)
+    sites = get_siteinds(W)
+    links = linkinds(W)
+    bufs = Vector{Array{Float64}}(undef, T)
+    chi = ones(Int32, T + 1)
+    for j in 1:T
+        inds_j = Index[sites[j]]
+        j > 1 && push!(inds_j, links[j-1]);  j > 1 && (chi[j] = dim(links[j-1]))
+        j < T && push!(inds_j, links[j])
+        j == pos && push!(inds_j, label_idx)
+        A = array(W[j], inds_j...)
+        dl, dr = j > 1 ? dim(links[j-1]) : 1, j < T ? dim(links[j]) : 1
+        bufs[j] = reshape(A, dim(sites[j]), dl, dr, (j == pos ? dim(label_idx) : 1))
+    end
+    return bufs, chi, pos - 1, label_idx, sites
+end
+
+function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeriesSet, opts::AbstractMPSOptions; device::Int=0)
+    opts = safe_options(opts)
+    T = length(W); d = opts.d
+    pos, label_idx = find_label(W)
+    C = dim(label_idx)
+    loss = opts.loss_grad isa KLDLoss ? 0 : opts.loss_grad isa MSELoss ? 1 : -1
+    optim = opts.bbopt.name == "CustomGD" ? (uppercase(opts.bbopt.fl) == "TSGO" ? 0 : 1) : -1
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(C_NULL, ccall((:mpst_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), ctx, device))
+    c = ctx[]
+    try
+        o = MpstOptions(opts.chi_max, opts.update_iters, loss, optim, opts.rescale[1], opts.rescale[2],
+                        opts.train_classes_separately, opts.svd_alg == "recursive" ? 1 : 0, 0, 0, opts.eta, opts.cutoff)
+        check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, o))
+        for (which, ets) in ((0, train), (1, test))
+            isempty(ets.timeseries) && continue
+            phi, lab = pack_states(ets, d, T)
+            check(c, ccall((:mpst_set_dataset, LIB), Cint,
+                  (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Int32}, Int64, Int32, Int32, Int32, Int32, Ptr{Int64}),
+                  c, which, phi, lab, length(lab), T, d, C, 0, C_NULL))
+        end
+        bufs, chi, ls, _, sites = pack_mps(W)
+        check(c, ccall((:mpst_set_mps, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Int32, Int32),
+              c, [pointer(b) for b in bufs], chi, T, ls))
+        check(c, ccall((:mpst_build_caches, LIB), Cint, (Ptr{Cvoid},), c))
+
+        has_test = !isempty(test.timeseries)
+        info = Dict{String,Vector}("train_loss" => Float64[], "train_acc" => Float64[], "test_loss" => Float64[],
+                                   "time_taken" => Float64[], "train_KL_div" => Float64[])
+        has_test && merge!(info, Dict("test_acc" => Float64[], "test_KL_div" => Float64[], "test_conf" => Matrix{Float64}[]))
+        function log!(t)
+            opts.log_level > 0 || return NaN
+            mse = Ref(0.0); kld = Ref(0.0); acc = Ref(0.0); conf = zeros(Int64, C, C)
+            check(c, ccall((:mpst_eval, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Int64}), c, 0, mse, kld, acc, conf))
+            push!(info["train_loss"], mse[]); push!(info["train_acc"], acc[]); push!(info["time_taken"], t); push!(info["train_KL_div"], kld[])
+            if has_test
+                check(c, ccall((:mpst_eval, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Int64}), c, 1, mse, kld, acc, conf))
+                push!(info["test_loss"], mse[]); push!(info["test_acc"], acc[]); push!(info["test_KL_div"], kld[])
+                push!(info["test_conf"], permutedims(Float64.(conf)))     # C row-major [truth][pred] -> Julia [truth, pred]
+            end
+            return acc[]
+        end
+        log!(0.0)
+        for its in 1:opts.nsweeps
+            st = Ref(MpstSweepStats(0, 0, 0, 0, 0))
+            check(c, ccall((:mpst_sweep, LIB), Cint, (Ptr{Cvoid}, Ref{MpstSweepStats}), c, st))
+            acc = log!(st[].seconds)
+            opts.exit_early && acc == 1.0 && break
+        end
+        check(c, ccall((:mpst_normalize, LIB), Cint, (Ptr{Cvoid},), c))
+        log!(NaN)
+
+        # read the MPS back into ITensors (label back on site T after the forward half-sweep)
+        chi_out = zeros(Int32, T + 1); ls_out = Ref{Int32}(0)
+        check(c, ccall((:mpst_get_chi, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int32}), c, chi_out, ls_out))
+        outs = [Array{Float64}(undef, d, chi_out[j], chi_out[j+1], (j - 1 == ls_out[] ? C : 1)) for j in 1:T]
+        check(c, ccall((:mpst_get_mps, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), c, [pointer(b) for b in outs]))
+        links = [Index(Int(chi_out[j+1]), "Link,l=$j") for j in 1:T-1]
+        Wn = MPS(T)
+        for j in 1:T
+            is = Index[sites[j]]
+            j > 1 && push!(is, links[j-1]); j < T && push!(is, links[j]); (j - 1 == ls_out[]) && push!(is, label_idx)
+            Wn[j] = itensor(reshape(outs[j], dim.(is)...), is...)
+        end
+        return TrainedMPS(Wn, MPSOptions(opts), train), info, test
+    finally
+        ccall((:mpst_destroy, LIB), Cvoid, (Ptr{Cvoid},), c)
+    end
+end
+
+end # module
