@@ -36,7 +36,7 @@ struct Ctx {
     double *LE = nullptr, *RE = nullptr;
     int64_t cache_elems = 0;
     double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
-    double *gram = nullptr, *lam = nullptr, *E = nullptr;
+    double *gram = nullptr, *lam = nullptr, *E = nullptr, *eig_ws = nullptr;
     int64_t partial_elems = 0;
     DevScalars* sc = nullptr;
     // eval scratch
@@ -108,7 +108,7 @@ View make_view(Ctx* c, int which) {
     v.ntiles = s.ntiles; v.nchunks = s.nchunks;
     v.chi = c->chi; v.label_site = c->label_site; v.sites = c->sites; v.site_stride = c->site_stride;
     v.LE = c->LE; v.RE = c->RE; v.bt = c->bt; v.yhat = c->yhat; v.tile_loss = c->tile_loss;
-    v.partial = c->partial; v.gradbuf = c->gradbuf; v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.sc = c->sc;
+    v.partial = c->partial; v.gradbuf = c->gradbuf; v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.eig_ws = c->eig_ws; v.sc = c->sc;
     v.loss = c->opt.loss; v.optimiser = c->opt.optimiser; v.rescale_before = c->opt.rescale_before;
     v.rescale_after = c->opt.rescale_after; v.train_sep = c->opt.train_classes_separately; v.svd_alg = c->opt.svd_alg;
     v.eta = c->opt.eta; v.cutoff = c->opt.cutoff;
@@ -141,6 +141,8 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->gram, (int64_t)MAX_DIM * MAX_DIM))) return rc;
     if ((rc = dalloc(c, &c->lam, MAX_DIM + 2))) return rc;
     if ((rc = dalloc(c, &c->E, (int64_t)MAX_DIM * c->cap))) return rc;
+    if ((rc = dalloc(c, &c->eig_ws, (int64_t)eig_workspace_doubles()))) return rc;
+    HIPC(c, hipMemset(c->eig_ws, 0, eig_workspace_doubles() * sizeof(double)));
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
     HIPC(c, hipMemset(c->sc, 0, sizeof(DevScalars)));
     if ((rc = dalloc(c, &c->norm2, 1))) return rc;
@@ -311,7 +313,7 @@ void mpst_destroy(void* ctx) {
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
-    dfree(&c->E); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
+    dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -683,8 +685,13 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     HIPC(c, hipStreamSynchronize(c->stream));
     DevScalars sc;
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
-    for (int i = 0; i < 5; ++i) us[i] = 0.01 * (double)(sc.eig_stamps[i + 1] - sc.eig_stamps[i]);   // 100 MHz ticks
-    us[5] = (double)(sc.eig_stamps[7] - sc.eig_stamps[6]);   // shader cycles spent in the tridiagonalisation
+    const unsigned long long* t = sc.eig_stamps;              // 100 MHz ticks
+    us[0] = 0.01 * (double)(t[1] - t[0]);                     // k_eig_tri: tridiagonalisation
+    us[1] = 0.01 * (double)(t[3] - t[2]);                     // k_eig_vec block 0: staging + bisection
+    us[2] = 0.01 * (double)(t[4] - t[3]);                     //                    twisted factorisation
+    us[3] = 0.01 * (double)(t[5] - t[4]);                     //                    back-transformation
+    us[4] = 0.01 * (double)(t[9] - t[8]);                     // k_eig_fin: truncation, verification, Loewdin
+    us[5] = (double)(t[7] - t[6]);                            // shader cycles spent in the tridiagonalisation
     return 0;
 }
 
@@ -709,18 +716,20 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
     if (!c) return MPST_ERR_INVALID;
     if (n < 1 || n > MAX_DIM) return fail(c, MPST_ERR_INVALID, "n must be in 1..%d", MAX_DIM);
     HIPC(c, hipSetDevice(c->device));
-    double *dG = nullptr, *dl = nullptr, *dE = nullptr;
+    double *dG = nullptr, *dl = nullptr, *dE = nullptr, *dws = nullptr;
     int32_t* ds = nullptr;
     int rc;
-    if ((rc = dalloc(c, &dG, n * n)) || (rc = dalloc(c, &dl, n)) || (rc = dalloc(c, &dE, n * n)) || (rc = dalloc(c, &ds, 1))) return rc;
+    if ((rc = dalloc(c, &dG, n * n)) || (rc = dalloc(c, &dl, n)) || (rc = dalloc(c, &dE, n * n)) || (rc = dalloc(c, &ds, 1)) ||
+        (rc = dalloc(c, &dws, (int64_t)eig_workspace_doubles()))) return rc;
     HIPC(c, hipMemcpy(dG, G, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
-    launch_eig_raw(dG, n, alg, dl, dE, ds, c->stream);
+    HIPC(c, hipMemset(dws, 0, eig_workspace_doubles() * sizeof(double)));
+    launch_eig_raw(dG, n, alg, dl, dE, ds, dws, c->stream);
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpy(lambda_out, dl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     HIPC(c, hipMemcpy(E_out, dE, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
     if (sweeps) HIPC(c, hipMemcpy(sweeps, ds, sizeof(int32_t), hipMemcpyDeviceToHost));
-    dfree(&dG); dfree(&dl); dfree(&dE); dfree(&ds);
+    dfree(&dG); dfree(&dl); dfree(&dE); dfree(&ds); dfree(&dws);
     return 0;
 }
 

@@ -7,15 +7,20 @@
 // Only the chi_max largest eigenpairs and the trace are needed: the truncation rule discards the
 // rest, and the discarded weight is trace - sum(kept).
 //
-// One workgroup (the problem is a latency chain, not a throughput problem), two algorithms:
+// Three launches per bond, two algorithms:
 //
-//  * default: Householder tridiagonalisation with the matrix held in registers (16 doubles per
-//    thread, thread (r, q) owns G[r][q + 8k]), 2 barriers per reflector; multisection Sturm
-//    bisection for the K largest eigenvalues (16 lanes per eigenvalue, 17-fold interval shrink
-//    per step, division-free recurrence); eigenvectors of the tridiagonal by twisted factorisation
-//    (one lane per eigenvalue); back-transformation through the stored reflectors (16 lanes per
-//    vector).  The result is verified on the device (residual in T, orthonormality of the output)
-//    and, if the check fails (clustered eigenvalues), the kernel falls through to
+//  * default:
+//    k_eig_tri  (1 workgroup)  Householder tridiagonalisation G = Q T Q^T with the matrix held in
+//               registers (32 doubles per thread), 2 barriers per reflector, look-ahead reflector
+//               construction; T, the reflectors and Gershgorin bounds go to a 100 KB workspace.
+//    k_eig_vec  (one workgroup PER EIGENVALUE, K <= 32 of them run concurrently on 32 CUs)
+//               256-way multisection Sturm bisection (7 steps, division-free recurrence), eigenvector
+//               of T by twisted factorisation with the two factorisations and the two substitution
+//               sweeps on different waves, back-transformation through the reflectors two at a time.
+//    k_eig_fin  (1 workgroup)  NDTensors truncation rule on the eigenvalues, on-device verification
+//               (residual in T, orthonormality) of the kept vectors, Loewdin re-orthonormalisation,
+//               publication of n_keep / chi / E.  If verification fails (genuinely clustered kept
+//               eigenvalues) it falls through to
 //  * MPST_SVD_JACOBI: one-sided (Hestenes) Jacobi on the columns of G in LDS - slow (ms) but
 //    unconditionally robust; column k converges to lambda_k v_k.
 #include "mpst_internal.h"
@@ -25,7 +30,8 @@ namespace mpst {
 constexpr int EIG_THREADS = 512;   // 8 waves = 2 per SIMD: the phases are VALU-issue bound, fewer fatter waves win
 constexpr int EIG_MAX_SWEEPS = 40;
 constexpr int TRI_KMAX = 32;      // eigenpairs the tridiagonal path can deliver
-constexpr int TRI_NSTEP = 14;     // 17^-14 = 6e-18 of the Gershgorin interval
+constexpr int VEC_THREADS = 256;  // k_eig_vec: one workgroup per eigenvalue
+constexpr int TRI_NSTEP = 7;      // 257^-7 = 1.4e-17 of the Gershgorin interval
 constexpr int EIG_LDS_DOUBLES = 17664;  // 138 KB: max over both algorithms
 
 __device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
@@ -237,20 +243,66 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n,
     return cnt;
 }
 
-// Top-K eigenpairs of the symmetric G (global, n x n, 2 <= n <= 128, K <= 32).
-// Outputs: t.lam[0..K) descending (LDS); eigenvectors in t.Z[c*32 + k].  Returns true if the
-// on-device verification passed.
-// `select(lam, K)` is called (by every thread, after a barrier) once the K largest eigenvalues are in
-// t.lam and returns how many eigenvectors are wanted (<= K): eigenvectors of values the truncation
-// rule is going to discard are never formed - those are the clustered, noise-level ones that make
-// the twisted factorisation lose orthogonality.
-template <typename Select>
-__device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared t, unsigned long long* stamps,
-                          Select select) {
+
+// ---- global workspace shared by the three kernels (doubles) ----------------------------------
+constexpr int WS_DE = 0;        // [128][2]  (d_j, e_{j-1}^2)
+constexpr int WS_ES = 256;      // [128]
+constexpr int WS_TAU = 384;     // [128]
+constexpr int WS_MISC = 512;    // [0] lo  [1] hi  [2] ||T||  [3] 1.0 if the tridiagonal path is active
+constexpr int WS_LAM = 528;     // [32]
+constexpr int WS_RES = 560;     // [32]  ||T z - lambda z||_inf
+constexpr int WS_VS = 592;      // [8128] packed reflectors
+constexpr int WS_Z = 8720;      // [32][128] eigenvectors of G, one row per eigenvalue
+constexpr int WS_TOTAL = 12816;
+
+struct EigProblem {
+    const double* G;
+    int n, rows, nspec, K0;
+    bool tri;       // tridiagonal path applicable
+};
+__device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_left, const double* rawG, int rawn,
+                                              int rawalg) {
+    EigProblem p;
+    if (rawn > 0) {
+        p.G = rawG;
+        p.n = rawn;
+        p.rows = rawn;
+        p.nspec = rawn;
+        p.K0 = rawn < TRI_KMAX ? rawn : TRI_KMAX;
+        p.tri = rawalg != MPST_SVD_JACOBI && rawn >= 2;
+    } else {
+        const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
+        const int X = Dl * v.d, Y = v.d * Dr;
+        p.G = v.gram;
+        p.n = going_left ? Y : X;
+        p.rows = v.C * (going_left ? X : Y);
+        p.nspec = p.rows < p.n ? p.rows : p.n;                    // LAPACK's min(m, n)
+        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;         // eigenpairs that can survive maxdim
+        p.tri = v.svd_alg != MPST_SVD_JACOBI && p.K0 <= TRI_KMAX && p.n >= 2;
+    }
+    return p;
+}
+
+// =====================================================================================
+// k_eig_tri
+// =====================================================================================
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                         int rawalg, double* __restrict__ ws,
+                                                         unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#define TRI_STAMP(i) do { if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    TRI_STAMP(0);
-    if (stamps && tid == 0) stamps[6] = __builtin_readcyclecounter();
+    if (!pb.tri) {
+        if (tid == 0) ws[WS_MISC + 3] = 0.0;
+        return;
+    }
+    const double* __restrict__ G = pb.G;
+    const int n = pb.n;
+    TriShared t = tri_carve(smem);
+    if (stamps && tid == 0) {
+        stamps[0] = __builtin_amdgcn_s_memrealtime();
+        stamps[6] = __builtin_readcyclecounter();
+    }
     const int r = tid >> 2, q = tid & 3;
     // ---- load: thread (r, q) owns the column pairs c = 2q + 8k + {0,1}, k = 0..15 of row r ----
     // (A[2k+h], 32 doubles); its LDS operands are 16-byte reads, broadcast across the 16 rows of a wave.
@@ -380,8 +432,10 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         }
         __syncthreads();
     }
-    TRI_STAMP(1);
-    if (stamps && tid == 0) stamps[7] = __builtin_readcyclecounter();
+    if (stamps && tid == 0) {
+        stamps[1] = __builtin_amdgcn_s_memrealtime();
+        stamps[7] = __builtin_readcyclecounter();
+    }
     // ---- e^2 and Gershgorin bounds ----------------------------------------------------------
     if (tid < n) t.de[2 * tid + 1] = tid > 0 ? t.es[tid - 1] * t.es[tid - 1] : 0.0;
     if (wave == 0) {
@@ -403,128 +457,233 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         }
     }
     __syncthreads();
-    // ---- multisection bisection for the K largest eigenvalues --------------------------------
-    {
-        const int grp = tid >> 4, sec = tid & 15;
-        if (grp < K) {
-            double lo = t.misc[0], hi = t.misc[1];
-            const int target = n - 1 - grp;   // ascending index of the grp-th largest
-            for (int it = 0; it < TRI_NSTEP; ++it) {
-                const double h = (hi - lo) * (1.0 / 17.0);
-                const double xq = lo + h * (sec + 1);
-                const int cnt = sturm_count(t.de, n, xq);
-                const unsigned long long b = __ballot(cnt <= target);
-                const int jj = __popc((unsigned)((b >> (lane & 48)) & 0xFFFFull));
-                const double nlo = jj > 0 ? lo + h * jj : lo;
-                const double nhi = jj < 16 ? lo + h * (jj + 1) : hi;
-                lo = nlo;
-                hi = nhi;
-            }
-            if (sec == 0) t.lam[grp] = 0.5 * (lo + hi);
-        }
+    // ---- publish T, the reflectors and the bounds ------------------------------------------------
+    if (tid < 256) ws[WS_DE + tid] = tid < 2 * n ? t.de[tid] : 0.0;
+    if (tid < 128) {
+        ws[WS_ES + tid] = tid < n ? t.es[tid] : 0.0;
+        ws[WS_TAU + tid] = tid < n - 1 ? t.taus[tid] : 0.0;
     }
+    const int nv = (n * (n - 1)) / 2;
+    for (int i = tid; i < nv; i += EIG_THREADS) ws[WS_VS + i] = t.Vs[i];
+    if (tid == 0) {
+        ws[WS_MISC + 0] = t.misc[0];
+        ws[WS_MISC + 1] = t.misc[1];
+        ws[WS_MISC + 2] = t.misc[2];
+        ws[WS_MISC + 3] = 1.0;
+    }
+}
+
+// =====================================================================================
+// k_eig_vec: one workgroup per eigenvalue
+// =====================================================================================
+__global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int going_left, int rawn, int rawalg,
+                                                         double* __restrict__ ws, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int cnt_s[8];
+    __shared__ double red_s[8];
+    __shared__ int arg_s[8];
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, rawalg);
+    const int k = blockIdx.x;
+    if (!pb.tri || k >= pb.K0) return;
+    const int n = pb.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* Vs = smem;              // [8128]
+    double* de = Vs + 8128;         // [256]
+    double* es = de + 256;          // [128]
+    double* taus = es + 128;        // [128]
+    double* Dm = taus + 128;        // [128] D^-_i  (bottom-up pivots)
+    double* Ub = Dm + 128;          // [128] U_i
+    double* Dp = Ub + 128;          // [128] D_i    (top-down pivots)
+    double* Lb = Dp + 128;          // [128] L_i
+    double* z = Lb + 128;           // [128]
+    const bool st = stamps && k == 0 && tid == 0;
+    if (st) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    // ---- stage T (needed now) and request the reflectors (needed last) ----------------------------
+    de[tid] = ws[WS_DE + tid];
+    if (tid < 128) {
+        es[tid] = ws[WS_ES + tid];
+        taus[tid] = ws[WS_TAU + tid];
+    }
+    const int nv = (n * (n - 1)) / 2;
+    double vstage[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const int i = tid + m * VEC_THREADS;
+        vstage[m] = i < nv ? ws[WS_VS + i] : 0.0;
+    }
+    double lo = ws[WS_MISC + 0], hi = ws[WS_MISC + 1];
+    const double tnorm = ws[WS_MISC + 2];
     __syncthreads();
-    K = select(t.lam, K);
-    TRI_STAMP(2);
-    // ---- eigenvectors of T: twisted factorisation, one lane per eigenvalue ------------------------
-    if (tid < K) {
-        const int k = tid;
-        const double lamk = t.lam[k];
-        const double pivmin = 1e-290 + 1e-30 * t.misc[2];
-        double* z = t.Z + k;     // stride 32
-        double* ub = t.Ub + k;
-        double dm = t.de[2 * (n - 1)] - lamk;
+    // ---- 256-way multisection for the k-th largest eigenvalue -------------------------------------
+    const int target = n - 1 - k;       // ascending index
+    for (int it = 0; it < TRI_NSTEP; ++it) {
+        const double h = (hi - lo) * (1.0 / (VEC_THREADS + 1));
+        const double xq = lo + h * (tid + 1);
+        const int cnt = sturm_count(de, n, xq);
+        const unsigned long long b = __ballot(cnt <= target);
+        if (lane == 0) cnt_s[wave] = __popcll(b);
+        __syncthreads();
+        const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        __syncthreads();
+        const double nlo = jj > 0 ? lo + h * jj : lo;
+        const double nhi = jj < VEC_THREADS ? lo + h * (jj + 1) : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    const double lamk = 0.5 * (lo + hi);
+    // reflectors -> LDS (the loads were issued before the bisection)
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        const int i = tid + m * VEC_THREADS;
+        if (i < nv) Vs[i] = vstage[m];
+    }
+    if (st) stamps[3] = __builtin_amdgcn_s_memrealtime();
+    // ---- eigenvector of T: twisted factorisation --------------------------------------------------
+    // wave 0 lane 0: bottom-up  D^-_i, U_i ;  wave 1 lane 0: top-down  D_i, L_i   (concurrently)
+    const double pivmin = 1e-290 + 1e-30 * tnorm;
+    if (tid == 0) {
+        double dm = de[2 * (n - 1)] - lamk;
         if (fabs(dm) < pivmin) dm = -pivmin;
-        z[(n - 1) * 32] = dm;                              // D^-_{n-1}
+        Dm[n - 1] = dm;
+        double e = n >= 2 ? es[n - 2] : 0.0, dd = n >= 2 ? de[2 * (n - 2)] : 0.0;
         for (int i = n - 2; i >= 0; --i) {
-            const double e = t.es[i];
+            const double en = i > 0 ? es[i - 1] : 0.0, dn = i > 0 ? de[2 * (i - 1)] : 0.0;   // prefetch
             const double u = e * frcp(dm);                 // U_i = e_i / D^-_{i+1}
-            ub[i * 32] = u;
-            dm = (t.de[2 * i] - lamk) - u * e;
+            Ub[i] = u;
+            dm = (dd - lamk) - u * e;
             if (fabs(dm) < pivmin) dm = -pivmin;
-            z[i * 32] = dm;
+            Dm[i] = dm;
+            e = en;
+            dd = dn;
         }
-        double dp = t.de[0] - lamk;
+    } else if (tid == 64) {
+        double dp = de[0] - lamk;
         if (fabs(dp) < pivmin) dp = -pivmin;
-        double gmin = fabs(z[0]);                          // gamma_0 = D^-_0
-        int rb = 0;
+        Dp[0] = dp;
+        double e = es[0], dd = n >= 2 ? de[2] : 0.0;
         for (int i = 0; i < n - 1; ++i) {
-            const double e = t.es[i];
+            const double en = es[i + 1], dn = i + 2 < n ? de[2 * (i + 2)] : 0.0;             // prefetch
             const double l = e * frcp(dp);                 // L_i = e_i / D_i
-            const double sh = t.de[2 * (i + 1)] - lamk;
-            double dn = sh - l * e;
-            if (fabs(dn) < pivmin) dn = -pivmin;
-            const double gam = dn + z[(i + 1) * 32] - sh;  // gamma_{i+1}
-            z[i * 32] = l;
-            if (fabs(gam) < gmin) {
-                gmin = fabs(gam);
-                rb = i + 1;
-            }
-            dp = dn;
+            Lb[i] = l;
+            dp = (dd - lamk) - l * e;
+            if (fabs(dp) < pivmin) dp = -pivmin;
+            Dp[i + 1] = dp;
+            e = en;
+            dd = dn;
         }
-        z[rb * 32] = 1.0;
-        double nrm = 1.0;
-        for (int i = rb - 1; i >= 0; --i) {
-            const double zi = -z[i * 32] * z[(i + 1) * 32];
-            z[i * 32] = zi;
-            nrm += zi * zi;
-        }
-        for (int i = rb; i < n - 1; ++i) {
-            const double zi = -ub[i * 32] * z[i * 32];
-            z[(i + 1) * 32] = zi;
-            nrm += zi * zi;
-        }
-        const double sc = 1.0 / sqrt(nrm);
-        // normalise + residual ||T z - lam z||_inf (verification)
-        double res = 0.0, zprev = 0.0, zc = z[0] * sc;
-        for (int i = 0; i < n; ++i) {
-            const double zn = (i < n - 1) ? z[(i + 1) * 32] * sc : 0.0;
-            const double ri = (t.de[2 * i] - lamk) * zc + (i > 0 ? t.es[i - 1] * zprev : 0.0) +
-                              (i < n - 1 ? t.es[i] * zn : 0.0);
-            res = fmax(res, fabs(ri));
-            z[i * 32] = zc;
-            zprev = zc;
-            zc = zn;
-        }
-        t.misc[32 + k] = res;
     }
     __syncthreads();
-    TRI_STAMP(3);
-    // ---- back-transformation z <- H(0) H(1) ... H(n-2) z, 16 lanes per vector --------------------
+    // twist index r = argmin |gamma_i|, gamma_i = D_i + D^-_i - (d_i - lambda)
     {
-        const int k = tid >> 4, j = tid & 15;
-        if (k < K) {
-            double zz[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int c = j + 16 * m;
-                zz[m] = c < n ? t.Z[c * 32 + k] : 0.0;
-            }
-            for (int i = n - 2; i >= 0; --i) {
-                const double tau = t.taus[i];
-                const double* vi = t.Vs + voff(i, n) - i - 1;    // vi[c] valid for i < c < n
-                double vv[8];
-                double dot = 0.0;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int c = j + 16 * m;
-                    vv[m] = (c > i && c < n) ? vi[c] : 0.0;
-                    dot += vv[m] * zz[m];
-                }
-                dot = sum16(dot);
-                const double f = tau * dot;
-#pragma unroll
-                for (int m = 0; m < 8; ++m) zz[m] -= f * vv[m];
-            }
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int c = j + 16 * m;
-                if (c < n) t.Z[c * 32 + k] = zz[m];
-            }
+        double g = 1e300;
+        int gi = 0;
+        if (tid < n) {
+            g = fabs(Dp[tid] + Dm[tid] - (de[2 * tid] - lamk));
+            gi = tid;
+        }
+        // wave-level argmin (ties -> smallest index), then across the 4 waves
+        const double gmin = -wave_max(-g);
+        const unsigned long long m = __ballot(g == gmin);
+        const int first = __ffsll((long long)m) - 1;
+        const int idx = __builtin_amdgcn_readlane(gi, first);
+        if (lane == 0) {
+            red_s[wave] = gmin;
+            arg_s[wave] = idx;
         }
     }
     __syncthreads();
-    TRI_STAMP(4);
+    int rb = arg_s[0];
+    {
+        double gm = red_s[0];
+        for (int w = 1; w < VEC_THREADS / 64; ++w)
+            if (red_s[w] < gm) {
+                gm = red_s[w];
+                rb = arg_s[w];
+            }
+    }
+    // substitution: downwards from the twist on wave 0, upwards on wave 1
+    if (tid == 0) {
+        double zc = 1.0, nrm = 1.0;
+        z[rb] = 1.0;
+        for (int i = rb - 1; i >= 0; --i) {
+            zc = -Lb[i] * zc;
+            z[i] = zc;
+            nrm += zc * zc;
+        }
+        red_s[4] = nrm;
+    } else if (tid == 64) {
+        double zc = 1.0, nrm = 0.0;
+        for (int i = rb; i < n - 1; ++i) {
+            zc = -Ub[i] * zc;
+            z[i + 1] = zc;
+            nrm += zc * zc;
+        }
+        red_s[5] = nrm;
+    }
+    __syncthreads();
+    const double sc = 1.0 / sqrt(red_s[4] + red_s[5]);
+    // normalise; residual ||T z - lambda z||_inf (verification)
+    double zi = 0.0, ri = 0.0;
+    if (tid < n) {
+        zi = z[tid] * sc;
+        const double zp = tid > 0 ? z[tid - 1] * sc : 0.0, zn = tid < n - 1 ? z[tid + 1] * sc : 0.0;
+        ri = fabs((de[2 * tid] - lamk) * zi + (tid > 0 ? es[tid - 1] * zp : 0.0) + (tid < n - 1 ? es[tid] * zn : 0.0));
+    }
+    ri = wave_max(ri);
+    __syncthreads();
+    if (tid < n) z[tid] = zi;
+    if (lane == 0) red_s[wave] = ri;
+    __syncthreads();
+    if (st) stamps[4] = __builtin_amdgcn_s_memrealtime();
+    // ---- back-transformation z <- H(0) H(1) ... H(n-2) z on wave 0, two reflectors per step -----------
+    //   z' = z - t2 v2 (v2.z);  z'' = z' - t1 v1 (v1.z'),  v1.z' = v1.z - t2 (v1.v2)(v2.z):
+    //   the three inner products reduce together, halving the length of the dependent chain.
+    if (wave == 0) {
+        const int c0 = lane, c1 = lane + 64;
+        double z0 = c0 < n ? z[c0] : 0.0, z1 = c1 < n ? z[c1] : 0.0;
+        int i = n - 2;
+        for (; i >= 1; i -= 2) {
+            const double* v2 = Vs + voff(i, n) - i - 1;          // reflector i     (applied first)
+            const double* v1 = Vs + voff(i - 1, n) - i;          // reflector i - 1
+            const double a20 = (c0 > i && c0 < n) ? v2[c0] : 0.0, a21 = (c1 > i && c1 < n) ? v2[c1] : 0.0;
+            const double a10 = (c0 > i - 1 && c0 < n) ? v1[c0] : 0.0, a11 = (c1 > i - 1 && c1 < n) ? v1[c1] : 0.0;
+            double pa = a20 * z0 + a21 * z1, pb2 = a10 * z0 + a11 * z1, pc = a10 * a20 + a11 * a21;
+            pa = sum16(pa);
+            pb2 = sum16(pb2);
+            pc = sum16(pc);
+            const double sa = (readlane_f64(pa, 0) + readlane_f64(pa, 16)) + (readlane_f64(pa, 32) + readlane_f64(pa, 48));
+            const double sb = (readlane_f64(pb2, 0) + readlane_f64(pb2, 16)) + (readlane_f64(pb2, 32) + readlane_f64(pb2, 48));
+            const double scc = (readlane_f64(pc, 0) + readlane_f64(pc, 16)) + (readlane_f64(pc, 32) + readlane_f64(pc, 48));
+            const double al2 = taus[i] * sa;
+            const double al1 = taus[i - 1] * (sb - scc * al2);
+            z0 -= al2 * a20 + al1 * a10;
+            z1 -= al2 * a21 + al1 * a11;
+        }
+        if (i == 0) {
+            const double* v0 = Vs - 1;                           // voff(0) - 0 - 1
+            const double a0 = (c0 > 0 && c0 < n) ? v0[c0] : 0.0, a1 = (c1 > 0 && c1 < n) ? v0[c1] : 0.0;
+            const double f = taus[0] * wave_sum(a0 * z0 + a1 * z1);
+            z0 -= f * a0;
+            z1 -= f * a1;
+        }
+        double* Zk = ws + WS_Z + (size_t)k * 128;
+        if (c0 < n) Zk[c0] = z0;
+        if (c1 < n) Zk[c1] = z1;
+        if (lane == 0) {
+            ws[WS_LAM + k] = lamk;
+            ws[WS_RES + k] = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
+        }
+    }
+    if (st) stamps[5] = __builtin_amdgcn_s_memrealtime();
+}
+
+// =====================================================================================
+// k_eig_fin: truncation, verification, re-orthonormalisation, publication (or Jacobi)
+// =====================================================================================
+// Verifies the K vectors in t.Z ([c*32 + k]) against the residuals in t.misc[32..] and
+// re-orthonormalises them; returns false if the Jacobi path has to take over.
+__device__ bool verify_and_polish(TriShared t, int n, int K) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- verification + symmetric (Loewdin) re-orthonormalisation ---------------------------------
     // D = Z^T Z - I; Z <- Z (I - D/2) squares the deviation without leaving the subspace.  Up to two
     // rounds: close (but separated) eigenvalues leave |D| ~ 1e-6, genuine clusters leave |D| ~ 1 and
@@ -589,40 +748,35 @@ __device__ bool tri_solve(const double* __restrict__ G, int n, int K, TriShared 
         __syncthreads();
         if (emax < 1e-8) break;                       // one round suffices: residual |D|^2 < 1e-16
     }
-    TRI_STAMP(5);
-#undef TRI_STAMP
     return ok;
 }
 
-// =====================================================================================
-// Engine kernel: eigen-decompose v.gram, apply the NDTensors truncation rule, publish
-// n_keep / chi / inv_norm / spectrum and the kept eigenvectors E[dim][ldE].
-// =====================================================================================
-__global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_left) {
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                         int rawalg, double* __restrict__ ws, double* rawlam,
+                                                         double* rawE, int32_t* rawinfo, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double lam_s[MAX_DIM + 2];
     __shared__ double red[16];
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
     const int tid = threadIdx.x;
-    const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
-    const int X = Dl * v.d, Y = v.d * Dr;
-    const int n = going_left ? Y : X;
-    const int rows = v.C * (going_left ? X : Y);
-    const int nspec = rows < n ? rows : n;                    // LAPACK's min(m, n)
-    const int K0 = nspec < v.chi_max ? nspec : v.chi_max;     // eigenpairs that can survive maxdim
-    const int ldE = v.cap;
+    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
+    const bool raw = rawn > 0;
+    double* Eout = raw ? rawE : v.E;
+    const int ldE = raw ? n : v.cap;
+    if (stamps && tid == 0) stamps[8] = __builtin_amdgcn_s_memrealtime();
     // trace = ||bt_new||_F^2 (fixed order)
     double tr = 0.0;
-    for (int i = tid; i < n; i += EIG_THREADS) tr += v.gram[(size_t)i * n + i];
+    for (int i = tid; i < n; i += EIG_THREADS) tr += pb.G[(size_t)i * n + i];
     tr = wave_sum(tr);
     if ((tid & 63) == 0) red[tid >> 6] = tr;
     __syncthreads();
     tr = 0.0;
     for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
     __syncthreads();
-
-    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+    const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
+    const double cutoff = raw ? -1.0 : v.cutoff;
     // NDTensors truncate! (relative cutoff) on P = lambda*inv^2.  The weight beyond the
-    // first K0 values is trace - sum(first K0).  Evaluated redundantly by every thread.
+    // first K values is trace - sum(first K).  Evaluated redundantly by every thread.
     auto truncate = [&](const double* lam, int K) -> int {
         const double inv2 = inv * inv;
         const double scale0 = tr * inv2;
@@ -633,107 +787,116 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig(View v, int lid, int going_
         double truncerr = scale0 - kept;
         if (truncerr < 0.0 || nspec <= K) truncerr = 0.0;
         if (nspec > 1) {
-            while (nk > 1 && truncerr + lam[nk - 1] * inv2 <= v.cutoff * scale) {
+            while (nk > 1 && truncerr + lam[nk - 1] * inv2 <= cutoff * scale) {
                 truncerr += lam[nk - 1] * inv2;
                 --nk;
             }
         }
         return nk;
     };
-    int sweeps = 0;
+    int sweeps = 0, nk = K0;
     bool done = false;
-    int nk = K0;
-    if (v.svd_alg != MPST_SVD_JACOBI && K0 <= TRI_KMAX && n >= 2) {
+    const bool tri = pb.tri && ws[WS_MISC + 3] == 1.0;
+    if (tri) {
         TriShared t = tri_carve(smem);
-        done = tri_solve(v.gram, n, K0, t, v.sc->eig_stamps, [&](const double* lam, int K) {
-            nk = truncate(lam, K);
-            return nk;
-        });
+        if (tid < K0) lam_s[tid] = ws[WS_LAM + tid];
+        __syncthreads();
+        nk = truncate(lam_s, K0);
+        // eigenvectors of values the truncation rule discards are never looked at: those are the
+        // clustered, noise-level ones for which the twisted factorisation loses orthogonality
+        for (int i = tid; i < 128 * 32; i += EIG_THREADS) {
+            const int c = i >> 5, kk = i & 31;
+            t.Z[i] = (c < n && kk < nk) ? ws[WS_Z + (size_t)kk * 128 + c] : 0.0;
+        }
+        if (tid < 32) t.misc[32 + tid] = tid < nk ? ws[WS_RES + tid] : 0.0;
+        if (tid == 0) t.misc[2] = ws[WS_MISC + 2];
+        __syncthreads();
+        done = verify_and_polish(t, n, nk);
         if (done) {
-            if (tid < K0) lam_s[tid] = t.lam[tid];
             for (int i = tid; i < n * nk; i += EIG_THREADS) {
-                const int c = i / nk, k = i - c * nk;
-                v.E[(size_t)c * ldE + k] = t.Z[c * 32 + k];
+                const int c = i / nk, kk = i - c * nk;
+                Eout[(size_t)c * ldE + kk] = t.Z[c * 32 + kk];
             }
         }
         __syncthreads();
     }
-    const bool fell_back = !done && v.svd_alg != MPST_SVD_JACOBI && K0 <= TRI_KMAX && n >= 2;
+    const bool fell_back = !done && pb.tri;
     if (!done) {
-        sweeps = jacobi_solve(v.gram, n, smem, lam_s, v.E, ldE, K0);
+        const int kc = raw ? n : K0;
+        sweeps = jacobi_solve(pb.G, n, smem, lam_s, Eout, ldE, kc);
         if (sweeps == 0) sweeps = 1;
         __syncthreads();
         nk = truncate(lam_s, K0);
     }
     __syncthreads();
-    if (tid < K0) v.lam[tid] = lam_s[tid];
-    if (tid == 0) {
-        bool bad = !(tr == tr) || tr > 1e300;
-        for (int i = 0; i < K0; ++i) {
-            const double P = lam_s[i] * inv * inv;
-            if (!(P == P) || P > 1e300) bad = true;
+    if (raw) {
+        const int nl = done ? K0 : n;
+        if (tid < nl) rawlam[tid] = lam_s[tid];
+        if (tid == 0) *rawinfo = done ? -1 : (pb.tri ? 0 : sweeps);
+    } else {
+        if (tid < K0) v.lam[tid] = lam_s[tid];
+        if (tid == 0) {
+            bool bad = !(tr == tr) || tr > 1e300;
+            for (int i = 0; i < K0; ++i) {
+                const double P = lam_s[i] * inv * inv;
+                if (!(P == P) || P > 1e300) bad = true;
+            }
+            v.sc->n_keep = nk;
+            v.sc->n_spec = K0;
+            v.sc->bt_norm2 = tr;
+            v.sc->inv_norm = inv;
+            v.sc->eig_sweeps = sweeps;
+            v.sc->eig_sweeps_total += sweeps;
+            if (fell_back) v.sc->eig_fallbacks += 1;
+            if (bad || sweeps >= EIG_MAX_SWEEPS) v.sc->status = MPST_ERR_SVD;
+            v.chi[lid + 1] = nk;
         }
-        v.sc->n_keep = nk;
-        v.sc->n_spec = K0;
-        v.sc->bt_norm2 = tr;
-        v.sc->inv_norm = inv;
-        v.sc->eig_sweeps = sweeps;
-        v.sc->eig_sweeps_total += sweeps;
-        if (fell_back) v.sc->eig_fallbacks += 1;
-        if (bad || sweeps >= EIG_MAX_SWEEPS) v.sc->status = MPST_ERR_SVD;
-        v.chi[lid + 1] = nk;
     }
+    if (stamps && tid == 0) stamps[9] = __builtin_amdgcn_s_memrealtime();
 }
 
-// Raw variant for tests.  alg 1: Jacobi, full spectrum, *info = sweeps.  alg 0/2: tridiagonal
-// path, top K = min(n, 32) eigenpairs (the remaining outputs are zero), *info = -1; if the
-// device-side verification failed Jacobi is used instead and *info = 0.
-__global__ __launch_bounds__(EIG_THREADS) void k_eig_raw(const double* G, int n, int alg, double* lam, double* E,
-                                                         int32_t* info) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double lam_s[MAX_DIM + 2];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < n * n; i += EIG_THREADS) E[i] = 0.0;
-    if (tid < n) lam[tid] = 0.0;
-    __syncthreads();
-    if (alg != MPST_SVD_JACOBI && n >= 2) {
-        const int K = n < TRI_KMAX ? n : TRI_KMAX;
-        TriShared t = tri_carve(smem);
-        const bool ok = tri_solve(G, n, K, t, nullptr, [](const double*, int K_) { return K_; });
-        if (ok) {
-            if (tid < K) lam[tid] = t.lam[tid];
-            for (int i = tid; i < n * K; i += EIG_THREADS) {
-                const int c = i / K, k = i - c * K;
-                E[(size_t)c * n + k] = t.Z[c * 32 + k];
-            }
-            if (tid == 0) *info = -1;
-            return;
-        }
-        __syncthreads();
-    }
-    const int sweeps = jacobi_solve(G, n, smem, lam_s, E, n, n);
-    if (tid < n) lam[tid] = lam_s[tid];
-    if (tid == 0) *info = (alg != MPST_SVD_JACOBI && n >= 2) ? 0 : sweeps;
+// raw-mode helper: clear the outputs of the test entry point
+__global__ void k_eig_clear(double* lam, double* E, int n) {
+    for (int i = threadIdx.x; i < n * n; i += blockDim.x) E[i] = 0.0;
+    if (threadIdx.x < (unsigned)n) lam[threadIdx.x] = 0.0;
 }
 
 static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double); }
+static size_t tri_lds_bytes() { return (size_t)(8128 + 256 * 3 + 128 * 2 + 32 + 192 + 64) * sizeof(double); }
+static size_t vec_lds_bytes() { return (size_t)(8128 + 256 + 128 * 7 + 16) * sizeof(double); }
 
 static bool g_attr_set = false;
 static void ensure_attrs() {
     if (g_attr_set) return;
-    (void)hipFuncSetAttribute((const void*)k_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_eig_raw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes());
     g_attr_set = true;
 }
 
+size_t eig_workspace_doubles() { return WS_TOTAL; }
+
 void launch_eig(const View& v, int lid, int going_left, hipStream_t s) {
     ensure_attrs();
-    hipLaunchKernelGGL(k_eig, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left);
+    unsigned long long* st = v.sc ? v.sc->eig_stamps : nullptr;
+    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
+                       (const double*)nullptr, 0, 0, v.eig_ws, st);
+    hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
+                       v.eig_ws, st);
+    hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
+                       (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
 }
 
-void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* sweeps, hipStream_t s) {
+void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {
     ensure_attrs();
-    hipLaunchKernelGGL(k_eig_raw, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, G, n, alg, lam, E, sweeps);
+    View v{};
+    hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
+    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
+                       (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
+                       (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws, lam, E, info,
+                       (unsigned long long*)nullptr);
 }
 
 }  // namespace mpst

@@ -97,7 +97,7 @@ struct DevScalars {
     int32_t eig_sweeps_total;
     int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
     int32_t pad[2];
-    unsigned long long eig_stamps[8];   // s_memrealtime (100 MHz) at the phase boundaries of the last k_eig
+    unsigned long long eig_stamps[12];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
 };
 
 // One encoded data set on the device.
@@ -143,6 +143,7 @@ struct View {
     double* gram;       // [MAX_DIM*MAX_DIM]
     double* lam;        // [MAX_DIM]
     double* E;          // [MAX_DIM][ldE = cap] eigenvectors of the kept subspace
+    double* eig_ws;     // eigensolver workspace (tridiagonal matrix, reflectors, eigenpairs)
     DevScalars* sc;
     // options
     int32_t loss, optimiser, rescale_before, rescale_after, train_sep, svd_alg;
@@ -174,6 +175,7 @@ void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hi
 
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, hipStream_t s);
-void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* sweeps, hipStream_t s);
+void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
+size_t eig_workspace_doubles();
 
 }  // namespace mpst
