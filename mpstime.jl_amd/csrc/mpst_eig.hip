@@ -221,28 +221,42 @@ __device__ __forceinline__ double frcp(double b) {
 }
 
 // # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free with
-// power-of-two rescaling every 8 steps.
+// power-of-two rescaling every 8 steps.  (d_j, e_{j-1}^2) pairs are fetched 8 at a time so the LDS
+// latency is paid once per 8 steps (this loop runs at one wave per SIMD).
 __device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n, double x) {
+    const double2* __restrict__ de2 = (const double2*)de;
     double pp = 1.0, p = de[0] - x;
     int cnt = ((unsigned)hi32(p)) >> 31;
-    for (int j = 1; j < n; ++j) {
-        const double t = de[2 * j] - x;
-        const double pn = fma(t, p, -de[2 * j + 1] * pp);
+    int j = 1;
+    for (; j + 8 <= n; j += 8) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = de2[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double t = v[u].x - x;
+            const double pn = fma(t, p, -v[u].y * pp);
+            cnt += ((unsigned)(hi32(pn) ^ hi32(p))) >> 31;
+            pp = p;
+            p = pn;
+        }
+        int e = (hi32(p) >> 20) & 0x7ff;
+        if (e == 0) e = (hi32(pp) >> 20) & 0x7ff;
+        e = e < 2 ? 2 : (e > 2044 ? 2044 : e);
+        const double sc = __hiloint2double((2046 - e) << 20, 0);
+        p *= sc;
+        pp *= sc;
+    }
+    for (; j < n; ++j) {
+        const double2 v = de2[j];
+        const double t = v.x - x;
+        const double pn = fma(t, p, -v.y * pp);
         cnt += ((unsigned)(hi32(pn) ^ hi32(p))) >> 31;
         pp = p;
         p = pn;
-        if ((j & 7) == 0) {
-            int e = (hi32(p) >> 20) & 0x7ff;
-            if (e == 0) e = (hi32(pp) >> 20) & 0x7ff;
-            e = e < 2 ? 2 : (e > 2044 ? 2044 : e);
-            const double sc = __hiloint2double((2046 - e) << 20, 0);
-            p *= sc;
-            pp *= sc;
-        }
     }
     return cnt;
 }
-
 
 // ---- global workspace shared by the three kernels (doubles) ----------------------------------
 constexpr int WS_DE = 0;        // [128][2]  (d_j, e_{j-1}^2)
@@ -286,7 +300,16 @@ __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_
 // =====================================================================================
 // k_eig_tri
 // =====================================================================================
-__global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
+// Layout constants of the register-resident matrix: TRI_T threads, thread (r, q) owns NE elements of
+// row r as column pairs c = 2q + 2*QN*k + {0,1}; a wave holds RPW consecutive rows.
+constexpr int TRI_T = 1024;
+constexpr int QN = TRI_T / 128;          // threads per row
+constexpr int NE = 16384 / TRI_T;        // elements per thread
+constexpr int NP = NE / 2;               // column pairs per thread
+constexpr int RPW = 64 / QN;             // rows per wave
+__device__ __forceinline__ double sum_q(double x) { return QN == 8 ? sum8(x) : sum4(x); }
+
+__global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
                                                          int rawalg, double* __restrict__ ws,
                                                          unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -303,15 +326,15 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
         stamps[0] = __builtin_amdgcn_s_memrealtime();
         stamps[6] = __builtin_readcyclecounter();
     }
-    const int r = tid >> 2, q = tid & 3;
+    const int r = tid / QN, q = tid % QN;
     // ---- load: thread (r, q) owns the column pairs c = 2q + 8k + {0,1}, k = 0..15 of row r ----
     // (A[2k+h], 32 doubles); its LDS operands are 16-byte reads, broadcast across the 16 rows of a wave.
-    double A[32];
+    double A[NE];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < NP; ++k) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int c = 2 * q + 8 * k + h;
+            const int c = 2 * q + 2 * QN * k + h;
             A[2 * k + h] = (r < n && c < n) ? G[(size_t)r * n + c] : 0.0;
         }
     }
@@ -334,7 +357,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
         double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
         if (r == i) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *(double2*)&xr[2 * q + 8 * k] = make_double2(A[2 * k], A[2 * k + 1]);
+            for (int k = 0; k < NP; ++k) *(double2*)&xr[2 * q + 2 * QN * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
         const int c0 = lane, c1 = lane + 64;
         const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
@@ -364,25 +387,25 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
     for (int i = 0; i < n - 1; ++i) {
         const double* vb = t.xs + (i & 1) * 128;
         double* p = t.ps + (i & 1) * 128;
-        const bool live = (wave * 16 + 15) > i;    // this wave still owns trailing rows
-        const bool next_owner = (i + 1 < n - 1) && wave == ((i + 1) >> 4);
+        const bool live = (wave * RPW + RPW - 1) > i;    // this wave still owns trailing rows
+        const bool next_owner = (i + 1 < n - 1) && wave == ((i + 1) / RPW);
         const double tau = t.taus[i];
-        double2 vv[16];
+        double2 vv[NP];
         if (live) {
             if (next_owner) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) vv[k] = *(const double2*)&vb[2 * q + 8 * k];
+            for (int k = 0; k < NP; ++k) vv[k] = *(const double2*)&vb[2 * q + 2 * QN * k];
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 16; k += 2) {
+            for (int k = 0; k < NP; k += 2) {
                 acc0 = fma(A[2 * k], vv[k].x, acc0);
                 acc1 = fma(A[2 * k + 1], vv[k].y, acc1);
                 acc2 = fma(A[2 * k + 2], vv[k + 1].x, acc2);
                 acc3 = fma(A[2 * k + 3], vv[k + 1].y, acc3);
             }
-            const double acc = sum4((acc0 + acc1) + (acc2 + acc3));
+            const double acc = sum_q((acc0 + acc1) + (acc2 + acc3));
             if (q == 0) p[r] = (r > i) ? tau * acc : 0.0;
-        } else if (wave * 16 + 15 == i) {
+        } else if (wave * RPW + RPW - 1 == i) {
             // this wave's rows have just retired: clear their p entries in both buffers for good
             if (q == 0) {
                 t.ps[r] = 0.0;
@@ -398,10 +421,10 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
             const double wr = pr + a2 * vr;
             const double g = a2 * vr + wr;
 #pragma unroll
-            for (int kb = 0; kb < 16; kb += 8) {
+            for (int kb = 0; kb < NP; kb += 8) {
                 double2 pv[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pv[k] = *(const double2*)&p[2 * q + 8 * (kb + k)];
+                for (int k = 0; k < 8; ++k) pv[k] = *(const double2*)&p[2 * q + 2 * QN * (kb + k)];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int kk = kb + k;
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
         __syncthreads();
         if (r == n - 1) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) *(double2*)&x[2 * q + 8 * k] = make_double2(A[2 * k], A[2 * k + 1]);
+            for (int k = 0; k < NP; ++k) *(double2*)&x[2 * q + 2 * QN * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
         __syncthreads();
         if (tid == 0) {
@@ -464,7 +487,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_tri(View v, int lid, int go
         ws[WS_TAU + tid] = tid < n - 1 ? t.taus[tid] : 0.0;
     }
     const int nv = (n * (n - 1)) / 2;
-    for (int i = tid; i < nv; i += EIG_THREADS) ws[WS_VS + i] = t.Vs[i];
+    for (int i = tid; i < nv; i += TRI_T) ws[WS_VS + i] = t.Vs[i];
     if (tid == 0) {
         ws[WS_MISC + 0] = t.misc[0];
         ws[WS_MISC + 1] = t.misc[1];
@@ -879,7 +902,7 @@ size_t eig_workspace_doubles() { return WS_TOTAL; }
 void launch_eig(const View& v, int lid, int going_left, hipStream_t s) {
     ensure_attrs();
     unsigned long long* st = v.sc ? v.sc->eig_stamps : nullptr;
-    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
+    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
                        (const double*)nullptr, 0, 0, v.eig_ws, st);
     hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
                        v.eig_ws, st);
@@ -891,7 +914,7 @@ void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int
     ensure_attrs();
     View v{};
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
-    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
+    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
                        (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
                        (unsigned long long*)nullptr);
