@@ -1,4 +1,4 @@
-"""ctypes driver of oracle/mps_oracle.c (TEST INFRASTRUCTURE ONLY; parity unpinned - see the C header).
+"""ctypes driver of oracle/mps_oracle.c (TEST INFRASTRUCTURE ONLY; sweep parity unpinned - see the C header).
 
 LAPACK ``dgesdd`` is taken from SciPy's bundled LAPACK through the C function pointer
 exported by ``scipy.linalg.cython_lapack`` - the same routine Julia's DivideAndConquer SVD calls.

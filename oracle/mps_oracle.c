@@ -3,8 +3,9 @@
  *
  * TEST INFRASTRUCTURE ONLY: the checker for tests/ and the "cpu_baseline" (kind "port")
  * leg of bench.py.  Never linked into or called by the shipped library.
- * PARITY UNPINNED against the Julia reference (it cannot run here); pinned against
- * oracle/ref_numpy.py (tests/test_oracle.py), which follows the same source lines.
+ * PARITY of the sweep itself UNPINNED against the Julia reference (it cannot run here); pinned against
+ * oracle/ref_numpy.py (tests/test_oracle.py), which follows the same source lines and whose encoding /
+ * contraction / container conventions ARE pinned on reference-produced tensors (see its header).
  *
  * It keeps the reference's loop structure so that it can stand in for "the reference CPU
  * path" when timed: one series at a time, the fused

@@ -1,6 +1,6 @@
 """Independent formulation of the per-bond loss and gradient (torch fp64 autograd).
 
-TEST INFRASTRUCTURE ONLY (see oracle/ref_numpy.py header; parity unpinned).
+TEST INFRASTRUCTURE ONLY (see oracle/ref_numpy.py header; sweep parity unpinned).
 
 Plays the role of the reference's own cross-check between its array engine and
 its legacy ITensor engine (test/classification.jl:24): the loss is written as

@@ -4,13 +4,24 @@ TEST INFRASTRUCTURE ONLY.  Nothing in the shipped package imports this file;
 it is the checker for tests/, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of bench.py.
 
-PARITY UNPINNED: the Julia/ITensors reference cannot be executed in the build
-container (no Julia, no network) and none of the reference's own known-answer
+PARITY PARTIALLY PINNED.  The Julia/ITensors reference cannot be executed in
+the build container (no Julia, no network) and none of its own known-answer
 tests for this path is evaluable without it (they need the ItalyPowerDemand
-download plus Julia's seeded ``random_mps``).  This restatement therefore
-follows the cited source lines literally and is cross-checked against an
-independent formulation (oracle/naive.py), but it has never been compared
-with output of the reference itself.
+download plus Julia's seeded ``random_mps``).  What IS pinned against
+reference-produced tensors (tests/golden/ref_ecg200_trained_mps.npz, extracted
+from the reference's serialised TrainedMPS test/Data/ecg200/mps_saves/
+test_dataset.jld2 by tests/golden/extract_jld2_fixture.py; checked in
+tests/test_reference_fixture.py):
+  * transform_train_data + legendre_encode reproduce the reference's stored
+    product states to 3e-15 (rows A14/A15 of SURVEY.md section 8);
+  * the container conventions, the canonical form a finished fitMPS leaves
+    (left-orthonormal sites, label on the last site, unit norm) and
+    contract_mps / mse_loss_acc / classify on that MPS (100 % train accuracy,
+    rows A12/A13/A17/A18).
+The sweep's optimiser trajectory itself (loss/gradient, update, truncated SVD:
+rows A1-A11) is still PARITY UNPINNED: it follows the cited source lines
+literally and is cross-checked against an independent formulation
+(oracle/naive.py), but has never been compared with output of the reference.
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference/).

@@ -72,3 +72,29 @@ def test_dimension_limit_is_reported(engine_cls):
             e.build_caches()
     finally:
         e.close()
+
+
+def test_rccl_single_rank_communicator_is_a_no_op(engine_cls):
+    """The all-reduce leg of the sharded sweep (mpst_comm_init + ncclAllReduce on the engine's stream)
+    with a 1-rank communicator must give the same bits as the engine without a communicator."""
+    import ctypes as C
+    from oracle import ref_numpy as R
+    from tests.helpers import load_engine, make_problem
+    ds, W = make_problem(96, 10, 3, 3, 2, seed=21, balanced=False)
+    opts = R.SweepOptions(chi_max=6, eta=0.05)
+    out = []
+    for use_comm in (False, True):
+        eng = engine_cls(0)
+        load_engine(eng, ds, W, opts)
+        if use_comm:
+            uid = (C.c_uint8 * 128)()
+            assert eng.lib.mpst_comm_unique_id(uid) == 0
+            eng._chk(eng.lib.mpst_comm_init(eng.ctx, uid, 1, 0))
+        eng.build_caches()
+        eng.sweep()
+        eng.sweep()
+        out.append((eng.get_mps(), eng.eval(0)))
+        eng.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b)
+    assert out[0][1][:3] == out[1][1][:3] and np.array_equal(out[0][1][3], out[1][1][3])

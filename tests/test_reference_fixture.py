@@ -1,0 +1,116 @@
+"""Pin against REFERENCE-PRODUCED data: tests/golden/ref_ecg200_trained_mps.npz holds the tensors of
+the reference's own serialised TrainedMPS (test/Data/ecg200/mps_saves/test_dataset.jld2, extracted by
+tests/golden/extract_jld2_fixture.py): class-sorted raw ECG200 series, the product states the reference
+encoded from them (default MPSOptions: RobustSigmoid + MinMax, Legendre_No_Norm d=5), and the MPS its
+fitMPS returned (chi_max=25, label index on the last site).
+
+What this pins: A14/A15 preprocessing+encoding bit-for-bit (1e-13), A12/A17/A18
+container conventions and the canonical form the sweep leaves behind (left-orthonormal sites, unit
+norm after normalize!), A13 contract_mps / classify on a real trained MPS.  The optimiser trajectory
+of the sweep itself (A1-A11) has no reference vectors and stays unpinned.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import mpstime_jl_amd as mt
+from oracle import ref_numpy as R
+
+FIX = os.path.join(os.path.dirname(__file__), "golden", "ref_ecg200_trained_mps.npz")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    z = np.load(FIX)
+    T = z["pstates"].shape[1]
+    W = [z[f"W_{j}"] for j in range(T)]
+    cd = z["class_distribution"]
+    label_index = np.repeat(np.arange(len(cd)), cd)          # original_data is class-sorted (encode_dataset)
+    return dict(X=z["original_data"], phi=z["pstates"], W=W, cd=cd, label_index=label_index,
+                d=int(z["d"]), chi_max=int(z["chi_max"]), chi=z["chi"])
+
+
+def test_oracle_encoding_reproduces_reference_pstates(ref):
+    Xs, _ = R.transform_train_data(ref["X"])
+    phi = R.legendre_encode(Xs, ref["d"])
+    assert phi.shape == ref["phi"].shape
+    assert np.max(np.abs(phi - ref["phi"])) < 1e-13
+
+
+def test_package_encoding_reproduces_reference_pstates(ref):
+    opts = mt.MPSOptions(verbosity=-1)                       # reference defaults: d=5, Legendre_No_Norm
+    assert opts.d == ref["d"] and opts.chi_max == ref["chi_max"]
+    enc = mt.model_encoding(opts.encoding)
+    Xs, _ = mt.transform_train_data(ref["X"], opts, enc.range)
+    y = ref["label_index"]
+    ds = mt.encode_dataset(ref["X"], Xs, y, enc, opts.d, {0: 0, 1: 1})
+    assert list(ds.class_distribution) == list(ref["cd"])
+    assert np.max(np.abs(ds.phi - ref["phi"])) < 1e-13
+    assert np.array_equal(ds.original_data, ref["X"])
+
+
+def test_reference_mps_canonical_form(ref):
+    W, chi = ref["W"], ref["chi"]
+    assert chi[0] == 1 and chi[-1] == 1 and chi.max() == ref["chi_max"]
+    assert W[-1].ndim == 4 and all(t.ndim == 3 for t in W[:-1])
+    # chi_max and the rank bound (C*d rows on the last bond) of decomposeBT's truncation
+    assert chi[-2] == len(ref["cd"]) * ref["d"]
+    for t in W[:-1]:                                          # a forward sweep leaves left-orthonormal sites
+        m = t.reshape(-1, t.shape[2])
+        assert np.max(np.abs(m.T @ m - np.eye(m.shape[1]))) < 1e-12
+    assert abs(R.mps_norm(W) - 1.0) < 1e-12                   # normalize!(W) at the end of fitMPS
+
+
+def test_oracle_contract_mps_on_reference_mps(ref):
+    ds = R.EncodedSet(ref["phi"], ref["label_index"], ref["cd"])
+    yhat = R.contract_mps(ref["W"], ds.phi)
+    pred = np.argmax(np.abs(yhat), axis=1)
+    assert np.array_equal(pred, ref["label_index"])           # the saved model fits its training set exactly
+    mse, kld, acc = R.mse_loss_acc(ref["W"], ds)[:3]
+    assert acc == 1.0
+    assert abs(kld - (-48.58386481729281)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_engine_eval_on_reference_mps(ref):
+    eng = mt.SweepEngine(0)
+    eng.set_options(chi_max=ref["chi_max"])
+    eng.set_dataset(0, ref["phi"], ref["label_index"], len(ref["cd"]))
+    eng.set_mps(ref["W"])
+    mse, kld, acc, conf = eng.eval(0)
+    ds = R.EncodedSet(ref["phi"], ref["label_index"], ref["cd"])
+    mse_o, kld_o, acc_o = R.mse_loss_acc(ref["W"], ds)[:3]
+    assert acc == 1.0 and np.array_equal(conf, np.diag(ref["cd"]))
+    assert abs(kld - kld_o) < 1e-10 * abs(kld_o)
+    assert abs(mse - mse_o) < 1e-10 * abs(mse_o)
+    pred, yh = eng.classify(0, return_overlaps=True)
+    yo = R.contract_mps(ref["W"], ref["phi"])
+    assert np.array_equal(pred, ref["label_index"])
+    assert np.max(np.abs(yh - yo) / np.abs(yo).max()) < 1e-11
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_engine_sweep_from_reference_mps_matches_oracle(ref):
+    """One teacher-free backward half sweep on the reference's real data from the reference's MPS:
+    per-bond loss / truncation agree with the oracle (d=5, chi=25: d*chi=125, the engine's non-power-of-two path)."""
+    from oracle.c_oracle import COracle
+    opts = R.SweepOptions(chi_max=ref["chi_max"], eta=0.01)
+    eng = mt.SweepEngine(0)
+    eng.set_options(chi_max=opts.chi_max, eta=opts.eta, cutoff=opts.cutoff)
+    eng.set_dataset(0, ref["phi"], ref["label_index"], len(ref["cd"]))
+    eng.set_mps(ref["W"])
+    eng.build_caches()
+    co = COracle(ref["W"], ref["phi"], ref["label_index"], ref["cd"], opts.chi_max, eta=opts.eta)
+    co.build_caches()
+    T = len(ref["W"])
+    nb = 12
+    rec = co.sweep(max_bonds=nb, record=True)
+    for k in range(nb):
+        lid = T - 2 - k
+        g = eng.bond_step(lid, True)
+        o = rec["bonds_rec"][k]
+        assert g["chi"] == o["chi"], (k, g["chi"], o["chi"])
+        assert abs(g["loss"] - o["loss"]) <= 1e-8 * max(1.0, abs(o["loss"])), (k, g["loss"], o["loss"])
+    eng.close()
