@@ -695,6 +695,18 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     return 0;
 }
 
+// not part of the ABI (include/mpstime_hip.h): raw stamp slots for kernel bring-up (-DMPST_TRI_DEBUG)
+int mpst_debug_stamps(void* ctx, unsigned long long* out64) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->sc || !out64) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    DevScalars sc;
+    HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 64; ++i) out64[i] = sc.eig_stamps[i];
+    return 0;
+}
+
 int mpst_selftest_mfma(void* ctx, const double* A, const double* B, int32_t K, double* C_out) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;

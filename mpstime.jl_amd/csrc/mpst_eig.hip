@@ -24,6 +24,7 @@
 //  * MPST_SVD_JACOBI: one-sided (Hestenes) Jacobi on the columns of G in LDS - slow (ms) but
 //    unconditionally robust; column k converges to lambda_k v_k.
 #include "mpst_internal.h"
+#include <type_traits>
 
 namespace mpst {
 
@@ -220,40 +221,50 @@ __device__ __forceinline__ double frcp(double b) {
     return r;
 }
 
-// # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free with
-// power-of-two rescaling every 8 steps.  (d_j, e_{j-1}^2) pairs are fetched 8 at a time so the LDS
-// latency is paid once per 8 steps (this loop runs at one wave per SIMD).
+// # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free, rescaled by
+// a power of two every 8 steps.  (d_j, e_{j-1}^2) pairs are fetched 8 at a time so the LDS latency
+// is paid once per 8 steps.
 __device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n, double x) {
+    // One wave per SIMD runs this loop, so what counts is the number of instructions per step: 3 fp64
+    // ops (d - x, e^2 * p_{j-2}, fma) + 1 integer op that shifts the sign of p_j into a bit queue; the
+    // sign changes of 8 steps are counted with one popcount, the rescaling is a frexp/ldexp pair, and
+    // the 8 (d, e^2) pairs of the next group are requested from LDS before the current 8 are consumed.
+    // (The scalar data path was tried for T - it is wave-uniform - and lost: s_load latency per group.)
     const double2* __restrict__ de2 = (const double2*)de;
     double pp = 1.0, p = de[0] - x;
-    int cnt = ((unsigned)hi32(p)) >> 31;
+    unsigned sb = ((unsigned)hi32(p)) >> 31;      // bit queue of signs, newest in bit 0
+    int cnt = (int)sb;
     int j = 1;
-    for (; j + 8 <= n; j += 8) {
-        double2 v[8];
+    double2 bufA[8], bufB[8];                     // ping-pong: no register copies
+    auto load8 = [&](double2 (&buf)[8], int j0) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = de2[j + u];
+        for (int u = 0; u < 8; ++u) buf[u] = de2[j0 + u];
+    };
+    auto run8 = [&](const double2 (&buf)[8]) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const double t = v[u].x - x;
-            const double pn = fma(t, p, -v[u].y * pp);
-            cnt += ((unsigned)(hi32(pn) ^ hi32(p))) >> 31;
+            const double t = buf[u].x - x;
+            const double pn = fma(t, p, -buf[u].y * pp);
+            sb = __builtin_amdgcn_alignbit(sb, (unsigned)hi32(pn), 31);   // (sb << 1) | sign(pn)
             pp = p;
             p = pn;
         }
-        int e = (hi32(p) >> 20) & 0x7ff;
-        if (e == 0) e = (hi32(pp) >> 20) & 0x7ff;
-        e = e < 2 ? 2 : (e > 2044 ? 2044 : e);
-        const double sc = __hiloint2double((2046 - e) << 20, 0);
-        p *= sc;
-        pp *= sc;
-    }
-    for (; j < n; ++j) {
-        const double2 v = de2[j];
-        const double t = v.x - x;
-        const double pn = fma(t, p, -v.y * pp);
-        cnt += ((unsigned)(hi32(pn) ^ hi32(p))) >> 31;
-        pp = p;
-        p = pn;
+        cnt += __popc((sb ^ (sb >> 1)) & 0xffu);
+        int e = __builtin_amdgcn_frexp_exp(p);
+        if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
+        p = __builtin_amdgcn_ldexp(p, -e);
+        pp = __builtin_amdgcn_ldexp(pp, -e);
+    };
+    // rows n .. n+7 are padding (see k_eig_vec): whole groups only
+    if (j < n) load8(bufA, j);
+    while (j < n) {
+        if (j + 8 < n) load8(bufB, j + 8);
+        run8(bufA);
+        j += 8;
+        if (j >= n) break;
+        if (j + 8 < n) load8(bufA, j + 8);
+        run8(bufB);
+        j += 8;
     }
     return cnt;
 }
@@ -344,41 +355,55 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
     }
     __syncthreads();
     // ---- Householder tridiagonalisation (dsytd2, full storage) -----------------------------
-    // Step i: (a) every live wave forms its rows of p = tau*A*v from the published reflector v_i
-    // (barrier), (b) the scalar v^T p and the rank-2 update A -= v w^T + w v^T on its register
-    // block, with w = p + a2 v folded into two FMAs per element:
-    //     A[r][c] -= v_r p_c + (a2 v_r + w_r) v_c.
-    // (c) Look-ahead: the wave that owns row i+1 runs at raised priority, so it finishes its part of
-    // the update first and builds reflector i+1 (row -> LDS, norm, beta, tau, v) while the other
-    // waves are still updating.  2 barriers per step.
-    auto build_reflector = [&](int i) {
-        // executed by all 64 lanes of the wave that owns row i
-        double* vbn = t.xs + (i & 1) * 128;
-        double* xr = t.misc + 64;                  // [128] raw row i (only this wave touches it)
-        if (r == i) {
+    // Step i, reflector v_i and tau_i published in LDS:
+    //  (a) every live wave forms its rows of p = tau*A*v.                                  | barrier
+    //  (b) live waves: the scalar v^T p (redundantly per wave) and the rank-2 update
+    //          A[r][c] -= v_r p_c + (a2 v_r + w_r) v_c,      w = p + a2 v,
+    //      after which the lanes that own row i+2 publish it for the next step, while ONE helper
+    //      wave - a retired one as soon as there is one - rebuilds the updated row i+1 from LDS
+    //      operands (row i+1 as published one step earlier, p, v) with the very same two FMAs
+    //      (64 lanes x 2 columns), and runs the norm -> sqrt -> reciprocal chain of reflector i+1:
+    //      that chain no longer waits for anybody's register update.                       | barrier
+    // Both phases are bound by LDS operand traffic (every lane reads v and p at its 16 columns), so
+    // the 16-column groups that are already entirely in the finished part (columns <= i) are
+    // skipped: a wave-uniform switch with fall-through keeps the register indices static.
+    double* xrb = t.Z;                             // [2][128] row j before the update of step j-1, parity j&1
+    auto publish_row = [&](int row) {
+        if (r == row) {
+            double* x = xrb + (row & 1) * 128;
 #pragma unroll
-            for (int k = 0; k < NP; ++k) *(double2*)&xr[2 * q + 2 * QN * k] = make_double2(A[2 * k], A[2 * k + 1]);
+            for (int k = 0; k < NP; ++k) *(double2*)&x[2 * q + 2 * QN * k] = make_double2(A[2 * k], A[2 * k + 1]);
         }
+    };
+    [[maybe_unused]] int dslot = -1;
+#ifdef MPST_TRI_DEBUG
+#define DBG(j) do { if (dslot >= 0) stamps[dslot + (j)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DBG(j) do { } while (0)
+#endif
+    auto finish_reflector = [&](int i, double x0, double x1) {
+        // all 64 lanes of one wave; lane holds columns c0 = lane, c1 = lane + 64 of row i
+        double* vbn = t.xs + (i & 1) * 128;
         const int c0 = lane, c1 = lane + 64;
-        const double x0 = xr[c0], x1 = xr[c1];     // same wave: LDS ops complete in order
-        const double s = wave_sum((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
-        const double al = xr[i + 1], di = xr[i];
-        double beta = al, tau = 0.0, scale = 0.0;
-        if (s != 0.0) {
-            const double xx = fma(al, al, s);
-            double nrm;
-            if (xx > 1e-280 && xx < 1e280) {       // rsq + two Heron steps: a quarter of the IEEE sqrt chain
-                const double rs = __builtin_amdgcn_rsq(xx);
-                nrm = xx * rs;
-                nrm = fma(fma(-nrm, nrm, xx), 0.5 * rs, nrm);
-                nrm = fma(fma(-nrm, nrm, xx), 0.5 * rs, nrm);
-            } else {
-                nrm = sqrt(xx);
-            }
-            beta = -copysign(nrm, al);
-            tau = (beta - al) * frcp(beta);
-            scale = frcp(al - beta);
-        }
+        const double s = wave_sum_fast((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
+        const double di = i < 64 ? readlane_f64(x0, i) : readlane_f64(x1, i - 64);
+        const double al = i + 1 < 64 ? readlane_f64(x0, i + 1) : readlane_f64(x1, i + 1 - 64);
+        // Branch-free: rsq + two Heron steps instead of the IEEE sqrt chain, reciprocals from the hardware
+        // seed + 2 Newton steps.  A row whose tail is below 1e-140 in norm is treated as already reduced
+        // (s == 0 path of dlarfg); squared norms above 1e280 would need rescaling and are left to the
+        // verification in k_eig_fin (-> Jacobi fallback).
+        const double xx = fma(al, al, s);
+        const bool nz = s != 0.0 && xx > 1e-280;
+        const double rs = __builtin_amdgcn_rsq(nz ? xx : 1.0);
+        double nrm = xx * rs;
+        const double hrs = 0.5 * rs;
+        nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
+        nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
+        const double bneg = copysign(nrm, al);                 // -beta
+        const double ib = frcp(bneg), is = frcp(al + bneg);
+        const double beta = nz ? -bneg : al;
+        const double tau = nz ? (bneg + al) * ib : 0.0;        // (beta - al) / beta
+        const double scale = nz ? is : 0.0;                    // 1 / (al - beta)
         const double v0 = (c0 == i + 1) ? 1.0 : (c0 > i + 1 ? x0 * scale : 0.0);
         const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
         vbn[c0] = v0;
@@ -392,28 +417,37 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
             t.taus[i] = tau;
         }
     };
-    if (wave == 0) build_reflector(0);
+    publish_row(0);
+    publish_row(1);
     __syncthreads();
-    for (int i = 0; i < n - 1; ++i) {
+    if (wave == 0) finish_reflector(0, xrb[lane], xrb[lane + 64]);
+    __syncthreads();
+    // One step, with the number K0 of finished 16-column groups as a compile-time constant: the main
+    // loop below is cut into 8 "eras" of 16 steps, each running its own branch-free copy of the body.
+    auto step = [&](auto K0c, const int i_) {
+        constexpr int K0 = decltype(K0c)::value;
+        const int i = __builtin_amdgcn_readfirstlane(i_);      // keep the step index (and all it feeds) scalar
         const double* vb = t.xs + (i & 1) * 128;
         double* p = t.ps + (i & 1) * 128;
         const bool live = (wave * RPW + RPW - 1) > i;    // this wave still owns trailing rows
-        const bool next_owner = (i + 1 < n - 1) && wave == ((i + 1) / RPW);
+        // the most recently retired wave: its SIMD has just lost a live wave
+        const int helper = i >= RPW - 1 ? (i + 1) / RPW - 1 : (TRI_T / 64 - 1);
         const double tau = t.taus[i];
         double2 vv[NP];
+#ifdef MPST_TRI_DEBUG
+        dslot = (stamps && i == 60 && lane == 0) ? (wave == 12 ? 16 : wave == 6 ? 24 : wave == 7 ? 32 : -1) : -1;
+#endif
+        DBG(0);
         if (live) {
-            if (next_owner) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) vv[k] = *(const double2*)&vb[2 * q + 2 * QN * k];
-            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            for (int k = K0; k < NP; ++k) vv[k] = *(const double2*)&vb[2 * q + 2 * QN * k];
+            double accx[2] = {0.0, 0.0}, accy[2] = {0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < NP; k += 2) {
-                acc0 = fma(A[2 * k], vv[k].x, acc0);
-                acc1 = fma(A[2 * k + 1], vv[k].y, acc1);
-                acc2 = fma(A[2 * k + 2], vv[k + 1].x, acc2);
-                acc3 = fma(A[2 * k + 3], vv[k + 1].y, acc3);
+            for (int k = K0; k < NP; ++k) {
+                accx[k & 1] = fma(A[2 * k], vv[k].x, accx[k & 1]);
+                accy[k & 1] = fma(A[2 * k + 1], vv[k].y, accy[k & 1]);
             }
-            const double acc = sum_q((acc0 + acc1) + (acc2 + acc3));
+            const double acc = sum_q((accx[0] + accy[0]) + (accx[1] + accy[1]));
             if (q == 0) p[r] = (r > i) ? tau * acc : 0.0;
         } else if (wave * RPW + RPW - 1 == i) {
             // this wave's rows have just retired: clear their p entries in both buffers for good
@@ -422,34 +456,61 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
                 t.ps[128 + r] = 0.0;
             }
         }
+        DBG(1);
         __syncthreads();
+        DBG(2);
+        const int c0 = lane, c1 = lane + 64;
+        if (wave == helper && i + 1 < n - 1) {
+#ifndef TRI_NOPRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            const int j = i + 1;
+            const double* xr = xrb + (j & 1) * 128;
+            const double p0 = p[c0], p1 = p[c1], v0 = vb[c0], v1 = vb[c1], a0 = xr[c0], a1 = xr[c1];
+            const double pj = p[j], vj = vb[j];
+            const double dot = wave_sum_fast(p0 * v0 + p1 * v1);
+            const double a2 = -0.5 * tau * dot;
+            const double wj = pj + a2 * vj;
+            const double g = a2 * vj + wj;
+            const double x0 = fma(-g, v0, fma(-vj, p0, a0));
+            const double x1 = fma(-g, v1, fma(-vj, p1, a1));
+            DBG(6);
+            finish_reflector(j, x0, x1);
+            __builtin_amdgcn_s_setprio(0);
+            DBG(7);
+        }
         if (live) {
-            const int c0 = lane, c1 = lane + 64;
+#ifdef TRI_SLEEP
+            for (int z = 0; z < TRI_SLEEP; ++z) __builtin_amdgcn_s_sleep(8);
+#endif
             const double pr = p[r], vr = vb[r];
-            const double dot = wave_sum(p[c0] * vb[c0] + p[c1] * vb[c1]);
+            const double dot = wave_sum_fast(p[c0] * vb[c0] + p[c1] * vb[c1]);
             const double a2 = -0.5 * tau * dot;
             const double wr = pr + a2 * vr;
             const double g = a2 * vr + wr;
+            DBG(3);
+            double2 pv[NP];
 #pragma unroll
-            for (int kb = 0; kb < NP; kb += 8) {
-                double2 pv[8];
+            for (int k = K0; k < NP; ++k) pv[k] = *(const double2*)&p[2 * q + 2 * QN * k];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pv[k] = *(const double2*)&p[2 * q + 2 * QN * (kb + k)];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int kk = kb + k;
-                    A[2 * kk] = fma(-vr, pv[k].x, A[2 * kk]);
-                    A[2 * kk + 1] = fma(-vr, pv[k].y, A[2 * kk + 1]);
-                    A[2 * kk] = fma(-g, vv[kk].x, A[2 * kk]);
-                    A[2 * kk + 1] = fma(-g, vv[kk].y, A[2 * kk + 1]);
-                }
+            for (int k = K0; k < NP; ++k) {
+                A[2 * k] = fma(-vr, pv[k].x, A[2 * k]);
+                A[2 * k + 1] = fma(-vr, pv[k].y, A[2 * k + 1]);
+                A[2 * k] = fma(-g, vv[k].x, A[2 * k]);
+                A[2 * k + 1] = fma(-g, vv[k].y, A[2 * k + 1]);
             }
-            if (next_owner) {
-                build_reflector(i + 1);
-                __builtin_amdgcn_s_setprio(0);
-            }
+            if (i + 2 < n - 1) publish_row(i + 2);
+            DBG(4);
         }
         __syncthreads();
+        DBG(5);
+    };
+    static_assert(NP == 8 && QN == 8, "the era loops assume 8 column groups of 16 columns per thread");
+    {
+        int i = 0;
+#define TRI_ERA(K) for (; i < n - 1 && ((i + 1) >> 4) == K; ++i) step(std::integral_constant<int, K>{}, i);
+        TRI_ERA(0) TRI_ERA(1) TRI_ERA(2) TRI_ERA(3) TRI_ERA(4) TRI_ERA(5) TRI_ERA(6) TRI_ERA(7)
+#undef TRI_ERA
     }
     {   // last diagonal element
         double* x = t.xs + ((n - 1) & 1) * 128;
@@ -521,18 +582,27 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     const int n = pb.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* Vs = smem;              // [8128]
-    double* de = Vs + 8128;         // [256]
-    double* es = de + 256;          // [128]
+    double* de = Vs + 8128;         // [272]: 128 (d, e^2) pairs + padding pairs for the 8-step Sturm groups
+    double* es = de + 272;          // [128]
     double* taus = es + 128;        // [128]
     double* Dm = taus + 128;        // [128] D^-_i  (bottom-up pivots)
     double* Ub = Dm + 128;          // [128] U_i
     double* Dp = Ub + 128;          // [128] D_i    (top-down pivots)
     double* Lb = Dp + 128;          // [128] L_i
-    double* z = Lb + 128;           // [128]
+    double* z = Lb + 128 + 8;       // [128] with 8 slack entries before and after
+    double* Fb = z + 128 + 8;       // [24] rescaled group-boundary minors, top-down
+    double* Bb = Fb + 24;           // [24] bottom-up
     const bool st = stamps && k == 0 && tid == 0;
+#ifdef MPST_TRI_DEBUG
+#define VDBG(j) do { if (st) stamps[40 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VDBG(j) do { } while (0)
+#endif
     if (st) stamps[2] = __builtin_amdgcn_s_memrealtime();
     // ---- stage T (needed now) and request the reflectors (needed last) ----------------------------
-    de[tid] = ws[WS_DE + tid];
+    double lo = ws[WS_MISC + 0], hi = ws[WS_MISC + 1];
+    const double tnorm = ws[WS_MISC + 2];
+    if ((tid >> 1) < n) de[tid] = ws[WS_DE + tid];
     if (tid < 128) {
         es[tid] = ws[WS_ES + tid];
         taus[tid] = ws[WS_TAU + tid];
@@ -544,9 +614,15 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         const int i = tid + m * VEC_THREADS;
         vstage[m] = i < nv ? ws[WS_VS + i] : 0.0;
     }
-    double lo = ws[WS_MISC + 0], hi = ws[WS_MISC + 1];
-    const double tnorm = ws[WS_MISC + 2];
+    // pad T to 1 + a multiple of 8 rows with decoupled rows (e^2 = 0) whose diagonal lies above every
+    // abscissa: they add no sign change and let the Sturm loop run in whole groups of 8
+    {
+        const double dpad = hi + (hi - lo) + 1.0;
+        if ((tid >> 1) >= n) de[tid] = (tid & 1) ? 0.0 : dpad;
+        if (tid < 16) de[256 + tid] = (tid & 1) ? 0.0 : dpad;
+    }
     __syncthreads();
+    VDBG(0);
     // ---- 256-way multisection for the k-th largest eigenvalue -------------------------------------
     const int target = n - 1 - k;       // ascending index
     for (int it = 0; it < TRI_NSTEP; ++it) {
@@ -564,6 +640,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         hi = nhi;
     }
     const double lamk = 0.5 * (lo + hi);
+    VDBG(1);
     // reflectors -> LDS (the loads were issued before the bisection)
 #pragma unroll
     for (int m = 0; m < 32; ++m) {
@@ -572,46 +649,118 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     }
     if (st) stamps[3] = __builtin_amdgcn_s_memrealtime();
     // ---- eigenvector of T: twisted factorisation --------------------------------------------------
-    // wave 0 lane 0: bottom-up  D^-_i, U_i ;  wave 1 lane 0: top-down  D_i, L_i   (concurrently)
+    // The pivots of the top-down and bottom-up factorisations of T - lambda are ratios of consecutive
+    // leading / trailing principal minors, D_j = P_{j+1}/P_j and D^-_j = Q_j/Q_{j+1}.  The minors obey
+    // the division-free three-term recurrence of the Sturm sequence (3 dependent fp64 ops per row instead
+    // of a reciprocal + Newton chain), so the serial part runs on two waves (forward / backward, every
+    // lane redundantly, lane 0 stores the (minor, previous minor) pairs, rescaled together every 8
+    // rows) and the 2n divisions, the safeguard and L_i = e_i/D_i, U_i = e_i/D^-_{i+1} are done in
+    // parallel afterwards.
     const double pivmin = 1e-290 + 1e-30 * tnorm;
-    if (tid == 0) {
-        double dm = de[2 * (n - 1)] - lamk;
-        if (fabs(dm) < pivmin) dm = -pivmin;
-        Dm[n - 1] = dm;
-        double e = n >= 2 ? es[n - 2] : 0.0, dd = n >= 2 ? de[2 * (n - 2)] : 0.0;
-        for (int i = n - 2; i >= 0; --i) {
-            const double en = i > 0 ? es[i - 1] : 0.0, dn = i > 0 ? de[2 * (i - 1)] : 0.0;   // prefetch
-            const double u = e * frcp(dm);                 // U_i = e_i / D^-_{i+1}
-            Ub[i] = u;
-            dm = (dd - lamk) - u * e;
-            if (fabs(dm) < pivmin) dm = -pivmin;
-            Dm[i] = dm;
-            e = en;
-            dd = dn;
-        }
-    } else if (tid == 64) {
-        double dp = de[0] - lamk;
-        if (fabs(dp) < pivmin) dp = -pivmin;
-        Dp[0] = dp;
-        double e = es[0], dd = n >= 2 ? de[2] : 0.0;
-        for (int i = 0; i < n - 1; ++i) {
-            const double en = es[i + 1], dn = i + 2 < n ? de[2 * (i + 2)] : 0.0;             // prefetch
-            const double l = e * frcp(dp);                 // L_i = e_i / D_i
-            Lb[i] = l;
-            dp = (dd - lamk) - l * e;
-            if (fabs(dp) < pivmin) dp = -pivmin;
-            Dp[i + 1] = dp;
-            e = en;
-            dd = dn;
+    double* F1 = Dp;                // [<= 137] P_j at F1[j]          (aliases Dp, Lb until the quotients are taken)
+    double* B1 = Dm + 8;            // [-7 .. 128] Q_j at B1[j]       (aliases Dm, Ub)
+    {
+        const double2* de2 = (const double2*)de;
+        if (wave == 1) {
+            double pm = 1.0, pc = de[0] - lamk;
+            if (lane == 0) {
+                F1[0] = pm;
+                F1[1] = pc;
+            }
+            int b = 0;
+            for (int j = 1; j < n; j += 8, ++b) {     // rows n.. are the padding rows: harmless
+                double2 v[8];
+                double o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = de2[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double t = v[u].x - lamk;
+                    const double pn = fma(t, pc, -v[u].y * pm);
+                    o[u] = pn;
+                    pm = pc;
+                    pc = pn;
+                }
+                int e = __builtin_amdgcn_frexp_exp(pc);
+                if (pc == 0.0) e = __builtin_amdgcn_frexp_exp(pm);
+                pc = __builtin_amdgcn_ldexp(pc, -e);
+                pm = __builtin_amdgcn_ldexp(pm, -e);
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) *(double2*)&F1[j + 1 + u] = make_double2(o[u], o[u + 1]);
+                    Fb[b] = pc;                       // P_{j+8} on the scale of the next group
+                }
+            }
+        } else if (wave == 0) {
+            double qm = 1.0, qc = de[2 * (n - 1)] - lamk;          // Q_n, Q_{n-1}
+            if (lane == 0) {
+                B1[n] = qm;
+                B1[n - 1] = qc;
+            }
+            double e2 = de[2 * (n - 1) + 1];                        // e_{n-2}^2 couples rows n-2, n-1
+            int b = 0;
+            for (int j = n - 2; j >= 0; j -= 8, ++b) {
+                double2 v[8];
+                double o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = de2[j - u];        // j - u < 0 reads the tail of Vs: finite, unused
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double t = v[u].x - lamk;
+                    const double qn = fma(t, qc, -e2 * qm);         // Q_j = (d_j - l) Q_{j+1} - e_j^2 Q_{j+2}
+                    o[u] = qn;
+                    e2 = v[u].y;                                    // e_{j-1}^2 for the next row up
+                    qm = qc;
+                    qc = qn;
+                }
+                int e = __builtin_amdgcn_frexp_exp(qc);
+                if (qc == 0.0) e = __builtin_amdgcn_frexp_exp(qm);
+                qc = __builtin_amdgcn_ldexp(qc, -e);
+                qm = __builtin_amdgcn_ldexp(qm, -e);
+                if (lane == 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) B1[j - u] = o[u];
+                    Bb[b] = qc;                       // Q_{j-7} on the scale of the next group
+                }
+            }
         }
     }
+    VDBG(2);
     __syncthreads();
+    VDBG(3);
+    // quotients + safeguard (mirrors the sequential rule: a pivot below pivmin is replaced by -pivmin and
+    // the next pivot of that recurrence is recomputed from the replaced value).  A minor that is the
+    // last of its group of 8 was rescaled before the next group used it: the rescaled copy is in Fb/Bb.
+    auto quotF = [&](int j) {      // D_j = P_{j+1} / P_j
+        const double den = (j >= 9 && (j & 7) == 1) ? Fb[(j - 9) >> 3] : F1[j];
+        return F1[j + 1] / den;
+    };
+    auto quotB = [&](int j) {      // D^-_j = Q_j / Q_{j+1}
+        const int m = n - 2 - j;   // position in the bottom-up order
+        const double den = (m >= 8 && (m & 7) == 0) ? Bb[(m >> 3) - 1] : B1[j + 1];
+        return B1[j] / den;
+    };
+    double dp_ = 0.0, dm_ = 0.0, dsh = 0.0;
+    if (tid < n) {
+        dsh = de[2 * tid] - lamk;
+        dp_ = quotF(tid);
+        dm_ = tid < n - 1 ? quotB(tid) : dsh;
+        if (tid > 0 && !(fabs(quotF(tid - 1)) >= pivmin)) dp_ = dsh + de[2 * tid + 1] / pivmin;
+        if (tid < n - 1) {
+            const double rnext = tid + 1 < n - 1 ? quotB(tid + 1) : de[2 * (n - 1)] - lamk;
+            if (!(fabs(rnext) >= pivmin)) dm_ = dsh + de[2 * (tid + 1) + 1] / pivmin;
+        }
+        if (!(fabs(dp_) >= pivmin)) dp_ = -pivmin;
+        if (!(fabs(dm_) >= pivmin)) dm_ = -pivmin;
+    }
+    __syncthreads();                 // all minors consumed: Dm/Ub/Dp/Lb may be overwritten
     // twist index r = argmin |gamma_i|, gamma_i = D_i + D^-_i - (d_i - lambda)
     {
         double g = 1e300;
         int gi = 0;
         if (tid < n) {
-            g = fabs(Dp[tid] + Dm[tid] - (de[2 * tid] - lamk));
+            Dm[tid] = dm_;
+            g = fabs(dp_ + dm_ - dsh);
             gi = tid;
         }
         // wave-level argmin (ties -> smallest index), then across the 4 waves
@@ -634,26 +783,60 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
                 rb = arg_s[w];
             }
     }
-    // substitution: downwards from the twist on wave 0, upwards on wave 1
-    if (tid == 0) {
-        double zc = 1.0, nrm = 1.0;
-        z[rb] = 1.0;
-        for (int i = rb - 1; i >= 0; --i) {
-            zc = -Lb[i] * zc;
-            z[i] = zc;
-            nrm += zc * zc;
-        }
-        red_s[4] = nrm;
-    } else if (tid == 64) {
-        double zc = 1.0, nrm = 0.0;
-        for (int i = rb; i < n - 1; ++i) {
-            zc = -Ub[i] * zc;
-            z[i + 1] = zc;
-            nrm += zc * zc;
-        }
-        red_s[5] = nrm;
+    rb = __builtin_amdgcn_readfirstlane(rb);
+    if (tid < 128) {
+        // L_i = e_i / D_i, U_i = e_i / D^-_{i+1}; zero beyond n-2 and in the (now dead) Dp array, so the
+        // substitution below can fetch whole groups of 8 on either side without masks
+        const bool in = tid < n - 1;
+        const double e = in ? es[tid] : 0.0;
+        Lb[tid] = in ? e / dp_ : 0.0;
+        Ub[tid] = in ? e / Dm[tid + 1] : 0.0;
+        Dp[tid] = 0.0;
     }
     __syncthreads();
+    VDBG(4);
+    // substitution: downwards from the twist on wave 0, upwards on wave 1 (serial products; operands are
+    // fetched 8 at a time, every lane computes, lane 0 stores - z has 8 slack entries on both sides)
+    if (wave == 0) {
+        double zc = 1.0, nrm = 1.0;
+        if (lane == 0) z[rb] = 1.0;
+        for (int i = rb - 1; i >= 0; i -= 8) {
+            double l[8], o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) l[u] = Lb[i - u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                zc = -l[u] * zc;
+                o[u] = zc;
+                nrm = fma(zc, zc, nrm);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) z[i - u] = o[u];
+            }
+        }
+        if (lane == 0) red_s[4] = nrm;
+    } else if (wave == 1) {
+        double zc = 1.0, nrm = 0.0;
+        for (int i = rb; i < n - 1; i += 8) {
+            double l[8], o[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) l[u] = Ub[i + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                zc = -l[u] * zc;
+                o[u] = zc;
+                nrm = fma(zc, zc, nrm);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) z[i + u + 1] = o[u];
+            }
+        }
+        if (lane == 0) red_s[5] = nrm;
+    }
+    __syncthreads();
+    VDBG(5);
     const double sc = 1.0 / sqrt(red_s[4] + red_s[5]);
     // normalise; residual ||T z - lambda z||_inf (verification)
     double zi = 0.0, ri = 0.0;
@@ -896,7 +1079,7 @@ __global__ void k_eig_clear(double* lam, double* E, int n) {
 
 static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double); }
 static size_t tri_lds_bytes() { return (size_t)(8128 + 256 * 3 + 128 * 2 + 32 + 192 + 64) * sizeof(double); }
-static size_t vec_lds_bytes() { return (size_t)(8128 + 256 + 128 * 7 + 16) * sizeof(double); }
+static size_t vec_lds_bytes() { return (size_t)(8128 + 272 + 128 * 6 + 144 + 48 + 16) * sizeof(double); }
 
 static bool g_attr_set = false;
 static void ensure_attrs() {

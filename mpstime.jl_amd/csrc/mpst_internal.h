@@ -58,6 +58,26 @@ __device__ __forceinline__ double wave_sum(double x) {
     x = sum16(x);
     return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
 }
+// same sum, same association ((r0+r1)+(r2+r3)), with the cross-row part as two DPP row broadcasts
+// (row_bcast:15 into rows 1,3; row_bcast:31 into rows 2,3) and a single read of lane 63: 8 dependent
+// instructions instead of 15 - for latency-critical single-wave chains.
+__device__ __forceinline__ double dpp_bcast_add(double x, const int ctrl15_or_31) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    if (ctrl15_or_31 == 15) {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xA, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xA, 0xF, false);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xC, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xC, 0xF, false);
+    }
+    return x + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_fast(double x) {
+    x = sum16(x);
+    x = dpp_bcast_add(x, 15);
+    x = dpp_bcast_add(x, 31);
+    return readlane_f64(x, 63);
+}
 __device__ __forceinline__ double max16(double x) {
     x = fmax(x, dpp_mov<DPP_XOR1>(x));
     x = fmax(x, dpp_mov<DPP_XOR2>(x));
@@ -97,7 +117,7 @@ struct DevScalars {
     int32_t eig_sweeps_total;
     int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
     int32_t pad[2];
-    unsigned long long eig_stamps[12];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
+    unsigned long long eig_stamps[64];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
 };
 
 // One encoded data set on the device.
