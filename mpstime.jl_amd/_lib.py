@@ -16,7 +16,8 @@ LOSS = {"KLD": 0, "MSE": 1}
 OPT = {"TSGO": 0, "GD": 1}
 F64 = 0
 MAX_SPECTRUM = 512
-KERNEL_CLASSES = ("yhat", "grad", "grad_reduce+update", "gram", "eig", "split", "env", "bt_assemble", "allreduce")
+KERNEL_CLASSES = ("yhat", "grad", "grad_reduce+update", "gram", "eig_tri", "split", "env", "bt_assemble", "allreduce",
+                  "eig_vec", "eig_fin")
 
 
 class mpst_options(C.Structure):

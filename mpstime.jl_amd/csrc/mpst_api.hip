@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "mpst_internal.h"
 
@@ -15,7 +16,7 @@ namespace {
 
 thread_local std::string g_err;  // errors raised without a context (mpst_create)
 
-enum KClass { K_YHAT = 0, K_GRAD, K_UPDATE, K_GRAM, K_EIG, K_SPLIT, K_ENV, K_BT, K_ALLREDUCE, K_NCLASS };
+enum KClass { K_YHAT = 0, K_GRAD, K_UPDATE, K_GRAM, K_EIG_TRI, K_SPLIT, K_ENV, K_BT, K_ALLREDUCE, K_EIG_VEC, K_EIG_FIN, K_NCLASS };
 
 struct Ctx {
     int device = 0;
@@ -58,6 +59,11 @@ struct Ctx {
     double prof_us[16] = {0};
     int64_t prof_cnt[16] = {0};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // one full sweep captured as a hipGraph (bond dimensions live on the device and every grid is sized
+    // for the capacity, so the launch sequence of a sweep never changes between sweeps); `epoch` is
+    // bumped by every call that changes what the captured kernels were given
+    hipGraphExec_t sweep_graph = nullptr;
+    uint64_t epoch = 1, graph_epoch = 0;
 };
 
 int fail(Ctx* c, int code, const char* fmt, ...) {
@@ -158,6 +164,7 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->pred, en))) return rc;
     init_kernel_attrs();
     c->ws_ready = true;
+    c->epoch++;
     return 0;
 }
 
@@ -210,7 +217,9 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left) {
         { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
     }
     { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
-    { ProfScope p(c, K_EIG); launch_eig(v, lid, going_left, s); }
+    { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
+    { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
+    { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
     { ProfScope p(c, K_SPLIT); launch_split(v, lid, going_left, s); }
     {
         ProfScope p(c, K_ENV);                                                  // update_caches! :759/:799
@@ -309,6 +318,7 @@ void mpst_destroy(void* ctx) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->sweep_graph) (void)hipGraphExecDestroy(c->sweep_graph);
     if (c->comm) ncclCommDestroy(c->comm);
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
@@ -337,7 +347,7 @@ int mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank
     HIPC(c, hipSetDevice(c->device));
     if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
     c->nranks = nranks; c->rank = rank;
-    if (nranks == 1) return 0;
+    c->epoch++;
     ncclUniqueId id;
     memcpy(&id, unique_id, 128);
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
@@ -361,6 +371,7 @@ int mpst_set_options(void* ctx, const mpst_options* o) {
     const bool resize = !c->have_opt || o->loss != c->opt.loss;
     c->opt = *o;
     c->have_opt = true;
+    c->epoch++;
     if (resize) c->ws_ready = false;
     return 0;
 }
@@ -480,6 +491,7 @@ int mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_t
     HIPC(c, hipMemcpy(c->chi, chi, (size_t)(T + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->label_site, &label_site, sizeof(int32_t), hipMemcpyHostToDevice));
     c->have_mps = true;
+    c->epoch++;
     return 0;
 }
 
@@ -549,13 +561,52 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     int rc = check_ready(c);
     if (rc) return rc;
     View v = make_view(c, MPST_TRAIN);
+    auto enqueue_sweep = [&]() -> int {
+        int r;
+        for (int j = c->T - 2; j >= 0; --j)                                        // :731
+            if ((r = enqueue_bond(c, v, j, 1))) return r;
+        if (c->opt.rebuild_caches) enqueue_caches(c, v, 0);                         // :770
+        for (int j = 0; j <= c->T - 2; ++j)                                        // :776
+            if ((r = enqueue_bond(c, v, j, 0))) return r;
+        if (c->opt.rebuild_caches) enqueue_caches(c, v, 1);                         // :804
+        return 0;
+    };
+    // The 2(T-1) x 11 launches of a sweep are replayed from a hipGraph: nothing in the sequence depends
+    // on host-side state (bond dimensions are read on the device), and the pre-built dispatch packets
+    // shorten the dependent kernel-to-kernel hand-over that dominates the small kernels.  Per-kernel
+    // profiling and the RCCL leg keep the plain stream path.
+    const bool use_graph = !c->comm && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
+    if (use_graph && (!c->sweep_graph || c->graph_epoch != c->epoch)) {
+        if (c->sweep_graph) {
+            (void)hipGraphExecDestroy(c->sweep_graph);
+            c->sweep_graph = nullptr;
+        }
+        init_kernel_attrs();
+        eig_init_attrs();
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_sweep();
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(c->stream, &g);
+        if (rc) {
+            if (g) (void)hipGraphDestroy(g);
+            return rc;
+        }
+        if (e != hipSuccess || !g) return fail(c, MPST_ERR_DEVICE, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&c->sweep_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            c->sweep_graph = nullptr;
+            return fail(c, MPST_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        }
+        c->graph_epoch = c->epoch;
+    }
     HIPC(c, hipEventRecord(c->ev_start, c->stream));
-    for (int j = c->T - 2; j >= 0; --j)                                        // :731
-        if ((rc = enqueue_bond(c, v, j, 1))) return rc;
-    if (c->opt.rebuild_caches) enqueue_caches(c, v, 0);                         // :770
-    for (int j = 0; j <= c->T - 2; ++j)                                        // :776
-        if ((rc = enqueue_bond(c, v, j, 0))) return rc;
-    if (c->opt.rebuild_caches) enqueue_caches(c, v, 1);                         // :804
+    if (use_graph) {
+        HIPC(c, hipGraphLaunch(c->sweep_graph, c->stream));
+    } else if ((rc = enqueue_sweep())) {
+        return rc;
+    }
     HIPC(c, hipEventRecord(c->ev_stop, c->stream));
     HIPC(c, hipEventSynchronize(c->ev_stop));
     float ms = 0.f;
@@ -664,6 +715,7 @@ int mpst_set_profile(void* ctx, uint32_t kernel_mask) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;
     c->prof_mask = kernel_mask;
+    c->epoch++;
     for (int i = 0; i < 16; ++i) { c->prof_us[i] = 0; c->prof_cnt[i] = 0; }
     return 0;
 }

@@ -276,9 +276,9 @@ constexpr int WS_TAU = 384;     // [128]
 constexpr int WS_MISC = 512;    // [0] lo  [1] hi  [2] ||T||  [3] 1.0 if the tridiagonal path is active
 constexpr int WS_LAM = 528;     // [32]
 constexpr int WS_RES = 560;     // [32]  ||T z - lambda z||_inf
-constexpr int WS_VS = 592;      // [8128] packed reflectors
-constexpr int WS_Z = 8720;      // [32][128] eigenvectors of G, one row per eigenvalue
-constexpr int WS_TOTAL = 12816;
+constexpr int WS_VS = 592;      // [8][128][16] reflectors, dense: block b, row c, reflector 16b+j (0 above its start)
+constexpr int WS_Z = 16976;     // [32][128] eigenvectors of G, one row per eigenvalue
+constexpr int WS_TOTAL = 21072;
 
 struct EigProblem {
     const double* G;
@@ -557,8 +557,12 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         ws[WS_ES + tid] = tid < n ? t.es[tid] : 0.0;
         ws[WS_TAU + tid] = tid < n - 1 ? t.taus[tid] : 0.0;
     }
-    const int nv = (n * (n - 1)) / 2;
-    for (int i = tid; i < nv; i += TRI_T) ws[WS_VS + i] = t.Vs[i];
+    // reflectors in the blocked dense layout the back-transformation wants (k_eig_vec): 16 per block,
+    // zero above the start of each reflector and beyond n
+    for (int i = tid; i < 8 * 128 * 16; i += TRI_T) {
+        const int j = i & 15, c = (i >> 4) & 127, jr = (i >> 11) * 16 + j;
+        ws[WS_VS + i] = (jr < n - 1 && c > jr && c < n) ? t.Vs[voff(jr, n) + c - jr - 1] : 0.0;
+    }
     if (tid == 0) {
         ws[WS_MISC + 0] = t.misc[0];
         ws[WS_MISC + 1] = t.misc[1];
@@ -581,8 +585,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     if (!pb.tri || k >= pb.K0) return;
     const int n = pb.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* Vs = smem;              // [8128]
-    double* de = Vs + 8128;         // [272]: 128 (d, e^2) pairs + padding pairs for the 8-step Sturm groups
+    double* Vd = smem;              // [8][128][16] reflectors (dense blocks of 16)
+    double* de = Vd + 16384;        // [272]: 128 (d, e^2) pairs + padding pairs for the 8-step Sturm groups
     double* es = de + 272;          // [128]
     double* taus = es + 128;        // [128]
     double* Dm = taus + 128;        // [128] D^-_i  (bottom-up pivots)
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     double* z = Lb + 128 + 8;       // [128] with 8 slack entries before and after
     double* Fb = z + 128 + 8;       // [24] rescaled group-boundary minors, top-down
     double* Bb = Fb + 24;           // [24] bottom-up
+    double* Tb = Bb + 24;           // [8][16][16] triangular factors of the blocked reflectors
     const bool st = stamps && k == 0 && tid == 0;
 #ifdef MPST_TRI_DEBUG
 #define VDBG(j) do { if (st) stamps[40 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -600,19 +605,16 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
 #endif
     if (st) stamps[2] = __builtin_amdgcn_s_memrealtime();
     // ---- stage T (needed now) and request the reflectors (needed last) ----------------------------
+    // T goes through registers and is consumed at once; the 128 KB of reflectors are then requested
+    // as direct global->LDS loads that stay in flight during the whole bisection (every barrier up to
+    // the point where they are needed is an LDS-only barrier, and no ordinary global load result is
+    // consumed in between - either would drain them).
     double lo = ws[WS_MISC + 0], hi = ws[WS_MISC + 1];
     const double tnorm = ws[WS_MISC + 2];
     if ((tid >> 1) < n) de[tid] = ws[WS_DE + tid];
     if (tid < 128) {
         es[tid] = ws[WS_ES + tid];
         taus[tid] = ws[WS_TAU + tid];
-    }
-    const int nv = (n * (n - 1)) / 2;
-    double vstage[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        const int i = tid + m * VEC_THREADS;
-        vstage[m] = i < nv ? ws[WS_VS + i] : 0.0;
     }
     // pad T to 1 + a multiple of 8 rows with decoupled rows (e^2 = 0) whose diagonal lies above every
     // abscissa: they add no sign change and let the Sturm loop run in whole groups of 8
@@ -621,7 +623,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         if ((tid >> 1) >= n) de[tid] = (tid & 1) ? 0.0 : dpad;
         if (tid < 16) de[256 + tid] = (tid & 1) ? 0.0 : dpad;
     }
-    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 32; ++m)
+        glds16(ws + WS_VS + 2 * (tid + m * VEC_THREADS), Vd + 2 * (wave * 64 + m * VEC_THREADS));
+    lds_barrier();
     VDBG(0);
     // ---- 256-way multisection for the k-th largest eigenvalue -------------------------------------
     const int target = n - 1 - k;       // ascending index
@@ -631,9 +636,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         const int cnt = sturm_count(de, n, xq);
         const unsigned long long b = __ballot(cnt <= target);
         if (lane == 0) cnt_s[wave] = __popcll(b);
-        __syncthreads();
+        lds_barrier();
         const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-        __syncthreads();
+        lds_barrier();
         const double nlo = jj > 0 ? lo + h * jj : lo;
         const double nhi = jj < VEC_THREADS ? lo + h * (jj + 1) : hi;
         lo = nlo;
@@ -641,12 +646,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     }
     const double lamk = 0.5 * (lo + hi);
     VDBG(1);
-    // reflectors -> LDS (the loads were issued before the bisection)
-#pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        const int i = tid + m * VEC_THREADS;
-        if (i < nv) Vs[i] = vstage[m];
-    }
+    // the reflectors have landed by now; make them visible to every wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
     if (st) stamps[3] = __builtin_amdgcn_s_memrealtime();
     // ---- eigenvector of T: twisted factorisation --------------------------------------------------
     // The pivots of the top-down and bottom-up factorisations of T - lambda are ratios of consecutive
@@ -722,6 +724,47 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
                     for (int u = 0; u < 8; ++u) B1[j - u] = o[u];
                     Bb[b] = qc;                       // Q_{j-7} on the scale of the next group
                 }
+            }
+        } else {
+            // Waves 2, 3 (idle otherwise): compact-WY factors of the reflector blocks for the
+            // back-transformation.  Q_b = H(16b) ... H(16b+15) = I - V_b T_b V_b^T with
+            // T_b^-1 = diag(1/tau) + striu(V_b^T V_b); the Gram matrix comes from the fp64 MFMA
+            // (A and B operand are the same register: lane l feeds row 4s + (l>>4), reflector l&15),
+            // the inverse of the triangular matrix column by column (lane = column, tau-multiplied
+            // form, so tau = 0 - an identity reflector - needs no special case).
+            const int jl = lane & 15, q4 = lane >> 4;
+            for (int bi = 0; bi < 4; ++bi) {
+                const int b = 2 * bi + (wave - 2);
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                const double* vb = Vd + (size_t)b * 2048 + jl;
+                for (int c = 16 * b + q4; c < 128; c += 16) {
+                    const double a0 = vb[(c + 0) * 16], a1 = vb[(c + 4) * 16], a2 = vb[(c + 8) * 16], a3 = vb[(c + 12) * 16];
+                    acc = mfma_f64(a0, a0, acc);
+                    acc = mfma_f64(a1, a1, acc);
+                    acc = mfma_f64(a2, a2, acc);
+                    acc = mfma_f64(a3, a3, acc);
+                }
+                double* S = Tb + b * 256;               // S[i][j'] at i*16 + j', i = q4 + 4r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S[(q4 + 4 * r) * 16 + jl] = acc[r];
+            }
+            // all 4 blocks of this wave at once: lane (column jl, block 2*q4 + wave-2)
+            {
+                const int b = 2 * q4 + (wave - 2);
+                const double* S = Tb + b * 256;
+                const double* tb = taus + 16 * b;
+                double tcol[16];
+#pragma unroll
+                for (int i = 15; i >= 0; --i) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int kk = i + 1; kk < 16; ++kk) sum = fma(S[i * 16 + kk], tcol[kk], sum);
+                    const double ti = tb[i];
+                    tcol[i] = (i == jl) ? ti : -ti * sum;
+                }
+                double* T = Tb + b * 256;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) T[i * 16 + jl] = tcol[i];
             }
         }
     }
@@ -847,40 +890,63 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     }
     ri = wave_max(ri);
     __syncthreads();
-    if (tid < n) z[tid] = zi;
+    if (tid < 128) z[tid] = zi;                    // zi = 0 for rows >= n: the blocked back-transformation reads all 128
     if (lane == 0) red_s[wave] = ri;
     __syncthreads();
     if (st) stamps[4] = __builtin_amdgcn_s_memrealtime();
-    // ---- back-transformation z <- H(0) H(1) ... H(n-2) z on wave 0, two reflectors per step -----------
-    //   z' = z - t2 v2 (v2.z);  z'' = z' - t1 v1 (v1.z'),  v1.z' = v1.z - t2 (v1.v2)(v2.z):
-    //   the three inner products reduce together, halving the length of the dependent chain.
+    // ---- back-transformation z <- H(0) H(1) ... H(n-2) z on wave 0, 16 reflectors per step ----------
+    // z <- z - V_b (T_b (V_b^T z)), b = last block .. 0.  Three short phases per block, each bound by
+    // its instruction count on one wave: (i) lane (j, h) sums V[c][j] z[c] over the rows c = 16b+h+4m,
+    // the 4 partial sums of a column meet through two permlane swaps; (ii) u = T_b y, 4 terms per lane
+    // + the same swap-sum; (iii) every lane updates its two rows with the 16 u's.
     if (wave == 0) {
+        const int jl = lane & 15, q4 = lane >> 4;
         const int c0 = lane, c1 = lane + 64;
-        double z0 = c0 < n ? z[c0] : 0.0, z1 = c1 < n ? z[c1] : 0.0;
-        int i = n - 2;
-        for (; i >= 1; i -= 2) {
-            const double* v2 = Vs + voff(i, n) - i - 1;          // reflector i     (applied first)
-            const double* v1 = Vs + voff(i - 1, n) - i;          // reflector i - 1
-            const double a20 = (c0 > i && c0 < n) ? v2[c0] : 0.0, a21 = (c1 > i && c1 < n) ? v2[c1] : 0.0;
-            const double a10 = (c0 > i - 1 && c0 < n) ? v1[c0] : 0.0, a11 = (c1 > i - 1 && c1 < n) ? v1[c1] : 0.0;
-            double pa = a20 * z0 + a21 * z1, pb2 = a10 * z0 + a11 * z1, pc = a10 * a20 + a11 * a21;
-            pa = sum16(pa);
-            pb2 = sum16(pb2);
-            pc = sum16(pc);
-            const double sa = (readlane_f64(pa, 0) + readlane_f64(pa, 16)) + (readlane_f64(pa, 32) + readlane_f64(pa, 48));
-            const double sb = (readlane_f64(pb2, 0) + readlane_f64(pb2, 16)) + (readlane_f64(pb2, 32) + readlane_f64(pb2, 48));
-            const double scc = (readlane_f64(pc, 0) + readlane_f64(pc, 16)) + (readlane_f64(pc, 32) + readlane_f64(pc, 48));
-            const double al2 = taus[i] * sa;
-            const double al1 = taus[i - 1] * (sb - scc * al2);
-            z0 -= al2 * a20 + al1 * a10;
-            z1 -= al2 * a21 + al1 * a11;
-        }
-        if (i == 0) {
-            const double* v0 = Vs - 1;                           // voff(0) - 0 - 1
-            const double a0 = (c0 > 0 && c0 < n) ? v0[c0] : 0.0, a1 = (c1 > 0 && c1 < n) ? v0[c1] : 0.0;
-            const double f = taus[0] * wave_sum(a0 * z0 + a1 * z1);
-            z0 -= f * a0;
-            z1 -= f * a1;
+        double z0 = z[c0], z1 = z[c1];                 // rows >= n hold zeros
+        double* yb = Fb;                               // [16]  (Fb, Bb are free now)
+        double* ub = Bb;                               // [16]
+        for (int b = (n - 2) >> 4; b >= 0; --b) {
+            const double* vb = Vd + (size_t)b * 2048;
+            // (i) y = V_b^T z
+            double part = 0.0;
+            for (int c = 16 * b + q4; c < 128; c += 16) {
+                const double w0 = vb[(c + 0) * 16 + jl], w1 = vb[(c + 4) * 16 + jl], w2 = vb[(c + 8) * 16 + jl],
+                             w3 = vb[(c + 12) * 16 + jl];
+                const double x0 = z[c], x1 = z[c + 4], x2 = z[c + 8], x3 = z[c + 12];
+                part = fma(w0, x0, part);
+                part = fma(w1, x1, part);
+                part = fma(w2, x2, part);
+                part = fma(w3, x3, part);
+            }
+            const double yj = row4_sum(part);
+            if (q4 == 0) yb[jl] = yj;
+            // (ii) u = T_b y
+            const double2 ya = *(const double2*)&yb[4 * q4], yc = *(const double2*)&yb[4 * q4 + 2];
+            const double2 ta = *(const double2*)&Tb[b * 256 + jl * 16 + 4 * q4], tc = *(const double2*)&Tb[b * 256 + jl * 16 + 4 * q4 + 2];
+            const double ui = row4_sum(fma(ta.x, ya.x, ta.y * ya.y) + fma(tc.x, yc.x, tc.y * yc.y));
+            if (q4 == 0) ub[jl] = ui;
+            // (iii) z -= V_b u
+            double2 u2[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u2[m] = *(const double2*)&ub[2 * m];
+            if (b < 4) {                                // rows 0..63 are above every reflector of blocks 4..7
+                const double2* r0 = (const double2*)&vb[c0 * 16];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const double2 w = r0[m];
+                    z0 = fma(-w.x, u2[m].x, z0);
+                    z0 = fma(-w.y, u2[m].y, z0);
+                }
+                z[c0] = z0;
+            }
+            const double2* r1 = (const double2*)&vb[c1 * 16];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const double2 w = r1[m];
+                z1 = fma(-w.x, u2[m].x, z1);
+                z1 = fma(-w.y, u2[m].y, z1);
+            }
+            z[c1] = z1;
         }
         double* Zk = ws + WS_Z + (size_t)k * 128;
         if (c0 < n) Zk[c0] = z0;
@@ -917,18 +983,37 @@ __device__ bool verify_and_polish(TriShared t, int n, int K) {
         for (int w = 0; w < EIG_THREADS / 64; ++w) rmax = fmax(rmax, t.misc[8 + w]);
         ok = rmax < 1e-8 && rmax == rmax;
     }
+    static_assert(EIG_THREADS == 512, "the MFMA tiling below is written for 8 waves");
+    double* Dh = t.Ub + 1024;       // [4][256] second-half partial tiles of the Gram matrix
+    const int jl = lane & 15, q4 = lane >> 4;
     for (int round = 0; round < 2 && ok; ++round) {
+        // ---- D = Z^T Z - I on the fp64 MFMA: wave w owns the 16x16 tile (w&3) over rows [64(w>>2), +64) ----
         double err = 0.0;
-        const int b = tid & 31;
-        for (int a = tid >> 5; a < 32; a += EIG_THREADS >> 5) {
-            double dv = 0.0;
-            if (a < K && b < K) {
-                double dot = 0.0;
-                for (int c = 0; c < n; ++c) dot += t.Z[c * 32 + a] * t.Z[c * 32 + b];
-                dv = dot - (a == b ? 1.0 : 0.0);
-                err = fmax(err, fabs(dv));
+        {
+            const int a0 = 16 * ((wave & 3) >> 1), b0 = 16 * (wave & 1), kb = 64 * (wave >> 2);
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int s4 = 0; s4 < 16; ++s4) {
+                const double* zr = t.Z + (kb + 4 * s4 + q4) * 32;
+                acc = mfma_f64(zr[a0 + jl], zr[b0 + jl], acc);
             }
-            D[a * 32 + b] = dv;
+            if (wave >= 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Dh[(wave & 3) * 256 + (q4 + 4 * r) * 16 + jl] = acc[r];
+            }
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aa = a0 + q4 + 4 * r, bb = b0 + jl;
+                    double dv = 0.0;
+                    if (aa < K && bb < K) {
+                        dv = (acc[r] + Dh[wave * 256 + (q4 + 4 * r) * 16 + jl]) - (aa == bb ? 1.0 : 0.0);
+                        err = fmax(err, fabs(dv));
+                    }
+                    D[aa * 32 + bb] = dv;
+                }
+            }
         }
         err = wave_max(err);
         __syncthreads();
@@ -941,25 +1026,25 @@ __device__ bool verify_and_polish(TriShared t, int n, int K) {
             break;
         }
         if (round == 1 && emax < 1e-13) break;       // already orthonormal to rounding
-        constexpr int NZ = 4096 / EIG_THREADS;
-        double zn[NZ];
+        // ---- Z <- Z - (Z D)/2: wave w owns the row tiles 2(w>>1), 2(w>>1)+1 of column tile (w&1) ----
+        d4 upd[2];
 #pragma unroll
-        for (int m = 0; m < NZ; ++m) {
-            const int idx = tid + m * EIG_THREADS;        // over [128][32]
-            const int c = idx >> 5, a = idx & 31;
-            double acc = 0.0;
-            if (c < n && a < K) {
-                for (int bb = 0; bb < K; ++bb) acc += t.Z[c * 32 + bb] * D[bb * 32 + a];
-                acc = t.Z[c * 32 + a] - 0.5 * acc;
-            }
-            zn[m] = acc;
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = 16 * (2 * (wave >> 1) + h), a0 = 16 * (wave & 1);
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) acc = mfma_f64(t.Z[(c0 + jl) * 32 + 4 * s4 + q4], D[(4 * s4 + q4) * 32 + a0 + jl], acc);
+            upd[h] = acc;
         }
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < NZ; ++m) {
-            const int idx = tid + m * EIG_THREADS;
-            const int c = idx >> 5, a = idx & 31;
-            if (c < n && a < K) t.Z[idx] = zn[m];
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = 16 * (2 * (wave >> 1) + h), a0 = 16 * (wave & 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + q4 + 4 * r, aa = a0 + jl;
+                if (c < n && aa < K) t.Z[c * 32 + aa] -= 0.5 * upd[h][r];
+            }
         }
         __syncthreads();
         if (emax < 1e-8) break;                       // one round suffices: residual |D|^2 < 1e-16
@@ -1079,7 +1164,7 @@ __global__ void k_eig_clear(double* lam, double* E, int n) {
 
 static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double); }
 static size_t tri_lds_bytes() { return (size_t)(8128 + 256 * 3 + 128 * 2 + 32 + 192 + 64) * sizeof(double); }
-static size_t vec_lds_bytes() { return (size_t)(8128 + 272 + 128 * 6 + 144 + 48 + 16) * sizeof(double); }
+static size_t vec_lds_bytes() { return (size_t)(16384 + 272 + 128 * 6 + 144 + 48 + 2048 + 16) * sizeof(double); }
 
 static bool g_attr_set = false;
 static void ensure_attrs() {
@@ -1091,16 +1176,20 @@ static void ensure_attrs() {
 }
 
 size_t eig_workspace_doubles() { return WS_TOTAL; }
+void eig_init_attrs() { ensure_attrs(); }
 
-void launch_eig(const View& v, int lid, int going_left, hipStream_t s) {
+void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s) {
     ensure_attrs();
     unsigned long long* st = v.sc ? v.sc->eig_stamps : nullptr;
-    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
-                       (const double*)nullptr, 0, 0, v.eig_ws, st);
-    hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
-                       v.eig_ws, st);
-    hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
-                       (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
+    if (stage == 0)
+        hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
+                           (const double*)nullptr, 0, 0, v.eig_ws, st);
+    else if (stage == 1)
+        hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
+                           v.eig_ws, st);
+    else
+        hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
+                           (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
 }
 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {

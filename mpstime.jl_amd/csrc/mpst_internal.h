@@ -28,6 +28,42 @@ __device__ __forceinline__ double dpp_mov(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain vmcnt, so
+// direct global->LDS loads (global_load_lds) issued earlier stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// 16 bytes per lane global -> LDS without a VGPR stop-over; the LDS destination of a wave is
+// lds_wave_base + lane * 16 (contiguous 1 KB), the global source is per lane.  Issued from inline asm
+// on purpose: hipcc drains vmcnt(0) before the first ds_read after a global_load_lds it can see (it
+// cannot prove the LDS ranges disjoint), which would serialise the copy with the work it is meant to
+// overlap.  The caller owns the wait: s_waitcnt vmcnt(0) + a barrier before anybody reads the data,
+// and no compiler-visible global load may be consumed while these are in flight.
+__device__ __forceinline__ void glds16(const double* gsrc_lane, double* lds_wave_base) {
+    unsigned keep;
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+        (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_wave_base);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+// sum over the 4 lanes l, l^16, l^32, l^48 (same position in each 16-lane row), result in all 4:
+// v_permlane32_swap(a, b) exchanges lanes 32-63 of a with lanes 0-31 of b; v_permlane16_swap the odd
+// rows of a with the even rows of b (gfx950).  With a = b = x the two halves add up lane-wise.
+__device__ __forceinline__ double row4_sum(double x) {
+    unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    x = __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+    lo = (unsigned)__double2loint(x);
+    hi = (unsigned)__double2hiint(x);
+    auto s0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)s1[0], (int)s0[0]) + __hiloint2double((int)s1[1], (int)s0[1]);
+}
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141; // reverse within each 8 lanes
@@ -187,6 +223,7 @@ enum { ENV_M_E = 0, ENV_M_SITE = 1, ENV_M_SITE_T = 2 };
 void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond,
                 int mode, int out_bond, double* out, hipStream_t s);
 void init_kernel_attrs();
+void eig_init_attrs();
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);
 void launch_eval_reduce(const View& v, const double* yhat_in, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
 void launch_norm2(const View& v, double* out_norm2, hipStream_t s);
@@ -194,7 +231,7 @@ void launch_scale_sites(const View& v, const double* norm2, hipStream_t s);
 void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s);
 
 // mpst_eig.hip
-void launch_eig(const View& v, int lid, int going_left, hipStream_t s);
+void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
 size_t eig_workspace_doubles();
 

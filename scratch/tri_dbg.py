@@ -26,3 +26,4 @@ for name, b in (("live w12", 16), ("helper w0", 24), ("owner w7", 32)):
 print("phases", eng.eig_phases())
 v = s[40:48]
 print("k_eig_vec (10ns ticks) from stamp2:", [int(x - s[2]) for x in v], "end-of-bisect/eigvec/backtr:", int(s[3]-s[2]), int(s[4]-s[2]), int(s[5]-s[2]))
+print("gaps (10ns ticks): tri_end->vec_start", int(s[2]-s[1]), " vec_blk0_end->fin_start", int(s[8]-s[5]), " fin", int(s[9]-s[8]), " tri", int(s[1]-s[0]), " vec blk0", int(s[5]-s[2]))
