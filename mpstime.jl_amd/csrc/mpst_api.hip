@@ -199,10 +199,12 @@ void prof_collect(Ctx* c) {
 }
 
 // ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
-int enqueue_bond(Ctx* c, const View& v, int lid, int going_left) {
+// have_bt: the bond tensor of this bond was already assembled by the previous bond's environment
+// kernel; next_bt_lid >= 0: assemble that bond's tensor inside this bond's environment kernel.
+int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = false, int next_bt_lid = -1) {
     hipStream_t s = c->stream;
     const int rid = lid + 1;
-    { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }                    // flatten_bt :733/:777
+    if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }      // flatten_bt :733/:777
     if (v.rescale_before) launch_bt_prescale(v, lid, s);                        // loss_functions.jl:109
     for (int it = 0; it < c->opt.update_iters; ++it) {                          // TSGO/custGD :44,:75
         { ProfScope p(c, K_YHAT); launch_yhat(v, lid, s); }
@@ -226,10 +228,10 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left) {
         const int64_t cs = (int64_t)v.N * v.cap;
         if (going_left)
             launch_env(v, rid, 0, rid < c->T - 1 ? c->RE + (int64_t)(rid + 1) * cs : nullptr, rid + 1, ENV_M_E, rid,
-                       c->RE + (int64_t)rid * cs, s);
+                       c->RE + (int64_t)rid * cs, s, next_bt_lid);
         else
             launch_env(v, lid, 1, lid > 0 ? c->LE + (int64_t)(lid - 1) * cs : nullptr, lid, ENV_M_E, lid + 1,
-                       c->LE + (int64_t)lid * cs, s);
+                       c->LE + (int64_t)lid * cs, s, next_bt_lid);
     }
     return 0;
 }
@@ -562,12 +564,21 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     if (rc) return rc;
     View v = make_view(c, MPST_TRAIN);
     auto enqueue_sweep = [&]() -> int {
+        // bond order of one sweep (:731, :776); unless the tensor is rescaled first or the caches are
+        // rebuilt in between, bond k+1's tensor is assembled by bond k's environment kernel
+        const int nb = c->T - 1;
+        const bool chain = !v.rescale_before;
         int r;
-        for (int j = c->T - 2; j >= 0; --j)                                        // :731
-            if ((r = enqueue_bond(c, v, j, 1))) return r;
-        if (c->opt.rebuild_caches) enqueue_caches(c, v, 0);                         // :770
-        for (int j = 0; j <= c->T - 2; ++j)                                        // :776
-            if ((r = enqueue_bond(c, v, j, 0))) return r;
+        for (int k = 0; k < 2 * nb; ++k) {
+            const int lid = k < nb ? nb - 1 - k : k - nb, left = k < nb;
+            const bool boundary_before = c->opt.rebuild_caches && (k == nb);
+            const bool boundary_after = c->opt.rebuild_caches && (k == nb - 1);
+            const bool have = chain && k > 0 && !boundary_before;
+            int next = -1;
+            if (chain && k + 1 < 2 * nb && !boundary_after) next = (k + 1) < nb ? nb - 1 - (k + 1) : (k + 1) - nb;
+            if ((r = enqueue_bond(c, v, lid, left, have, next))) return r;
+            if (c->opt.rebuild_caches && k == nb - 1) enqueue_caches(c, v, 0);      // :770
+        }
         if (c->opt.rebuild_caches) enqueue_caches(c, v, 1);                         // :804
         return 0;
     };

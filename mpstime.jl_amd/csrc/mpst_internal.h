@@ -221,7 +221,7 @@ void launch_split(const View& v, int lid, int going_left, hipStream_t s);
 // mode 2: M = site tensor transposed, M[(s,b)][k] = W[k][(s,b)].
 enum { ENV_M_E = 0, ENV_M_SITE = 1, ENV_M_SITE_T = 2 };
 void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond,
-                int mode, int out_bond, double* out, hipStream_t s);
+                int mode, int out_bond, double* out, hipStream_t s, int bt_lid = -1);   // bt_lid: also assemble that bond's tensor
 void init_kernel_attrs();
 void eig_init_attrs();
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);

@@ -109,12 +109,11 @@ __device__ __forceinline__ void stage_tile16(double* __restrict__ Zs, int ZS, co
 // ---------------------------------------------------------------------------------------
 // flatten_bt  (RealRealHighDimension.jl:221-238):  B_c = W[lid] * W[rid] per class
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bt_assemble(View v, int lid) {
+__device__ __forceinline__ void bt_assemble_block(const View& v, int lid, int bx, int c) {
     const BondDims b = bond_dims(v, lid);
-    const int c = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tx = (b.X + 15) >> 4, ty = (b.Y + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = bx * 4 + wave;
     if (tile >= tx * ty) return;
     const int m0 = (tile / ty) * 16, n0 = (tile % ty) * 16;
     const int ls = *v.label_site;
@@ -131,6 +130,7 @@ __global__ __launch_bounds__(256) void k_bt_assemble(View v, int lid) {
         if (row < b.X && col < b.Y) out[(int64_t)row * b.Y + col] = acc[r];
     }
 }
+__global__ __launch_bounds__(256) void k_bt_assemble(View v, int lid) { bt_assemble_block(v, lid, blockIdx.x, blockIdx.y); }
 
 // normalize!(BT_init) when rescale[1] (loss_functions.jl:109-111): one workgroup, C*L <= 2*16384.
 __global__ __launch_bounds__(1024) void k_bt_prescale(View v, int lid) {
@@ -519,9 +519,18 @@ __global__ __launch_bounds__(256) void k_split(View v, int lid, int going_left) 
 // right side: Z_i[s*Dp+b] = phi_i[s] * prev_i[b]    (RE)
 // prev == nullptr means the boundary (Dp = 1, value 1).
 // ---------------------------------------------------------------------------------------
+// Blocks [ntiles, gridDim.x) do not belong to the environment update: they assemble the bond tensor of
+// the NEXT bond (bt_lid >= 0), which depends on the same inputs (the site tensors k_split just wrote) -
+// one dependent kernel hand-over (~5 us) less per bond.
 __global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, const double* __restrict__ prev,
-                                             int prev_bond, int mode, int out_bond, double* __restrict__ out) {
+                                             int prev_bond, int mode, int out_bond, double* __restrict__ out,
+                                             int bt_lid, int bt_bx) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x >= v.ntiles) {
+        const int idx = (int)blockIdx.x - v.ntiles;
+        bt_assemble_block(v, bt_lid, idx % bt_bx, idx / bt_bx);
+        return;
+    }
     const int d = v.d;
     const int Dp = prev ? v.chi[prev_bond] : 1;
     const int Dout = v.chi[out_bond];
@@ -759,11 +768,13 @@ void launch_split(const View& v, int lid, int going_left, hipStream_t s) {
     hipLaunchKernelGGL(k_split, dim3(cdiv(tiles, 4)), dim3(256), 0, s, v, lid, going_left);
 }
 void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond, int mode,
-                int out_bond, double* out, hipStream_t s) {
+                int out_bond, double* out, hipStream_t s, int bt_lid) {
     const int dm = v.d * v.cap;
     const size_t lds = (size_t)16 * (((dm + 3) & ~3) + 2) * sizeof(double);
-    hipLaunchKernelGGL(k_env, dim3(v.ntiles), dim3(256), lds, s, v, site, left_side, prev, prev_bond, mode,
-                       out_bond, out);
+    const int bt_bx = cdiv(cdiv(dm, 16) * cdiv(dm, 16), 4);
+    const int extra = bt_lid >= 0 ? bt_bx * v.C : 0;
+    hipLaunchKernelGGL(k_env, dim3(v.ntiles + extra), dim3(256), lds, s, v, site, left_side, prev, prev_bond, mode,
+                       out_bond, out, bt_lid, bt_bx);
 }
 void init_kernel_attrs() {
     static bool done = false;
