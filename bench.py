@@ -159,6 +159,18 @@ def main():
             kernels[k] = {"avg_us": round(per, 3), "launches_per_sweep": c, "share": round(us / max(sum(v[0] for v in breakdown.values()), 1e-9), 4),
                           "bound": b, "achieved": round(a / (per * 1e-6) / (1e12 if b == "mfma" else 1e9), 4),
                           "unit": "TFLOP/s" if b == "mfma" else "GB/s"}
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the
+        # per-launch figure of the committed rocprofv3 --pmc passes over this same command is quoted
+        # (profiles/aggregate_pmc.py; FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
+            kname = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin", "yhat": "mpst::k_yhat",
+                     "grad": "mpst::k_grad", "gram": "mpst::k_gram", "split": "mpst::k_split", "env": "mpst::k_env"}.get(dominant)
+            if kname in pmc and world == 1 and (N, T, chi, d) == (4096, 100, 32, 4):
+                traffic, traffic_src = pmc[kname]["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_hbm_traffic.json"
+        except Exception:
+            pass
         out = {
             "metric": "full sweeps/sec (N=4096,T=100,chi=32,d=4)", "value": args.steps / elapsed, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -176,8 +188,9 @@ def main():
                           "avg_us": round(sum(breakdown[k][0] / max(breakdown[k][1], 1) for k in ("gram", "eig_tri", "eig_vec", "eig_fin")
                                               if k in breakdown), 3)},
             "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": None, "avg_launch_us": avg_us, "launches": cnt,
-                         "algorithmic_per_launch": alg},
+                         "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "avg_launch_us": avg_us, "launches": cnt, "algorithmic_per_launch": alg,
+                         "in_kernel_us_last_launch": eng.eig_phases()["tridiag"] if dominant == "eig_tri" else None},
             "kernels": kernels,
         }
 
