@@ -104,6 +104,22 @@ def main():
         eng.set_dataset(0, local.phi, local.label_index, C, gcounts)
     else:
         eng.set_dataset(0, full.phi, full.label_index, C)
+    # side measurement (not part of the timed sweeps): device-side preprocessing + encoding of the same raw matrix
+    # (SURVEY 8f row 2), into the unused test slot; algorithmic bytes = 8 N T (1 + d)
+    encode_info = None
+    if world == 1:
+        try:
+            eng.encode_dataset(1, full.original_data, full.label_index, C, basis="Legendre_No_Norm", d=d)      # warm-up
+            _, enc_s = eng.encode_dataset(1, full.original_data, full.label_index, C, basis="Legendre_No_Norm", d=d)
+            err = float(np.max(np.abs(eng.get_encoded(1) - full.phi)))
+            nbytes = 8.0 * N * T * (1 + d)
+            encode_info = {"kernels": "k_enc_range + k_enc_range_final + k_encode", "device_us": 1e6 * enc_s, "algorithmic_bytes": nbytes,
+                           "achieved_GBs": nbytes / enc_s / 1e9, "frac_of_hbm_peak": nbytes / enc_s / 1e9 / PEAK_HBM_GBS,
+                           "max_abs_diff_vs_host_encoding": err}
+            eng.set_dataset(1, np.zeros((0, T, d)), np.zeros(0, dtype=np.int32), C)
+        except Exception as e:
+            encode_info = {"error": str(e)}
+
     eng.set_mps(W0)
     eng.build_caches()
 
@@ -192,6 +208,7 @@ def main():
                          "avg_launch_us": avg_us, "launches": cnt, "algorithmic_per_launch": alg,
                          "in_kernel_us_last_launch": eng.eig_phases()["tridiag"] if dominant == "eig_tri" else None},
             "kernels": kernels,
+            "device_encode": encode_info,
         }
 
     # ---- CPU baseline: the C restatement of the reference loop structure, bounded sample --------

@@ -117,6 +117,37 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
                       int64_t N, int32_t T, int32_t d, int32_t C, int32_t dtype,
                       const int64_t* n_global_per_class);
 
+/* Device-side preprocessing + encoding: the raw N x T matrix (row-major, already sorted by
+ * class like mpst_set_dataset's input) goes through transform_train_data / transform_test_data
+ * (src/utils.jl:161-275) and the Legendre basis (src/Encodings/bases.jl:70-108) on the GPU and becomes data set
+ * `which`, instead of uploading the d times larger product states (encode_dataset,
+ * src/Encodings/encodings.jl:120-150).  Order statistics stay on the host: `median`, `iqr` are the
+ * RobustSigmoid parameters of the TRAINING set (Normalization.jl fit, utils.jl:171-176).  Training set
+ * (is_test = 0): the min / max of the sigmoid-transformed data are fitted on the device and returned in
+ * lo / hi.  Test set (is_test = 1): lo / hi are inputs (the training fit); with rescale_out_of_bounds each
+ * series is shifted / scaled into [0, 1] (utils.jl:243-266) and `oob_fix` ([N][2], may be NULL) receives the
+ * (shift, scale) applied to every series - (0, 1) where nothing was done.  `seconds` (may be NULL) receives
+ * the device time of the encoding kernels. */
+#define MPST_BASIS_LEGENDRE         0   /* legendre(norm = true),  bases.jl:81-92 */
+#define MPST_BASIS_LEGENDRE_NO_NORM 1   /* legendre_no_norm,       bases.jl:108  (MPSOptions default) */
+typedef struct {
+    int32_t basis;
+    int32_t sigmoid_transform;      /* MPSOptions.sigmoid_transform */
+    int32_t minmax;                 /* MPSOptions.minmax */
+    int32_t is_test;
+    int32_t rescale_out_of_bounds;  /* test sets only */
+    int32_t reserved;
+    double  median, iqr;            /* in */
+    double  lo, hi;                 /* out for the training set, in for a test set */
+    double  data_lb, data_ub;       /* MPSOptions.data_bounds */
+    double  range_a, range_b;       /* the basis' input range (-1, 1 for Legendre) */
+} mpst_encode_opts;
+int  mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* label_idx,
+                         int64_t N, int32_t T, int32_t d, int32_t C, mpst_encode_opts* eo,
+                         const int64_t* n_global_per_class, double* oob_fix, double* seconds);
+/* Encoded values of data set `which` back to the host, [N][T][d] (EncodedTimeSeriesSet.timeseries). */
+int  mpst_get_encoded(void* ctx, int which, double* phi_out);
+
 int  mpst_set_options(void* ctx, const mpst_options* o);
 
 /* MPS in / out (the W::MPS argument and the TrainedMPS.mps result). `site[j]` points at

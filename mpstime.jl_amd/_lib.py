@@ -38,6 +38,15 @@ class mpst_bond_debug(C.Structure):
                 ("spectrum", C.c_double * MAX_SPECTRUM)]
 
 
+class mpst_encode_opts(C.Structure):
+    _fields_ = [("basis", C.c_int32), ("sigmoid_transform", C.c_int32), ("minmax", C.c_int32), ("is_test", C.c_int32),
+                ("rescale_out_of_bounds", C.c_int32), ("reserved", C.c_int32),
+                ("median", C.c_double), ("iqr", C.c_double), ("lo", C.c_double), ("hi", C.c_double),
+                ("data_lb", C.c_double), ("data_ub", C.c_double), ("range_a", C.c_double), ("range_b", C.c_double)]
+
+
+BASIS = {"Legendre": 0, "Legendre_Norm": 0, "Legendre_No_Norm": 1}
+
 # every symbol include/mpstime_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
 SYMBOLS = {
@@ -48,6 +57,9 @@ SYMBOLS = {
     "mpst_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "mpst_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
     "mpst_set_dataset": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i32), _i64, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
+    "mpst_encode_dataset": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i32), _i64, _i32, _i32, _i32, C.POINTER(mpst_encode_opts),
+                                      C.POINTER(_i64), _dp, _dp]),
+    "mpst_get_encoded": (C.c_int, [_vp, C.c_int, _dp]),
     "mpst_set_options": (C.c_int, [_vp, C.POINTER(mpst_options)]),
     "mpst_set_mps": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32), _i32, _i32]),
     "mpst_get_chi": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),

@@ -378,13 +378,10 @@ int mpst_set_options(void* ctx, const mpst_options* o) {
     return 0;
 }
 
-int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
-                     int32_t C, int32_t dtype, const int64_t* n_global_per_class) {
-    Ctx* c = (Ctx*)ctx;
-    if (!c) return MPST_ERR_INVALID;
+// Everything of a data set except the encoded values: validation, class counts, class-pure spans.
+static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N, int32_t T, int32_t d, int32_t C,
+                          const int64_t* n_global_per_class, bool have_values) {
     if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 (train) or 1 (test)");
-    if (dtype != MPST_F64)
-        return fail(c, MPST_ERR_UNSUPPORTED, "only Float64 encodings are supported by the array sweep (complex encodings need use_legacy_ITensor, loss_functions.jl:203-217)");
     if (N < 0 || T < 2 || d < 1 || C < 1) return fail(c, MPST_ERR_INVALID, "bad data set dimensions");
     if ((c->T && c->T != T) || (c->d && c->d != d) || (c->C && c->C != C)) {
         if (c->have_mps || c->ds[which ^ 1].N > 0)
@@ -399,7 +396,7 @@ int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* labe
     s.N = N;
     s.counts.assign(C, 0);
     if (N == 0) return 0;
-    if (!phi_ || !label_idx) return fail(c, MPST_ERR_INVALID, "NULL data pointer");
+    if (!have_values || !label_idx) return fail(c, MPST_ERR_INVALID, "NULL data pointer");
     for (int64_t i = 0; i < N; ++i) {
         const int32_t l = label_idx[i];
         if (l < 0 || l >= C) return fail(c, MPST_ERR_INVALID, "label_idx[%lld] = %d out of range", (long long)i, l);
@@ -412,15 +409,8 @@ int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* labe
         s.gcounts[k] = n_global_per_class ? n_global_per_class[k] : s.counts[k];
         s.Nglobal += s.gcounts[k];
     }
-    // site-major copy [T][N][d]
-    const double* phi = (const double*)phi_;
-    std::vector<double> tmp((size_t)N * T * d);
-    for (int64_t i = 0; i < N; ++i)
-        for (int t = 0; t < T; ++t)
-            memcpy(&tmp[((size_t)t * N + i) * d], &phi[((size_t)i * T + t) * d], (size_t)d * sizeof(double));
     int rc;
-    if ((rc = dalloc(c, &s.phi, (int64_t)tmp.size()))) return rc;
-    HIPC(c, hipMemcpy(s.phi, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = dalloc(c, &s.phi, N * T * d))) return rc;
     if ((rc = dalloc(c, &s.label, N))) return rc;
     HIPC(c, hipMemcpy(s.label, label_idx, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     // class-pure spans
@@ -448,6 +438,90 @@ int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* labe
     for (int k = 0; k < C; ++k) inv[k] = s.gcounts[k] > 0 ? 1.0 / (double)s.gcounts[k] : 0.0;
     if ((rc = dalloc(c, &s.inv_count, C))) return rc;
     HIPC(c, hipMemcpy(s.inv_count, inv.data(), (size_t)C * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
+                     int32_t C, int32_t dtype, const int64_t* n_global_per_class) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (dtype != MPST_F64)
+        return fail(c, MPST_ERR_UNSUPPORTED, "only Float64 encodings are supported by the array sweep (complex encodings need use_legacy_ITensor, loss_functions.jl:203-217)");
+    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, phi_ != nullptr);
+    if (rc || N == 0) return rc;
+    DataSet& s = c->ds[which];
+    // site-major copy [T][N][d]
+    const double* phi = (const double*)phi_;
+    std::vector<double> tmp((size_t)N * T * d);
+    for (int64_t i = 0; i < N; ++i)
+        for (int t = 0; t < T; ++t)
+            memcpy(&tmp[((size_t)t * N + i) * d], &phi[((size_t)i * T + t) * d], (size_t)d * sizeof(double));
+    HIPC(c, hipMemcpy(s.phi, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
+                        int32_t C, mpst_encode_opts* eo, const int64_t* n_global_per_class, double* oob_fix, double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (!eo) return fail(c, MPST_ERR_INVALID, "NULL encode options");
+    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the real Legendre bases only (complex bases cannot be trained by the array sweep, loss_functions.jl:203-217)");
+    if (eo->sigmoid_transform && !(eo->iqr > 0.0)) return fail(c, MPST_ERR_INVALID, "robust sigmoid needs iqr > 0");
+    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
+    if (rc || N == 0) return rc;
+    DataSet& s = c->ds[which];
+    double *dX = nullptr, *part = nullptr, *lohi = nullptr, *fix = nullptr;
+    if ((rc = dalloc(c, &dX, N * T)) || (rc = dalloc(c, &part, 512)) || (rc = dalloc(c, &lohi, 2))) return rc;
+    const bool test = eo->is_test != 0;
+    if (test && eo->rescale_out_of_bounds && (rc = dalloc(c, &fix, 2 * N))) return rc;
+    HIPC(c, hipMemcpy(dX, X, (size_t)N * T * sizeof(double), hipMemcpyHostToDevice));
+    if (test || !eo->minmax) {
+        const double h[2] = {eo->lo, eo->hi};
+        HIPC(c, hipMemcpy(lohi, h, sizeof h, hipMemcpyHostToDevice));
+    }
+    EncDev e{};
+    e.N = N; e.T = T; e.d = d;
+    e.norm = eo->basis == MPST_BASIS_LEGENDRE;
+    e.sigmoid = eo->sigmoid_transform; e.minmax = eo->minmax; e.is_test = test;
+    e.med = eo->median; e.s = eo->iqr / 1.35;
+    e.lb = eo->data_lb; e.ub = eo->data_ub; e.a = eo->range_a; e.b = eo->range_b;
+    e.nrm = std::sqrt(std::sqrt((2 * d + 1) / 2.0) * d);
+    e.lohi = lohi; e.fix = fix;
+    HIPC(c, hipEventRecord(c->ev_start, c->stream));
+    launch_encode(e, dX, s.phi, part, lohi, fix, !test && eo->minmax, c->stream);
+    HIPC(c, hipEventRecord(c->ev_stop, c->stream));
+    HIPC(c, hipEventSynchronize(c->ev_stop));
+    HIPC(c, hipGetLastError());
+    float ms = 0.f;
+    HIPC(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+    if (seconds) *seconds = 1e-3 * ms;
+    if (!test && eo->minmax) {
+        double h[2];
+        HIPC(c, hipMemcpy(h, lohi, sizeof h, hipMemcpyDeviceToHost));
+        eo->lo = h[0];
+        eo->hi = h[1];
+    }
+    if (fix && oob_fix) HIPC(c, hipMemcpy(oob_fix, fix, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
+    dfree(&dX); dfree(&part); dfree(&lohi); dfree(&fix);
+    return 0;
+}
+
+int mpst_get_encoded(void* ctx, int which, double* phi_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !phi_out) return MPST_ERR_INVALID;
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 (train) or 1 (test)");
+    const DataSet& s = c->ds[which];
+    if (s.N == 0) return 0;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const int64_t N = s.N;
+    const int T = c->T, d = c->d;
+    std::vector<double> tmp((size_t)N * T * d);
+    HIPC(c, hipMemcpy(tmp.data(), s.phi, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < N; ++i)
+        for (int t = 0; t < T; ++t)
+            memcpy(&phi_out[((size_t)i * T + t) * d], &tmp[((size_t)t * N + i) * d], (size_t)d * sizeof(double));
     return 0;
 }
 

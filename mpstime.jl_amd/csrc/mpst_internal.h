@@ -222,6 +222,19 @@ void launch_split(const View& v, int lid, int going_left, hipStream_t s);
 enum { ENV_M_E = 0, ENV_M_SITE = 1, ENV_M_SITE_T = 2 };
 void launch_env(const View& v, int site, int left_side, const double* prev, int prev_bond,
                 int mode, int out_bond, double* out, hipStream_t s, int bt_lid = -1);   // bt_lid: also assemble that bond's tensor
+// device-side preprocessing + encoding (mpst_encode.hip)
+struct EncDev {
+    int64_t N;
+    int32_t T, d;
+    int32_t norm, sigmoid, minmax, is_test;
+    double med, s;          // robust sigmoid: 1 / (1 + exp(-(x - med) / s)), s = iqr / 1.35
+    double lb, ub, a, b;    // data_bounds and the basis' input range
+    double nrm;             // legendre: sqrt(Pl(1, d; normalized) * d)
+    const double* lohi;     // device [2] min, max of the (sigmoid-transformed) training data
+    const double* fix;      // device [N][2] per-series (shift, scale) of the out-of-bounds rescale, or null
+};
+void launch_encode(const EncDev& e, const double* X, double* phi, double* part, double* lohi, double* fix, int fit_range,
+                   hipStream_t s);
 void init_kernel_attrs();
 void eig_init_attrs();
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);

@@ -82,6 +82,56 @@ class SweepEngine:
         self.T, self.d, self.C = T, d, int(C_classes)
         self.N[which] = N
 
+    def encode_dataset(self, which, X_sorted, label_index, C_classes, basis="Legendre_No_Norm", d=None, sigmoid_transform=True,
+                       minmax=True, data_bounds=(0.0, 1.0), enc_range=(-1.0, 1.0), norms=None, rescale_out_of_bounds=True,
+                       global_counts=None):
+        """Preprocess + encode the raw (N, T) matrix on the device (mpst_encode_dataset).  ``X_sorted`` must already be
+        sorted by class.  ``norms=None`` fits a training set (median/IQR on the host, min/max on the device) and
+        returns ``(norms, seconds)``; with ``norms`` from the training fit the data is treated as a test set and
+        ``(oob, seconds)`` comes back, ``oob`` in the format of transform_test_data (utils.jl:243-266)."""
+        from .encodings import Norms
+        if basis not in L.BASIS:
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the real Legendre bases only, not {basis!r}")
+        X = np.ascontiguousarray(X_sorted, dtype=np.float64)
+        lab = np.ascontiguousarray(label_index, dtype=np.int32)
+        N, T = X.shape
+        d = int(d if d is not None else self.d)
+        eo = L.mpst_encode_opts()
+        eo.basis, eo.sigmoid_transform, eo.minmax = L.BASIS[basis], int(bool(sigmoid_transform)), int(bool(minmax))
+        eo.is_test, eo.rescale_out_of_bounds = int(norms is not None), int(bool(rescale_out_of_bounds))
+        eo.data_lb, eo.data_ub = map(float, data_bounds)
+        eo.range_a, eo.range_b = map(float, enc_range)
+        if norms is None:
+            if sigmoid_transform:
+                q75, q25 = np.percentile(X, [75.0, 25.0])
+                eo.median, eo.iqr = float(np.median(X)), float(q75 - q25)
+        else:
+            if norms.sigmoid is not None:
+                eo.median, eo.iqr = norms.sigmoid
+            eo.sigmoid_transform = int(norms.sigmoid is not None)
+            if norms.minmax is not None:
+                eo.lo, eo.hi = norms.minmax
+        gc = np.ascontiguousarray(global_counts, dtype=np.int64) if global_counts is not None else None
+        fix = np.zeros((N, 2)) if norms is not None else None
+        sec = C.c_double()
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mpst_encode_dataset(
+            self.ctx, which, X.ctypes.data_as(dp), lab.ctypes.data_as(C.POINTER(C.c_int32)), N, T, d, int(C_classes), C.byref(eo),
+            gc.ctypes.data_as(C.POINTER(C.c_int64)) if gc is not None else None,
+            fix.ctypes.data_as(dp) if fix is not None else None, C.byref(sec)))
+        self.T, self.d, self.C = T, d, int(C_classes)
+        self.N[which] = N
+        if norms is None:
+            out = Norms(sigmoid=(eo.median, eo.iqr) if sigmoid_transform else None, minmax=(eo.lo, eo.hi) if minmax else None)
+            return out, sec.value
+        oob = [[i, float(fix[i, 0]), float(fix[i, 1])] for i in range(N) if fix[i, 0] != 0.0 or fix[i, 1] != 1.0]
+        return oob, sec.value
+
+    def get_encoded(self, which=0):
+        phi = np.zeros((self.N[which], self.T, self.d))
+        self._chk(self.lib.mpst_get_encoded(self.ctx, which, phi.ctypes.data_as(C.POINTER(C.c_double))))
+        return phi
+
     def set_mps(self, W, label_site=None):
         T = len(W)
         if label_site is None:

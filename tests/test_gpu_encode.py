@@ -1,0 +1,79 @@
+"""Device-side preprocessing + encoding (mpst_encode_dataset) against the host restatement of
+src/utils.jl:161-275 and src/Encodings/bases.jl:70-108."""
+import numpy as np
+import pytest
+
+import mpstime_jl_amd as mt
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(N, T, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    X = spread * rng.standard_normal((N, T)).cumsum(axis=1) / 3.0
+    y = np.sort(rng.integers(0, 3, N))
+    y[:3] = 0
+    y[-3:] = 2
+    return X, np.sort(y)
+
+
+@pytest.mark.parametrize("basis,d", [("Legendre_No_Norm", 4), ("Legendre_No_Norm", 7), ("Legendre", 5)])
+@pytest.mark.parametrize("sig,mm", [(True, True), (False, True), (True, False)])
+def test_train_encoding_matches_oracle(engine_cls, basis, d, sig, mm):
+    X, y = _data(97, 41, 5)
+    if not mm:
+        X = 1.0 / (1.0 + np.exp(-X)) if not sig else X      # without minmax the data must already sit in [0, 1]
+    eng = engine_cls(0)
+    norms, sec = eng.encode_dataset(0, X, y, 3, basis=basis, d=d, sigmoid_transform=sig, minmax=mm)
+    phi = eng.get_encoded(0)
+    Xs, norms_o = R.transform_train_data(X, sigmoid_transform=sig, minmax=mm)
+    ref = R.legendre_encode(Xs, d, norm=(basis == "Legendre"))
+    assert phi.shape == ref.shape
+    assert np.max(np.abs(phi - ref)) < 1e-13
+    if mm:
+        assert abs(norms.minmax[0] - norms_o[1][0]) < 1e-15 and abs(norms.minmax[1] - norms_o[1][1]) < 1e-15
+    assert sec > 0
+    eng.close()
+
+
+def test_test_set_out_of_bounds_rescale_matches_oracle(engine_cls):
+    Xtr, ytr = _data(64, 30, 1)
+    Xte, yte = _data(50, 30, 2, spread=2.5)       # wider than the training data: some series leave [0, 1]
+    eng = engine_cls(0)
+    norms, _ = eng.encode_dataset(0, Xtr, ytr, 3, d=4)
+    oob, _ = eng.encode_dataset(1, Xte, yte, 3, d=4, norms=norms)
+    phi = eng.get_encoded(1)
+    _, norms_o = R.transform_train_data(Xtr)
+    Xs, oob_o = R.transform_test_data(Xte, norms_o)
+    ref = R.legendre_encode(Xs, 4)
+    assert np.max(np.abs(phi - ref)) < 1e-13
+    assert len(oob) == len(oob_o) and len(oob) > 0
+    for a, b in zip(oob, oob_o):
+        assert a[0] == b[0] and abs(a[1] - b[1]) < 1e-14 and abs(a[2] - b[2]) < 1e-14
+    eng.close()
+
+
+def test_encoded_on_device_trains_like_uploaded(engine_cls):
+    """A sweep on device-encoded data equals the sweep on the same values uploaded through mpst_set_dataset."""
+    X, y = _data(80, 12, 9)
+    opts = dict(chi_max=6, eta=0.05)
+    W = R.random_mps(12, 4, 3, 3, np.random.default_rng(3))
+    eng = engine_cls(0)
+    eng.encode_dataset(0, X, y, 3, d=4)
+    phi = eng.get_encoded(0)
+    eng.set_options(**opts); eng.set_mps(W); eng.build_caches(); eng.sweep()
+    a = eng.eval(0)
+    eng.close()
+    eng = engine_cls(0)
+    eng.set_options(**opts); eng.set_dataset(0, phi, y, 3); eng.set_mps(W); eng.build_caches(); eng.sweep()
+    b = eng.eval(0)
+    eng.close()
+    assert a[:3] == b[:3]
+
+
+def test_unsupported_basis_is_reported(engine_cls):
+    eng = engine_cls(0)
+    with pytest.raises(mt.MPSTError):
+        eng.encode_dataset(0, np.zeros((4, 5)), np.zeros(4, dtype=np.int32), 1, basis="Fourier", d=4)
+    eng.close()

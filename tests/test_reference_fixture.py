@@ -114,3 +114,20 @@ def test_engine_sweep_from_reference_mps_matches_oracle(ref):
         assert g["chi"] == o["chi"], (k, g["chi"], o["chi"])
         assert abs(g["loss"] - o["loss"]) <= 1e-8 * max(1.0, abs(o["loss"])), (k, g["loss"], o["loss"])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_device_encoding_reproduces_reference_pstates(ref):
+    """mpst_encode_dataset (device-side preprocessing + Legendre_No_Norm d=5) against the product states the
+    reference itself stored: rows A14/A15 pinned for the HIP path too."""
+    eng = mt.SweepEngine(0)
+    norms, sec = eng.encode_dataset(0, ref["X"], ref["label_index"], len(ref["cd"]), basis="Legendre_No_Norm", d=ref["d"])
+    phi = eng.get_encoded(0)
+    assert phi.shape == ref["phi"].shape
+    assert np.max(np.abs(phi - ref["phi"])) < 1e-13
+    # and the engine can evaluate the reference's MPS on what it encoded itself
+    eng.set_options(chi_max=ref["chi_max"])
+    eng.set_mps(ref["W"])
+    mse, kld, acc, conf = eng.eval(0)
+    assert acc == 1.0 and abs(kld - (-48.58386481729281)) < 1e-8
+    eng.close()
