@@ -34,3 +34,36 @@ def bond_matrix(Wl, Wr):
     """Gauge-invariant two-site tensor (s_l, a, s_r, b, c)."""
     bt, shape4 = R.flatten_bt(Wl, Wr)
     return R.unflatten_bt(bt, shape4)
+
+
+def teacher_forced_sweep(eng, co, phi, T, nbonds=None, overlap_every=9, sub=slice(None)):
+    """Every bond update of a sweep compared with the C oracle, each starting from the ORACLE's state
+    (set_mps + build_caches): free-running trajectories diverge chaotically (oracle/sensitivity_study.py),
+    one update from a common state is well conditioned.  Returns the worst relative deviations and the
+    number of bonds whose kept dimension differs by one because a singular value sits on the cutoff."""
+    worst = dict(loss=0.0, grad=0.0, S=0.0, overlap=0.0)
+    chi_flips = 0
+    nb = 2 * (T - 1) if nbonds is None else nbonds
+    for q in range(nb):
+        going_left = q < T - 1
+        lid = (T - 2 - q) if going_left else (q - (T - 1))
+        eng.set_mps(co.get_mps())
+        eng.build_caches()
+        ref = co.sweep(max_bonds=1, first_bond=q, record=True)["bonds_rec"][0]
+        tr = eng.bond_step(lid, going_left)
+        worst["loss"] = max(worst["loss"], abs(tr["loss"] - ref["loss"]) / max(1.0, abs(ref["loss"])))
+        worst["grad"] = max(worst["grad"], abs(tr["grad_norm"] - ref["grad_norm"]) / ref["grad_norm"])
+        nk = min(tr["chi"], ref["chi"])
+        worst["S"] = max(worst["S"], np.abs(tr["S"][:nk] - ref["S"][:nk]).max() / ref["S"][0])
+        if tr["chi"] != ref["chi"]:
+            # only a singular value sitting on the cutoff may be decided differently
+            P = ref["S"] ** 2 / np.sum(ref["S"] ** 2)
+            lo, hi = sorted((tr["chi"], ref["chi"]))
+            tail = P[lo:].sum()
+            assert hi - lo == 1 and abs(tail - 1e-10) < 1e-3 * 1e-10, (q, lid, tr["chi"], ref["chi"], tail)
+            chi_flips += 1
+        elif q % overlap_every == 0:
+            yo = R.contract_mps(co.get_mps(), phi[sub])
+            yg = R.contract_mps(eng.get_mps(), phi[sub])
+            worst["overlap"] = max(worst["overlap"], np.abs(yo - yg).max() / np.abs(yo).max())
+    return worst, chi_flips

@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 import mpstime_jl_amd as mt
+from tests.helpers import teacher_forced_sweep
 from oracle import ref_numpy as R
 from tests.helpers import load_engine
 from tests.test_oracle import load_golden
@@ -127,8 +128,9 @@ def _config3(N=4096, T=100, d=4):
     return full, W0
 
 
-def test_full_size_config3_against_c_oracle(engine_cls):
-    """BASELINE.json configs[2] (N=4096, T=100, chi=32, d=4): every bond update of the first full
+@pytest.mark.parametrize("chi", [16, 32])
+def test_full_size_config3_against_c_oracle(engine_cls, chi):
+    """BASELINE.json configs[1] and configs[2] (N=4096, T=100, chi=16 / 32, d=4): every bond update of the first full
     sweep against the C restatement, each starting from the oracle's state (set_mps + build_caches).
 
     Free-running comparison is meaningless at this size: oracle/sensitivity_study.py shows the oracle
@@ -138,7 +140,7 @@ def test_full_size_config3_against_c_oracle(engine_cls):
     properties are checked on the engine's own free-running sweep."""
     from oracle.c_oracle import COracle
     full, W0 = _config3()
-    T, chi = 100, 32
+    T = 100
     co = COracle(W0, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=False)
     co.build_caches()
     eng = engine_cls(0)
@@ -146,30 +148,7 @@ def test_full_size_config3_against_c_oracle(engine_cls):
     try:
         eng.set_options(chi_max=chi, eta=0.01)
         eng.set_dataset(0, full.phi, full.label_index, 2)
-        worst = dict(loss=0.0, grad=0.0, S=0.0, overlap=0.0)
-        chi_flips = 0
-        for q in range(2 * (T - 1)):
-            going_left = q < T - 1
-            lid = (T - 2 - q) if going_left else (q - (T - 1))
-            eng.set_mps(co.get_mps())
-            eng.build_caches()
-            ref = co.sweep(max_bonds=1, first_bond=q, record=True)["bonds_rec"][0]
-            tr = eng.bond_step(lid, going_left)
-            worst["loss"] = max(worst["loss"], abs(tr["loss"] - ref["loss"]) / max(1.0, abs(ref["loss"])))
-            worst["grad"] = max(worst["grad"], abs(tr["grad_norm"] - ref["grad_norm"]) / ref["grad_norm"])
-            nk = min(tr["chi"], ref["chi"])
-            worst["S"] = max(worst["S"], np.abs(tr["S"][:nk] - ref["S"][:nk]).max() / ref["S"][0])
-            if tr["chi"] != ref["chi"]:
-                # only a singular value sitting on the cutoff may be decided differently
-                P = ref["S"] ** 2 / np.sum(ref["S"] ** 2)
-                lo, hi = sorted((tr["chi"], ref["chi"]))
-                tail = P[lo:].sum()
-                assert hi - lo == 1 and abs(tail - 1e-10) < 1e-3 * 1e-10, (q, lid, tr["chi"], ref["chi"], tail)
-                chi_flips += 1
-            elif q % 9 == 0:
-                yo = R.contract_mps(co.get_mps(), full.phi[sub])
-                yg = R.contract_mps(eng.get_mps(), full.phi[sub])
-                worst["overlap"] = max(worst["overlap"], np.abs(yo - yg).max() / np.abs(yo).max())
+        worst, chi_flips = teacher_forced_sweep(eng, co, full.phi, T, sub=sub)
         assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, worst
         assert chi_flips <= 2
         # free-running sweep of the engine itself: properties
@@ -186,7 +165,8 @@ def test_full_size_config3_against_c_oracle(engine_cls):
         yall = R.contract_mps(Wg, full.phi)
         assert abs(kld - np.mean(-np.log(yall[np.arange(4096), full.label_index] ** 2))) < 1e-9 * max(1, abs(kld))
         assert conf.sum() == 4096 and acc == np.mean(np.argmax(np.abs(yall), 1) == full.label_index)
-        assert kld < kld0 - 10 and acc > 0.9          # it trains: same regime as the oracle (KLD -23.5, acc 0.96)
+        # it trains: same regime as the oracle (chi=32: KLD -23.5, acc 0.96 after one sweep; chi=16 is slower)
+        assert kld < kld0 - 10 and acc > (0.9 if chi == 32 else 0.6)
     finally:
         eng.close()
 

@@ -131,3 +131,26 @@ def test_device_encoding_reproduces_reference_pstates(ref):
     mse, kld, acc, conf = eng.eval(0)
     assert acc == 1.0 and abs(kld - (-48.58386481729281)) < 1e-8
     eng.close()
+
+
+@pytest.mark.gpu
+def test_sweeps_on_reference_ecg200_data_match_oracle(ref):
+    """The real data of the reference's fixture (ECG200 train set, N=100, T=96) with the reference's default
+    hyper-parameters (d=5, chi_max=25, KLD/TSGO, eta=0.01) from a fresh random MPS: every bond update of the
+    first two sweeps against the C oracle, teacher-forced (a free-running fit diverges chaotically here as well:
+    train KLD -44.25 vs -44.81 after one sweep).  d*chi = 125 exercises the non-power-of-two eigensolver path."""
+    from oracle.c_oracle import COracle
+    from tests.helpers import teacher_forced_sweep
+    opts = mt.MPSOptions(verbosity=-1)
+    T = ref["phi"].shape[1]
+    W0 = mt.generate_startingMPS(opts.chi_init, T, opts.d, 2, 4321)
+    co = COracle(W0, ref["phi"], ref["label_index"], ref["cd"], opts.chi_max, eta=opts.eta, rebuild_caches=False)
+    co.build_caches()
+    eng = mt.SweepEngine(0)
+    eng.set_options(chi_max=opts.chi_max, eta=opts.eta, cutoff=opts.cutoff)
+    eng.set_dataset(0, ref["phi"], ref["label_index"], 2)
+    for sweep in range(2):
+        worst, flips = teacher_forced_sweep(eng, co, ref["phi"], T, overlap_every=7)
+        assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, (sweep, worst)
+        assert flips <= 2
+    eng.close()
