@@ -108,6 +108,25 @@ __device__ __forceinline__ double dpp_bcast_add(double x, const int ctrl15_or_31
     }
     return x + __hiloint2double(hi, lo);
 }
+// 64-lane sum on the matrix pipe: v_mfma_f64_4x4x4 (4 independent 4x4x4 products; A lane = 16k + 4b + i,
+// B lane = 16k + 4b + j, D lane = 16i + 4b + j - measured) with an all-ones partner first adds the four
+// 16-lane rows (k), then the four lanes of a quad group (i <-> k); two DPP rotations add the four groups b.
+// 2 MFMA + 6 VALU instructions instead of 30, result in every lane; fixed order, so every wave that calls
+// it on the same data gets the same bits.
+__device__ __forceinline__ double wave_sum_mfma(double x) {
+    x = __builtin_amdgcn_mfma_f64_4x4x4f64(x, 1.0, 0.0, 0, 0, 0);
+    x = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, x, 0.0, 0, 0, 0);
+    x += dpp_mov<0x128>(x);       // row_ror:8
+    x += dpp_mov<0x124>(x);       // row_ror:4
+    return x;
+}
+// x(lane) + x(lane ^ 16): one v_permlane16_swap per dword (odd 16-lane rows of a <-> even rows of b)
+__device__ __forceinline__ double pair16_sum(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    auto s0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)s1[0], (int)s0[0]) + __hiloint2double((int)s1[1], (int)s0[1]);
+}
 __device__ __forceinline__ double wave_sum_fast(double x) {
     x = sum16(x);
     x = dpp_bcast_add(x, 15);
