@@ -98,3 +98,22 @@ def test_rccl_single_rank_communicator_is_a_no_op(engine_cls):
     for a, b in zip(out[0][0], out[1][0]):
         assert np.array_equal(a, b)
     assert out[0][1][:3] == out[1][1][:3] and np.array_equal(out[0][1][3], out[1][1][3])
+
+
+def test_exit_early_stops_at_perfect_training_accuracy():
+    """exit_early (RealRealHighDimension.jl:847): the sweep loop ends as soon as the logged training accuracy is 1."""
+    Xtr, ytr = _toy(40, 16, 5)
+    opts = mt.MPSOptions(d=3, chi_max=8, nsweeps=12, eta=0.1, verbosity=-1, exit_early=True)
+    mps, info, _ = mt.fitMPS(Xtr, ytr, opts=opts)
+    accs = info["train_acc"]
+    if 1.0 in accs[:-1]:
+        first = accs.index(1.0)
+        # entries: initial, one per executed sweep, final (after normalize!)
+        assert len(accs) == first + 2 and len(accs) < opts.nsweeps + 2
+    else:
+        assert len(accs) == opts.nsweeps + 2
+    # TrainedMPS equality compares options and tensors elementwise (src/Structs/operations.jl:4-36)
+    mps_b, _, _ = mt.fitMPS(Xtr, ytr, opts=opts)
+    assert mps == mps_b
+    mps_c, _, _ = mt.fitMPS(Xtr, ytr, opts=opts.set(eta=0.05))
+    assert mps != mps_c
