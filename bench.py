@@ -65,6 +65,11 @@ def kernel_model(N, d, chi, C):
 
 
 def main():
+    # Exactly one line may reach stdout: native libraries (the RCCL init banner, rocm-smi notices) write to fd 1
+    # behind Python's back, so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -236,7 +241,8 @@ def main():
         except Exception as e:      # the baseline is a reported extra, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     eng.close()
     if dist is not None:
         dist.destroy_process_group()
