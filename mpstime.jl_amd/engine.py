@@ -89,7 +89,11 @@ class SweepEngine:
         sorted by class.  ``norms=None`` fits a training set (median/IQR on the host, min/max on the device) and
         returns ``(norms, seconds)``; with ``norms`` from the training fit the data is treated as a test set and
         ``(oob, seconds)`` comes back, ``oob`` in the format of transform_test_data (utils.jl:243-266)."""
-        from .encodings import Norms
+        from .encodings import Norms, model_encoding
+        try:
+            basis = model_encoding(basis).name           # canonical name; :Legendre is :Legendre_No_Norm (options.jl:245-246)
+        except Exception:
+            pass
         if basis not in L.BASIS:
             raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the real Legendre bases only, not {basis!r}")
         X = np.ascontiguousarray(X_sorted, dtype=np.float64)

@@ -58,12 +58,13 @@ _INFO_TEST_KEYS = ("test_acc", "test_KL_div", "test_conf")
 
 def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_meta: Optional[EncodedTimeSeriesSet],
                 opts: MPSOptions = MPSOptions(), engine: Optional[SweepEngine] = None, device: int = 0,
-                shard=None):
+                shard=None, preloaded: bool = False):
     """fitMPS(W::MPS, training_states_meta, testing_states_meta, opts) (:587-890).
 
     Returns (TrainedMPS, training_information, testing_states_meta).  training_information has the
     reference's keys and lengths (nsweeps+2 when log_level > 0; time_taken 0.0 first, NaN last).
     ``shard`` = (rank, world_size, communicator-setup callable) for batch sharding (see distributed.py).
+    ``preloaded``: the engine already holds both data sets (device-side encoding, fitMPS(device_encode=True)).
     """
     opts = safe_options(opts)
     eopt = engine_options(opts)
@@ -91,9 +92,10 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
             shard.attach(eng)
         else:
             tr_local, te_local = tr, te
-        eng.set_dataset(0, tr_local.phi, tr_local.label_index, C, gcounts)
-        if has_test:
-            eng.set_dataset(1, te_local.phi, te_local.label_index, C)
+        if not preloaded:
+            eng.set_dataset(0, tr_local.phi, tr_local.label_index, C, gcounts)
+            if has_test:
+                eng.set_dataset(1, te_local.phi, te_local.label_index, C)
         eng.set_mps(W)
         verbosity > -1 and print(f"Using {opts.update_iters} iterations per update.")
         eng.build_caches()                                                       # :631
@@ -144,10 +146,14 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
 
 
 def fitMPS(X_train, y_train=None, X_test=None, y_test=None, opts: MPSOptions = MPSOptions(),
-           custom_encoding: Optional[Encoding] = None, W=None, **kw):
+           custom_encoding: Optional[Encoding] = None, W=None, device_encode: bool = False, **kw):
     """fitMPS(X_train, y_train, X_test, y_test, opts[, custom_encoding]) (:383-416) and the
     overloads without test data / labels (:413,:416).  X_* are (N, T) matrices, rows = series.
-    Returns (TrainedMPS, training_information, encoded_test_states)."""
+    Returns (TrainedMPS, training_information, encoded_test_states).
+
+    ``device_encode=True`` (real Legendre bases only) preprocesses and encodes on the GPU
+    (mpst_encode_dataset): the raw matrices are uploaded, the product states are downloaded once for the
+    returned EncodedTimeSeriesSets."""
     opts = safe_options(opts)
     X_train = np.asarray(X_train, dtype=np.float64)
     N, T = X_train.shape
@@ -175,11 +181,45 @@ def fitMPS(X_train, y_train=None, X_test=None, y_test=None, opts: MPSOptions = M
     num_classes = len(classes)
     if W is None:
         W = generate_startingMPS(opts.chi_init, T, opts.d, num_classes, opts.init_rng)                   # :433-435
+    if device_encode:
+        return _fit_device_encoded(W, X_train, y_train, X_test, y_test, opts, enc, class_keys, **kw)
     Xtr_s, Xte_s, norms, oob = transform_data(X_train, X_test, opts, enc.range)                          # :445
     train_states = encode_dataset(X_train, Xtr_s, y_train, enc, opts.d, class_keys)                      # :489
     test_states = encode_dataset(X_test, Xte_s, y_test, enc, opts.d, class_keys) if X_test.size else \
         EncodedTimeSeriesSet.empty()
     return fit_encoded(W, train_states, test_states, opts, **kw)                                         # :556-560
+
+
+def _fit_device_encoded(W, X_train, y_train, X_test, y_test, opts, enc, class_keys, engine=None, device=0, **kw):
+    """fitMPS with transform_data + encode_dataset (:445, :489) done by the engine."""
+    if kw.get("shard") is not None:
+        raise NotImplementedError("device_encode together with batch sharding: encode per shard with mpst_encode_dataset")
+    C = len(class_keys)
+
+    def sorted_set(X, y):
+        order = np.argsort(y, kind="stable")                                      # encodings.jl:43
+        ys = np.asarray(y)[order]
+        li = np.array([class_keys[v] for v in ys.tolist()], dtype=np.int32)
+        _, counts = np.unique(ys, return_counts=True)
+        return np.ascontiguousarray(X[order]), ys, li, counts.astype(np.int64)
+
+    own = engine is None
+    eng = engine or SweepEngine(device)
+    try:
+        Xs, ys, li, counts = sorted_set(X_train, y_train)
+        common = dict(basis=enc.name, d=opts.d, sigmoid_transform=opts.sigmoid_transform, minmax=opts.minmax,
+                      data_bounds=opts.data_bounds, enc_range=enc.range)
+        norms, _ = eng.encode_dataset(0, Xs, li, C, **common)
+        train_states = EncodedTimeSeriesSet(eng.get_encoded(0), ys, li, Xs, counts)
+        test_states = EncodedTimeSeriesSet.empty()
+        if X_test.size:
+            Xt, yt, lt, ct = sorted_set(X_test, y_test)
+            eng.encode_dataset(1, Xt, lt, C, norms=norms, **common)
+            test_states = EncodedTimeSeriesSet(eng.get_encoded(1), yt, lt, Xt, ct)
+        return fit_encoded(W, train_states, test_states, opts, engine=eng, preloaded=True)
+    finally:
+        if own:
+            eng.close()
 
 
 def classify(mps: TrainedMPS, X_or_states, engine: Optional[SweepEngine] = None, device: int = 0):

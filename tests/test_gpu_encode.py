@@ -18,7 +18,7 @@ def _data(N, T, seed, spread=1.0):
     return X, np.sort(y)
 
 
-@pytest.mark.parametrize("basis,d", [("Legendre_No_Norm", 4), ("Legendre_No_Norm", 7), ("Legendre", 5)])
+@pytest.mark.parametrize("basis,d", [("Legendre_No_Norm", 4), ("Legendre", 7), ("Legendre_Norm", 5)])
 @pytest.mark.parametrize("sig,mm", [(True, True), (False, True), (True, False)])
 def test_train_encoding_matches_oracle(engine_cls, basis, d, sig, mm):
     X, y = _data(97, 41, 5)
@@ -28,7 +28,7 @@ def test_train_encoding_matches_oracle(engine_cls, basis, d, sig, mm):
     norms, sec = eng.encode_dataset(0, X, y, 3, basis=basis, d=d, sigmoid_transform=sig, minmax=mm)
     phi = eng.get_encoded(0)
     Xs, norms_o = R.transform_train_data(X, sigmoid_transform=sig, minmax=mm)
-    ref = R.legendre_encode(Xs, d, norm=(basis == "Legendre"))
+    ref = R.legendre_encode(Xs, d, norm=(basis == "Legendre_Norm"))
     assert phi.shape == ref.shape
     assert np.max(np.abs(phi - ref)) < 1e-13
     if mm:
@@ -77,3 +77,21 @@ def test_unsupported_basis_is_reported(engine_cls):
     with pytest.raises(mt.MPSTError):
         eng.encode_dataset(0, np.zeros((4, 5)), np.zeros(4, dtype=np.int32), 1, basis="Fourier", d=4)
     eng.close()
+
+
+def test_fitmps_with_device_encoding_matches_host_encoding():
+    """fitMPS(device_encode=True): same encoded sets (1e-13) and, from them, the same first logged losses."""
+    rng = np.random.default_rng(11)
+    Xtr, _ = mt.trendy_sine(24, 60, sigma=0.1, rng=rng)
+    ytr = np.arange(60) % 2
+    Xte, _ = mt.trendy_sine(24, 20, sigma=0.1, rng=rng)
+    yte = np.arange(20) % 2
+    opts = mt.MPSOptions(d=4, chi_max=8, nsweeps=1, verbosity=-1)
+    a, info_a, te_a = mt.fitMPS(Xtr, ytr, Xte, yte, opts)
+    b, info_b, te_b = mt.fitMPS(Xtr, ytr, Xte, yte, opts, device_encode=True)
+    assert np.max(np.abs(a.train_data.phi - b.train_data.phi)) < 1e-13
+    assert np.max(np.abs(te_a.phi - te_b.phi)) < 1e-13
+    assert np.array_equal(a.train_data.label_index, b.train_data.label_index)
+    assert np.array_equal(a.train_data.original_data, b.train_data.original_data)
+    assert abs(info_a["train_KL_div"][0] - info_b["train_KL_div"][0]) < 1e-10
+    assert abs(info_a["test_KL_div"][0] - info_b["test_KL_div"][0]) < 1e-10
