@@ -277,7 +277,7 @@ constexpr int WS_MISC = 512;    // [0] lo  [1] hi  [2] ||T||  [3] 1.0 if the tri
 constexpr int WS_LAM = 528;     // [32]
 constexpr int WS_RES = 560;     // [32]  ||T z - lambda z||_inf
 constexpr int WS_VS = 592;      // [8][128][16] reflectors, dense: block b, row c, reflector 16b+j (0 above its start)
-constexpr int WS_Z = 16976;     // [32][128] eigenvectors of G, one row per eigenvalue
+constexpr int WS_Z = 16976;     // [128][32] eigenvectors of G: component c of vector k at c*32 + k
 constexpr int WS_TOTAL = 21072;
 
 struct EigProblem {
@@ -948,9 +948,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
             }
             z[c1] = z1;
         }
-        double* Zk = ws + WS_Z + (size_t)k * 128;
-        if (c0 < n) Zk[c0] = z0;
-        if (c1 < n) Zk[c1] = z1;
+        double* Zk = ws + WS_Z + k;                    // [c][32] layout: k_eig_fin reads it linearly
+        if (c0 < n) Zk[c0 * 32] = z0;
+        if (c1 < n) Zk[c1 * 32] = z1;
         if (lane == 0) {
             ws[WS_LAM + k] = lamk;
             ws[WS_RES + k] = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
@@ -1065,10 +1065,22 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     double* Eout = raw ? rawE : v.E;
     const int ldE = raw ? n : v.cap;
     if (stamps && tid == 0) stamps[8] = __builtin_amdgcn_s_memrealtime();
+    // everything this kernel reads from global memory is requested up front (one round trip instead of three
+    // dependent ones): the diagonal of G, the flag / eigenvalues / residuals and the K0 candidate vectors
+    const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
+    const bool tri = pb.tri && ws[WS_MISC + 3] == 1.0;
+    double lam_in = 0.0, res_in = 0.0, tnorm_in = 0.0;
+    constexpr int NZL = 4096 / EIG_THREADS;
+    double zin[NZL];
+    if (pb.tri) {
+        lam_in = tid < K0 ? ws[WS_LAM + tid] : 0.0;
+        res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+        tnorm_in = ws[WS_MISC + 2];
+#pragma unroll
+        for (int m = 0; m < NZL; ++m) zin[m] = ws[WS_Z + tid + m * EIG_THREADS];
+    }
     // trace = ||bt_new||_F^2 (fixed order)
-    double tr = 0.0;
-    for (int i = tid; i < n; i += EIG_THREADS) tr += pb.G[(size_t)i * n + i];
-    tr = wave_sum(tr);
+    double tr = wave_sum(gdiag);
     if ((tid & 63) == 0) red[tid >> 6] = tr;
     __syncthreads();
     tr = 0.0;
@@ -1097,20 +1109,21 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     };
     int sweeps = 0, nk = K0;
     bool done = false;
-    const bool tri = pb.tri && ws[WS_MISC + 3] == 1.0;
     if (tri) {
         TriShared t = tri_carve(smem);
-        if (tid < K0) lam_s[tid] = ws[WS_LAM + tid];
+        if (tid < K0) lam_s[tid] = lam_in;
         __syncthreads();
         nk = truncate(lam_s, K0);
         // eigenvectors of values the truncation rule discards are never looked at: those are the
         // clustered, noise-level ones for which the twisted factorisation loses orthogonality
-        for (int i = tid; i < 128 * 32; i += EIG_THREADS) {
+#pragma unroll
+        for (int m = 0; m < NZL; ++m) {
+            const int i = tid + m * EIG_THREADS;
             const int c = i >> 5, kk = i & 31;
-            t.Z[i] = (c < n && kk < nk) ? ws[WS_Z + (size_t)kk * 128 + c] : 0.0;
+            t.Z[i] = (c < n && kk < nk) ? zin[m] : 0.0;
         }
-        if (tid < 32) t.misc[32 + tid] = tid < nk ? ws[WS_RES + tid] : 0.0;
-        if (tid == 0) t.misc[2] = ws[WS_MISC + 2];
+        if (tid < 32) t.misc[32 + tid] = tid < nk ? res_in : 0.0;
+        if (tid == 0) t.misc[2] = tnorm_in;
         __syncthreads();
         done = verify_and_polish(t, n, nk);
         if (done) {
