@@ -42,6 +42,12 @@ CASES = [
     (33, 3, 3, 2, 5, 1, "KLD", "TSGO", False, 2, True),
     (20, 2, 3, 1, 5, 2, "KLD", "TSGO", False, 1, True),
     (50, 7, 2, 2, 7, 4, "MSE", "GD", False, 2, False),
+    # edges: the maximum number of classes (MAX_C = 16), fewer series than one tile, the largest d*chi the
+    # eigensolver holds (7*18 = 126 <= 128) with a non-power-of-two d, and chi_max = 32 with d = 4 (128)
+    (70, 4, 2, 2, 6, 16, "KLD", "TSGO", False, 1, False),
+    (3, 5, 3, 2, 6, 2, "KLD", "TSGO", False, 1, True),
+    (60, 4, 7, 6, 18, 2, "KLD", "TSGO", False, 1, True),
+    (96, 4, 4, 8, 32, 3, "MSE", "TSGO", False, 1, False),
 ]
 
 
