@@ -346,12 +346,12 @@ __global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid) {
             scale = -(v.train_sep ? v.inv_count[c] : v.invN);      // :367 / :424
         }
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = k0; k < k1; k += 8) {
-            double t[8];
+        for (int k = k0; k < k1; k += 16) {                       // 16 loads in flight; same association as 8 + 8
+            double t[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (k + u < k1) ? p[(int64_t)(k + u) * b.L] : 0.0;
+            for (int u = 0; u < 16; ++u) t[u] = (k + u < k1) ? p[(int64_t)(k + u) * b.L] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] += t[u];
+            for (int u = 0; u < 16; ++u) acc[u & 7] += t[u];
         }
         double s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
         s *= scale;
@@ -384,14 +384,15 @@ __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter)
     const int n = v.C * b.L;
     const double* g = v.gradbuf + 2;
     // ||grad||^2: every workgroup sums the whole (L2-resident) gradient in the same order
+    // 16 independent 16-byte loads in flight per thread: 4 round trips to L2 for the 256 KB of config 3
     double s4[4] = {0, 0, 0, 0};
     const int n4 = n & ~7;
-    for (int i = threadIdx.x * 2; i < n4; i += 2048) {
-        double2 t[4];
+    for (int i = threadIdx.x * 2; i < n4; i += 8192) {
+        double2 t[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) t[u] = (i + 512 * u < n4) ? *(const double2*)&g[i + 512 * u] : make_double2(0.0, 0.0);
+        for (int u = 0; u < 16; ++u) t[u] = (i + 512 * u < n4) ? *(const double2*)&g[i + 512 * u] : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += t[u].x * t[u].x + t[u].y * t[u].y;
+        for (int u = 0; u < 16; ++u) s4[u & 3] += t[u].x * t[u].x + t[u].y * t[u].y;
     }
     double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     for (int i = n4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
