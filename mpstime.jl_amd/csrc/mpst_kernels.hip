@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
 
     // index tables: one integer division per column of the block instead of one per element
     __shared__ int xa_[GB], xs_[GB], yb_[GB], ys_[GB];
+    __shared__ double w_[CHUNK_S];       // per-series weight: one IEEE division per series, not one per thread
     if (tid < GB) {
         const int x = bx * GB + tid;
         const int a = x / d;
@@ -261,6 +262,10 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
         const int sy = y / b.Dr;
         yb_[tid - GB] = y < b.Y ? y - sy * b.Dr : -1;
         ys_[tid - GB] = sy;
+    } else if (tid < 2 * GB + CHUNK_S) {
+        const int i = tid - 2 * GB;
+        const double yv = i < ch.count ? yh[ch.start + i] : 1.0;
+        w_[i] = mse ? (yv - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yv;
     }
     __syncthreads();
     {
@@ -278,8 +283,7 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
             pl[m] = (ok && a >= 0) ? phl[smp * d + sx] : 0.0;
             re[m] = (ok && bb >= 0) ? (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
             pr[m] = (ok && bb >= 0) ? phr[smp * d + sy] : 0.0;
-            const double yv = ok ? yh[smp] : 1.0;
-            w[m] = mse ? (yv - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yv;
+            w[m] = w_[i];
         }
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
