@@ -175,27 +175,37 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     const int i16 = lane & 15, kq = lane >> 4;
     double p[4] = {0, 0, 0, 0};
     const int nty = YP >> 4;
-    for (int nt = wave; nt < nty; nt += 4) {
-        d4 acc = {0, 0, 0, 0};
-        const int col = nt * 16 + i16;
-        const bool cv = col < b.Y;
-        // the whole B_c column slice this lane needs (<= 32 k-steps for d*chi <= 128) is requested
-        // from L2 up front; the MFMAs then run back to back with the A operand from LDS
-        for (int kb = 0; kb < XP; kb += 128) {
-            double bv[32];
+    // Each wave owns the column tiles nt = wave and wave + 4 (d*chi <= 128: at most 8 tiles).  The whole B_c
+    // column slice a lane needs for BOTH tiles (<= 2 x 32 k-steps) is requested from L2 up front - one round
+    // trip - and the MFMAs then run back to back with the A operand from LDS.
+    static_assert(MAX_DIM <= 128, "k_yhat keeps the B operand of two 16-column tiles (32 k-steps each) in registers");
+    {
+        double bv[2][32];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = (wave + 4 * h) * 16 + i16;
+            const bool cv = wave + 4 * h < nty && col < b.Y;
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
-                const int kx = kb + 4 * u + kq;
-                bv[u] = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int k0 = kb + 4 * u;
-                if (k0 < XP) acc = mfma_f64(Xs[i16 * XS + k0 + kq], bv[u], acc);
+                const int kx = 4 * u + kq;
+                bv[h][u] = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] += acc[r] * Ys[(kq + 4 * r) * YS + col];
+        for (int h = 0; h < 2; ++h) {
+            const int nt = wave + 4 * h;
+            if (nt < nty) {
+                const int col = nt * 16 + i16;
+                d4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int k0 = 4 * u;
+                    if (k0 < XP) acc = mfma_f64(Xs[i16 * XS + k0 + kq], bv[h][u], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] += acc[r] * Ys[(kq + 4 * r) * YS + col];
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
