@@ -57,18 +57,19 @@ __device__ __forceinline__ d4 wave_gemm_tile(const double* __restrict__ A, int64
     const double* ap = A + (int64_t)m * sam;
     const double* bp = B + (int64_t)n * sbn;
     if (kend < 0) kend = K;
-    // 8 k-steps (32 columns of K) per batch: 16 independent loads are in flight before the MFMAs
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        double a[8], b[8];
+    // 16 k-steps (64 columns of K) per batch: 32 independent loads are in flight before the MFMAs, so a
+    // K = 128 product costs two round trips to L2 (the callers are latency-, not throughput-bound)
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        double a[16], b[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int k = k0 + 4 * u + kq;
             const bool kv = k < kend;
             a[u] = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
             b[u] = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (k0 + 4 * u < kend) acc = mfma_f64(a[u], b[u], acc);
     }
     return acc;
