@@ -381,6 +381,8 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
 #else
 #define DBG(j) do { } while (0)
 #endif
+    int pend_i = -1;                               // reflector this wave still has to write out (wave-uniform)
+    double pend_v0 = 0.0, pend_v1 = 0.0, pend_d = 0.0, pend_e = 0.0;
     auto finish_reflector = [&](int i, double x0, double x1) {
         // all 64 lanes of one wave; lane holds columns c0 = lane, c1 = lane + 64 of row i
         double* vbn = t.xs + (i & 1) * 128;
@@ -408,13 +410,26 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
         vbn[c0] = v0;
         vbn[c1] = v1;
-        const int off = voff(i, n) - i - 1;
-        if (c0 > i && c0 < n) t.Vs[off + c0] = v0;
-        if (c1 > i && c1 < n) t.Vs[off + c1] = v1;
-        if (lane == 0) {
-            t.de[2 * i] = di;
-            t.es[i] = beta;
-            t.taus[i] = tau;
+        if (lane == 0) t.taus[i] = tau;
+        // what only the later kernels read (the stored reflector, d_i, e_i) is written by flush_reflector()
+        // while this wave idles in the next step's first phase - off the chain the barrier waits for
+        pend_i = i;
+        pend_v0 = v0;
+        pend_v1 = v1;
+        pend_d = di;
+        pend_e = beta;
+    };
+    auto flush_reflector = [&]() {
+        if (pend_i >= 0) {
+            const int i = pend_i, c0 = lane, c1 = lane + 64;
+            const int off = voff(i, n) - i - 1;
+            if (c0 > i && c0 < n) t.Vs[off + c0] = pend_v0;
+            if (c1 > i && c1 < n) t.Vs[off + c1] = pend_v1;
+            if (lane == 0) {
+                t.de[2 * i] = pend_d;
+                t.es[i] = pend_e;
+            }
+            pend_i = -1;
         }
     };
     publish_row(0);
@@ -438,6 +453,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         dslot = (stamps && i == 60 && lane == 0) ? (wave == 12 ? 16 : wave == 6 ? 24 : wave == 7 ? 32 : -1) : -1;
 #endif
         DBG(0);
+        if (!live) flush_reflector();              // a helper wave is idle in this phase
         if (live) {
 #pragma unroll
             for (int k = K0; k < NP; ++k) vv[k] = *(const double2*)&vb[2 * q + 2 * QN * k];
@@ -500,6 +516,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
                 A[2 * k + 1] = fma(-g, vv[k].y, A[2 * k + 1]);
             }
             if (i + 2 < n - 1) publish_row(i + 2);
+            flush_reflector();                     // early steps: the helper is still a live wave
             DBG(4);
         }
         __syncthreads();
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         TRI_ERA(0) TRI_ERA(1) TRI_ERA(2) TRI_ERA(3) TRI_ERA(4) TRI_ERA(5) TRI_ERA(6) TRI_ERA(7)
 #undef TRI_ERA
     }
+    flush_reflector();
     {   // last diagonal element
         double* x = t.xs + ((n - 1) & 1) * 128;
         __syncthreads();
