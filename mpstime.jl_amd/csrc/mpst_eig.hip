@@ -383,13 +383,14 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
 #endif
     int pend_i = -1;                               // reflector this wave still has to write out (wave-uniform)
     double pend_v0 = 0.0, pend_v1 = 0.0, pend_d = 0.0, pend_e = 0.0;
-    auto finish_reflector = [&](int i, double x0, double x1) {
-        // all 64 lanes of one wave; lane holds columns c0 = lane, c1 = lane + 64 of row i
+    auto finish_reflector = [&](int i, double x0, double x1, double di, double al) {
+        // all 64 lanes of one wave; lane holds columns c0 = lane, c1 = lane + 64 of row i; di = x[i] and
+        // al = x[i+1] arrive as wave-uniform values (formed from LDS scalars, no cross-lane reads on the chain)
         double* vbn = t.xs + (i & 1) * 128;
         const int c0 = lane, c1 = lane + 64;
-        const double s = wave_sum_mfma((c0 >= i + 2 ? x0 * x0 : 0.0) + (c1 >= i + 2 ? x1 * x1 : 0.0));
-        const double di = i < 64 ? readlane_f64(x0, i) : readlane_f64(x1, i - 64);
-        const double al = i + 1 < 64 ? readlane_f64(x0, i + 1) : readlane_f64(x1, i + 1 - 64);
+        const double xm0 = c0 >= i + 2 ? x0 : 0.0, xm1 = c1 >= i + 2 ? x1 : 0.0;     // the part that is scaled
+        const double e0 = c0 == i + 1 ? 1.0 : 0.0, e1 = c1 == i + 1 ? 1.0 : 0.0;     // the unit entry of v
+        const double s = wave_sum_mfma(xm0 * xm0 + xm1 * xm1);
         // Branch-free: rsq + two Heron steps instead of the IEEE sqrt chain, reciprocals from the hardware
         // seed + 2 Newton steps.  A row whose tail is below 1e-140 in norm is treated as already reduced
         // (s == 0 path of dlarfg); squared norms above 1e280 would need rescaling and are left to the
@@ -406,8 +407,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         const double beta = nz ? -bneg : al;
         const double tau = nz ? (bneg + al) * ib : 0.0;        // (beta - al) / beta
         const double scale = nz ? is : 0.0;                    // 1 / (al - beta)
-        const double v0 = (c0 == i + 1) ? 1.0 : (c0 > i + 1 ? x0 * scale : 0.0);
-        const double v1 = (c1 == i + 1) ? 1.0 : (c1 > i + 1 ? x1 * scale : 0.0);
+        const double v0 = fma(xm0, scale, e0), v1 = fma(xm1, scale, e1);
         vbn[c0] = v0;
         vbn[c1] = v1;
         if (lane == 0) t.taus[i] = tau;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
     publish_row(0);
     publish_row(1);
     __syncthreads();
-    if (wave == 0) finish_reflector(0, xrb[lane], xrb[lane + 64]);
+    if (wave == 0) finish_reflector(0, xrb[lane], xrb[lane + 64], xrb[0], xrb[1]);
     __syncthreads();
     // One step, with the number K0 of finished 16-column groups as a compile-time constant: the main
     // loop below is cut into 8 "eras" of 16 steps, each running its own branch-free copy of the body.
@@ -483,15 +483,18 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
             const int j = i + 1;
             const double* xr = xrb + (j & 1) * 128;
             const double p0 = p[c0], p1 = p[c1], v0 = vb[c0], v1 = vb[c1], a0 = xr[c0], a1 = xr[c1];
-            const double pj = p[j], vj = vb[j];
+            // wave-uniform operands of the two leading entries of the updated row (v_j = 1 exactly)
+            const double pj = p[j], pj1 = p[j + 1], vj1 = vb[j + 1], aj = xr[j], aj1 = xr[j + 1];
             const double dot = wave_sum_mfma(p0 * v0 + p1 * v1);
             const double a2 = -0.5 * tau * dot;
-            const double wj = pj + a2 * vj;
-            const double g = a2 * vj + wj;
-            const double x0 = fma(-g, v0, fma(-vj, p0, a0));
-            const double x1 = fma(-g, v1, fma(-vj, p1, a1));
+            const double g = a2 + (pj + a2);                    // a2 v_j + (p_j + a2 v_j) with v_j = 1
+            // same two roundings per entry as the register update: (a - 1 p) first, then the fma with g
+            const double x0 = fma(-g, v0, a0 - p0);
+            const double x1 = fma(-g, v1, a1 - p1);
+            const double di = (aj - pj) - g;
+            const double al = fma(-g, vj1, aj1 - pj1);
             DBG(6);
-            finish_reflector(j, x0, x1);
+            finish_reflector(j, x0, x1, di, al);
             __builtin_amdgcn_s_setprio(0);
             DBG(7);
         }
