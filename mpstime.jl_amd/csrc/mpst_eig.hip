@@ -477,9 +477,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         DBG(2);
         const int c0 = lane, c1 = lane + 64;
         if (wave == helper && i + 1 < n - 1) {
-#ifndef TRI_NOPRIO
             __builtin_amdgcn_s_setprio(3);
-#endif
             const int j = i + 1;
             const double* xr = xrb + (j & 1) * 128;
             const double p0 = p[c0], p1 = p[c1], v0 = vb[c0], v1 = vb[c1], a0 = xr[c0], a1 = xr[c1];
@@ -499,9 +497,6 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
             DBG(7);
         }
         if (live) {
-#ifdef TRI_SLEEP
-            for (int z = 0; z < TRI_SLEEP; ++z) __builtin_amdgcn_s_sleep(8);
-#endif
             const double pr = p[r], vr = vb[r];
             const double dot = wave_sum_mfma(p[c0] * vb[c0] + p[c1] * vb[c1]);
             const double a2 = -0.5 * tau * dot;
