@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,7 +47,10 @@ struct Ctx {
     int32_t* pred = nullptr;
     int64_t eval_N = 0;
     double* norm2 = nullptr;
-    bool ws_ready = false;
+    bool ws_ready = false;      // training workspace (caches, bond tensor, gradient, eigensolver) allocated for the current sizes
+    bool eval_ready = false;    // evaluation scratch (chains, yeval, pred) allocated for max(N_train, N_test)
+    bool caches_valid = false;  // LE / RE describe the current MPS: set by mpst_build_caches, cleared by whatever invalidates them
+    int host_label_site = -1;   // host mirror of *label_site (set_mps, bond_step and sweep move it deterministically)
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
@@ -121,11 +125,30 @@ View make_view(Ctx* c, int which) {
     return v;
 }
 
-// (re)allocate everything whose size depends on (dataset, options, capacity)
+// (re)allocate the evaluation scratch: sized by the larger of the two data sets, independent of the training
+// workspace, so that (re)loading a TEST set never touches the environment caches
+int ensure_eval(Ctx* c) {
+    if (c->eval_ready) return 0;
+    int rc;
+    const int64_t en = std::max<int64_t>(1, std::max(c->ds[0].N, c->ds[1].N));
+    c->eval_N = en;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = dalloc(c, &c->chainL[k], en * c->cap))) return rc;
+        if ((rc = dalloc(c, &c->chainR[k], en * c->cap))) return rc;
+    }
+    if ((rc = dalloc(c, &c->yeval, en * c->C))) return rc;
+    if ((rc = dalloc(c, &c->out3, 4))) return rc;
+    if ((rc = dalloc(c, &c->conf, (int64_t)MAX_C * MAX_C))) return rc;
+    if ((rc = dalloc(c, &c->pred, en))) return rc;
+    c->eval_ready = true;
+    return 0;
+}
+
+// (re)allocate everything whose size depends on (training set, options, capacity)
 int ensure_workspace(Ctx* c) {
-    if (c->ws_ready) return 0;
     if (!c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options must be called first");
     if (!c->have_mps) return fail(c, MPST_ERR_INVALID, "mpst_set_mps must be called first");
+    if (c->ws_ready) return ensure_eval(c);
     const DataSet& tr = c->ds[MPST_TRAIN];
     if (tr.N <= 0) return fail(c, MPST_ERR_INVALID, "no training data set (mpst_set_dataset)");
     const int dm = c->d * c->cap;
@@ -134,6 +157,7 @@ int ensure_workspace(Ctx* c) {
     if (c->C > MAX_C) return fail(c, MPST_ERR_UNSUPPORTED, "more than %d classes unsupported", MAX_C);
     const int64_t Lmax = (int64_t)dm * dm;
     int rc;
+    c->caches_valid = false;
     c->cache_elems = (int64_t)c->T * tr.N * c->cap;
     if ((rc = dalloc(c, &c->LE, c->cache_elems))) return rc;
     if ((rc = dalloc(c, &c->RE, c->cache_elems))) return rc;
@@ -152,19 +176,21 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
     HIPC(c, hipMemset(c->sc, 0, sizeof(DevScalars)));
     if ((rc = dalloc(c, &c->norm2, 1))) return rc;
-    int64_t en = std::max(c->ds[0].N, c->ds[1].N);
-    c->eval_N = en;
-    for (int k = 0; k < 2; ++k) {
-        if ((rc = dalloc(c, &c->chainL[k], en * c->cap))) return rc;
-        if ((rc = dalloc(c, &c->chainR[k], en * c->cap))) return rc;
-    }
-    if ((rc = dalloc(c, &c->yeval, en * c->C))) return rc;
-    if ((rc = dalloc(c, &c->out3, 4))) return rc;
-    if ((rc = dalloc(c, &c->conf, (int64_t)MAX_C * MAX_C))) return rc;
-    if ((rc = dalloc(c, &c->pred, en))) return rc;
-    init_kernel_attrs();
+    hipError_t ea = init_kernel_attrs(c->device);
+    if (ea == hipSuccess) ea = eig_init_attrs(c->device);
+    if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
     c->ws_ready = true;
+    c->eval_ready = false;
     c->epoch++;
+    return ensure_eval(c);
+}
+
+// clears the sticky error flag and the per-sweep diagnostics (status, eig_sweeps_total, eig_fallbacks are adjacent);
+// enqueued at the head of every sweep / bond step - inside the captured graph too - so that a context recovers
+// after a failed decomposition (the class of failure tune() retries on)
+int enqueue_reset_status(Ctx* c) {
+    static_assert(offsetof(DevScalars, eig_fallbacks) == offsetof(DevScalars, status) + 8, "status / eig_sweeps_total / eig_fallbacks adjacent");
+    HIPC(c, hipMemsetAsync((char*)c->sc + offsetof(DevScalars, status), 0, 12, c->stream));
     return 0;
 }
 
@@ -392,7 +418,12 @@ static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N
     c->T = T; c->d = d; c->C = C;
     DataSet& s = c->ds[which];
     free_dataset(s);
-    c->ws_ready = false;
+    if (which == MPST_TRAIN) {
+        c->ws_ready = false;        // caches, yhat, partials are sized by the training set
+        c->caches_valid = false;
+    }
+    c->eval_ready = false;
+    c->epoch++;
     s.N = N;
     s.counts.assign(C, 0);
     if (N == 0) return 0;
@@ -472,6 +503,10 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     if (rc || N == 0) return rc;
     DataSet& s = c->ds[which];
     double *dX = nullptr, *part = nullptr, *lohi = nullptr, *fix = nullptr;
+    struct Temps {      // released on every exit path, the HIPC early returns included
+        double **a, **b, **cc, **d;
+        ~Temps() { dfree(a); dfree(b); dfree(cc); dfree(d); }
+    } temps{&dX, &part, &lohi, &fix};
     if ((rc = dalloc(c, &dX, N * T)) || (rc = dalloc(c, &part, 512)) || (rc = dalloc(c, &lohi, 2))) return rc;
     const bool test = eo->is_test != 0;
     if (test && eo->rescale_out_of_bounds && (rc = dalloc(c, &fix, 2 * N))) return rc;
@@ -503,7 +538,6 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
         eo->hi = h[1];
     }
     if (fix && oob_fix) HIPC(c, hipMemcpy(oob_fix, fix, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
-    dfree(&dX); dfree(&part); dfree(&lohi); dfree(&fix);
     return 0;
 }
 
@@ -567,6 +601,8 @@ int mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_t
     HIPC(c, hipMemcpy(c->chi, chi, (size_t)(T + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->label_site, &label_site, sizeof(int32_t), hipMemcpyHostToDevice));
     c->have_mps = true;
+    c->caches_valid = false;
+    c->host_label_site = label_site;
     c->epoch++;
     return 0;
 }
@@ -611,9 +647,7 @@ int mpst_build_caches(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     int rc = check_ready(c);
     if (rc) return rc;
-    int32_t ls;
-    HIPC(c, hipStreamSynchronize(c->stream));
-    HIPC(c, hipMemcpy(&ls, c->label_site, sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int32_t ls = c->host_label_site;
     // environments on both sides of the label site p: LE[0..p-1] and RE[T-1..p+1].  With the label
     // on the last site (the state fitMPS starts from) this is construct_caches(W; going_left=true).
     View v = make_view(c, MPST_TRAIN);
@@ -627,8 +661,10 @@ int mpst_build_caches(void* ctx) {
             launch_env(v, j, 0, j < c->T - 1 ? c->RE + (int64_t)(j + 1) * cs : nullptr, j + 1, ENV_M_SITE_T, j,
                        c->RE + (int64_t)j * cs, c->stream);
     }
+    HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
+    c->caches_valid = true;
     return 0;
 }
 
@@ -636,8 +672,14 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     Ctx* c = (Ctx*)ctx;
     int rc = check_ready(c);
     if (rc) return rc;
+    if (!c->caches_valid)
+        return fail(c, MPST_ERR_INVALID, "the environment caches do not describe the current MPS / data set: call mpst_build_caches first");
+    if (c->host_label_site != c->T - 1)
+        return fail(c, MPST_ERR_INVALID, "a sweep starts with the label index on the last site (RealRealHighDimension.jl:19-29), it is on site %d", c->host_label_site);
     View v = make_view(c, MPST_TRAIN);
     auto enqueue_sweep = [&]() -> int {
+        int r0 = enqueue_reset_status(c);
+        if (r0) return r0;
         // bond order of one sweep (:731, :776); unless the tensor is rescaled first or the caches are
         // rebuilt in between, bond k+1's tensor is assembled by bond k's environment kernel
         const int nb = c->T - 1;
@@ -666,8 +708,6 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             (void)hipGraphExecDestroy(c->sweep_graph);
             c->sweep_graph = nullptr;
         }
-        init_kernel_attrs();
-        eig_init_attrs();
         HIPC(c, hipStreamSynchronize(c->stream));
         HIPC(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         rc = enqueue_sweep();
@@ -678,6 +718,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             return rc;
         }
         if (e != hipSuccess || !g) return fail(c, MPST_ERR_DEVICE, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        HIPC(c, hipGetLastError());     // a launch rejected during capture (bad configuration) surfaces here
         e = hipGraphInstantiate(&c->sweep_graph, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) {
@@ -692,6 +733,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     } else if ((rc = enqueue_sweep())) {
         return rc;
     }
+    HIPC(c, hipGetLastError());         // launch-time failures of the ~2000 enqueues above
     HIPC(c, hipEventRecord(c->ev_stop, c->stream));
     HIPC(c, hipEventSynchronize(c->ev_stop));
     float ms = 0.f;
@@ -708,7 +750,10 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         out->eig_sweeps_total = sc.eig_sweeps_total;
         out->eig_fallbacks = sc.eig_fallbacks;
     }
-    if (sc.status) return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
+    if (sc.status) {
+        c->caches_valid = false;        // the state after a failed bond is unspecified: set_mps + build_caches to go on
+        return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
+    }
     return 0;
 }
 
@@ -717,8 +762,15 @@ int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* 
     int rc = check_ready(c);
     if (rc) return rc;
     if (lid < 0 || lid > c->T - 2) return fail(c, MPST_ERR_INVALID, "lid out of range");
+    if (!c->caches_valid)
+        return fail(c, MPST_ERR_INVALID, "the environment caches do not describe the current MPS / data set: call mpst_build_caches first");
+    if (c->host_label_site != lid && c->host_label_site != lid + 1)
+        return fail(c, MPST_ERR_INVALID, "bond (%d,%d) does not hold the label index (it is on site %d)", lid, lid + 1, c->host_label_site);
     View v = make_view(c, MPST_TRAIN);
+    if ((rc = enqueue_reset_status(c))) return rc;
     if ((rc = enqueue_bond(c, v, lid, going_left ? 1 : 0))) return rc;
+    HIPC(c, hipGetLastError());
+    c->host_label_site = going_left ? lid : lid + 1;
     HIPC(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     DevScalars sc;
@@ -735,7 +787,10 @@ int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* 
         dbg->reserved = 0;
         for (int i = 0; i < sc.n_spec && i < MPST_MAX_SPECTRUM; ++i) dbg->spectrum[i] = std::sqrt(std::max(lam[i], 0.0)) * sc.inv_norm;
     }
-    if (sc.status) return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed at bond %d", lid);
+    if (sc.status) {
+        c->caches_valid = false;
+        return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed at bond %d", lid);
+    }
     return 0;
 }
 
@@ -747,6 +802,7 @@ int mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64
     if ((rc = enqueue_eval(c, which))) return rc;
     View v = make_view(c, which);
     launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     double o[3];
     HIPC(c, hipMemcpy(o, c->out3, sizeof o, hipMemcpyDeviceToHost));
@@ -779,6 +835,7 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
     if ((rc = enqueue_eval(c, which))) return rc;
     View v = make_view(c, which);
     launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     if (pred) HIPC(c, hipMemcpy(pred, c->pred, (size_t)v.N * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (yhat) HIPC(c, hipMemcpy(yhat, c->yeval, (size_t)v.N * c->C * sizeof(double), hipMemcpyDeviceToHost));
@@ -792,6 +849,7 @@ int mpst_normalize(void* ctx) {
     View v = make_view(c, MPST_TRAIN);
     launch_norm2(v, c->norm2, c->stream);
     launch_scale_sites(v, c->norm2, c->stream);
+    HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -849,14 +907,15 @@ int mpst_selftest_mfma(void* ctx, const double* A, const double* B, int32_t K, d
     if (!c) return MPST_ERR_INVALID;
     HIPC(c, hipSetDevice(c->device));
     double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    struct Temps { double **a, **b, **cc; ~Temps() { dfree(a); dfree(b); dfree(cc); } } temps{&dA, &dB, &dC};
     int rc;
     if ((rc = dalloc(c, &dA, 16 * K)) || (rc = dalloc(c, &dB, 16 * K)) || (rc = dalloc(c, &dC, 256))) return rc;
     HIPC(c, hipMemcpy(dA, A, (size_t)16 * K * sizeof(double), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(dB, B, (size_t)16 * K * sizeof(double), hipMemcpyHostToDevice));
     launch_selftest_mfma(dA, dB, K, dC, c->stream);
     HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpy(C_out, dC, 256 * sizeof(double), hipMemcpyDeviceToHost));
-    dfree(&dA); dfree(&dB); dfree(&dC);
     return 0;
 }
 
@@ -867,6 +926,10 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
     HIPC(c, hipSetDevice(c->device));
     double *dG = nullptr, *dl = nullptr, *dE = nullptr, *dws = nullptr;
     int32_t* ds = nullptr;
+    struct Temps { double **a, **b, **cc, **d; int32_t** e; ~Temps() { dfree(a); dfree(b); dfree(cc); dfree(d); dfree(e); } }
+        temps{&dG, &dl, &dE, &dws, &ds};
+    hipError_t ea = eig_init_attrs(c->device);
+    if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
     int rc;
     if ((rc = dalloc(c, &dG, n * n)) || (rc = dalloc(c, &dl, n)) || (rc = dalloc(c, &dE, n * n)) || (rc = dalloc(c, &ds, 1)) ||
         (rc = dalloc(c, &dws, (int64_t)eig_workspace_doubles()))) return rc;
@@ -878,7 +941,6 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
     HIPC(c, hipMemcpy(lambda_out, dl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     HIPC(c, hipMemcpy(E_out, dE, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost));
     if (sweeps) HIPC(c, hipMemcpy(sweeps, ds, sizeof(int32_t), hipMemcpyDeviceToHost));
-    dfree(&dG); dfree(&dl); dfree(&dE); dfree(&ds); dfree(&dws);
     return 0;
 }
 

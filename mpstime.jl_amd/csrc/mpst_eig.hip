@@ -1195,20 +1195,19 @@ static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double);
 static size_t tri_lds_bytes() { return (size_t)(8128 + 256 * 3 + 128 * 2 + 32 + 192 + 64) * sizeof(double); }
 static size_t vec_lds_bytes() { return (size_t)(16384 + 272 + 128 * 6 + 144 + 48 + 2048 + 16) * sizeof(double); }
 
-static bool g_attr_set = false;
-static void ensure_attrs() {
-    if (g_attr_set) return;
-    (void)hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes());
-    g_attr_set = true;
+size_t eig_workspace_doubles() { return WS_TOTAL; }
+hipError_t eig_init_attrs(int device) {
+    static unsigned long long done = 0;
+    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if (device >= 0 && device < 64) done |= 1ull << device;
+    return hipSuccess;
 }
 
-size_t eig_workspace_doubles() { return WS_TOTAL; }
-void eig_init_attrs() { ensure_attrs(); }
-
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s) {
-    ensure_attrs();
     unsigned long long* st = v.sc ? v.sc->eig_stamps : nullptr;
     if (stage == 0)
         hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
@@ -1222,7 +1221,6 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
 }
 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {
-    ensure_attrs();
     View v{};
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
     hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,

@@ -254,8 +254,9 @@ struct EncDev {
 };
 void launch_encode(const EncDev& e, const double* X, double* phi, double* part, double* lohi, double* fix, int fit_range,
                    hipStream_t s);
-void init_kernel_attrs();
-void eig_init_attrs();
+// per-device opt-in to large dynamic LDS (hipFuncSetAttribute applies to the current device only)
+hipError_t init_kernel_attrs(int device);
+hipError_t eig_init_attrs(int device);
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);
 void launch_eval_reduce(const View& v, const double* yhat_in, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
 void launch_norm2(const View& v, double* out_norm2, hipStream_t s);

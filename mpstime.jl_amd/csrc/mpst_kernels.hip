@@ -792,15 +792,17 @@ void launch_env(const View& v, int site, int left_side, const double* prev, int 
     hipLaunchKernelGGL(k_env, dim3(v.ntiles + extra), dim3(256), lds, s, v, site, left_side, prev, prev_bond, mode,
                        out_bond, out, bt_lid, bt_bx);
 }
-void init_kernel_attrs() {
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)(2 * CHUNK_S * (GB + 16) * sizeof(double)));
-    (void)hipFuncSetAttribute((const void*)k_yhat, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    done = true;
+hipError_t init_kernel_attrs(int device) {
+    static unsigned long long done = 0;      // one bit per device: the attribute is per device and per process
+    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)(2 * CHUNK_S * (GB + 16) * sizeof(double)))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+    if (device >= 0 && device < 64) done |= 1ull << device;
+    return hipSuccess;
 }
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yout, hipStream_t s) {
     hipLaunchKernelGGL(k_eval_final, dim3((unsigned)((v.N + 255) / 256)), dim3(256), 0, s, v, Lc, Rc, yout);

@@ -38,9 +38,9 @@ def build(native=False, out_dir=None):
     out_dir = out_dir or _HERE
     name = "libmps_oracle_native.so" if native else "libmps_oracle.so"
     path = os.path.join(out_dir, name)
-    march = "native" if native else "x86-64-v3"
-    subprocess.check_call(["gcc", "-O3", f"-march={march}", "-ffast-math", "-fPIC", "-std=gnu11", "-shared", _SRC,
-                           "-o", path, "-lm"])
+    # the parity checker never gets -ffast-math; the timed cpu_baseline copy does (like the reference's @fastmath loops)
+    flags = ["-march=native", "-ffast-math"] if native else ["-march=x86-64-v3"]
+    subprocess.check_call(["gcc", "-O3", *flags, "-fPIC", "-std=gnu11", "-shared", _SRC, "-o", path, "-lm"])
     return path
 
 
@@ -108,8 +108,9 @@ class COracle:
                                  "S": r[5:5 + int(r[4])].copy()} for r in dbg[:int(secs[1])]]
         return out
 
-    def build_caches(self):
-        return self._run(1)
+    def build_caches(self, around_label=False):
+        """construct_caches(going_left=true); around_label=True: the environments on both sides of the label site."""
+        return self._run(2 if around_label else 1)
 
     def sweep(self, max_bonds=0, record=False, first_bond=0):
         """Bonds [first_bond, first_bond+max_bonds) of one sweep (all of it by default)."""

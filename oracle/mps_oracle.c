@@ -286,10 +286,15 @@ static int bond_step(orc_state* st, int lid, int going_left, double* dbg) {
     return 0;
 }
 
+/* the truncation rule alone, for tests */
+int orc_truncate(const double* S, int n, int maxdim, double cutoff) { return truncate_spectrum(S, n, maxdim, cutoff); }
+
 /* Exported entry point.  mode 0: bond updates of one full sweep (:727-808), numbered 0..2(T-1)-1 in
  * sweep order (backward half-sweep first); the call performs bonds [first_bond, first_bond+max_bonds)
  * (max_bonds <= 0: to the end of the sweep) and the cache rebuilds (:770,:804) that fall inside that
- * range when rebuild_caches is set.  mode 1: construct_caches(going_left=true) only.
+ * range when rebuild_caches is set.  mode 1: construct_caches(going_left=true) only.  mode 2: the environments on
+ * both sides of the current label site p (LE of the sites left of p, RE of the sites right of p) - what a sweep
+ * resumed in the middle needs; with p = T-1 it is mode 1.
  * dbg: NULL or one record of dbg_stride doubles per bond performed.  seconds_out: [seconds, bonds done]. */
 int orc_run(const orc_opts* o, const double* phi, const int* label, const long* counts, double* sites, long slot,
             int* chi, int* label_site, double* LE, double* RE, dgesdd_fn gesdd, int mode, int first_bond,
@@ -320,6 +325,10 @@ int orc_run(const orc_opts* o, const double* phi, const int* label, const long* 
     const double t0 = now_s();
     if (mode == 1) {
         construct_caches(&st, 1);
+    } else if (mode == 2) {
+        const int p = *label_site;
+        for (int j = 0; j < p && j <= o->T - 2; ++j) env_left(&st, j, st.sites + st.slot * j, st.chi[j], st.chi[j + 1]);
+        for (int j = o->T - 1; j > p && j >= 1; --j) env_right(&st, j, st.sites + st.slot * j, st.chi[j], st.chi[j + 1]);
     } else {
         for (int q = first_bond; q < last && !rc; ++q) {
             if (q < nb) {

@@ -36,17 +36,22 @@ def bond_matrix(Wl, Wr):
     return R.unflatten_bt(bt, shape4)
 
 
-def teacher_forced_sweep(eng, co, phi, T, nbonds=None, overlap_every=9, sub=slice(None)):
+def bond_of(q, T):
+    """Bond q of a sweep in sweep order (backward half-sweep first): (lid, going_left)."""
+    going_left = q < T - 1
+    return ((T - 2 - q) if going_left else (q - (T - 1))), going_left
+
+
+def teacher_forced_sweep(eng, co, phi, T, nbonds=None, overlap_every=9, sub=slice(None), first=0):
     """Every bond update of a sweep compared with the C oracle, each starting from the ORACLE's state
     (set_mps + build_caches): free-running trajectories diverge chaotically (oracle/sensitivity_study.py),
     one update from a common state is well conditioned.  Returns the worst relative deviations and the
     number of bonds whose kept dimension differs by one because a singular value sits on the cutoff."""
     worst = dict(loss=0.0, grad=0.0, S=0.0, overlap=0.0)
     chi_flips = 0
-    nb = 2 * (T - 1) if nbonds is None else nbonds
-    for q in range(nb):
-        going_left = q < T - 1
-        lid = (T - 2 - q) if going_left else (q - (T - 1))
+    nb = 2 * (T - 1) - first if nbonds is None else nbonds
+    for q in range(first, first + nb):
+        lid, going_left = bond_of(q, T)
         eng.set_mps(co.get_mps())
         eng.build_caches()
         ref = co.sweep(max_bonds=1, first_bond=q, record=True)["bonds_rec"][0]
@@ -67,3 +72,17 @@ def teacher_forced_sweep(eng, co, phi, T, nbonds=None, overlap_every=9, sub=slic
             yg = R.contract_mps(eng.get_mps(), phi[sub])
             worst["overlap"] = max(worst["overlap"], np.abs(yo - yg).max() / np.abs(yo).max())
     return worst, chi_flips
+
+
+def teacher_forced_segment(eng, make_oracle, W0, phi, T, first, count, sub=slice(None), overlap_every=5):
+    """Bonds [first, first+count) of the FIRST sweep compared one by one with the C oracle.  The engine free-runs from
+    W0 up to bond `first` (cheap on the GPU); the oracle is then initialised from the engine's state (label site
+    wherever the sweep has carried it, environments rebuilt on both sides of it) and from there on every update of both
+    starts from the oracle's state, as in teacher_forced_sweep."""
+    eng.set_mps(W0)
+    eng.build_caches()
+    for q in range(first):
+        eng.bond_step(*bond_of(q, T))
+    co = make_oracle(eng.get_mps() if first else W0)
+    co.build_caches(around_label=True)
+    return teacher_forced_sweep(eng, co, phi, T, nbonds=count, overlap_every=overlap_every, sub=sub, first=first)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import mpstime_jl_amd as mt
-from tests.helpers import teacher_forced_sweep
+from tests.helpers import teacher_forced_segment, teacher_forced_sweep
 from oracle import ref_numpy as R
 from tests.helpers import load_engine
 from tests.test_oracle import load_golden
@@ -167,6 +167,69 @@ def test_full_size_config3_against_c_oracle(engine_cls, chi):
         assert conf.sum() == 4096 and acc == np.mean(np.argmax(np.abs(yall), 1) == full.label_index)
         # it trains: same regime as the oracle (chi=32: KLD -23.5, acc 0.96 after one sweep; chi=16 is slower)
         assert kld < kld0 - 10 and acc > (0.9 if chi == 32 else 0.6)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("kw", [dict(update_iters=2), dict(loss="MSE", bbopt="GD", eta=0.05),
+                                dict(update_iters=2, loss="MSE", rescale=(True, True))],
+                         ids=["iters2", "mse_gd", "mse_iters2_rescale_before"])
+def test_full_size_option_paths_against_c_oracle(engine_cls, kw):
+    """update_iters > 1, the MSE loss and rescale[1] at BASELINE's full size (N=4096, T=100, chi=32, d=4): 8 bonds where
+    the sweep starts and 10 bulk bonds of the forward half-sweep (all at chi_max), each update of engine and C oracle
+    from a common state."""
+    from oracle.c_oracle import COracle
+    full, W0 = _config3()
+    T, chi = 100, 32
+    eta = kw.get("eta", 0.01)
+    okw = dict(eta=eta, update_iters=kw.get("update_iters", 1), loss=kw.get("loss", "KLD"), bbopt=kw.get("bbopt", "TSGO"),
+               rescale=kw.get("rescale", (False, True)))
+    mk = lambda W: COracle(W, full.phi, full.label_index, full.class_distribution, chi, rebuild_caches=False, **okw)
+    eng = engine_cls(0)
+    sub = slice(0, 4096, 32)
+    try:
+        eng.set_options(chi_max=chi, **okw)
+        eng.set_dataset(0, full.phi, full.label_index, 2)
+        for first, count in ((0, 8), (140, 10)):
+            worst, flips = teacher_forced_segment(eng, mk, W0, full.phi, T, first, count, sub=sub)
+            assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, (first, worst)
+            assert flips <= 1
+    finally:
+        eng.close()
+
+
+def test_config4_n32768_on_one_gpu(engine_cls):
+    """BASELINE.json configs[3] (N=32768, T=100, chi=32, d=4) on ONE GPU (it fits: 2 x 839 MB of environments): the first
+    and the last 20 bonds of the first sweep against the C oracle from a common state, then the size-independent
+    properties of a free-running sweep."""
+    from oracle.c_oracle import COracle
+    N, T, chi = 32768, 100, 32
+    full, W0 = _config3(N=N)
+    mk = lambda W: COracle(W, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=False)
+    eng = engine_cls(0)
+    sub = slice(0, N, 256)
+    try:
+        eng.set_options(chi_max=chi, eta=0.01)
+        eng.set_dataset(0, full.phi, full.label_index, 2)
+        for first in (0, 2 * (T - 1) - 20):
+            worst, flips = teacher_forced_segment(eng, mk, W0, full.phi, T, first, 20, sub=sub)
+            assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, (first, worst)
+            assert flips <= 1
+        eng.set_mps(W0)
+        eng.build_caches()
+        kld0 = eng.eval(0)[1]
+        st = eng.sweep()
+        assert st["eig_fallbacks"] == 0
+        Wg = eng.get_mps()
+        assert abs(R.mps_norm(Wg) - 1.0) < 1e-10
+        for t in Wg[:-1]:
+            m = t.reshape(-1, t.shape[2])
+            assert np.abs(m.T @ m - np.eye(m.shape[1])).max() < 1e-10
+        mse, kld, acc, conf = eng.eval(0)
+        yall = R.contract_mps(Wg, full.phi)
+        assert abs(kld - np.mean(-np.log(yall[np.arange(N), full.label_index] ** 2))) < 1e-9 * max(1, abs(kld))
+        assert conf.sum() == N and acc == np.mean(np.argmax(np.abs(yall), 1) == full.label_index)
+        assert kld < kld0 - 10 and acc > 0.9
     finally:
         eng.close()
 

@@ -62,6 +62,44 @@ def test_reference_mps_canonical_form(ref):
     assert abs(R.mps_norm(W) - 1.0) < 1e-12                   # normalize!(W) at the end of fitMPS
 
 
+def test_truncation_rule_on_reference_spectra(ref):
+    """The only reference OUTPUT of decomposeBT's truncation in the tree: the bond spectra of the MPS the reference's
+    fitMPS returned (cutoff 1e-10, maxdim 25).  With every site left of the last one left-orthonormal, the Schmidt
+    spectrum of bond j is the singular-value set of the centre matrix moved there.  The last bond's spectrum is exactly
+    what the final SVD of the run kept (then normalize!); the oracle's restatement of NDTensors' truncate! must be
+    idempotent on all of them (keep everything the reference kept), the weight it kept must be 1 to rounding, and where
+    the reference kept FEWER states than maxdim and than the rank bound (bond 2: 23 < 25 = d^2) the relative cutoff
+    was the active rule: the smallest kept weight sits above it."""
+    W, chi, chi_max = ref["W"], ref["chi"], ref["chi_max"]
+    cur = W[-1].reshape(W[-1].shape[0], -1)
+    spectra = {}
+    for j in range(len(W) - 1, 0, -1):
+        U, S, _ = np.linalg.svd(cur, full_matrices=False)
+        spectra[j] = S
+        cur = np.einsum("asb,bk->ask", W[j - 1], U * S).reshape(W[j - 1].shape[0], -1)
+    for j, S in spectra.items():
+        assert len(S) == chi[j]
+        assert R.truncate_spectrum(S, chi_max, 1e-10) == chi[j]
+        assert abs(np.sum(S ** 2) - 1.0) < 1e-12
+        P = S ** 2
+        assert P.min() > 1e-10 * P.sum()
+    # the C restatement applies the same rule (same decisions on the same spectra)
+    import ctypes as C
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    if hasattr(lib, "orc_truncate"):
+        lib.orc_truncate.restype = C.c_int
+        for j, S in spectra.items():
+            buf = np.ascontiguousarray(S)
+            assert lib.orc_truncate(buf.ctypes.data_as(C.POINTER(C.c_double)), len(S), chi_max, C.c_double(1e-10)) == chi[j]
+    assert chi[2] == 23 < min(chi_max, ref["d"] ** 2)          # cutoff-limited, not maxdim- or rank-limited
+    # had the two discarded states carried more than the cutoff, they would have been kept: re-attach a tail and check
+    S2 = np.concatenate([spectra[2], [2e-5, 1e-6]])              # weights 4e-10 and 1e-12 of a unit-norm state
+    assert R.truncate_spectrum(S2, chi_max, 1e-10) == 24        # the 1e-12 one goes, the 4e-10 one stays
+    S3 = np.concatenate([spectra[2], [7e-6, 6e-6]])              # 4.9e-11 + 3.6e-11 = 8.5e-11 <= 1e-10: both go
+    assert R.truncate_spectrum(S3, chi_max, 1e-10) == 23
+
+
 def test_oracle_contract_mps_on_reference_mps(ref):
     ds = R.EncodedSet(ref["phi"], ref["label_index"], ref["cd"])
     yhat = R.contract_mps(ref["W"], ds.phi)
