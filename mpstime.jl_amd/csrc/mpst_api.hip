@@ -47,6 +47,8 @@ struct Ctx {
     int32_t* pred = nullptr;
     int64_t eval_N = 0;
     double* norm2 = nullptr;
+    double* norm_scratch = nullptr;   // 3*cap*cap doubles for k_norm2 when they exceed its LDS
+    BigEig* big = nullptr;            // d*cap > MAX_DIM: library eigensolver at the capacity size
     bool ws_ready = false;      // training workspace (caches, bond tensor, gradient, eigensolver) allocated for the current sizes
     bool eval_ready = false;    // evaluation scratch (chains, yeval, pred) allocated for max(N_train, N_test)
     bool caches_valid = false;  // LE / RE describe the current MPS: set by mpst_build_caches, cleared by whatever invalidates them
@@ -152,8 +154,8 @@ int ensure_workspace(Ctx* c) {
     const DataSet& tr = c->ds[MPST_TRAIN];
     if (tr.N <= 0) return fail(c, MPST_ERR_INVALID, "no training data set (mpst_set_dataset)");
     const int dm = c->d * c->cap;
-    if (dm > MAX_DIM)
-        return fail(c, MPST_ERR_UNSUPPORTED, "d*chi_max = %d exceeds the %d supported by the LDS-resident eigensolver", dm, MAX_DIM);
+    if (dm > DIM_LIMIT || c->cap > CAP_LIMIT)
+        return fail(c, MPST_ERR_UNSUPPORTED, "d*chi_max = %d (chi_max = %d) exceeds the engine's limits d*chi_max <= %d, chi_max <= %d", dm, c->cap, DIM_LIMIT, CAP_LIMIT);
     if (c->C > MAX_C) return fail(c, MPST_ERR_UNSUPPORTED, "more than %d classes unsupported", MAX_C);
     const int64_t Lmax = (int64_t)dm * dm;
     int rc;
@@ -168,9 +170,16 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
     if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax))) return rc;
     HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax) * sizeof(double)));
-    if ((rc = dalloc(c, &c->gram, (int64_t)MAX_DIM * MAX_DIM))) return rc;
-    if ((rc = dalloc(c, &c->lam, MAX_DIM + 2))) return rc;
-    if ((rc = dalloc(c, &c->E, (int64_t)MAX_DIM * c->cap))) return rc;
+    const int dmx = std::max(dm, MAX_DIM);
+    if ((rc = dalloc(c, &c->gram, (int64_t)dmx * dmx))) return rc;
+    if ((rc = dalloc(c, &c->lam, dmx + 2))) return rc;
+    if ((rc = dalloc(c, &c->E, (int64_t)dmx * c->cap))) return rc;
+    if ((rc = dalloc(c, &c->norm_scratch, (int64_t)3 * c->cap * c->cap))) return rc;
+    if (c->big) { big_eig_destroy(c->big); c->big = nullptr; }
+    if (dm > MAX_DIM) {
+        std::string e;
+        if ((rc = big_eig_create(&c->big, dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+    }
     if ((rc = dalloc(c, &c->eig_ws, (int64_t)eig_workspace_doubles()))) return rc;
     HIPC(c, hipMemset(c->eig_ws, 0, eig_workspace_doubles() * sizeof(double)));
     if ((rc = dalloc(c, &c->sc, 1))) return rc;
@@ -245,9 +254,14 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
         { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
     }
     { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
-    { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
-    { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
-    { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
+    if (c->big) {
+        ProfScope p(c, K_EIG_TRI);
+        if (launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
+    } else {
+        { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
+        { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
+        { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
+    }
     { ProfScope p(c, K_SPLIT); launch_split(v, lid, going_left, s); }
     {
         ProfScope p(c, K_ENV);                                                  // update_caches! :759/:799
@@ -351,6 +365,8 @@ void mpst_destroy(void* ctx) {
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
+    if (c->big) big_eig_destroy(c->big);
+    dfree(&c->norm_scratch);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -702,7 +718,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // on host-side state (bond dimensions are read on the device), and the pre-built dispatch packets
     // shorten the dependent kernel-to-kernel hand-over that dominates the small kernels.  Per-kernel
     // profiling and the RCCL leg keep the plain stream path.
-    const bool use_graph = !c->comm && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
+    const bool use_graph = !c->comm && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
     if (use_graph && (!c->sweep_graph || c->graph_epoch != c->epoch)) {
         if (c->sweep_graph) {
             (void)hipGraphExecDestroy(c->sweep_graph);
@@ -776,8 +792,8 @@ int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* 
     DevScalars sc;
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
     if (dbg) {
-        double lam[MAX_DIM + 2];
-        HIPC(c, hipMemcpy(lam, c->lam, sizeof lam, hipMemcpyDeviceToHost));
+        std::vector<double> lam((size_t)std::max(sc.n_spec, 1));
+        HIPC(c, hipMemcpy(lam.data(), c->lam, lam.size() * sizeof(double), hipMemcpyDeviceToHost));
         dbg->loss = sc.loss;
         dbg->grad_norm = sc.grad_norm;
         dbg->bt_norm = std::sqrt(sc.bt_norm2);
@@ -847,7 +863,7 @@ int mpst_normalize(void* ctx) {
     int rc = check_ready(c);
     if (rc) return rc;
     View v = make_view(c, MPST_TRAIN);
-    launch_norm2(v, c->norm2, c->stream);
+    launch_norm2(v, c->norm2, c->norm_scratch, c->stream);
     launch_scale_sites(v, c->norm2, c->stream);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -922,7 +938,7 @@ int mpst_selftest_mfma(void* ctx, const double* A, const double* B, int32_t K, d
 int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double* lambda_out, double* E_out, int32_t* sweeps) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;
-    if (n < 1 || n > MAX_DIM) return fail(c, MPST_ERR_INVALID, "n must be in 1..%d", MAX_DIM);
+    if (n < 1 || n > DIM_LIMIT) return fail(c, MPST_ERR_INVALID, "n must be in 1..%d", DIM_LIMIT);
     HIPC(c, hipSetDevice(c->device));
     double *dG = nullptr, *dl = nullptr, *dE = nullptr, *dws = nullptr;
     int32_t* ds = nullptr;
@@ -935,7 +951,17 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
         (rc = dalloc(c, &dws, (int64_t)eig_workspace_doubles()))) return rc;
     HIPC(c, hipMemcpy(dG, G, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     HIPC(c, hipMemset(dws, 0, eig_workspace_doubles() * sizeof(double)));
-    launch_eig_raw(dG, n, alg, dl, dE, ds, dws, c->stream);
+    if (n > MAX_DIM) {
+        BigEig* be = nullptr;
+        std::string e;
+        if ((rc = big_eig_create(&be, n, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        rc = launch_eig_big_raw(dG, n, dl, dE, ds, be, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        big_eig_destroy(be);
+        if (rc) return fail(c, rc, "rocsolver_dsyevd failed");
+    } else {
+        launch_eig_raw(dG, n, alg, dl, dE, ds, dws, c->stream);
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
     HIPC(c, hipGetLastError());
     HIPC(c, hipMemcpy(lambda_out, dl, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));

@@ -24,13 +24,15 @@
 //  * MPST_SVD_JACOBI: one-sided (Hestenes) Jacobi on the columns of G in LDS - slow (ms) but
 //    unconditionally robust; column k converges to lambda_k v_k.
 #include "mpst_internal.h"
+#include <rocsolver/rocsolver.h>
 #include <type_traits>
 
 namespace mpst {
 
 constexpr int EIG_THREADS = 512;   // 8 waves = 2 per SIMD: the phases are VALU-issue bound, fewer fatter waves win
 constexpr int EIG_MAX_SWEEPS = 40;
-constexpr int TRI_KMAX = 32;      // eigenpairs the tridiagonal path can deliver
+constexpr int TRI_KMAX = 64;      // eigenpairs the tridiagonal path can deliver (n <= 128 and d >= 2 bound chi_max by 64)
+constexpr int RAW_KMAX = 32;      // eigenpairs mpst_selftest_eig asks of it
 constexpr int VEC_THREADS = 256;  // k_eig_vec: one workgroup per eigenvalue
 constexpr int TRI_NSTEP = 7;      // 257^-7 = 1.4e-17 of the Gershgorin interval
 constexpr int EIG_LDS_DOUBLES = 17664;  // 138 KB: max over both algorithms
@@ -193,7 +195,7 @@ struct TriShared {
     double* es;    // [128]
     double* taus;  // [128]
     double* lam;   // [32]
-    double* Z;     // [128][32]  eigenvectors of T, later of G
+    double* Z;     // [128][32]  k_eig_tri: published rows (k_eig_fin carves its own layout, see FinShared)
     double* Ub;    // [128][32]
     double* misc;  // [64] scalars + [128] raw row
 };
@@ -207,8 +209,8 @@ __device__ __forceinline__ TriShared tri_carve(double* smem) {
     t.taus = t.es + 128;
     t.lam = t.taus + 128;
     t.Z = t.lam + 32;
-    t.Ub = t.Z + 128 * TRI_KMAX;
-    t.misc = t.Ub + 128 * TRI_KMAX;   // total 17440 + 192 <= EIG_LDS_DOUBLES
+    t.Ub = t.Z + 128 * 32;
+    t.misc = t.Ub + 128 * 32;         // total 17440 + 192 <= EIG_LDS_DOUBLES
     return t;
 }
 __device__ __forceinline__ int voff(int i, int n) { return i * (n - 1) - (i * (i - 1)) / 2; }
@@ -274,11 +276,13 @@ constexpr int WS_DE = 0;        // [128][2]  (d_j, e_{j-1}^2)
 constexpr int WS_ES = 256;      // [128]
 constexpr int WS_TAU = 384;     // [128]
 constexpr int WS_MISC = 512;    // [0] lo  [1] hi  [2] ||T||  [3] 1.0 if the tridiagonal path is active
-constexpr int WS_LAM = 528;     // [32]
-constexpr int WS_RES = 560;     // [32]  ||T z - lambda z||_inf
 constexpr int WS_VS = 592;      // [8][128][16] reflectors, dense: block b, row c, reflector 16b+j (0 above its start)
-constexpr int WS_Z = 16976;     // [128][32] eigenvectors of G: component c of vector k at c*32 + k
-constexpr int WS_TOTAL = 21072;
+constexpr int WS_Z = 16976;     // [128][KS] eigenvectors of G: component c of vector k at c*KS + k, KS = 32 or 64 (kstride)
+constexpr int WS_LAM = 25168;   // [64]
+constexpr int WS_RES = 25232;   // [64]  ||T z - lambda z||_inf
+constexpr int WS_TOTAL = 25296;
+// row stride of the eigenvector block: 32 columns while at most 32 eigenpairs are wanted (the headline shapes), else 64
+__device__ __forceinline__ int kstride(int K0) { return K0 <= 32 ? 32 : 64; }
 
 struct EigProblem {
     const double* G;
@@ -293,7 +297,7 @@ __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_
         p.n = rawn;
         p.rows = rawn;
         p.nspec = rawn;
-        p.K0 = rawn < TRI_KMAX ? rawn : TRI_KMAX;
+        p.K0 = rawn < RAW_KMAX ? rawn : RAW_KMAX;
         p.tri = rawalg != MPST_SVD_JACOBI && rawn >= 2;
     } else {
         const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
@@ -964,9 +968,10 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
             }
             z[c1] = z1;
         }
-        double* Zk = ws + WS_Z + k;                    // [c][32] layout: k_eig_fin reads it linearly
-        if (c0 < n) Zk[c0 * 32] = z0;
-        if (c1 < n) Zk[c1 * 32] = z1;
+        double* Zk = ws + WS_Z + k;                    // [c][KS] layout: k_eig_fin reads it linearly
+        const int ks = kstride(pb.K0);
+        if (c0 < n) Zk[c0 * ks] = z0;
+        if (c1 < n) Zk[c1 * ks] = z1;
         if (lane == 0) {
             ws[WS_LAM + k] = lamk;
             ws[WS_RES + k] = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
@@ -978,15 +983,33 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
 // =====================================================================================
 // k_eig_fin: truncation, verification, re-orthonormalisation, publication (or Jacobi)
 // =====================================================================================
-// Verifies the K vectors in t.Z ([c*32 + k]) against the residuals in t.misc[32..] and
+// LDS layout of k_eig_fin's tridiagonal branch: KS = 32 (at most 32 eigenpairs wanted) or 64 columns per row.
+struct FinShared {
+    double* Z;     // [128][KS] candidate eigenvectors of G
+    double* D;     // [KS][KS]  Z^T Z - I
+    double* Dh;    // KS = 32 only: [4][256] second-half partial tiles of the Gram matrix
+    double* misc;  // [2] ||T||, [8..16) per-wave scratch, [32..32+KS) residuals
+};
+template <int KS>
+__device__ __forceinline__ FinShared fin_carve(double* smem) {
+    FinShared f;
+    f.Z = smem;
+    f.D = f.Z + 128 * KS;
+    f.Dh = f.D + KS * KS;
+    f.misc = f.Dh + (KS == 32 ? 1024 : 0);      // KS = 64: 8192 + 4096 + 128 doubles
+    return f;
+}
+
+// Verifies the K vectors in t.Z ([c*KS + k]) against the residuals in t.misc[32..] and
 // re-orthonormalises them; returns false if the Jacobi path has to take over.
-__device__ bool verify_and_polish(TriShared t, int n, int K) {
+template <int KS>
+__device__ bool verify_and_polish(FinShared t, int n, int K) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ---- verification + symmetric (Loewdin) re-orthonormalisation ---------------------------------
     // D = Z^T Z - I; Z <- Z (I - D/2) squares the deviation without leaving the subspace.  Up to two
     // rounds: close (but separated) eigenvalues leave |D| ~ 1e-6, genuine clusters leave |D| ~ 1 and
     // are handed to the Jacobi path, as is a residual ||T z - lambda z|| above 1e-8 ||T||.
-    double* D = t.Ub;      // [32][32], Ub is free now
+    double* D = t.D;
     bool ok = true;
     {
         double rres = 0.0;
@@ -1000,12 +1023,12 @@ __device__ bool verify_and_polish(TriShared t, int n, int K) {
         ok = rmax < 1e-8 && rmax == rmax;
     }
     static_assert(EIG_THREADS == 512, "the MFMA tiling below is written for 8 waves");
-    double* Dh = t.Ub + 1024;       // [4][256] second-half partial tiles of the Gram matrix
     const int jl = lane & 15, q4 = lane >> 4;
     for (int round = 0; round < 2 && ok; ++round) {
-        // ---- D = Z^T Z - I on the fp64 MFMA: wave w owns the 16x16 tile (w&3) over rows [64(w>>2), +64) ----
         double err = 0.0;
-        {
+        if constexpr (KS == 32) {
+            // ---- D = Z^T Z - I on the fp64 MFMA: wave w owns the 16x16 tile (w&3) over rows [64(w>>2), +64) ----
+            double* Dh = t.Dh;
             const int a0 = 16 * ((wave & 3) >> 1), b0 = 16 * (wave & 1), kb = 64 * (wave >> 2);
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll 4
@@ -1030,6 +1053,29 @@ __device__ bool verify_and_polish(TriShared t, int n, int K) {
                     D[aa * 32 + bb] = dv;
                 }
             }
+        } else {
+            // 4 x 4 tiles of 16 x 16, two per wave, each over all 128 rows
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tile = wave + 8 * h;
+                const int a0 = 16 * (tile >> 2), b0 = 16 * (tile & 3);
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                for (int s4 = 0; s4 < 32; ++s4) {
+                    const double* zr = t.Z + (4 * s4 + q4) * KS;
+                    acc = mfma_f64(zr[a0 + jl], zr[b0 + jl], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aa = a0 + q4 + 4 * r, bb = b0 + jl;
+                    double dv = 0.0;
+                    if (aa < K && bb < K) {
+                        dv = acc[r] - (aa == bb ? 1.0 : 0.0);
+                        err = fmax(err, fabs(dv));
+                    }
+                    D[aa * KS + bb] = dv;
+                }
+            }
         }
         err = wave_max(err);
         __syncthreads();
@@ -1042,30 +1088,60 @@ __device__ bool verify_and_polish(TriShared t, int n, int K) {
             break;
         }
         if (round == 1 && emax < 1e-13) break;       // already orthonormal to rounding
-        // ---- Z <- Z - (Z D)/2: wave w owns the row tiles 2(w>>1), 2(w>>1)+1 of column tile (w&1) ----
-        d4 upd[2];
+        // ---- Z <- Z - (Z D)/2: 8 row tiles x KS/16 column tiles, KS/16 per wave ----
+        constexpr int CT = KS / 16, PER = CT;         // 8*CT tiles over 8 waves
+        d4 upd[PER];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c0 = 16 * (2 * (wave >> 1) + h), a0 = 16 * (wave & 1);
+        for (int h = 0; h < PER; ++h) {
+            const int tile = wave * PER + h;
+            const int c0 = 16 * (tile / CT), a0 = 16 * (tile % CT);
             d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) acc = mfma_f64(t.Z[(c0 + jl) * 32 + 4 * s4 + q4], D[(4 * s4 + q4) * 32 + a0 + jl], acc);
+            for (int s4 = 0; s4 < KS / 4; ++s4) acc = mfma_f64(t.Z[(c0 + jl) * KS + 4 * s4 + q4], D[(4 * s4 + q4) * KS + a0 + jl], acc);
             upd[h] = acc;
         }
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c0 = 16 * (2 * (wave >> 1) + h), a0 = 16 * (wave & 1);
+        for (int h = 0; h < PER; ++h) {
+            const int tile = wave * PER + h;
+            const int c0 = 16 * (tile / CT), a0 = 16 * (tile % CT);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c = c0 + q4 + 4 * r, aa = a0 + jl;
-                if (c < n && aa < K) t.Z[c * 32 + aa] -= 0.5 * upd[h][r];
+                if (c < n && aa < K) t.Z[c * KS + aa] -= 0.5 * upd[h][r];
             }
         }
         __syncthreads();
         if (emax < 1e-8) break;                       // one round suffices: residual |D|^2 < 1e-16
     }
     return ok;
+}
+
+// tridiagonal branch of k_eig_fin: candidates (already in registers) -> LDS, verification, polish, publication
+template <int KS>
+__device__ bool fin_tri(double* smem, const double* zin, int n, int nk, double res_in, double tnorm_in, double* Eout, int ldE) {
+    const int tid = threadIdx.x;
+    FinShared t = fin_carve<KS>(smem);
+    // eigenvectors of values the truncation rule discards are never looked at: those are the
+    // clustered, noise-level ones for which the twisted factorisation loses orthogonality
+#pragma unroll
+    for (int m = 0; m < 128 * KS / EIG_THREADS; ++m) {
+        const int i = tid + m * EIG_THREADS;
+        const int c = i / KS, kk = i % KS;
+        t.Z[i] = (c < n && kk < nk) ? zin[m] : 0.0;
+    }
+    if (tid < KS) t.misc[32 + tid] = tid < nk ? res_in : 0.0;
+    if (tid == 0) t.misc[2] = tnorm_in;
+    __syncthreads();
+    const bool done = verify_and_polish<KS>(t, n, nk);
+    if (done) {
+        for (int i = tid; i < n * nk; i += EIG_THREADS) {
+            const int c = i / nk, kk = i - c * nk;
+            Eout[(size_t)c * ldE + kk] = t.Z[c * KS + kk];
+        }
+    }
+    __syncthreads();
+    return done;
 }
 
 __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int going_left, const double* rawG, int rawn,
@@ -1086,14 +1162,15 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
     const bool tri = pb.tri && ws[WS_MISC + 3] == 1.0;
     double lam_in = 0.0, res_in = 0.0, tnorm_in = 0.0;
-    constexpr int NZL = 4096 / EIG_THREADS;
+    constexpr int NZL = 128 * TRI_KMAX / EIG_THREADS;
     double zin[NZL];
+    const int ks = kstride(K0);
     if (pb.tri) {
         lam_in = tid < K0 ? ws[WS_LAM + tid] : 0.0;
-        res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+        res_in = tid < TRI_KMAX ? ws[WS_RES + tid] : 0.0;
         tnorm_in = ws[WS_MISC + 2];
 #pragma unroll
-        for (int m = 0; m < NZL; ++m) zin[m] = ws[WS_Z + tid + m * EIG_THREADS];
+        for (int m = 0; m < NZL; ++m) zin[m] = (m < NZL / 2 || ks == 64) ? ws[WS_Z + tid + m * EIG_THREADS] : 0.0;
     }
     // trace = ||bt_new||_F^2 (fixed order)
     double tr = wave_sum(gdiag);
@@ -1126,29 +1203,11 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     int sweeps = 0, nk = K0;
     bool done = false;
     if (tri) {
-        TriShared t = tri_carve(smem);
         if (tid < K0) lam_s[tid] = lam_in;
         __syncthreads();
         nk = truncate(lam_s, K0);
-        // eigenvectors of values the truncation rule discards are never looked at: those are the
-        // clustered, noise-level ones for which the twisted factorisation loses orthogonality
-#pragma unroll
-        for (int m = 0; m < NZL; ++m) {
-            const int i = tid + m * EIG_THREADS;
-            const int c = i >> 5, kk = i & 31;
-            t.Z[i] = (c < n && kk < nk) ? zin[m] : 0.0;
-        }
-        if (tid < 32) t.misc[32 + tid] = tid < nk ? res_in : 0.0;
-        if (tid == 0) t.misc[2] = tnorm_in;
-        __syncthreads();
-        done = verify_and_polish(t, n, nk);
-        if (done) {
-            for (int i = tid; i < n * nk; i += EIG_THREADS) {
-                const int c = i / nk, kk = i - c * nk;
-                Eout[(size_t)c * ldE + kk] = t.Z[c * 32 + kk];
-            }
-        }
-        __syncthreads();
+        done = ks == 32 ? fin_tri<32>(smem, zin, n, nk, res_in, tnorm_in, Eout, ldE)
+                        : fin_tri<64>(smem, zin, n, nk, res_in, tnorm_in, Eout, ldE);
     }
     const bool fell_back = !done && pb.tri;
     if (!done) {
@@ -1213,7 +1272,7 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
         hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
                            (const double*)nullptr, 0, 0, v.eig_ws, st);
     else if (stage == 1)
-        hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
+        hipLaunchKernelGGL(k_eig_vec, dim3(v.chi_max < TRI_KMAX ? (v.chi_max < 32 ? 32 : v.chi_max) : TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
                            v.eig_ws, st);
     else
         hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
@@ -1225,10 +1284,147 @@ void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
     hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
                        (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_eig_vec, dim3(TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
+    hipLaunchKernelGGL(k_eig_vec, dim3(RAW_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
                        (unsigned long long*)nullptr);
     hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws, lam, E, info,
                        (unsigned long long*)nullptr);
+}
+
+
+// =====================================================================================
+// Bond tensors beyond 128 x 128 (d*chi_max in (128, DIM_LIMIT]): library slow path
+// =====================================================================================
+// The register/LDS-resident solver above holds n <= 128.  Larger Gram matrices (the reference's documented
+// d = 8..12, chi_max = 37..64 runs, docs/src/hyperparameters.md:65,127,241-245) go through rocSOLVER's dsyevd
+// (blocked tridiagonalisation + divide and conquer - the LAPACK routine family the reference's own gesdd belongs to) on
+// the engine's stream.  Bond dimensions live on the device, so the problem is always solved at the CAPACITY size
+// ncap = d*cap with the live n x n Gram matrix zero-padded: the padding adds exact zero eigenvalues below the spectrum
+// of the positive semi-definite G and leaves the eigenvectors of its non-zero eigenvalues untouched.
+struct BigEig {
+    rocblas_handle h = nullptr;
+    int ncap = 0;
+    double *A = nullptr, *D = nullptr, *Ew = nullptr;
+    rocblas_int* info = nullptr;
+};
+
+__global__ __launch_bounds__(256) void k_big_prep(View v, int lid, int going_left, const double* rawG, int rawn, double* A, int ncap) {
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, 0);
+    const int n = pb.n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)ncap * ncap; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / ncap), c = (int)(i - (int64_t)r * ncap);
+        A[i] = (r < n && c < n) ? pb.G[(size_t)r * n + c] : 0.0;       // symmetric: row- and column-major coincide
+    }
+}
+
+// eigenvalues D (ascending, ncap of them), eigenvectors in the columns of A (column-major): truncation rule and
+// publication exactly as in k_eig_fin
+__global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                         const double* __restrict__ A, const double* __restrict__ D,
+                                                         const rocblas_int* info, int ncap, double* rawlam, double* rawE,
+                                                         int32_t* rawinfo) {
+    __shared__ double lam_s[CAP_LIMIT + 2];
+    __shared__ double red[16];
+    EigProblem pb = resolve(v, lid, going_left, rawG, rawn, 0);
+    const bool raw = rawn > 0;
+    const int tid = threadIdx.x;
+    const int n = pb.n, nspec = pb.nspec;
+    const int K0 = raw ? (n < CAP_LIMIT ? n : CAP_LIMIT) : (nspec < v.chi_max ? nspec : v.chi_max);
+    double* Eout = raw ? rawE : v.E;
+    const int ldE = raw ? n : v.cap;
+    double part = 0.0;
+    for (int i = tid; i < n; i += EIG_THREADS) part += pb.G[(size_t)i * n + i];
+    double tr = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    __syncthreads();
+    tr = 0.0;
+    for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
+    if (tid < K0) lam_s[tid] = fmax(D[ncap - 1 - tid], 0.0);
+    __syncthreads();
+    const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
+    const double cutoff = raw ? -1.0 : v.cutoff;
+    const double inv2 = inv * inv;
+    const double scale0 = tr * inv2;
+    const double scale = scale0 == 0.0 ? 1.0 : scale0;
+    double kept = 0.0;
+    for (int i = 0; i < K0; ++i) kept += lam_s[i] * inv2;
+    int nk = K0;
+    double truncerr = scale0 - kept;
+    if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
+    if (nspec > 1) {
+        while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= cutoff * scale) {
+            truncerr += lam_s[nk - 1] * inv2;
+            --nk;
+        }
+    }
+    const int kout = raw ? K0 : nk;
+    for (int i = tid; i < n * kout; i += EIG_THREADS) {
+        const int k = i / n, c = i - k * n;
+        Eout[(size_t)c * ldE + k] = A[(size_t)(ncap - 1 - k) * ncap + c];
+    }
+    if (raw) {
+        if (tid < K0) rawlam[tid] = lam_s[tid];
+        if (tid == 0) *rawinfo = *info ? 1000 + *info : -2;
+    } else {
+        if (tid < K0) v.lam[tid] = lam_s[tid];
+        if (tid == 0) {
+            bool bad = !(tr == tr) || tr > 1e300 || *info != 0;
+            for (int i = 0; i < K0; ++i) {
+                const double P = lam_s[i] * inv2;
+                if (!(P == P) || P > 1e300) bad = true;
+            }
+            v.sc->n_keep = nk;
+            v.sc->n_spec = K0;
+            v.sc->bt_norm2 = tr;
+            v.sc->inv_norm = inv;
+            v.sc->eig_sweeps = 0;
+            if (bad) v.sc->status = MPST_ERR_SVD;
+            v.chi[lid + 1] = nk;
+        }
+    }
+}
+
+int big_eig_create(BigEig** out, int ncap, hipStream_t s, std::string* err) {
+    BigEig* b = new BigEig();
+    b->ncap = ncap;
+    auto bail = [&](const char* what) {
+        if (err) *err = what;
+        big_eig_destroy(b);
+        return MPST_ERR_DEVICE;
+    };
+    if (rocblas_create_handle(&b->h) != rocblas_status_success) return bail("rocblas_create_handle failed");
+    if (rocblas_set_stream(b->h, s) != rocblas_status_success) return bail("rocblas_set_stream failed");
+    if (hipMalloc((void**)&b->A, sizeof(double) * (size_t)ncap * ncap) != hipSuccess || hipMalloc((void**)&b->D, sizeof(double) * ncap) != hipSuccess ||
+        hipMalloc((void**)&b->Ew, sizeof(double) * ncap) != hipSuccess || hipMalloc((void**)&b->info, sizeof(rocblas_int)) != hipSuccess)
+        return bail("hipMalloc of the rocSOLVER buffers failed");
+    *out = b;
+    return 0;
+}
+void big_eig_destroy(BigEig* b) {
+    if (!b) return;
+    if (b->A) (void)hipFree(b->A);
+    if (b->D) (void)hipFree(b->D);
+    if (b->Ew) (void)hipFree(b->Ew);
+    if (b->info) (void)hipFree(b->info);
+    if (b->h) rocblas_destroy_handle(b->h);
+    delete b;
+}
+int launch_eig_big(const View& v, int lid, int going_left, BigEig* b, hipStream_t s) {
+    const int ncap = b->ncap;
+    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->A, ncap);
+    if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, ncap, b->A, ncap, b->D, b->Ew, b->info) != rocblas_status_success)
+        return MPST_ERR_DEVICE;
+    hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(EIG_THREADS), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->A, b->D, b->info, ncap,
+                       (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
+    return 0;
+}
+int launch_eig_big_raw(const double* G, int n, double* lam, double* E, int32_t* info, BigEig* b, hipStream_t s) {
+    View v{};
+    hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
+    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, 0, 0, G, n, b->A, b->ncap);
+    if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, b->ncap, b->A, b->ncap, b->D, b->Ew, b->info) != rocblas_status_success)
+        return MPST_ERR_DEVICE;
+    hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(EIG_THREADS), 0, s, v, 0, 0, G, n, b->A, b->D, b->info, b->ncap, lam, E, info);
+    return 0;
 }
 
 }  // namespace mpst

@@ -156,7 +156,9 @@ struct Span {
 constexpr int TILE_S = 16;    // series per yhat/env tile (one MFMA M-tile)
 constexpr int CHUNK_S = 64;   // series per gradient chunk (the GEMM K extent of one partial)
 constexpr int GB = 64;        // gradient output block edge per workgroup
-constexpr int MAX_DIM = 128;  // d*chi_max limit of the LDS-resident eigensolver
+constexpr int MAX_DIM = 128;  // d*chi_max limit of the register/LDS-resident eigensolver and of the single-pass bond kernels
+constexpr int DIM_LIMIT = 1024;  // d*chi_max limit of the engine (LDS tile of 16 series x d*chi doubles)
+constexpr int CAP_LIMIT = 128;   // largest bond dimension (environment rows are staged 16 lanes x 8 values)
 constexpr int MAX_C = 16;
 
 // Device-resident scalars of the running sweep (never read by the host inside a sweep).
@@ -259,7 +261,7 @@ hipError_t init_kernel_attrs(int device);
 hipError_t eig_init_attrs(int device);
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yhat_out, hipStream_t s);
 void launch_eval_reduce(const View& v, const double* yhat_in, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
-void launch_norm2(const View& v, double* out_norm2, hipStream_t s);
+void launch_norm2(const View& v, double* out_norm2, double* gscratch /* 3*cap*cap doubles */, hipStream_t s);
 void launch_scale_sites(const View& v, const double* norm2, hipStream_t s);
 void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s);
 
@@ -267,5 +269,11 @@ void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hi
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
 size_t eig_workspace_doubles();
+// library slow path for d*chi_max > MAX_DIM (rocSOLVER dsyevd at the capacity size, see mpst_eig.hip)
+struct BigEig;
+int big_eig_create(BigEig** out, int ncap, hipStream_t s, std::string* err);
+void big_eig_destroy(BigEig* b);
+int launch_eig_big(const View& v, int lid, int going_left, BigEig* b, hipStream_t s);
+int launch_eig_big_raw(const double* G, int n, double* lam, double* E, int32_t* info, BigEig* b, hipStream_t s);
 
 }  // namespace mpst

@@ -233,6 +233,102 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     }
 }
 
+// Same contraction for bond tensors beyond 128 x 128 (d*chi_max up to DIM_LIMIT): the X tile stays in LDS, the B_c panel
+// of a pair of 16-column tiles streams through registers 128 rows at a time, and Y_i[y] = phi_i[s] * RE_i[b] is applied
+// from its factors ([16][d] and [16][Dr] in LDS) instead of a staged Khatri-Rao tile.
+__global__ __launch_bounds__(256) void k_yhat_gen(View v, int lid) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const BondDims b = bond_dims(v, lid);
+    const int d = v.d, rid = lid + 1;
+    const Span tl = v.tiles[blockIdx.x];
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int c = mse ? (int)blockIdx.y : tl.cls;
+    const int XP = (b.X + 3) & ~3, XS = XP + 2;
+    double* Xs = smem;                      // [16][XS]
+    double* Pr = Xs + 16 * XS;              // [16][d]     phi of the right site
+    double* Rr = Pr + 16 * d;               // [16][Dr+1]  right environment rows
+    double* red = Rr + 16 * (b.Dr + 1);     // [4][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+    stage_tile16(Xs, XS, tl, LEp, b.Dl, phl, d, v.cap, true);
+    {
+        const int i = tid >> 4, j = tid & 15;
+        const bool valid = i < tl.count;
+        const int64_t smp = tl.start + (valid ? i : 0);
+        for (int s = j; s < d; s += 16) Pr[i * d + s] = valid ? phr[smp * d + s] : 0.0;
+        for (int a = j; a < b.Dr; a += 16) Rr[i * (b.Dr + 1) + a] = valid ? (REn ? REn[smp * v.cap + a] : 1.0) : 0.0;
+    }
+    __syncthreads();
+    const double* Bc = v.bt + (int64_t)c * b.L;
+    const int i16 = lane & 15, kq = lane >> 4;
+    double p[4] = {0, 0, 0, 0};
+    const int nty = (b.Y + 15) >> 4;
+    for (int nt0 = wave; nt0 < nty; nt0 += 8) {
+        d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
+        for (int kb = 0; kb < XP; kb += 128) {
+            double bv[2][32];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = (nt0 + 4 * h) * 16 + i16;
+                const bool cv = col < b.Y;
+#pragma unroll
+                for (int u = 0; u < 32; ++u) {
+                    const int kx = kb + 4 * u + kq;
+                    bv[h][u] = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (nt0 + 4 * h < nty) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) {
+                        const int k0 = kb + 4 * u;
+                        if (k0 < XP) acc[h] = mfma_f64(Xs[i16 * XS + k0 + kq], bv[h][u], acc[h]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col = (nt0 + 4 * h) * 16 + i16;
+            if (col < b.Y) {
+                const int sy = col / b.Dr, bb = col - sy * b.Dr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = kq + 4 * r;
+                    p[r] += acc[h][r] * (Pr[i * d + sy] * Rr[i * (b.Dr + 1) + bb]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const double x = sum16(p[r]);
+        if (i16 == 0) red[wave * 16 + kq + 4 * r] = x;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double term = 0.0;
+        if (tid < 16) {
+            const double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            if (tid < tl.count) {
+                v.yhat[(int64_t)c * v.N + tl.start + tid] = yh;
+                if (mse) {
+                    const double m = (tl.cls == c) ? 1.0 : 0.0;
+                    term = 0.5 * (yh - m) * (yh - m);
+                } else {
+                    term = -log(yh * yh);
+                }
+            }
+        }
+        term = sum16(term);
+        if (tid == 0) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + blockIdx.x] = term;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // gradient partials: P[chunk] (64x64 block) = sum_{i in chunk} w_i X_i Y_i^T
 //   KLD: w_i = 1/yhat_i                      (loss_functions.jl:258, :367)
@@ -676,10 +772,12 @@ __global__ __launch_bounds__(1024) void k_eval_reduce(View v, const double* __re
 // normalize!(W) (RealRealHighDimension.jl:852; ITensors: every site / exp(lognorm/T)).
 // <W|W> by transfer matrices in one workgroup: E <- sum_{s(,c)} A_s^T E A_s.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_norm2(View v, double* out_norm2) {
+__global__ __launch_bounds__(1024) void k_norm2(View v, double* out_norm2, double* gscratch) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int cm = v.cap;
-    double* E = smem;             // [cm][cm]
+    // three cm x cm matrices: in LDS while they fit, else in the global scratch the caller provides (a single workgroup:
+    // its own global writes are visible to it after a barrier)
+    double* E = gscratch ? gscratch : smem;   // [cm][cm]
     double* Tm = E + cm * cm;     // [cm][cm]  T = E * A_s
     double* En = Tm + cm * cm;    // [cm][cm]
     const int tid = threadIdx.x;
@@ -755,9 +853,14 @@ void launch_bt_prescale(const View& v, int lid, hipStream_t s) {
 }
 void launch_yhat(const View& v, int lid, hipStream_t s) {
     const int dm = v.d * v.cap;
-    const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * (((dm + 15) & ~15) + 2) + 64) * sizeof(double);
     const int gy = v.loss == MPST_LOSS_MSE ? v.C : 1;
-    hipLaunchKernelGGL(k_yhat, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
+    if (dm <= MAX_DIM) {
+        const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * (((dm + 15) & ~15) + 2) + 64) * sizeof(double);
+        hipLaunchKernelGGL(k_yhat, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
+    } else {
+        const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * v.d + 16 * (v.cap + 1) + 64) * sizeof(double);
+        hipLaunchKernelGGL(k_yhat_gen, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
+    }
 }
 void launch_grad(const View& v, int lid, hipStream_t s) {
     const int dm = v.d * v.cap;
@@ -799,7 +902,8 @@ hipError_t init_kernel_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(2 * CHUNK_S * (GB + 16) * sizeof(double)))) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
@@ -811,9 +915,10 @@ void launch_eval_reduce(const View& v, const double* yin, double* out3, int64_t*
                         hipStream_t s) {
     hipLaunchKernelGGL(k_eval_reduce, dim3(1), dim3(1024), 0, s, v, yin, out3, conf, pred);
 }
-void launch_norm2(const View& v, double* out_norm2, hipStream_t s) {
+void launch_norm2(const View& v, double* out_norm2, double* gscratch, hipStream_t s) {
     const size_t lds = (size_t)3 * v.cap * v.cap * sizeof(double);
-    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(1024), lds, s, v, out_norm2);
+    const bool fits = lds <= 128 * 1024;
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(1024), fits ? lds : 0, s, v, out_norm2, fits ? (double*)nullptr : gscratch);
 }
 void launch_scale_sites(const View& v, const double* norm2, hipStream_t s) {
     hipLaunchKernelGGL(k_scale_sites, dim3(v.T), dim3(256), 0, s, v, norm2);

@@ -61,19 +61,6 @@ def test_abi_error_paths(engine_cls):
         e.close()
 
 
-def test_dimension_limit_is_reported(engine_cls):
-    e = engine_cls(0)
-    try:
-        e.set_options(chi_max=40)
-        phi = np.random.default_rng(0).uniform(-1, 1, (8, 4, 4))
-        e.set_dataset(0, phi, np.zeros(8, dtype=int), 1)
-        e.set_mps(mt.generate_startingMPS(2, 4, 4, 1, 0))
-        with pytest.raises(mt.MPSTError, match="exceeds the 128"):
-            e.build_caches()
-    finally:
-        e.close()
-
-
 def test_rccl_single_rank_communicator_is_a_no_op(engine_cls):
     """The all-reduce leg of the sharded sweep (mpst_comm_init + ncclAllReduce on the engine's stream)
     with a 1-rank communicator must give the same bits as the engine without a communicator."""

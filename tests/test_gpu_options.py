@@ -22,7 +22,7 @@ def eng(engine_cls):
     e.close()
 
 
-def _sweep_bond_by_bond(eng, ds, W0, opts, tol_S=1e-9, tol_y=1e-9, **kw):
+def _sweep_bond_by_bond(eng, ds, W0, opts, tol_S=1e-9, tol_y=1e-9, tol_g=1e-11, **kw):
     T = ds.phi.shape[1]
     load_engine(eng, ds, W0, opts, **kw)
     eng.build_caches()
@@ -37,7 +37,7 @@ def _sweep_bond_by_bond(eng, ds, W0, opts, tol_S=1e-9, tol_y=1e-9, **kw):
             tr_g = eng.bond_step(lid, going_left)
             assert tr_g["chi"] == tr_o["chi"], (lid, going_left)
             assert abs(tr_g["loss"] - tr_o["loss"]) <= 1e-11 * max(1.0, abs(tr_o["loss"]))
-            assert abs(tr_g["grad_norm"] - tr_o["grad_norm"]) <= 1e-11 * tr_o["grad_norm"]
+            assert abs(tr_g["grad_norm"] - tr_o["grad_norm"]) <= tol_g * tr_o["grad_norm"]
             if not opts.rescale[1]:     # the oracle records ||bt_new|| after normalize!, the engine before it
                 assert abs(tr_g["bt_new_norm"] - tr_o["bt_new_norm"]) <= 1e-11 * tr_o["bt_new_norm"]
             So = np.asarray(tr_o["S"])
@@ -109,13 +109,14 @@ def test_recursive_svd_inside_a_sweep(eng):
     assert np.abs(yg - yo).max() <= 1e-8 * np.abs(yo).max()
 
 
-@pytest.mark.parametrize("d,chi_max", [(3, 40), (2, 64), (2, 50)])
-def test_more_than_32_kept_states(eng, d, chi_max):
+@pytest.mark.parametrize("d,chi_max,T", [(3, 40, 9), (2, 64, 15), (2, 50, 14)])
+def test_more_than_32_kept_states(eng, d, chi_max, T):
     """chi_max in (32, 64] with d*chi_max <= 128: the reference's tutorial range chi_max=(20,40)
-    (docs/src/hyperparameters.md:44-45) at small d."""
-    ds, W0 = make_problem(160, 5, d, chi_max - 3, 2, seed=41)
+    (docs/src/hyperparameters.md:44-45) at small d.  The chain is long enough for the bond dimension to get there
+    (it is capped by d^j near the ends); the gradient tolerance allows for the 1/yhat weights of a random start."""
+    ds, W0 = make_problem(200, T, d, chi_max - 3, 2, seed=41)
     opts = R.SweepOptions(nsweeps=1, chi_max=chi_max, eta=0.05, cutoff=1e-14)
-    W = _sweep_bond_by_bond(eng, ds, W0, opts, tol_S=1e-9, tol_y=1e-8)
+    W = _sweep_bond_by_bond(eng, ds, W0, opts, tol_S=1e-9, tol_y=1e-8, tol_g=1e-9)
     assert max(t.shape[2] for t in W) > 32          # the case really keeps more than 32 states
 
 
