@@ -39,6 +39,9 @@ struct Ctx {
     int64_t cache_elems = 0;
     double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
     double *gram = nullptr, *lam = nullptr, *E = nullptr, *eig_ws = nullptr;
+    double *btn = nullptr, *norm_part = nullptr;
+    int n_norm_part = 0;
+    bool fused = false;        // bond tensors <= MAX_DIM^2 and no rescale[1]: the 7-launch chain of mpst_fused.hip
     int64_t partial_elems = 0;
     DevScalars* sc = nullptr;
     // eval scratch
@@ -106,6 +109,7 @@ void dfree(T** p) {
 
 void free_dataset(DataSet& s) {
     dfree(&s.phi); dfree(&s.label); dfree(&s.tiles); dfree(&s.chunks); dfree(&s.cls_chunk_off); dfree(&s.inv_count);
+    for (int k = 0; k < 2; ++k) { dfree(&s.parts[k]); dfree(&s.part_off[k]); }
     s = DataSet();
 }
 
@@ -124,6 +128,9 @@ View make_view(Ctx* c, int which) {
     v.loss = c->opt.loss; v.optimiser = c->opt.optimiser; v.rescale_before = c->opt.rescale_before;
     v.rescale_after = c->opt.rescale_after; v.train_sep = c->opt.train_classes_separately; v.svd_alg = c->opt.svd_alg;
     v.eta = c->opt.eta; v.cutoff = c->opt.cutoff;
+    const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
+    v.parts = s.parts[pk]; v.part_off = s.part_off[pk]; v.nparts = s.nparts[pk];
+    v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
     return v;
 }
 
@@ -165,9 +172,18 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->RE, c->cache_elems))) return rc;
     if ((rc = dalloc(c, &c->bt, c->C * Lmax))) return rc;
     if ((rc = dalloc(c, &c->yhat, (int64_t)c->C * tr.N))) return rc;
-    if ((rc = dalloc(c, &c->tile_loss, (int64_t)c->C * tr.ntiles))) return rc;
-    c->partial_elems = (int64_t)(c->opt.loss == MPST_LOSS_MSE ? c->C : 1) * tr.nchunks * Lmax;
+    if ((rc = dalloc(c, &c->tile_loss, std::max<int64_t>((int64_t)c->C * tr.ntiles, std::max(tr.nparts[0], tr.nparts[1])))) ) return rc;
+    c->fused = dm <= MAX_DIM && !c->opt.rescale_before && getenv("MPST_NO_FUSED") == nullptr;
+    const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
+    if (c->fused) {
+        c->partial_elems = (int64_t)tr.nparts[pk] * Lmax;        // independent of N: one partial per persistent workgroup
+    } else {
+        c->partial_elems = (int64_t)(pk ? c->C : 1) * tr.nchunks * Lmax;
+    }
     if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
+    if ((rc = dalloc(c, &c->btn, c->C * Lmax))) return rc;
+    c->n_norm_part = (int)((c->C * Lmax + 63) / 64);      // RED_E entries per workgroup of k_fused_reduce
+    if ((rc = dalloc(c, &c->norm_part, c->n_norm_part))) return rc;
     if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax))) return rc;
     HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax) * sizeof(double)));
     const int dmx = std::max(dm, MAX_DIM);
@@ -239,6 +255,39 @@ void prof_collect(Ctx* c) {
 int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = false, int next_bt_lid = -1) {
     hipStream_t s = c->stream;
     const int rid = lid + 1;
+    if (c->fused) {
+        const int iters = c->opt.update_iters;
+        // the next bond's tensor is assembled by this bond's last launch when the sweep moves on in the same direction
+        const int chain = (next_bt_lid >= 0 && next_bt_lid == (going_left ? lid - 1 : lid + 1)) ? 1 : 0;
+        if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }   // flatten_bt :733/:777
+        for (int it = 0; it < iters; ++it) {                                     // TSGO/custGD :44,:75
+            { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }        // yhat + gradient partials
+            { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
+            if (c->comm) {
+                ProfScope p(c, K_ALLREDUCE);
+                const size_t cnt = 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap;
+                ncclResult_t r = ncclAllReduce(c->gradbuf, c->gradbuf, cnt, ncclDouble, ncclSum, c->comm, s);
+                if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+                launch_grad_norm(v, lid, s);
+            }
+            if (it + 1 < iters) { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
+        }
+        { ProfScope p(c, K_GRAM); launch_gram_upd(v, lid, going_left, iters == 1, s); }   // last step + decomposeBT :756/:798
+        { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
+        { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
+        { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
+        {
+            ProfScope p(c, K_ENV);                                                // back-split + update_caches! :759/:799
+            const int64_t cs = (int64_t)v.N * v.cap;
+            if (going_left)
+                launch_env_split(v, lid, 1, rid, 0, rid < c->T - 1 ? c->RE + (int64_t)(rid + 1) * cs : nullptr, rid + 1, rid,
+                                 c->RE + (int64_t)rid * cs, chain, s);
+            else
+                launch_env_split(v, lid, 0, lid, 1, lid > 0 ? c->LE + (int64_t)(lid - 1) * cs : nullptr, lid, lid + 1,
+                                 c->LE + (int64_t)lid * cs, chain, s);
+        }
+        return 0;
+    }
     if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }      // flatten_bt :733/:777
     if (v.rescale_before) launch_bt_prescale(v, lid, s);                        // loss_functions.jl:109
     for (int it = 0; it < c->opt.update_iters; ++it) {                          // TSGO/custGD :44,:75
@@ -366,7 +415,7 @@ void mpst_destroy(void* ctx) {
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
     if (c->big) big_eig_destroy(c->big);
-    dfree(&c->norm_scratch);
+    dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -412,7 +461,7 @@ int mpst_set_options(void* ctx, const mpst_options* o) {
         return fail(c, MPST_ERR_UNSUPPORTED, "no Loss_Grad_MSE method for TrainSeparate{true} (loss_functions.jl:561)");
     if (c->have_mps && o->chi_max > c->cap)
         return fail(c, MPST_ERR_INVALID, "chi_max %d exceeds the capacity %d fixed when the MPS was set; call mpst_set_options before mpst_set_mps", o->chi_max, c->cap);
-    const bool resize = !c->have_opt || o->loss != c->opt.loss;
+    const bool resize = !c->have_opt || o->loss != c->opt.loss || o->rescale_before != c->opt.rescale_before;
     c->opt = *o;
     c->have_opt = true;
     c->epoch++;
@@ -481,6 +530,51 @@ static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N
     HIPC(c, hipMemcpy(s.chunks, chunks.data(), chunks.size() * sizeof(Span), hipMemcpyHostToDevice));
     if ((rc = dalloc(c, &s.cls_chunk_off, C + 1))) return rc;
     HIPC(c, hipMemcpy(s.cls_chunk_off, coff.data(), (size_t)(C + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    // parts of the fused gradient kernel: class-pure runs of whole 16-series tiles, about PARTS_TARGET of them
+    {
+        int64_t tiles_total = 0;
+        for (int k = 0; k < C; ++k) tiles_total += (s.counts[k] + TILE_S - 1) / TILE_S;
+        int target = tiles_total >= 4 * PARTS_TARGET ? 2 * PARTS_TARGET : PARTS_TARGET;
+        if (const char* e = getenv("MPST_PARTS")) target = std::max(1, atoi(e));
+        for (int pk = 0; pk < 2; ++pk) {
+            const int tgt = pk ? std::max(1, target / C) : target;      // MSE: every run is walked once per class
+            std::vector<Part> runs;
+            int64_t st = 0;
+            for (int k = 0; k < C; ++k) {
+                const int64_t tk = (s.counts[k] + TILE_S - 1) / TILE_S;
+                if (tk > 0) {
+                    int64_t pkn = (tgt * tk + tiles_total / 2) / std::max<int64_t>(tiles_total, 1);
+                    pkn = std::max<int64_t>(1, std::min(pkn, tk));
+                    for (int64_t q = 0; q < pkn; ++q) {
+                        const int64_t t0 = tk * q / pkn, t1 = tk * (q + 1) / pkn;
+                        const int64_t a = st + t0 * TILE_S, bnd = std::min(st + t1 * TILE_S, st + s.counts[k]);
+                        runs.push_back({(int32_t)a, (int32_t)(bnd - a), k, k, 0, 0, 0, 0});
+                    }
+                }
+                st += s.counts[k];
+            }
+            std::vector<Part> parts;
+            std::vector<int32_t> poff(C + 1, 0);
+            for (int cc = 0; cc < C; ++cc) {
+                poff[cc] = (int32_t)parts.size();
+                bool first = true;
+                for (const Part& r : runs) {
+                    if (!pk && r.own != cc) continue;
+                    Part q = r;
+                    q.cls = cc;
+                    q.first_of_cls = first ? 1 : 0;
+                    first = false;
+                    parts.push_back(q);
+                }
+            }
+            poff[C] = (int32_t)parts.size();
+            s.nparts[pk] = (int32_t)parts.size();
+            if ((rc = dalloc(c, &s.parts[pk], (int64_t)parts.size()))) return rc;
+            if (!parts.empty()) HIPC(c, hipMemcpy(s.parts[pk], parts.data(), parts.size() * sizeof(Part), hipMemcpyHostToDevice));
+            if ((rc = dalloc(c, &s.part_off[pk], C + 1))) return rc;
+            HIPC(c, hipMemcpy(s.part_off[pk], poff.data(), (size_t)(C + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
     std::vector<double> inv(C);
     for (int k = 0; k < C; ++k) inv[k] = s.gcounts[k] > 0 ? 1.0 / (double)s.gcounts[k] : 0.0;
     if ((rc = dalloc(c, &s.inv_count, C))) return rc;
@@ -705,7 +799,8 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             const int lid = k < nb ? nb - 1 - k : k - nb, left = k < nb;
             const bool boundary_before = c->opt.rebuild_caches && (k == nb);
             const bool boundary_after = c->opt.rebuild_caches && (k == nb - 1);
-            const bool have = chain && k > 0 && !boundary_before;
+            bool have = chain && k > 0 && !boundary_before;
+            if (c->fused && k == nb) have = false;      // turning point: the same bond again, nothing was chained
             int next = -1;
             if (chain && k + 1 < 2 * nb && !boundary_after) next = (k + 1) < nb ? nb - 1 - (k + 1) : (k + 1) - nb;
             if ((r = enqueue_bond(c, v, lid, left, have, next))) return r;

@@ -1,0 +1,716 @@
+// Fused per-bond kernels for bond tensors up to 128 x 128 (the headline shapes): 7 dependent launches per bond
+// instead of 10, a gradient workspace whose size does not depend on N, and the bond tensor held in registers.
+//
+//   k_bond_fused   flatten_bt (RealRealHighDimension.jl:221-238) + the fused phi-tilde / yhat / gradient loop
+//                  (loss_functions.jl:248-262,322-379 / :435-531,561-619).  One persistent workgroup per PART - a
+//                  class-pure run of series - keeps its class' B_c in registers (column tile per wave), walks its
+//                  series 16 at a time (yhat on the MFMA, weights w_i, rank-16 update of the 128 x 128 gradient
+//                  accumulators in registers) and writes ONE partial gradient.  #parts is fixed (<= PARTS_TARGET).
+//   k_fused_reduce grad[c] = scale_c * sum of the class' partials, loss, and per-workgroup pieces of ||grad||^2
+//   k_gram_upd     TSGO / GD step (loss_functions.jl:49,79) applied on the fly to the operands of the Gram matrix of
+//                  decomposeBT's matrix (RealRealHighDimension.jl:166-169,185-188); the diagonal tiles write bt_new
+//   k_env_split    update_caches! (:107-144) and the back-split of decomposeBT (:172-176,190-194) in one launch:
+//                  both depend only on the kept eigenvectors E and bt_new
+#include "mpst_internal.h"
+#include <algorithm>
+
+namespace mpst {
+
+struct BondDimsF {
+    int Dl, Dm, Dr, X, Y, L;
+};
+__device__ __forceinline__ BondDimsF bond_dims_f(const View& v, int lid) {
+    BondDimsF b;
+    b.Dl = v.chi[lid];
+    b.Dm = v.chi[lid + 1];
+    b.Dr = v.chi[lid + 2];
+    b.X = b.Dl * v.d;
+    b.Y = v.d * b.Dr;
+    b.L = b.X * b.Y;
+    return b;
+}
+
+constexpr int FUSED_T = 512;          // 8 waves: wave w owns the 16 columns [16w, 16w+16) of B_c and of the gradient
+constexpr int FXS = MAX_DIM + 2;      // LDS row stride of the Khatri-Rao tiles
+
+// Khatri-Rao tile of 16 series by 256 threads (16 per series), as stage_tile16 of mpst_kernels.hip, split into the
+// global loads (issued early, results parked in registers) and the products written to LDS; `t` = thread index
+// within the 256.
+template <int DM>
+struct StageRegs {
+    double pa[8], pp[DM];
+};
+template <int DM>
+__device__ __forceinline__ void stage16_load(StageRegs<DM>& r, const int32_t start, const int32_t count, const double* __restrict__ prev,
+                                             int Dp, const double* __restrict__ ph, int d, int cap, int t) {
+    const int i = t >> 4, j = t & 15;
+    const bool valid = i < count;
+    const int64_t smp = start + (valid ? i : 0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = j + 16 * m;
+        r.pa[m] = (valid && a < Dp) ? (prev ? prev[smp * cap + a] : 1.0) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < DM; ++s) r.pp[s] = (valid && s < d) ? ph[smp * d + s] : 0.0;
+}
+template <int DM>
+__device__ __forceinline__ void stage16_store(const StageRegs<DM>& r, double* __restrict__ Zs, const int32_t start, const int32_t count,
+                                              int Dp, const double* __restrict__ ph, int d, bool left, int t) {
+    const int i = t >> 4, j = t & 15;
+    const bool valid = i < count;
+    const int64_t smp = start + (valid ? i : 0);
+    double* row = Zs + i * FXS;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int a = j + 16 * m;
+        if (a < Dp) {
+#pragma unroll
+            for (int s = 0; s < DM; ++s)
+                if (s < d) row[left ? a * d + s : s * Dp + a] = r.pa[m] * r.pp[s];
+            for (int s = DM; s < d; ++s) row[left ? a * d + s : s * Dp + a] = valid ? r.pa[m] * ph[smp * d + s] : 0.0;
+        }
+    }
+    for (int z = Dp * d + j; z < MAX_DIM; z += 16) row[z] = 0.0;
+}
+__device__ __forceinline__ void stage16(double* __restrict__ Zs, const int32_t start, const int32_t count,
+                                        const double* __restrict__ prev, int Dp, const double* __restrict__ ph, int d, int cap,
+                                        bool left, int t) {
+    StageRegs<8> r;
+    stage16_load(r, start, count, prev, Dp, ph, d, cap, t);
+    stage16_store(r, Zs, start, count, Dp, ph, d, left, t);
+}
+
+constexpr int WLS = 34;     // LDS row stride of the staged 32-column slice of W[lid]
+
+template <int DM>
+__global__ __launch_bounds__(FUSED_T) void k_bond_fused(View v, int lid, int assemble) {
+    __shared__ __attribute__((aligned(16))) double Xs[16 * FXS];
+    __shared__ __attribute__((aligned(16))) double Ys[16 * FXS];
+    __shared__ __attribute__((aligned(16))) double Wls[MAX_DIM * WLS];
+    __shared__ double red[8 * 16];
+    const BondDimsF b = bond_dims_f(v, lid);
+    const Part pt = v.parts[blockIdx.x];
+    const int d = v.d, rid = lid + 1;
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int c = pt.cls;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int col = 16 * wave + i16;
+    const bool cv = col < b.Y;
+#ifdef MPST_FUSED_DEBUG
+    // bring-up only: 100 MHz stamps of workgroup 0 (read with mpst_debug_stamps, slots 32..)
+    unsigned long long* dbg = (blockIdx.x == 0 && tid == 0) ? v.sc->eig_stamps + 32 : nullptr;
+    int dbgi = 0;
+#define FSTAMP() do { if (dbg && dbgi < 30) dbg[dbgi++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FSTAMP() do { } while (0)
+#endif
+    FSTAMP();
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+    const bool xhalf = tid < 256;                 // threads 0..255 stage the X tile, 256..511 the Y tile
+    const int st = xhalf ? tid : tid - 256;
+    const double* s_prev = xhalf ? LEp : REn;
+    const double* s_ph = xhalf ? phl : phr;
+    const int s_D = xhalf ? b.Dl : b.Dr;
+    double* s_dst = xhalf ? Xs : Ys;
+    // the first tile's environment rows and site vectors are requested before anything else: their latency is
+    // covered by the assembly of the bond tensor
+    StageRegs<DM> sr;
+    stage16_load(sr, pt.start, min(16, pt.count), s_prev, s_D, s_ph, d, v.cap, st);
+
+    // ---- B_c column tile of this wave: bq[mt][r] = B_c[16mt + kq + 4r][col] (k-step u = 4mt + r of the yhat product) ----
+    d4 bq[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) bq[mt] = d4{0.0, 0.0, 0.0, 0.0};
+    if (assemble) {
+        // flatten_bt: B_c = W[lid] W[rid] (the label index sits on one of the two sites); W[lid] goes through LDS
+        // 32 columns of the shared bond at a time, this wave's 16 columns of W[rid] through registers
+        const int ls = *v.label_site;
+        const int cl = (ls == lid) ? c : 0, cr = (ls == rid) ? c : 0;
+        const double* Wl = v.sites + (int64_t)lid * v.site_stride + (int64_t)cl * b.X * b.Dm;   // [x][m]
+        const double* Wr = v.sites + (int64_t)rid * v.site_stride + (int64_t)cr * b.Dm * b.Y;   // [m][y]
+        for (int m0 = 0; m0 < b.Dm; m0 += 32) {
+            double wr[8], wlv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + FUSED_T * j, x = idx >> 5, m = m0 + (idx & 31);
+                wlv[j] = (x < b.X && m < b.Dm) ? Wl[(int64_t)x * b.Dm + m] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int m = m0 + 4 * s + kq;
+                wr[s] = (cv && m < b.Dm) ? Wr[(int64_t)m * b.Y + col] : 0.0;
+            }
+            if (m0) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int idx = tid + FUSED_T * j;
+                Wls[(idx >> 5) * WLS + (idx & 31)] = wlv[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                if (16 * mt < b.X) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        if (m0 + 4 * s < b.Dm) bq[mt] = mfma_f64(Wls[(16 * mt + i16) * WLS + 4 * s + kq], wr[s], bq[mt]);
+                }
+            }
+        }
+        if (pt.first_of_cls) {
+            double* out = v.bt + (int64_t)c * b.L;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int x = 16 * mt + kq + 4 * r;
+                    if (cv && x < b.X) out[(int64_t)x * b.Y + col] = bq[mt][r];
+                }
+        }
+    } else {
+        const double* Bc = v.bt + (int64_t)c * b.L;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = 16 * mt + kq + 4 * r;
+                bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
+            }
+    }
+    FSTAMP();
+    const int XP = (b.X + 3) & ~3;
+    const int nmt = (b.X + 15) >> 4;
+
+    d4 gacc[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) gacc[mt] = d4{0.0, 0.0, 0.0, 0.0};
+    double loss = 0.0;
+    const double delta = (pt.own == c) ? 1.0 : 0.0;
+
+    for (int t0 = 0; t0 < pt.count; t0 += 16) {
+        const int cnt = min(16, pt.count - t0);
+        __syncthreads();                                   // the previous tile's operands are consumed
+        stage16_store(sr, s_dst, pt.start + t0, cnt, s_D, s_ph, d, xhalf, st);
+        __syncthreads();
+        // the next tile's loads fly during this tile's matrix work
+        if (t0 + 16 < pt.count) stage16_load(sr, pt.start + t0 + 16, min(16, pt.count - t0 - 16), s_prev, s_D, s_ph, d, v.cap, st);
+        FSTAMP();
+        // ---- yhat_i = X_i^T B_c Y_i: this wave's 16 columns (two accumulation chains) ---------------------------
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            if (4 * u < XP) acc0 = mfma_f64(Xs[i16 * FXS + 4 * u + kq], bq[u >> 2][u & 3], acc0);
+            if (4 * u + 4 < XP) acc1 = mfma_f64(Xs[i16 * FXS + 4 * u + 4 + kq], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+            // at most 8 operand reads ahead of the matrix pipe: the whole tile's worth (64 VGPRs) would spill
+            if ((u & 7) == 6) asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double x = sum16((acc0[r] + acc1[r]) * Ys[(kq + 4 * r) * FXS + col]);
+            if (i16 == 0) red[wave * 16 + kq + 4 * r] = x;
+        }
+        FSTAMP();
+        __syncthreads();
+        FSTAMP();
+        // every wave forms the 16 weights itself (same fixed-order sum -> same bits), lane j < 16 holds series j
+        double wj = 0.0;
+        {
+            const int j = lane & 15;
+            const double yh = ((red[j] + red[16 + j]) + (red[32 + j] + red[48 + j])) + ((red[64 + j] + red[80 + j]) + (red[96 + j] + red[112 + j]));
+            if (j < cnt) {
+                wj = mse ? (yh - delta) : 1.0 / yh;                                  // :489,:608 / :258,:367
+                if (wave == 0 && lane < 16) loss += mse ? 0.5 * (yh - delta) * (yh - delta) : -log(yh * yh);   // :554 / :318
+            }
+        }
+        // ---- G_c += sum_i w_i X_i Y_i^T: 8 row tiles x this wave's column tile, K = 16 series -------------------
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = 4 * u + kq;
+            const double wi = __shfl(wj, i, 64);
+            const double bop = wi * Ys[i * FXS + col];
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                if (mt < nmt) gacc[mt] = mfma_f64(Xs[i * FXS + 16 * mt + i16], bop, gacc[mt]);
+            asm volatile("" ::: "memory");
+        }
+        FSTAMP();
+    }
+    // ---- one partial per part ------------------------------------------------------------------------------------
+    double* out = v.partial + (int64_t)blockIdx.x * b.L;
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + kq + 4 * r;
+            if (row < b.X && cv) out[(int64_t)row * b.Y + col] = gacc[mt][r];
+        }
+    }
+    if (wave == 0) {
+        loss = sum16(loss);
+        if (lane == 0) v.tile_loss[blockIdx.x] = loss;
+    }
+    FSTAMP();
+}
+
+// Deterministic block-wide sum (fixed tree) for 256 threads.
+__device__ __forceinline__ double block_sum256(double x, double* red) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// grad[c] = scale_c * sum of the partials of class c (fixed order); gradbuf = [loss, 0, grad...] is what the multi-GPU
+// all-reduce sums.  64 gradient entries per workgroup, wave g sums the partials k = k0 + g, k0 + g + 4, ... (16 loads
+// in flight), the four wave sums meet in LDS: (g0 + g1) + (g2 + g3).  norm_part[block] = sum of squares of the block's
+// 64 entries (single GPU: pieces of the norm of the complete gradient; with a communicator k_grad_norm recomputes
+// them after the all-reduce).
+constexpr int RED_E = 64;
+__global__ __launch_bounds__(256) void k_fused_reduce(View v, int lid) {
+    __shared__ double red[4];
+    __shared__ double part[4][RED_E];
+    const BondDimsF b = bond_dims_f(v, lid);
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int64_t total = (int64_t)v.C * b.L;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t idx = (int64_t)blockIdx.x * RED_E + lane;
+    double s = 0.0;
+    int c = 0;
+    if (idx < total) {
+        c = (int)(idx / b.L);
+        const int64_t e = idx - (int64_t)c * b.L;
+        const int k0 = v.part_off[c], k1 = v.part_off[c + 1];
+        const double* p = v.partial + e;
+        double acc[4] = {0, 0, 0, 0};
+        for (int k = k0 + g; k < k1; k += 64) {
+            double t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = (k + 4 * u < k1) ? p[(int64_t)(k + 4 * u) * b.L] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u & 3] += t[u];
+        }
+        s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    part[g][lane] = s;
+    __syncthreads();
+    double gsum = 0.0;
+    if (g == 0) {
+        if (idx < total) {
+            const double scale = mse ? v.invN : -(v.train_sep ? v.inv_count[c] : v.invN);     // :608 / :367,:424
+            gsum = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * scale;
+            v.gradbuf[2 + idx] = gsum;
+        }
+        const double n2 = wave_sum(gsum * gsum);
+        if (lane == 0) v.norm_part[blockIdx.x] = n2;
+    }
+    if (blockIdx.x == 0) {
+        double l = 0.0;
+        for (int i = threadIdx.x; i < v.nparts; i += 256) {
+            const Part pt = v.parts[i];
+            const double w = mse ? v.invN : (v.train_sep ? v.inv_count[pt.own] : v.invN);   // :612 / :423,:371
+            l += v.tile_loss[i] * w;
+        }
+        const double tot = block_sum256(l, red);
+        if (threadIdx.x == 0) {
+            v.gradbuf[0] = tot;
+            v.gradbuf[1] = 0.0;
+        }
+    }
+}
+
+// ||grad||^2 pieces of the (all-reduced) gradient, same slicing as k_fused_reduce
+__global__ __launch_bounds__(64) void k_grad_norm(View v, int lid) {
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int64_t total = (int64_t)v.C * b.L;
+    const int64_t idx = (int64_t)blockIdx.x * RED_E + threadIdx.x;
+    const double g = idx < total ? v.gradbuf[2 + idx] : 0.0;
+    const double n2 = wave_sum(g * g);
+    if (threadIdx.x == 0) v.norm_part[blockIdx.x] = n2;
+}
+
+// step of TSGO / GD from the norm pieces: every caller sums them in the same order, so all see the same bits
+__device__ __forceinline__ double step_from_parts(const View& v, double* red, double* nrm_out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < v.n_norm_part; i += 256) s += v.norm_part[i];
+    const double nrm2 = block_sum256(s, red);
+    const double nrm = sqrt(nrm2);
+    if (nrm_out) *nrm_out = nrm;
+    return (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
+}
+
+// Gram matrix of bt_new = bt - step*grad viewed as the matrix decomposeBT hands to svd, one 16 x 16 tile per
+// workgroup, K split over the 4 waves.  The diagonal tiles see every entry of bt_new exactly once (their A-operand
+// panel) and write it to v.btn - a second buffer, the other tiles are still reading the old one.
+__global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_left, int first_iter) {
+    __shared__ double part[4][256];
+    __shared__ double red[4];
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int n = going_left ? b.Y : b.X;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tn = (n + 15) >> 4;
+    const int tile = blockIdx.x;
+    const bool live = tile < tn * tn;
+    const int m0 = (tile / tn) * 16, n0 = (tile % tn) * 16;
+    const bool diag = m0 == n0;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m = m0 + i, nn = n0 + i;
+    const bool mv = live && m < n, nv = live && nn < n;
+    const double* g = v.gradbuf + 2;
+    // element (k, p) of the matrix: going left  k = (c, x) jointly, p = y:  bt[k*Y + p]
+    //                               going right k = y, p = x, per class:    bt[c*L + p*Y + k]
+    const int nc = going_left ? 1 : v.C;
+    const int K = going_left ? v.C * b.X : b.Y;
+    const int kq4 = (((K + 3) >> 2) + 3) & ~3;
+    const int kbeg = wave * kq4, kend = min(K, (wave + 1) * kq4);
+    const int64_t sa_m = going_left ? 1 : b.Y, sa_k = going_left ? b.Y : 1;
+    // The first batch of operands (all of them for the headline shapes) is requested BEFORE the step size is formed:
+    // the norm reduction (a dependent global round trip + two barriers) then overlaps the operand latency.
+    double a_bt[16], a_g[16], b_bt[16], b_g[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int k = kbeg + 4 * u + kq;
+        const bool kv = k < kend;
+        const int64_t ia = (int64_t)m * sa_m + (int64_t)k * sa_k, ib = (int64_t)nn * sa_m + (int64_t)k * sa_k;
+        a_bt[u] = (mv && kv) ? v.bt[ia] : 0.0;
+        a_g[u] = (mv && kv) ? g[ia] : 0.0;
+        b_bt[u] = (nv && kv) ? v.bt[ib] : 0.0;
+        b_g[u] = (nv && kv) ? g[ib] : 0.0;
+    }
+    double nrm;
+    const double step = step_from_parts(v, red, &nrm);
+    if (tile == 0 && threadIdx.x == 0 && first_iter) {
+        v.sc->loss = v.gradbuf[0];
+        v.sc->grad_norm = nrm;
+    }
+    if (!live) return;
+    d4 acc = {0, 0, 0, 0};
+    for (int c = 0; c < nc; ++c) {
+        const int64_t base = (int64_t)c * b.L;
+        for (int k0 = kbeg; k0 < kend; k0 += 64) {
+            double a[16], bb[16];
+            int64_t ia[16];
+            const bool first = c == 0 && k0 == kbeg;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + 4 * u + kq;
+                const bool kv = k < kend;
+                ia[u] = base + (int64_t)m * sa_m + (int64_t)k * sa_k;
+                const int64_t ib = base + (int64_t)nn * sa_m + (int64_t)k * sa_k;
+                if (first) {
+                    a[u] = fma(-step, a_g[u], a_bt[u]);
+                    bb[u] = fma(-step, b_g[u], b_bt[u]);
+                } else {
+                    a[u] = (mv && kv) ? fma(-step, g[ia[u]], v.bt[ia[u]]) : 0.0;
+                    bb[u] = (nv && kv) ? fma(-step, g[ib], v.bt[ib]) : 0.0;
+                }
+            }
+            if (diag) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (mv && k0 + 4 * u + kq < kend) v.btn[ia[u]] = a[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (k0 + 4 * u < kend) acc = mfma_f64(a[u], bb[u], acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        const int col = n0 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + (lane >> 4) + 4 * r;
+            const double sum = (part[0][r * 64 + lane] + part[1][r * 64 + lane]) + (part[2][r * 64 + lane] + part[3][r * 64 + lane]);
+            if (row < n && col < n) v.gram[(int64_t)row * n + col] = sum;
+        }
+    }
+}
+
+// ---- environment update + back-split in one launch ---------------------------------------------------------------
+// wave-level 16 x 16 tile with operands from global / L2 (as wave_gemm_tile of mpst_kernels.hip)
+__device__ __forceinline__ d4 gemm_tile_g(const double* __restrict__ A, int64_t sam, int64_t sak, int M,
+                                          const double* __restrict__ B, int64_t sbk, int64_t sbn, int N, int K, int m0, int n0) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m = m0 + i, n = n0 + i;
+    const bool mv = m < M, nv = n < N;
+    const double* ap = A + (int64_t)m * sam;
+    const double* bp = B + (int64_t)n * sbn;
+    d4 acc = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        double a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < K;
+            a[u] = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
+            b[u] = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (k0 + 4 * u < K) acc = mfma_f64(a[u], b[u], acc);
+    }
+    return acc;
+}
+
+// decomposeBT back-split from the kept eigenvectors E (as k_split, reading bt_new from v.btn); `blk` of `nblk` workgroups
+__device__ __forceinline__ void split_block(const View& v, int lid, int going_left, int blk, int nblk) {
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int nk = v.sc->n_keep;
+    const int ldE = v.cap;
+    const double inv = v.sc->inv_norm;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* Wl = v.sites + (int64_t)lid * v.site_stride;
+    double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
+    const int tk = (nk + 15) >> 4;
+    const int col = lane & 15, rq = lane >> 4;
+    if (going_left) {
+        const int tx = (b.X + 15) >> 4;
+        const int ntile = v.C * tx * tk;
+        for (int tile = blk * 4 + wave; tile < ntile; tile += nblk * 4) {
+            const int c = tile / (tx * tk), rem = tile - c * tx * tk;
+            const int m0 = (rem / tk) * 16, n0 = (rem % tk) * 16;
+            const double* Bc = v.btn + (int64_t)c * b.L;
+            const d4 acc = gemm_tile_g(Bc, b.Y, 1, b.X, v.E, ldE, 1, nk, b.Y, m0, n0);
+            double* out = Wl + (int64_t)c * b.X * nk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + rq + 4 * r;
+                if (row < b.X && n0 + col < nk) out[(int64_t)row * nk + n0 + col] = acc[r] * inv;
+            }
+        }
+        for (int i = blk * 256 + threadIdx.x; i < nk * b.Y; i += nblk * 256) {
+            const int k = i / b.Y, y = i - k * b.Y;
+            Wr[i] = v.E[(int64_t)y * ldE + k];
+        }
+        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid;
+    } else {
+        const int ty = (b.Y + 15) >> 4;
+        const int ntile = v.C * tk * ty;
+        for (int tile = blk * 4 + wave; tile < ntile; tile += nblk * 4) {
+            const int c = tile / (tk * ty), rem = tile - c * tk * ty;
+            const int m0 = (rem / ty) * 16, n0 = (rem % ty) * 16;
+            const double* Bc = v.btn + (int64_t)c * b.L;
+            const d4 acc = gemm_tile_g(v.E, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0);
+            double* out = Wr + (int64_t)c * nk * b.Y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + rq + 4 * r;
+                if (row < nk && n0 + col < b.Y) out[(int64_t)row * b.Y + n0 + col] = acc[r] * inv;
+            }
+        }
+        for (int i = blk * 256 + threadIdx.x; i < b.X * nk; i += nblk * 256) {
+            const int x = i / nk, k = i - x * nk;
+            Wl[i] = v.E[(int64_t)x * ldE + k];
+        }
+        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid + 1;
+    }
+}
+
+// flatten_bt of the NEXT bond (RealRealHighDimension.jl:221-238) without waiting for the back-split to land in
+// memory: with T = bt_new * E (the site that keeps the label, up to 1/||bt_new||) the next bond tensor is
+//   going left : bt'[c][(a',s')][(s,k)]  = sum_a W[lid-1][(a',s')][a] * T_c[(a,s)][k]
+//   going right: bt'[c][(k,s)][(s'',b'')] = sum_b T_c[k][(s,b)] * W[lid+2][b][(s'',b'')]
+// One workgroup per (class c, site value s, 16 kept states k): each wave forms the 16 x 16 tiles of T for that (s, k)
+// block on the MFMA and feeds them straight back as operand of the second product - register r of a 16 x 16 fp64
+// accumulator tile holds rows 4r .. 4r+3 (lane>>4) of the tile, which is exactly the B (or, transposed, the A) operand
+// of k-step r - then the waves share out the row (column) tiles of bt'.
+constexpr int CHAIN_J = 4;      // 16-row blocks of the contracted bond: chi <= 64 whenever d*chi <= 128 and d >= 2
+__device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going_left, int job, double* __restrict__ cpart /* [4][CHAIN_J][256] */) {
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int nk = v.sc->n_keep;
+    const double inv = v.sc->inv_norm;
+    const int ldE = v.cap, d = v.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int ktc = (v.cap + 15) >> 4;                 // jobs are laid out for the capacity
+    const int kt = job % ktc, s = (job / ktc) % d, c = job / (ktc * d);
+    const int k0 = 16 * kt;
+    if (k0 >= nk || c >= v.C) return;
+    const int kcol = k0 + i16;
+    const bool kv = kcol < nk;
+    const double* Bc = v.btn + (int64_t)c * b.L;
+    // ---- T tiles: the contraction index (y going left, x going right) is split over the 4 waves, partial tiles meet in LDS
+    const int Kc = going_left ? b.Y : b.X;             // contraction length of the first product
+    const int Dc = going_left ? b.Dl : b.Dr;           // rows of T: the bond shared with the neighbouring site
+    const int nj = (Dc + 15) >> 4;
+    const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;         // k-steps per wave
+    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
+#pragma unroll
+    for (int j = 0; j < CHAIN_J; ++j) {
+        d4 t = {0, 0, 0, 0};
+        if (j < nj) {
+            const int row = 16 * j + i16;                // a (going left) or b (going right)
+            const double* ap = going_left ? Bc + (int64_t)(row * d + s) * b.Y : Bc + s * b.Dr + row;
+            const int64_t astr = going_left ? 1 : b.Y;
+            for (int q0 = kbeg; q0 < kend; q0 += 32) {
+                double av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = q0 + 4 * u + kq;
+                    av[u] = (row < Dc && q < kend) ? ap[(int64_t)q * astr] : 0.0;
+                    bv[u] = (kv && q < kend) ? v.E[(int64_t)q * ldE + kcol] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (q0 + 4 * u < kend) t = mfma_f64(av[u], bv[u], t);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart[(wave * CHAIN_J + j) * 256 + r * 64 + lane] = t[r];
+    }
+    __syncthreads();
+    d4 T[CHAIN_J];
+#pragma unroll
+    for (int j = 0; j < CHAIN_J; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = j * 256 + r * 64 + lane;
+            T[j][r] = ((cpart[o] + cpart[CHAIN_J * 256 + o]) + (cpart[2 * CHAIN_J * 256 + o] + cpart[3 * CHAIN_J * 256 + o])) * inv;
+        }
+    if (going_left) {
+        const int Dlp = v.chi[lid - 1], Xp = Dlp * d, Yp = d * nk;
+        const int64_t Lp = (int64_t)Xp * Yp;
+        const double* Wl = v.sites + (int64_t)(lid - 1) * v.site_stride;       // [x'][a], a < Dl
+        double* out = v.bt + (int64_t)c * Lp;
+        const int ntx = (Xp + 15) >> 4;
+        for (int mt = wave; mt < ntx; mt += 4) {
+            const int x = 16 * mt + i16;
+            d4 acc = {0, 0, 0, 0};
+            double wl[CHAIN_J][4];
+#pragma unroll
+            for (int j = 0; j < CHAIN_J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * j + 4 * r + kq;
+                    wl[j][r] = (j < nj && x < Xp && a < b.Dl) ? Wl[(int64_t)x * b.Dl + a] : 0.0;
+                }
+#pragma unroll
+            for (int j = 0; j < CHAIN_J; ++j)
+                if (j < nj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(wl[j][r], T[j][r], acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xr = 16 * mt + kq + 4 * r;
+                if (xr < Xp && kv) out[(int64_t)xr * Yp + s * nk + kcol] = acc[r];
+            }
+        }
+    } else {
+        const int Drr = v.chi[lid + 3], Ypp = d * Drr, Xp = nk * d;
+        const int64_t Lp = (int64_t)Xp * Ypp;
+        const double* Wr = v.sites + (int64_t)(lid + 2) * v.site_stride;       // [b][y''], b < Dr
+        double* out = v.bt + (int64_t)c * Lp;
+        const int nty = (Ypp + 15) >> 4;
+        for (int nt = wave; nt < nty; nt += 4) {
+            const int y = 16 * nt + i16;
+            d4 acc = {0, 0, 0, 0};
+            double wr[CHAIN_J][4];
+#pragma unroll
+            for (int j = 0; j < CHAIN_J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bb = 16 * j + 4 * r + kq;
+                    wr[j][r] = (j < nj && y < Ypp && bb < b.Dr) ? Wr[(int64_t)bb * Ypp + y] : 0.0;
+                }
+#pragma unroll
+            for (int j = 0; j < CHAIN_J; ++j)
+                if (j < nj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], wr[j][r], acc);    // A[m = k][kk = b] = T^T tile, register r
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + kq + 4 * r;
+                if (k < nk && y < Ypp) out[(int64_t)(k * d + s) * Ypp + y] = acc[r];
+            }
+        }
+    }
+}
+
+// blocks [0, ntiles): new environment rows out_i = Z_i E (update_caches!); [ntiles, ntiles + nsplit): the back-split;
+// beyond: the next bond's tensor (chain_bt_block)
+__global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_left, int site, int left_side,
+                                                   const double* __restrict__ prev, int prev_bond, int out_bond,
+                                                   double* __restrict__ out, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x >= v.ntiles + nsplit) {
+        chain_bt_block(v, lid, going_left, (int)blockIdx.x - v.ntiles - nsplit, smem);
+        return;
+    }
+    if ((int)blockIdx.x >= v.ntiles) {
+        split_block(v, lid, going_left, (int)blockIdx.x - v.ntiles, nsplit);
+        return;
+    }
+    const int d = v.d;
+    const int Dp = prev ? v.chi[prev_bond] : 1;
+    const int Dout = v.chi[out_bond];
+    const int Z = Dp * d;
+    const double* __restrict__ M = v.E;
+    const int64_t sz = v.cap;
+    const int ZP = (Z + 3) & ~3;
+    const Span tl = v.tiles[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double* ph = v.phi + (int64_t)site * v.N * d;
+    stage16(smem, tl.start, tl.count, prev, Dp, ph, d, v.cap, left_side != 0, tid);
+    __syncthreads();
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int nt_out = (Dout + 15) >> 4;
+    for (int nt = wave; nt < nt_out; nt += 4) {
+        const int col = nt * 16 + i16;
+        const bool cv = col < Dout;
+        d4 acc = {0, 0, 0, 0};
+        double bv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int z = 4 * u + kq;
+            bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u)
+            if (4 * u < ZP) acc = mfma_f64(smem[i16 * FXS + 4 * u + kq], bv[u], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = kq + 4 * r;
+            if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+        }
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static inline int cdivf(int a, int b) { return (a + b - 1) / b; }
+
+void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s) {
+    if (v.d <= 4) hipLaunchKernelGGL(k_bond_fused<4>, dim3(v.nparts), dim3(FUSED_T), 0, s, v, lid, assemble);
+    else hipLaunchKernelGGL(k_bond_fused<8>, dim3(v.nparts), dim3(FUSED_T), 0, s, v, lid, assemble);
+}
+void launch_fused_reduce(const View& v, int lid, hipStream_t s) {
+    hipLaunchKernelGGL(k_fused_reduce, dim3(v.n_norm_part), dim3(256), 0, s, v, lid);
+}
+void launch_grad_norm(const View& v, int lid, hipStream_t s) {
+    hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);
+}
+void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    hipLaunchKernelGGL(k_gram_upd, dim3(cdivf(dm, 16) * cdivf(dm, 16)), dim3(256), 0, s, v, lid, going_left, first_iter);
+}
+void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
+                      int out_bond, double* out, int chain, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
+    const int nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
+    const size_t lds = std::max((size_t)16 * FXS, chain ? (size_t)4 * CHAIN_J * 256 : (size_t)0) * sizeof(double);
+    hipLaunchKernelGGL(k_env_split, dim3(v.ntiles + nsplit + nchain), dim3(256), lds, s, v, lid, going_left,
+                       site, left_side, prev, prev_bond, out_bond, out, nsplit);
+}
+
+}  // namespace mpst

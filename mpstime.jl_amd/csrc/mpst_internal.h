@@ -153,6 +153,15 @@ struct Span {
     int32_t pad;
 };
 
+// A part = the series one persistent workgroup of k_bond_fused walks: a class-pure run [start, start+count) of class
+// `own`, contracted with the bond tensor of class `cls` (KLD: cls == own; MSE: every class).  Parts are ordered by
+// `cls`, so the partial gradients of one class are consecutive.
+struct Part {
+    int32_t start, count, own, cls;
+    int32_t first_of_cls, pad0, pad1, pad2;
+};
+constexpr int PARTS_TARGET = 128;   // persistent workgroups of the fused gradient kernel (256 for >= 512 tiles of 16 series)
+
 constexpr int TILE_S = 16;    // series per yhat/env tile (one MFMA M-tile)
 constexpr int CHUNK_S = 64;   // series per gradient chunk (the GEMM K extent of one partial)
 constexpr int GB = 64;        // gradient output block edge per workgroup
@@ -188,6 +197,9 @@ struct DataSet {
     int32_t nchunks = 0;
     int32_t* cls_chunk_off = nullptr;  // [C+1] first chunk of each class
     double* inv_count = nullptr;       // [C] 1 / (global series count of the class)
+    Part* parts[2] = {nullptr, nullptr};          // [0] KLD, [1] MSE
+    int32_t nparts[2] = {0, 0};
+    int32_t* part_off[2] = {nullptr, nullptr};    // [C+1] first part of each bond-tensor class
     std::vector<int64_t> counts;       // local per-class counts
     std::vector<int64_t> gcounts;      // global per-class counts
     int64_t Nglobal = 0;
@@ -216,6 +228,11 @@ struct View {
     double* yhat;       // [C][N]
     double* tile_loss;  // [C][ntiles]
     double* partial;    // gradient partials
+    const Part* parts;  // fused path: persistent workgroups of k_bond_fused
+    const int32_t* part_off;
+    int32_t nparts, n_norm_part;
+    double* norm_part;  // [n_norm_part] pieces of ||grad||^2
+    double* btn;        // bt_new, written by k_gram_upd
     double* gradbuf;    // [2 + C*Lmax]: loss, pad, grad[c][x][y]
     double* gram;       // [MAX_DIM*MAX_DIM]
     double* lam;        // [MAX_DIM]
@@ -227,6 +244,13 @@ struct View {
     double eta, cutoff;
 };
 
+// fused path for bond tensors up to MAX_DIM x MAX_DIM (mpst_fused.hip)
+void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s);
+void launch_fused_reduce(const View& v, int lid, hipStream_t s);
+void launch_grad_norm(const View& v, int lid, hipStream_t s);
+void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
+void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
+                      int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);
 // launchers (mpst_kernels.hip)
 void launch_bt_assemble(const View& v, int lid, hipStream_t s);
 void launch_bt_prescale(const View& v, int lid, hipStream_t s);
