@@ -44,12 +44,12 @@ def make_inputs(N, T, d, seed=1):
     return mt.encode_dataset(X, Xs, y, enc, d, {1: 0, 2: 1})
 
 
-def kernel_model(N, d, chi, C):
-    """Algorithmic flops / bytes per launch of each kernel class at steady state (all bulk bonds at
-    chi_max); formulas from SURVEY.md 8(d), stated again in DESIGN.md."""
+def kernel_model(N, d, chi, C, info):
+    """Algorithmic flops / bytes per launch of each kernel class at steady state (all bulk bonds at chi_max); formulas
+    from SURVEY.md 8(d), stated again in DESIGN.md.  `info` = SweepEngine.info(): which launch chain is in use."""
     X = Y = d * chi
     m, n = chi * C * d, d * chi
-    return {
+    model = {
         "yhat": ("mfma", 2.0 * N * X * Y),                 # Z = X B_c, rowdot with Y
         "grad": ("mfma", 2.0 * N * X * Y),                 # G_c = X^T diag(w) Y
         # SVD of the (chi C d) x (d chi) bond matrix, done as Gram matrix + symmetric eigensolver:
@@ -62,6 +62,24 @@ def kernel_model(N, d, chi, C):
         "env": ("hbm", 8.0 * N * (chi + d + chi)),         # read env row + site vector, write new env row
         "grad_reduce+update": ("hbm", 8.0 * (N / 64.0 + 3.0) * C * X * Y),
     }
+    if info.get("fused"):
+        P = info["nparts"]
+        model["grad"] = ("mfma", 4.0 * N * X * Y)           # k_bond_fused: yhat AND the gradient partials
+        model["grad_reduce+update"] = ("hbm", 8.0 * (P + C) * X * Y)   # k_fused_reduce: read P partials, write the gradient
+        model["env"] = ("hbm", 8.0 * N * (chi + d + chi))  # k_env_split (+ 2mn chi flops of the back-split, + next bond tensor)
+    if info.get("large_bond"):
+        model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n ** 3)   # rocSOLVER dsyevd: sytrd + stedc + ormtr back-transformation
+    return model
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -150,23 +168,21 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warmup: chi grows to chi_max during the first sweep; the last warmup sweep is profiled per
-    # kernel class to find the dominant kernel
+    # warmup: chi grows to chi_max during the first sweep
     for w in range(args.warmup):
-        if w == args.warmup - 1:
-            eng.set_profile(0x7FF)
         eng.sweep()
-    breakdown = eng.get_profile() if args.warmup > 0 else {}
-    dominant = max(breakdown, key=lambda k: breakdown[k][0]) if breakdown else "eig_tri"
-    kidx = list(mt._lib.KERNEL_CLASSES).index(dominant)
-    eng.set_profile(1 << kidx)          # HIP events on the engine's stream around the dominant kernel only
+    info = eng.info()
 
+    # ---- the timed region: K sweeps exactly as fitMPS runs them (profiling off: replayed from the captured hipGraph on
+    # one GPU, plain stream with the RCCL all-reduce on several) ----------------------------------------------------
     sync()
     t0 = time.perf_counter()
     dev_s = 0.0
+    fallbacks = 0
     for _ in range(args.steps):
         st = eng.sweep()
         dev_s += st["seconds"]
+        fallbacks += st["eig_fallbacks"]
     sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -174,13 +190,25 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    prof = eng.get_profile()
     mse, kld, acc, _ = eng.eval(0)
     chi_now, _ = eng.get_chi()
 
+    # ---- separate, untimed passes for the roofline: HIP events on the engine's own stream around every launch of every
+    # kernel class (one sweep), then around the dominant class only over the same K sweeps as the timed region ---------
+    eng.set_profile(0x7FF)
+    eng.sweep()
+    breakdown = eng.get_profile()
+    dominant = max(breakdown, key=lambda k: breakdown[k][0]) if breakdown else "eig_tri"
+    kidx = list(mt._lib.KERNEL_CLASSES).index(dominant)
+    eng.set_profile(1 << kidx)
+    for _ in range(args.steps):
+        eng.sweep()
+    prof = eng.get_profile()
+    eng.set_profile(0)
+
     out = None
     if rank == 0:
-        model = kernel_model(N / world, d, chi, C)
+        model = kernel_model(N / world, d, chi, C, info)
         us_tot, cnt = prof[dominant]
         avg_us = us_tot / max(cnt, 1)
         bound, alg = model.get(dominant, ("mfma", 0.0))
@@ -201,14 +229,25 @@ def main():
         # per-launch figure of the committed rocprofv3 --pmc passes over this same command is quoted
         # (profiles/aggregate_pmc.py; FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
         traffic, traffic_src = None, None
+        fused = info.get("fused")
+        knames = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin", "yhat": "mpst::k_yhat",
+                  "grad": "mpst::k_bond_fused" if fused else "mpst::k_grad", "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
+                  "split": "mpst::k_split", "env": "mpst::k_env_split" if fused else "mpst::k_env",
+                  "grad_reduce+update": "mpst::k_fused_reduce" if fused else "mpst::k_grad_reduce"}
+        pmc_file = os.path.join("profiles", "r02_pmc_counters.json")
+        pmc = {}
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))["kernels"]
-            kname = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin", "yhat": "mpst::k_yhat",
-                     "grad": "mpst::k_grad", "gram": "mpst::k_gram", "split": "mpst::k_split", "env": "mpst::k_env"}.get(dominant)
-            if kname in pmc and world == 1 and (N, T, chi, d) == (4096, 100, 32, 4):
-                traffic, traffic_src = pmc[kname]["hbm_bytes_per_launch_corrected"], "profiles/r01_pmc_hbm_traffic.json"
+            pmc = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
         except Exception:
             pass
+        headline = world == 1 and (N, T, chi, d) == (4096, 100, 32, 4)
+        kname = knames.get(dominant)
+        if headline and kname in pmc and "hbm_bytes_per_launch_corrected" in pmc[kname]:
+            traffic, traffic_src = pmc[kname]["hbm_bytes_per_launch_corrected"], pmc_file
+        for k, kn in knames.items():
+            if headline and k in kernels and kn in pmc and "mfma_util" in pmc[kn]:
+                kernels[k]["mfma_util"] = pmc[kn]["mfma_util"]            # committed rocprofv3 --pmc pass of this command
+                kernels[k]["hbm_bytes_per_launch"] = pmc[kn].get("hbm_bytes_per_launch_corrected")
         out = {
             "metric": "full sweeps/sec (N=4096,T=100,chi=32,d=4)", "value": args.steps / elapsed, "unit": "sweeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -220,7 +259,9 @@ def main():
                        "bond_dims_max": int(chi_now.max())},
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "train_KL_div_after": kld, "train_acc_after": acc,
-            "eig_fallbacks_total": st["eig_fallbacks"], "eig_phases_us_last_bond": eng.eig_phases(),
+            "eig_fallbacks_total": fallbacks, "eig_phases_us_last_bond": eng.eig_phases(), "launch_chain": info,
+            "timed_region": "K sweeps with profiling off" + (" (hipGraph replay)" if info.get("graph") else " (plain stream)") +
+                            "; per-kernel figures from separate event-instrumented sweeps after it",
             # the whole SVD (gram + eig_tri + eig_vec + eig_fin) against SURVEY 8(d)'s dense-SVD count 4mn^2 + 8n^3
             "svd_group": {"algorithmic_flops_dense_svd": 4.0 * (chi * C * d) * (d * chi) ** 2 + 8.0 * (d * chi) ** 3,
                           "avg_us": round(sum(breakdown[k][0] / max(breakdown[k][1], 1) for k in ("gram", "eig_tri", "eig_vec", "eig_fin")
@@ -248,13 +289,42 @@ def main():
             r = co.sweep(max_bonds=args.cpu_bonds, first_bond=skip)
             per_bond = r["seconds"] / max(r["bonds"], 1)
             sweep_s = per_bond * 2 * (T - 1) + 2 * t_cache
+            # (i) the SVD with every host core (as OpenBLAS would run it for Julia), (ii) the
+            # NumPy / SciPy-gesdd oracle on the same inputs as a second data point
+            import scipy.linalg
+            A = np.random.default_rng(0).standard_normal((chi * C * d, d * chi))
+            t_s0 = time.perf_counter()
+            for _ in range(20):
+                scipy.linalg.svd(A, full_matrices=False, lapack_driver="gesdd")
+            svd_ms = 1e3 * (time.perf_counter() - t_s0) / 20
+            np_per_bond = None
+            try:
+                from oracle import ref_numpy as R
+                Wn = [t.copy() for t in Wnow]
+                dsn = R.EncodedSet(full.phi, full.label_index, full.class_distribution)
+                opts_n = R.SweepOptions(nsweeps=1, chi_max=chi, eta=0.01)
+                nb_np = 3
+                # run the bonds in sweep order from the right end so that the oracle's caches are valid
+                Wn = [t.copy() for t in Wnow]
+                LEn, REn = R.construct_caches(Wn, dsn.phi, True)
+                t_n0 = time.perf_counter()
+                for q in range(skip + nb_np):
+                    R.bond_step(Wn, LEn, REn, T - 2 - q, dsn, opts_n, True, {})
+                np_per_bond = (time.perf_counter() - t_n0) / (skip + nb_np)
+            except Exception:
+                pass
             out["cpu_baseline"] = {
                 "value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
                 "sample": f"oracle/mps_oracle.c (-O3 -march=native -ffast-math, 1 thread for the per-series loops, SciPy "
                           f"OpenBLAS dgesdd): {r['bonds']} steady-state bulk bond updates ({per_bond:.3f} s each) + one "
                           f"construct_caches ({t_cache:.2f} s) timed on this host, extrapolated to 2(T-1)={2 * (T - 1)} bonds "
                           f"+ 2 cache rebuilds; the Julia reference itself cannot run here",
-                "host_cpus": os.cpu_count(), "seconds_sampled": r["seconds"] + t_cache}
+                "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model(), "seconds_sampled": r["seconds"] + t_cache,
+                "svd_gesdd_all_cores_ms": svd_ms,
+                "numpy_oracle": None if np_per_bond is None else {
+                    "value": 1.0 / (np_per_bond * 2 * (T - 1)), "unit": "sweeps/s",
+                    "sample": f"oracle/ref_numpy.py (vectorised NumPy + SciPy gesdd, {os.cpu_count()} BLAS threads available): "
+                              f"{skip + 3} bond updates from the right end ({np_per_bond:.3f} s each) extrapolated to {2 * (T - 1)}"}}
         except Exception as e:      # the baseline is a reported extra, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "sweeps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     if rank == 0:

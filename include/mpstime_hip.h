@@ -78,8 +78,8 @@ typedef struct {
     double  seconds;            /* device time of the sweep (HIP events) */
     int32_t svd_status;         /* 0 or MPST_ERR_SVD */
     int32_t max_chi;            /* largest bond dimension after the sweep */
-    int32_t eig_sweeps_total;   /* diagnostic: Jacobi sweeps summed over bonds */
-    int32_t eig_fallbacks;      /* diagnostic: bonds (cumulative) on which the fast eigensolver's on-device
+    int32_t eig_sweeps_total;   /* diagnostic: Jacobi sweeps summed over the bonds of this sweep */
+    int32_t eig_fallbacks;      /* diagnostic: bonds of this sweep on which the fast eigensolver's on-device
                                    verification failed and the Jacobi path was used */
 } mpst_sweep_stats;
 
@@ -186,11 +186,18 @@ int  mpst_selftest_eig(void* ctx, const double* G /*n*n symmetric*/, int32_t n, 
                        double* lambda_out /*n*/, double* E_out /*n*n row-major [i][k]*/, int32_t* sweeps);
 /* Per-kernel timing with HIP events recorded on the engine's own stream around every launch
  * of the selected kernel classes during mpst_sweep / mpst_bond_step (bit k of kernel_mask):
- * 0 yhat, 1 grad, 2 grad_reduce+update, 3 gram, 4 eig, 5 split, 6 env, 7 bt_assemble, 8 all-reduce.
+ * 0 yhat, 1 grad (fused chain: yhat + gradient partials), 2 grad_reduce + update, 3 gram (fused chain: with the optimiser
+ * step), 4 eig_tri (large-bond path: the whole library eigensolver), 5 split, 6 env (fused chain: + back-split + next
+ * bond tensor), 7 bt_assemble, 8 all-reduce, 9 eig_vec, 10 eig_fin.
  * mpst_set_profile also resets the accumulators; mpst_get_profile returns the summed device
  * microseconds and the launch count per class (arrays of 16). */
 int  mpst_set_profile(void* ctx, uint32_t kernel_mask);
 int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16]*/);
+/* which launch chain the context resolved to for its current sizes / options: out[0] fused chain (bond tensors up to
+ * 128 x 128, 7 launches per bond), out[1] large-bond path (d*chi_max > 128), out[2] partial gradients per optimiser step
+ * of the fused chain, out[3] 64-series chunks of the unfused chain, out[4] capacity bond dimension, out[5] ranks,
+ * out[6] sweeps replayed from a hipGraph, out[7] reserved */
+int  mpst_get_info(void* ctx, int32_t* out /*[8]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */

@@ -984,6 +984,23 @@ int mpst_get_profile(void* ctx, double* total_us, int64_t* count) {
     return 0;
 }
 
+int mpst_get_info(void* ctx, int32_t* out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !out) return MPST_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
+    out[0] = c->fused ? 1 : 0;
+    out[1] = c->big ? 1 : 0;
+    out[2] = c->ds[MPST_TRAIN].nparts[pk];
+    out[3] = c->ds[MPST_TRAIN].nchunks;
+    out[4] = c->cap;
+    out[5] = c->nranks;
+    out[6] = (!c->comm && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
+    out[7] = 0;
+    return 0;
+}
+
 int mpst_get_eig_phases(void* ctx, double* us) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->sc || !us) return MPST_ERR_INVALID;

@@ -209,6 +209,12 @@ class SweepEngine:
                                             cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
 
+    def info(self):
+        out = (C.c_int32 * 8)()
+        self._chk(self.lib.mpst_get_info(self.ctx, out))
+        return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
+                "ranks": out[5], "graph": bool(out[6])}
+
     def eig_phases(self):
         us = np.zeros(6)
         self._chk(self.lib.mpst_get_eig_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
