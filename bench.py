@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--rebuild-caches", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=24)
+    ap.add_argument("--allreduce", choices=["auto", "rccl", "oneshot"], default="auto",
+                    help="collective of the sharded sweep: RCCL, the one-shot direct-write kernel, or whichever one trial sweep shows faster")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -123,24 +125,38 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # MPST_BENCH_SHARE_GPU=1 (test mode for 1-GPU boxes): every rank on GPU local_rank mod #GPUs, host-side group on gloo,
+    # no RCCL (it refuses two ranks on one device) - the sharded sweep then runs on the one-shot all-reduce alone
+    share = os.environ.get("MPST_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    hdev = "cpu" if share else "cuda"
+
+    def host_reduce(vals, op):
+        t = torch.tensor(vals, dtype=torch.float64, device=hdev)
+        dist.all_reduce(t, op=op)
+        return t.tolist()
 
     import mpstime_jl_amd as mt
     N, T, d, chi, C = args.N, args.T, args.d, args.chi, 2
     full = make_inputs(N, T, d)
     W0 = mt.generate_startingMPS(4, T, d, C, 1234)
 
-    eng = mt.SweepEngine(local_rank)
+    eng = mt.SweepEngine(dev_index)
     eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO",
                     rescale=(False, True), rebuild_caches=args.rebuild_caches)
+    sh = None
     if world > 1:
-        sh = mt.Shard(rank, world)
+        sh = mt.Shard(rank, world, rccl=not share)
         local, gcounts = sh.split(full)
-        sh.attach(eng)
+        sh.attach(eng)                   # RCCL communicator (the baseline collective)
         eng.set_dataset(0, local.phi, local.label_index, C, gcounts)
     else:
         eng.set_dataset(0, full.phi, full.label_index, C)
@@ -161,12 +177,56 @@ def main():
             encode_info = {"error": str(e)}
 
     eng.set_mps(W0)
+    allreduce = {"path": "none"}
+    if world > 1:
+        # the collective of the sharded sweep: RCCL's all-reduce and, next to it, the one-shot direct-write kernel over
+        # peer-mapped inboxes.  Each candidate runs two trial sweeps (bounded spins: a failing path costs about a
+        # second, not the run); all ranks agree on the outcome over the host-side group and keep the faster working one.
+        paths = [] if share else ["rccl"]
+        if args.allreduce != "rccl":
+            ok = 1.0
+            try:
+                sh.attach_oneshot(eng)
+            except Exception as e:
+                ok = 0.0
+                allreduce["oneshot_error"] = str(e)
+            if host_reduce([ok], dist.ReduceOp.MIN)[0] > 0:
+                paths.append("oneshot")
+        times = {}
+        for name in paths:
+            if "oneshot" in paths:
+                sh.select(eng, name == "oneshot")
+            eng.set_mps(W0)
+            eng.build_caches()
+            good, dt = 1.0, 1e9
+            try:
+                eng.sweep()
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                eng.sweep()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - tq
+            except Exception as e:
+                good = 0.0
+                allreduce[name + "_error"] = str(e)
+            good = host_reduce([good], dist.ReduceOp.MIN)[0]
+            dt = host_reduce([dt], dist.ReduceOp.MAX)[0]
+            times[name] = dt if good > 0 else None
+        allreduce["trial_sweep_s"] = times
+        working = [n for n in paths if times.get(n) is not None]
+        assert working, f"no working collective: {allreduce}"
+        pick = args.allreduce if args.allreduce in working else min(working, key=lambda n: times[n])
+        if "oneshot" in paths:
+            sh.select(eng, pick == "oneshot")
+        allreduce["path"] = pick
+        eng.set_mps(W0)
     eng.build_caches()
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+
 
     # warmup: chi grows to chi_max during the first sweep
     for w in range(args.warmup):
@@ -187,9 +247,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = host_reduce([elapsed], dist.ReduceOp.MAX)[0]
     mse, kld, acc, _ = eng.eval(0)
     chi_now, _ = eng.get_chi()
 
@@ -259,6 +317,8 @@ def main():
                        "bond_dims_max": int(chi_now.max())},
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "train_KL_div_after": kld, "train_acc_after": acc,
+            "allreduce": dict(allreduce, us_per_optimiser_step=(breakdown["allreduce"][0] / max(breakdown["allreduce"][1], 1)
+                                                                 if breakdown.get("allreduce", (0, 0))[1] else None)),
             "eig_fallbacks_total": fallbacks, "eig_phases_us_last_bond": eng.eig_phases(), "launch_chain": info,
             "timed_region": "K sweeps with profiling off" + (" (hipGraph replay)" if info.get("graph") else " (plain stream)") +
                             "; per-kernel figures from separate event-instrumented sweeps after it",

@@ -110,6 +110,18 @@ void mpst_destroy(void* ctx);
 int  mpst_comm_unique_id(uint8_t out_id[128]);
 int  mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank);
 
+/* One-shot direct-write all-reduce over xGMI, next to the RCCL path (the 262 KB message is latency-bound).
+ * Every rank allocates an inbox in fine-grained device memory and exports it (64-byte hipIpcMemHandle_t); the host
+ * gathers the handles of all ranks (torch.distributed all_gather, MPI, ...) and hands the rank-ordered array to
+ * mpst_comm_ipc_attach, after which gradient and evaluation sums go through the one-shot kernel (peer writes + flags,
+ * fixed rank-order sum: bit-identical replicas).  Call after mpst_set_options / mpst_set_dataset / mpst_set_mps (the slot
+ * size follows the gradient buffer) and again if those change the capacity.  RCCL is not required: without
+ * mpst_comm_init the pair (export, attach) alone defines the communicator.  mpst_comm_select switches between the two
+ * paths when both exist (0 = RCCL, 1 = one-shot).  2..8 ranks (one node). */
+int  mpst_comm_ipc_export(void* ctx, int nranks, int rank, uint8_t handle_out[64]);
+int  mpst_comm_ipc_attach(void* ctx, const uint8_t* all_handles /* nranks * 64 bytes, rank order */);
+int  mpst_comm_select(void* ctx, int oneshot);
+
 /* EncodedTimeSeriesSet -> device (src/Structs/structs.jl:12-33).  `n_global_per_class`
  * may be NULL on a single GPU; with sharding it carries the global class counts that
  * the loss normalisation uses (loss_functions.jl:367,371,423-424). */

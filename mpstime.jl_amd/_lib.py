@@ -56,6 +56,9 @@ SYMBOLS = {
     "mpst_destroy": (None, [_vp]),
     "mpst_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "mpst_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "mpst_comm_ipc_export": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
+    "mpst_comm_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
+    "mpst_comm_select": (C.c_int, [_vp, C.c_int]),
     "mpst_set_dataset": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i32), _i64, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
     "mpst_encode_dataset": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i32), _i64, _i32, _i32, _i32, C.POINTER(mpst_encode_opts),
                                       C.POINTER(_i64), _dp, _dp]),

@@ -59,6 +59,14 @@ struct Ctx {
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    // one-shot direct-write all-reduce (mpst_allreduce.hip): this rank's inbox (fine-grained device memory, exported
+    // over IPC) and the peers' inboxes as mapped here
+    void* ipc_local = nullptr;           // [2][nranks][slot] doubles | 16 flags | 2 counters
+    void* ipc_peer[AR_MAX_RANKS] = {nullptr};
+    int64_t ipc_slot = 0;
+    size_t ipc_flag_off = 0, ipc_ctr_off = 0, ipc_bytes = 0;
+    bool use_ipc = false;                // all peers attached: gradient and evaluation sums go through the one-shot path
+    unsigned long long ar_epoch = 0;
     // profiling
     unsigned prof_mask = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -134,6 +142,8 @@ View make_view(Ctx* c, int which) {
     return v;
 }
 
+void ipc_release(struct Ctx* c);
+
 // (re)allocate the evaluation scratch: sized by the larger of the two data sets, independent of the training
 // workspace, so that (re)loading a TEST set never touches the environment caches
 int ensure_eval(Ctx* c) {
@@ -166,6 +176,7 @@ int ensure_workspace(Ctx* c) {
     if (c->C > MAX_C) return fail(c, MPST_ERR_UNSUPPORTED, "more than %d classes unsupported", MAX_C);
     const int64_t Lmax = (int64_t)dm * dm;
     int rc;
+    if (c->ipc_local && 2 + c->C * Lmax > c->ipc_slot) ipc_release(c);   // inbox slots too small for the new capacity: export again
     c->caches_valid = false;
     c->cache_elems = (int64_t)c->T * tr.N * c->cap;
     if ((rc = dalloc(c, &c->LE, c->cache_elems))) return rc;
@@ -249,6 +260,41 @@ void prof_collect(Ctx* c) {
     c->ev_used = 0;
 }
 
+// ---- sum over ranks of a device buffer: the one-shot path when the inboxes are attached, else RCCL ---------------
+void ipc_release(struct Ctx* c) {
+    for (int r = 0; r < AR_MAX_RANKS; ++r) {
+        if (c->ipc_peer[r] && c->ipc_peer[r] != c->ipc_local) (void)hipIpcCloseMemHandle(c->ipc_peer[r]);
+        c->ipc_peer[r] = nullptr;
+    }
+    if (c->ipc_local) (void)hipFree(c->ipc_local);
+    c->ipc_local = nullptr;
+    c->use_ipc = false;
+}
+int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
+    if (c->nranks <= 1) return 0;
+    if (c->use_ipc) {
+        ArParams p{};
+        for (int r = 0; r < c->nranks; ++r) {
+            p.inbox[r] = (double*)c->ipc_peer[r];
+            p.flags[r] = (unsigned long long*)((char*)c->ipc_peer[r] + c->ipc_flag_off);
+        }
+        p.buf = buf;
+        p.status = &c->sc->status;
+        p.counter = (unsigned int*)((char*)c->ipc_local + c->ipc_ctr_off);
+        p.nranks = c->nranks; p.rank = c->rank; p.slot = c->ipc_slot;
+        p.epoch = ++c->ar_epoch;
+        p.chi = c->chi; p.lid = lid; p.C = c->C; p.d = c->d; p.n_fixed = n_fixed;
+        if (lid < 0 && n_fixed > c->ipc_slot) return fail(c, MPST_ERR_INVALID, "all-reduce message exceeds the inbox slot");
+        launch_allreduce_oneshot(p, c->stream);
+        return 0;
+    }
+    if (!c->comm) return fail(c, MPST_ERR_INVALID, "%d ranks but neither an RCCL communicator nor attached inboxes", c->nranks);
+    const size_t cnt = lid >= 0 ? 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap : (size_t)n_fixed;
+    ncclResult_t r = ncclAllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    return 0;
+}
+
 // ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
 // have_bt: the bond tensor of this bond was already assembled by the previous bond's environment
 // kernel; next_bt_lid >= 0: assemble that bond's tensor inside this bond's environment kernel.
@@ -263,11 +309,10 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
         for (int it = 0; it < iters; ++it) {                                     // TSGO/custGD :44,:75
             { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }        // yhat + gradient partials
             { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
-            if (c->comm) {
+            if (c->nranks > 1) {
                 ProfScope p(c, K_ALLREDUCE);
-                const size_t cnt = 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap;
-                ncclResult_t r = ncclAllReduce(c->gradbuf, c->gradbuf, cnt, ncclDouble, ncclSum, c->comm, s);
-                if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+                int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
+                if (rc) return rc;
                 launch_grad_norm(v, lid, s);
             }
             if (it + 1 < iters) { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
@@ -294,11 +339,10 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
         { ProfScope p(c, K_YHAT); launch_yhat(v, lid, s); }
         { ProfScope p(c, K_GRAD); launch_grad(v, lid, s); }
         { ProfScope p(c, K_UPDATE); launch_grad_reduce(v, lid, s); }
-        if (c->comm) {
+        if (c->nranks > 1) {
             ProfScope p(c, K_ALLREDUCE);
-            const size_t cnt = 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap;
-            ncclResult_t r = ncclAllReduce(c->gradbuf, c->gradbuf, cnt, ncclDouble, ncclSum, c->comm, s);
-            if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+            int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
+            if (rc) return rc;
         }
         { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
     }
@@ -411,6 +455,7 @@ void mpst_destroy(void* ctx) {
     (void)hipStreamSynchronize(c->stream);
     if (c->sweep_graph) (void)hipGraphExecDestroy(c->sweep_graph);
     if (c->comm) ncclCommDestroy(c->comm);
+    ipc_release(c);
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
@@ -445,6 +490,65 @@ int mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank
     memcpy(&id, unique_id, 128);
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
     if (r != ncclSuccess) { c->comm = nullptr; return fail(c, MPST_ERR_DEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    return 0;
+}
+
+int mpst_comm_ipc_export(void* ctx, int nranks, int rank, uint8_t handle_out[64]) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !handle_out || nranks < 2 || nranks > AR_MAX_RANKS || rank < 0 || rank >= nranks)
+        return fail(c, MPST_ERR_INVALID, "one-shot all-reduce: 2..%d ranks", AR_MAX_RANKS);
+    int rc = check_ready(c);             // the slot size follows the gradient buffer: options, data set and MPS first
+    if (rc) return rc;
+    if (c->comm && (c->nranks != nranks || c->rank != rank)) return fail(c, MPST_ERR_INVALID, "rank / size disagree with the RCCL communicator");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+    ipc_release(c);
+    c->nranks = nranks; c->rank = rank;
+    const int64_t dm = (int64_t)c->d * c->cap;
+    c->ipc_slot = std::max<int64_t>(2 + c->C * dm * dm, 4 + (int64_t)c->C * c->C);
+    c->ipc_slot = (c->ipc_slot + 15) & ~15ll;
+    c->ipc_flag_off = (size_t)2 * nranks * c->ipc_slot * sizeof(double);
+    c->ipc_ctr_off = c->ipc_flag_off + 16 * sizeof(unsigned long long);
+    c->ipc_bytes = c->ipc_ctr_off + 64;
+    // fine-grained device memory: peers write it and this device polls it while kernels run
+    hipError_t e = hipExtMallocWithFlags(&c->ipc_local, c->ipc_bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) return fail(c, MPST_ERR_NOMEM, "hipExtMallocWithFlags(fine-grained, %zu bytes): %s", c->ipc_bytes, hipGetErrorString(e));
+    HIPC(c, hipMemset(c->ipc_local, 0, c->ipc_bytes));
+    HIPC(c, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, c->ipc_local);
+    if (e != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipIpcGetMemHandle: %s", hipGetErrorString(e));
+    memcpy(handle_out, &h, 64);
+    c->ar_epoch = 0;
+    c->epoch++;
+    return 0;
+}
+
+int mpst_comm_ipc_attach(void* ctx, const uint8_t* all_handles) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !all_handles || !c->ipc_local) return fail(c, MPST_ERR_INVALID, "call mpst_comm_ipc_export first");
+    HIPC(c, hipSetDevice(c->device));
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) { c->ipc_peer[r] = c->ipc_local; continue; }
+        hipIpcMemHandle_t h;
+        memcpy(&h, all_handles + (size_t)64 * r, 64);
+        hipError_t e = hipIpcOpenMemHandle(&c->ipc_peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            c->ipc_peer[r] = nullptr;
+            return fail(c, MPST_ERR_DEVICE, "hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+        }
+    }
+    c->use_ipc = true;
+    c->epoch++;
+    return 0;
+}
+
+int mpst_comm_select(void* ctx, int oneshot) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (oneshot && !c->ipc_peer[c->nranks > 1 ? (c->rank ^ 1) % c->nranks : 0]) return fail(c, MPST_ERR_INVALID, "inboxes are not attached");
+    if (!oneshot && !c->comm) return fail(c, MPST_ERR_INVALID, "no RCCL communicator");
+    c->use_ipc = oneshot != 0;
+    c->epoch++;
     return 0;
 }
 
@@ -813,7 +917,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // on host-side state (bond dimensions are read on the device), and the pre-built dispatch packets
     // shorten the dependent kernel-to-kernel hand-over that dominates the small kernels.  Per-kernel
     // profiling and the RCCL leg keep the plain stream path.
-    const bool use_graph = !c->comm && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
+    const bool use_graph = c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
     if (use_graph && (!c->sweep_graph || c->graph_epoch != c->epoch)) {
         if (c->sweep_graph) {
             (void)hipGraphExecDestroy(c->sweep_graph);
@@ -921,15 +1025,19 @@ int mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64
     double tot[4] = {o[0], o[1], o[2], (double)v.N};
     std::vector<int64_t> cf((size_t)c->C * c->C);
     HIPC(c, hipMemcpy(cf.data(), c->conf, cf.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (c->comm) {
-        double* dtmp = c->out3;
-        HIPC(c, hipMemcpy(dtmp, tot, sizeof tot, hipMemcpyHostToDevice));
-        if (ncclAllReduce(dtmp, dtmp, 4, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess ||
-            ncclAllReduce(c->conf, c->conf, cf.size(), ncclInt64, ncclSum, c->comm, c->stream) != ncclSuccess)
-            return fail(c, MPST_ERR_DEVICE, "ncclAllReduce (eval) failed");
+    if (c->nranks > 1) {
+        // sums over shards: the 4 scalars and the C x C counts (exact in fp64) travel as one message
+        std::vector<double> msg(4 + cf.size());
+        for (int i = 0; i < 4; ++i) msg[i] = tot[i];
+        for (size_t i = 0; i < cf.size(); ++i) msg[4 + i] = (double)cf[i];
+        double* dmsg = c->yeval;                       // scratch of at least N*C >= ... doubles; the message is small
+        if ((int64_t)msg.size() > c->eval_N * c->C) return fail(c, MPST_ERR_INVALID, "evaluation scratch too small for the all-reduce message");
+        HIPC(c, hipMemcpy(dmsg, msg.data(), msg.size() * sizeof(double), hipMemcpyHostToDevice));
+        if ((rc = enqueue_allreduce(c, dmsg, (int64_t)msg.size(), -1))) return rc;
         HIPC(c, hipStreamSynchronize(c->stream));
-        HIPC(c, hipMemcpy(tot, dtmp, sizeof tot, hipMemcpyDeviceToHost));
-        HIPC(c, hipMemcpy(cf.data(), c->conf, cf.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(msg.data(), dmsg, msg.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; ++i) tot[i] = msg[i];
+        for (size_t i = 0; i < cf.size(); ++i) cf[i] = (int64_t)llround(msg[4 + i]);
     }
     if (mse) *mse = tot[0] / tot[3];
     if (kld) *kld = tot[1] / tot[3];
@@ -996,7 +1104,7 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[3] = c->ds[MPST_TRAIN].nchunks;
     out[4] = c->cap;
     out[5] = c->nranks;
-    out[6] = (!c->comm && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
+    out[6] = (c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
     out[7] = 0;
     return 0;
 }

@@ -251,6 +251,22 @@ void launch_grad_norm(const View& v, int lid, hipStream_t s);
 void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
 void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);
+// one-shot direct-write all-reduce over peer-mapped inboxes (mpst_allreduce.hip)
+constexpr int AR_MAX_RANKS = 8;
+struct ArParams {
+    double* inbox[AR_MAX_RANKS];             // base of every rank's inbox (own one included), as mapped in THIS process
+    unsigned long long* flags[AR_MAX_RANKS]; // base of every rank's flag block: [2 parities][8 ranks]
+    double* buf;                // local message, replaced by the sum
+    int32_t* status;            // device status word (DevScalars.status), set on time-out
+    unsigned int* counter;      // [2] local arrival counters
+    int nranks, rank;
+    int64_t slot;               // doubles per inbox slot
+    unsigned long long epoch;   // 1, 2, 3, ... identical on every rank
+    const int32_t* chi;         // live message length 2 + C * d*chi[lid] * d*chi[lid+2] when lid >= 0
+    int lid, C, d;
+    int64_t n_fixed;            // message length when lid < 0
+};
+void launch_allreduce_oneshot(const ArParams& p, hipStream_t s);
 // launchers (mpst_kernels.hip)
 void launch_bt_assemble(const View& v, int lid, hipStream_t s);
 void launch_bt_prescale(const View& v, int lid, hipStream_t s);

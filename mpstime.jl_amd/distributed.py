@@ -28,6 +28,13 @@ def split_encoded(ets: EncodedTimeSeriesSet, rank: int, world: int):
     if len(ets) == 0:
         return ets, np.zeros(0, dtype=np.int64)
     counts = np.asarray(ets.class_distribution, dtype=np.int64)
+    # every rank must hold at least one series: a rank with an empty shard would return from the engine before the
+    # collective and leave the others waiting.  The split is a pure function of (counts, world), so every rank reaches
+    # the same verdict and raises together.
+    for r in range(world):
+        if sum(shard_bounds(int(n), r, world)[1] - shard_bounds(int(n), r, world)[0] for n in counts) == 0:
+            raise ValueError(f"cannot shard {int(counts.sum())} series with class counts {counts.tolist()} over {world} ranks: "
+                             f"rank {r} would hold no series")
     starts = np.concatenate([[0], np.cumsum(counts)])
     idx = []
     for c, n in enumerate(counts):
@@ -42,17 +49,20 @@ def split_encoded(ets: EncodedTimeSeriesSet, rank: int, world: int):
 
 
 class Shard:
-    """rank/world + the torch.distributed process group used to hand out the ncclUniqueId."""
+    """rank/world + the torch.distributed process group used to hand out the ncclUniqueId (``attach``) and to gather
+    the inbox handles of the one-shot all-reduce (``attach_oneshot``).  ``rccl=False`` skips the RCCL communicator:
+    the one-shot path alone then carries every sum over ranks."""
 
-    def __init__(self, rank: int, world: int, group=None):
+    def __init__(self, rank: int, world: int, group=None, rccl: bool = True, oneshot: bool = False):
         self.rank, self.world, self.group = rank, world, group
+        self.rccl, self.oneshot = rccl, oneshot
 
     def split(self, ets):
         return split_encoded(ets, self.rank, self.world)
 
     def attach(self, eng):
         """Create the RCCL communicator inside the engine (mpst_comm_init)."""
-        if self.world == 1:
+        if self.world == 1 or not self.rccl:
             return
         import torch
         import torch.distributed as dist
@@ -67,3 +77,24 @@ class Shard:
         dist.broadcast(t, src=0, group=self.group)
         uid = (C.c_uint8 * 128)(*t.cpu().tolist())
         eng._chk(lib.mpst_comm_init(eng.ctx, uid, self.world, self.rank))
+
+    def attach_oneshot(self, eng):
+        """Export this rank's inbox, gather every rank's handle over the host-side process group and map the peers
+        (mpst_comm_ipc_export / mpst_comm_ipc_attach).  Call after set_options / set_dataset / set_mps."""
+        if self.world == 1:
+            return
+        import torch
+        import torch.distributed as dist
+        lib = L.load()
+        h = (C.c_uint8 * 64)()
+        eng._chk(lib.mpst_comm_ipc_export(eng.ctx, self.world, self.rank, h))
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.tensor(list(h), dtype=torch.uint8, device=dev)
+        allh = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+        dist.all_gather(allh, mine, group=self.group)
+        flat = (C.c_uint8 * (64 * self.world))(*[int(x) for t in allh for x in t.cpu().tolist()])
+        eng._chk(lib.mpst_comm_ipc_attach(eng.ctx, flat))
+        dist.barrier(group=self.group)       # nobody pushes before every rank has mapped every inbox
+
+    def select(self, eng, oneshot: bool):
+        eng._chk(L.load().mpst_comm_select(eng.ctx, int(bool(oneshot))))

@@ -97,6 +97,8 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
             if has_test:
                 eng.set_dataset(1, te_local.phi, te_local.label_index, C)
         eng.set_mps(W)
+        if shard is not None and getattr(shard, "oneshot", False):
+            shard.attach_oneshot(eng)                                           # inbox slots are sized from the gradient buffer
         verbosity > -1 and print(f"Using {opts.update_iters} iterations per update.")
         eng.build_caches()                                                       # :631
 

@@ -1,0 +1,165 @@
+"""The sharded sweep of libmpstime_hip.so itself on two ranks (one process per GPU, RCCL all-reduce of the bond gradient
+once per optimiser step) against the same sweep on one GPU.  Needs two GPUs: skipped on the 1-GPU boxes of this pool."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MPST_ROOT"])
+import numpy as np
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+import mpstime_jl_amd as mt
+from oracle import ref_numpy as R
+from tests.helpers import make_problem
+loss, sep = os.environ["MPST_LOSS"], os.environ["MPST_SEP"] == "1"
+ds, W0 = make_problem(150, 8, 4, 4, 3, seed=21, balanced=False)
+full = mt.EncodedTimeSeriesSet(ds.phi, ds.label_index.astype(np.int64), ds.label_index, np.zeros((0, 0)), ds.class_distribution)
+sh = mt.Shard(rank, world)
+local, gcounts = sh.split(full)
+eng = mt.SweepEngine(rank)
+eng.set_options(chi_max=10, eta=0.05, loss=loss, train_classes_separately=sep)
+sh.attach(eng)
+eng.set_dataset(0, local.phi, local.label_index, 3, gcounts)
+eng.set_mps(W0)
+eng.build_caches()
+for _ in range(2):
+    eng.sweep()
+ev = eng.eval(0)
+np.savez(os.path.join(os.environ["MPST_OUT"], f"rank{rank}.npz"), mse=ev[0], kld=ev[1], acc=ev[2], conf=ev[3],
+         **{f"W{j}": t for j, t in enumerate(eng.get_mps())})
+eng.close()
+dist.destroy_process_group()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("loss,sep", [("KLD", False), ("KLD", True), ("MSE", False)])
+def test_two_rank_sweep_equals_single_gpu(tmp_path, loss, sep):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import mpstime_jl_amd as mt
+    from oracle import ref_numpy as R
+    from tests.helpers import make_problem
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MPST_ROOT=ROOT, MPST_OUT=str(tmp_path), MPST_LOSS=loss, MPST_SEP="1" if sep else "0",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), str(script)], check=True, env=env, timeout=600)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    ds, W0 = make_problem(150, 8, 4, 4, 3, seed=21, balanced=False)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=10, eta=0.05, loss=loss, train_classes_separately=sep)
+        eng.set_dataset(0, ds.phi, ds.label_index, 3)
+        eng.set_mps(W0)
+        eng.build_caches()
+        for _ in range(2):
+            eng.sweep()
+        ev = eng.eval(0)
+        W1 = eng.get_mps()
+    finally:
+        eng.close()
+    T = len(W0)
+    # replicas are bit-identical: every rank applied the same update and SVD to the same all-reduced bits
+    for j in range(T):
+        assert np.array_equal(outs[0][f"W{j}"], outs[1][f"W{j}"])
+    # evaluation sums over shards (all-reduced inside mpst_eval): same numbers on both ranks, equal to the single-GPU run
+    assert outs[0]["kld"] == outs[1]["kld"] and np.array_equal(outs[0]["conf"], outs[1]["conf"])
+    assert abs(float(outs[0]["kld"]) - ev[1]) <= 1e-8 * max(1.0, abs(ev[1]))
+    assert np.array_equal(outs[0]["conf"], ev[3])
+    yo = R.contract_mps(W1, ds.phi)
+    ys = R.contract_mps([outs[0][f"W{j}"] for j in range(T)], ds.phi)
+    assert np.abs(yo - ys).max() < 1e-8 * np.abs(yo).max()
+
+
+ONESHOT_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MPST_ROOT"])
+import numpy as np
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+import mpstime_jl_amd as mt
+from tests.helpers import make_problem
+loss = os.environ["MPST_LOSS"]
+dev = rank % max(torch.cuda.device_count(), 1)
+ds, W0 = make_problem(150, 8, 4, 4, 3, seed=21, balanced=False)
+full = mt.EncodedTimeSeriesSet(ds.phi, ds.label_index.astype(np.int64), ds.label_index, np.zeros((0, 0)), ds.class_distribution)
+sh = mt.Shard(rank, world, rccl=False, oneshot=True)
+local, gcounts = sh.split(full)
+eng = mt.SweepEngine(dev)
+eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2)
+eng.set_dataset(0, local.phi, local.label_index, 3, gcounts)
+eng.set_mps(W0)
+sh.attach_oneshot(eng)
+eng.build_caches()
+for _ in range(2):
+    eng.sweep()
+ev = eng.eval(0)
+np.savez(os.path.join(os.environ["MPST_OUT"], f"rank{rank}.npz"), mse=ev[0], kld=ev[1], acc=ev[2], conf=ev[3],
+         **{f"W{j}": t for j, t in enumerate(eng.get_mps())})
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("loss", ["KLD", "MSE"])
+def test_oneshot_allreduce_ranks_sharing_the_gpus(tmp_path, loss, world):
+    """The one-shot direct-write all-reduce (peer-mapped inboxes over hipIpc, flags, rank-order sum) without RCCL: `world`
+    processes, rank r on GPU r mod #GPUs - on a 1-GPU box all ranks share the device, which exercises the whole
+    protocol (IPC export / attach, push, flags, parity double-buffering, bounded spins) except the xGMI hop itself."""
+    import mpstime_jl_amd as mt
+    from oracle import ref_numpy as R
+    from tests.helpers import make_problem
+    script = tmp_path / "worker.py"
+    script.write_text(ONESHOT_WORKER)
+    env = dict(os.environ, MPST_ROOT=ROOT, MPST_OUT=str(tmp_path), MPST_LOSS=loss,
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), str(script)], check=True, env=env, timeout=600)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    ds, W0 = make_problem(150, 8, 4, 4, 3, seed=21, balanced=False)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2)
+        eng.set_dataset(0, ds.phi, ds.label_index, 3)
+        eng.set_mps(W0)
+        eng.build_caches()
+        for _ in range(2):
+            eng.sweep()
+        ev = eng.eval(0)
+        W1 = eng.get_mps()
+    finally:
+        eng.close()
+    T = len(W0)
+    for r in range(1, world):
+        for j in range(T):
+            assert np.array_equal(outs[0][f"W{j}"], outs[r][f"W{j}"])           # bit-identical replicas
+        assert outs[0]["kld"] == outs[r]["kld"] and np.array_equal(outs[0]["conf"], outs[r]["conf"])
+    assert abs(float(outs[0]["kld"]) - ev[1]) <= 1e-8 * max(1.0, abs(ev[1]))
+    assert np.array_equal(outs[0]["conf"], ev[3])
+    yo = R.contract_mps(W1, ds.phi)
+    ys = R.contract_mps([outs[0][f"W{j}"] for j in range(T)], ds.phi)
+    assert np.abs(yo - ys).max() < 1e-8 * np.abs(yo).max()

@@ -129,3 +129,16 @@ def test_fitmps_input_validation_needs_no_gpu():
         mt.fitMPS(X, np.zeros(10, dtype=int), opts=mt.MPSOptions(encoding="Fourier", dtype="Float64"))
     with pytest.raises(ValueError, match="Custom"):
         mt.fitMPS(X, np.zeros(10, dtype=int), custom_encoding=mt.model_encoding("Legendre"))
+
+
+def test_shard_split_rejects_empty_shards_on_every_rank():
+    """A rank without series would leave the collectives of the others hanging: the split refuses, identically on all ranks."""
+    import numpy as np
+    import pytest
+    phi = np.zeros((3, 4, 2))
+    ets = mt.EncodedTimeSeriesSet(phi, np.array([1, 1, 2]), np.array([0, 0, 1]), np.zeros((3, 0)), np.array([2, 1]))
+    for r in range(8):
+        with pytest.raises(ValueError, match="would hold no series"):
+            mt.split_encoded(ets, r, 8)
+    loc, gc = mt.split_encoded(ets, 1, 2)
+    assert len(loc) >= 1 and list(gc) == [2, 1]
