@@ -188,6 +188,24 @@ int  mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int6
  * and optionally the raw overlaps yhat[N][C]. */
 int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[N][C] or NULL*/);
 
+/* Imputation of missing values, batched over the instances of data set `which`:
+ * impute_median / impute_mode / impute_ITS of src/Imputation/MPS_methods.jl:198-330, i.e. precondition (:42-99) +
+ * impute_at! (:103-177) with get_median_from_rdm / get_mode_from_rdm / get_sample_from_rdm (sampling_utils.jl:98-275),
+ * for every instance at once instead of one @distributed task per instance.  The context holds the trained MPS (label
+ * index anywhere); instance i is imputed with the class MPS of its label (expand_label_index, utils.jl:356-370).
+ *   missing[N][T]   1 where the value is to be imputed (row-major, instances in the order of the data set);
+ *                   the encoded values the data set holds at those sites are ignored
+ *   grid_x[ngrid]   the candidate values x_k (range(guess_range...; step = dx), imputation.jl:90) and
+ *   grid_phi[ngrid][d]  their encoded states (time-independent encodings, :100-106)
+ *   method          MPST_IMPUTE_MEDIAN (+ weighted median absolute deviation when get_wmad), MPST_IMPUTE_MODE,
+ *                   MPST_IMPUTE_QUANTILE: inverse-transform sampling with the caller's uniform numbers u[N][T]
+ *                   (impute_ITS without rejection; the reference draws them from a MersenneTwister)
+ *   x_out[N][T]     imputed value at every missing site (in the encoding's domain; 0 elsewhere), err_out[N][T] the WMAD
+ * Forward imputation order only; chi_max <= 64, d <= 16, real fp64. */
+enum { MPST_IMPUTE_MEDIAN = 0, MPST_IMPUTE_MODE = 1, MPST_IMPUTE_QUANTILE = 2 };
+int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
+                 int32_t method, int32_t get_wmad, const double* u, double* x_out, double* err_out, double* seconds);
+
 /* normalize!(W), RealRealHighDimension.jl:852. */
 int  mpst_normalize(void* ctx);
 

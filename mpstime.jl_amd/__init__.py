@@ -11,7 +11,11 @@ from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_en
                         uniform_encode)
 from .training import TrainedMPS, fitMPS, fit_encoded, classify, generate_startingMPS, trendy_sine
 from .distributed import Shard, split_encoded
+from .imputation import (ImputationProblem, init_imputation_problem, MPS_impute, impute_dataset, kNN_impute, mar,
+                         invert_test_transform)
+from . import options
 
 __all__ = ["SweepEngine", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
            "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
-           "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError"]
+           "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError", "ImputationProblem",
+           "init_imputation_problem", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform"]

@@ -73,6 +73,7 @@ SYMBOLS = {
     "mpst_eval": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.POINTER(_i64)]),
     "mpst_classify": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _dp]),
     "mpst_normalize": (C.c_int, [_vp]),
+    "mpst_impute": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint8), _dp, _dp, _i32, _i32, _i32, _dp, _dp, _dp, _dp]),
     "mpst_selftest_mfma": (C.c_int, [_vp, _dp, _dp, _i32, _dp]),
     "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),

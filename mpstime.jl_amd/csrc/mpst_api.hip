@@ -1061,6 +1061,72 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
     return 0;
 }
 
+int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
+                int32_t method, int32_t get_wmad, const double* u, double* x_out, double* err_out, double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
+    if (!missing || !grid_x || !grid_phi || !x_out || ngrid < 2) return fail(c, MPST_ERR_INVALID, "NULL argument or fewer than 2 grid values");
+    if (method < MPST_IMPUTE_MEDIAN || method > MPST_IMPUTE_QUANTILE) return fail(c, MPST_ERR_INVALID, "unknown imputation method");
+    if (method == MPST_IMPUTE_QUANTILE && !u) return fail(c, MPST_ERR_INVALID, "the quantile method needs the uniform numbers u[N][T]");
+    if (!c->have_mps || !c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options / mpst_set_mps must be called first");
+    const DataSet& s = c->ds[which];
+    if (s.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
+    if (c->cap > 64 || c->d > 16) return fail(c, MPST_ERR_UNSUPPORTED, "the imputation engine holds chi_max <= 64 and d <= 16 (got %d, %d)", c->cap, c->d);
+    HIPC(c, hipSetDevice(c->device));
+    hipError_t ea = impute_init_attrs(c->device);
+    if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
+    const int64_t N = s.N;
+    const int T = c->T, d = c->d;
+    int maxm = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        int m = 0;
+        for (int j = 0; j < T; ++j) m += missing[i * T + j] ? 1 : 0;
+        maxm = std::max(maxm, m);
+    }
+    std::vector<double> xo((size_t)N * T, 0.0), eo((size_t)N * T, 0.0);
+    if (maxm > 0) {
+        // instances are processed in chunks so that the per-instance scratch (right environments of the missing sites,
+        // p_k and its prefix sums) stays below ~8 GB
+        const int64_t per = (int64_t)maxm * c->cap * c->cap + 2ll * ngrid;
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
+        uint8_t* dmiss = nullptr;
+        double *dR = nullptr, *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
+        struct Temps {
+            uint8_t** m; double **a, **b, **cc, **dd, **e, **f, **g, **h;
+            ~Temps() { dfree(m); dfree(a); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
+        } temps{&dmiss, &dR, &dgx, &dgp, &du, &dp, &dS, &dx, &de};
+        int rc;
+        if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, chunk * maxm * c->cap * c->cap)) || (rc = dalloc(c, &dgx, ngrid)) ||
+            (rc = dalloc(c, &dgp, (int64_t)ngrid * d)) || (rc = dalloc(c, &dp, chunk * ngrid)) || (rc = dalloc(c, &dS, chunk * ngrid)) ||
+            (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
+        if (u && (rc = dalloc(c, &du, N * T))) return rc;
+        HIPC(c, hipMemcpy(dmiss, missing, (size_t)N * T, hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(dgx, grid_x, (size_t)ngrid * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(dgp, grid_phi, (size_t)ngrid * d * sizeof(double), hipMemcpyHostToDevice));
+        if (u) HIPC(c, hipMemcpy(du, u, (size_t)N * T * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(c, hipMemset(dx, 0, (size_t)N * T * sizeof(double)));
+        HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
+        View v = make_view(c, which);
+        HIPC(c, hipEventRecord(c->ev_start, c->stream));
+        for (int64_t i0 = 0; i0 < N; i0 += chunk)
+            launch_impute(v, dmiss, dR, maxm, dgx, dgp, ngrid, method, get_wmad, du, dp, dS, dx, de, i0, std::min(chunk, N - i0), c->stream);
+        HIPC(c, hipEventRecord(c->ev_stop, c->stream));
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipEventSynchronize(c->ev_stop));
+        float ms = 0.f;
+        HIPC(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        if (seconds) *seconds = 1e-3 * ms;
+        HIPC(c, hipMemcpy(xo.data(), dx, xo.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPC(c, hipMemcpy(eo.data(), de, eo.size() * sizeof(double), hipMemcpyDeviceToHost));
+    } else if (seconds) {
+        *seconds = 0.0;
+    }
+    memcpy(x_out, xo.data(), xo.size() * sizeof(double));
+    if (err_out) memcpy(err_out, eo.data(), eo.size() * sizeof(double));
+    return 0;
+}
+
 int mpst_normalize(void* ctx) {
     Ctx* c = (Ctx*)ctx;
     int rc = check_ready(c);

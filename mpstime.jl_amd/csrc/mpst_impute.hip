@@ -1,0 +1,367 @@
+// Imputation engine: src/Imputation/MPS_methods.jl:42-330 + sampling_utils.jl:98-275 of the
+// reference, batched over test instances - the reference works one instance at a time (and farms instances out with
+// @distributed, hyperopt_utils.jl:201).
+//
+// The reference conditions the class MPS on the known values (precondition, :42-99), moves the orthogonality centre to
+// the first missing site (orthogonalize!, :115) and then walks the missing sites: reduced density matrix rho = A A'
+// of the centre tensor, "probability" of every grid value x_k (20 001 of them), cumulative trapezoid, median / mode /
+// inverse-transform sample, projection onto the chosen state, next site (impute_at!, :103-177).  Canonical forms are a
+// gauge choice: the same rho (up to a positive scale that cancels everywhere) is
+//     rho = (L W_j) R_{j+1} (L W_j)^T,
+// with L the left environment VECTOR of the known / already imputed sites and R_{j+1} the right environment MATRIX in
+// which known sites are projected and missing sites are traced out.  That turns one instance into two sweeps over the
+// chain with chi x chi state, and the batch into two launches of one persistent workgroup per instance:
+//   k_imp_right : R_T = 1, R_j = M_j R_{j+1} M_j^T (known, M_j = sum_s phi_s W_j[s]) or sum_s W_j[s] R_{j+1} W_j[s]^T
+//                 (missing); R_{j+1} is stored for every missing j.  Rescaled by its trace at every site.
+//   k_imp_left  : L_0 = 1; known site: L <- L M_j; missing site: rho, p_k = |rho phi_k|^2 over the grid (the value the
+//                 reference computes: rdm is a plain Matrix there, so get_conditional_probability(state, rdm) takes the
+//                 (state, A::Matrix) method, sampling_utils.jl:19-41, and returns |state' * rdm|^2, not state' rdm state), block-wide prefix sums, selection,
+//                 weighted median absolute deviation, L <- phi* (L W_j).
+// Real fp64; chi <= 64 (four chi x chi matrices in LDS), d <= 16.
+#include "mpst_internal.h"
+
+namespace mpst {
+
+constexpr int IMP_T = 256;
+constexpr int IMP_MAXD = 16;
+
+__device__ __forceinline__ double blk_sum(double x, double* red) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double blk_max(double x, double* red) {
+    x = wave_max(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// site tensor j of the class MPS of class `cls`: [a][s][b] with live dimensions
+__device__ __forceinline__ const double* class_site(const View& v, int j, int cls, int Dl, int Dr) {
+    const double* W = v.sites + (int64_t)j * v.site_stride;
+    if (j == *v.label_site) W += (int64_t)cls * Dl * v.d * Dr;
+    return W;
+}
+
+// ---- right environments ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __restrict__ missing, double* __restrict__ Rbuf,
+                                                     int max_missing, int64_t i0) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    const int64_t i = i0 + blockIdx.x;          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
+    const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
+    const uint8_t* mi = missing + i * T;
+    int nm = 0;
+    for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
+    if (nm == 0) return;
+    const int cls = v.label[i];
+    double* Ra = smem;                 // [cm][cm] current R
+    double* Rb = Ra + cm * cm;         // [cm][cm] next R
+    double* Ms = Rb + cm * cm;         // [cm][cm] M_j or W_j[s]
+    double* T1 = Ms + cm * cm;         // [cm][cm] (M or W_s) * R
+    double* R = Ra;
+    double* Rn = Rb;
+    if (tid == 0) R[0] = 1.0;
+    __syncthreads();
+    int slot = 0;
+    for (int j = T - 1; j >= 0; --j) {
+        const int Dl = v.chi[j], Dr = v.chi[j + 1];
+        const bool miss = mi[j] != 0;
+        if (miss) {
+            // the environment of the sites right of j is what site j's density matrix needs
+            double* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm;
+            for (int e = tid; e < Dr * Dr; e += IMP_T) out[e] = R[(e / Dr) * cm + (e % Dr)];
+            ++slot;
+            if (slot == nm) break;                 // nothing left of the first missing site needs a right environment
+        }
+        const double* W = class_site(v, j, cls, Dl, Dr);
+        const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
+        for (int e = tid; e < Dl * Dl; e += IMP_T) Rn[(e / Dl) * cm + (e % Dl)] = 0.0;
+        const int ns = miss ? d : 1;
+        for (int s = 0; s < ns; ++s) {
+            // Ms = M_j (known) or W_j[s] (missing)
+            for (int e = tid; e < Dl * Dr; e += IMP_T) {
+                const int a = e / Dr, b = e - a * Dr;
+                double m;
+                if (miss) {
+                    m = W[((int64_t)a * d + s) * Dr + b];
+                } else {
+                    m = 0.0;
+                    for (int q = 0; q < d; ++q) m = fma(ph[q], W[((int64_t)a * d + q) * Dr + b], m);
+                }
+                Ms[a * cm + b] = m;
+            }
+            __syncthreads();
+            for (int e = tid; e < Dl * Dr; e += IMP_T) {           // T1 = Ms * R
+                const int a = e / Dr, b = e - a * Dr;
+                double t = 0.0;
+                for (int k = 0; k < Dr; ++k) t = fma(Ms[a * cm + k], R[k * cm + b], t);
+                T1[a * cm + b] = t;
+            }
+            __syncthreads();
+            for (int e = tid; e < Dl * Dl; e += IMP_T) {           // Rn += T1 * Ms^T
+                const int a = e / Dl, a2 = e - a * Dl;
+                double t = 0.0;
+                for (int k = 0; k < Dr; ++k) t = fma(T1[a * cm + k], Ms[a2 * cm + k], t);
+                Rn[a * cm + a2] += t;
+            }
+            __syncthreads();
+        }
+        // rescale by the trace (every density below is scale-free) and swap
+        double tr = 0.0;
+        for (int a = tid; a < Dl; a += IMP_T) tr += Rn[a * cm + a];
+        tr = blk_sum(tr, red);
+        const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
+        for (int e = tid; e < Dl * Dl; e += IMP_T) Rn[(e / Dl) * cm + (e % Dl)] *= sc;
+        __syncthreads();
+        double* tmp = R;
+        R = Rn;
+        Rn = tmp;
+    }
+}
+
+// ---- left sweep with the imputation itself -------------------------------------------------------------------------------
+struct ImpArgs {
+    const uint8_t* missing;     // [N][T]
+    const double* Rbuf;         // [N][max_missing][cap*cap]
+    const double* grid_x;       // [ngrid]
+    const double* grid_phi;     // [ngrid][d]
+    const double* u;            // [N][T] quantile targets (method 2) or null
+    double* pbuf;               // [N][ngrid] scratch: p_k
+    double* sbuf;               // [N][ngrid] scratch: prefix sums S_k
+    double* x_out;              // [N][T]
+    double* err_out;            // [N][T]
+    int max_missing, ngrid, method, get_wmad;
+    int64_t i0;                 // first instance of this chunk
+};
+
+__global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    __shared__ double rho[IMP_MAXD * IMP_MAXD];
+    __shared__ double segsum[IMP_T];
+    __shared__ int isel[4];
+    __shared__ double dsel[4];
+    const int64_t i = g.i0 + blockIdx.x;
+    const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
+    const uint8_t* mi = g.missing + i * T;
+    int nm = 0;
+    for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
+    if (nm == 0) return;
+    const int cls = v.label[i];
+    double* L = smem;                      // [cm]
+    double* Ln = L + cm;                   // [cm]
+    double* LW = Ln + cm;                  // [d][cm]
+    double* U = LW + IMP_MAXD * cm;        // [d][cm]
+    double* ms = U + IMP_MAXD * cm;        // [d] chosen state
+    double* p = g.pbuf + (int64_t)blockIdx.x * g.ngrid;
+    double* S = g.sbuf + (int64_t)blockIdx.x * g.ngrid;
+    const int n = g.ngrid;
+    const int seg = (n + IMP_T - 1) / IMP_T;
+    const int k0 = min(n, tid * seg), k1 = min(n, k0 + seg);
+    const double dx = g.grid_x[1] - g.grid_x[0];
+    if (tid == 0) L[0] = 1.0;
+    __syncthreads();
+    int seen = 0;
+    for (int j = 0; j < T; ++j) {
+        const int Dl = v.chi[j], Dr = v.chi[j + 1];
+        const bool miss = mi[j] != 0;
+        const double* W = class_site(v, j, cls, Dl, Dr);
+        if (!miss) {
+            const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
+            for (int b = tid; b < Dr; b += IMP_T) {
+                double t = 0.0;
+                for (int a = 0; a < Dl; ++a) {
+                    const double la = L[a];
+                    for (int q = 0; q < d; ++q) t = fma(la * ph[q], W[((int64_t)a * d + q) * Dr + b], t);
+                }
+                Ln[b] = t;
+            }
+        } else {
+            const double* R = g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm;      // [Dr][Dr] compact
+            ++seen;
+            // LW[s][b] = sum_a L[a] W[a][s][b]
+            for (int e = tid; e < d * Dr; e += IMP_T) {
+                const int s = e / Dr, b = e - s * Dr;
+                double t = 0.0;
+                for (int a = 0; a < Dl; ++a) t = fma(L[a], W[((int64_t)a * d + s) * Dr + b], t);
+                LW[s * cm + b] = t;
+            }
+            __syncthreads();
+            // U = LW R;  rho = U LW^T
+            for (int e = tid; e < d * Dr; e += IMP_T) {
+                const int s = e / Dr, b = e - s * Dr;
+                double t = 0.0;
+                for (int k = 0; k < Dr; ++k) t = fma(LW[s * cm + k], R[(int64_t)k * Dr + b], t);
+                U[s * cm + b] = t;
+            }
+            __syncthreads();
+            for (int e = tid; e < d * d; e += IMP_T) {
+                const int s = e / d, s2 = e - s * d;
+                double t = 0.0;
+                for (int k = 0; k < Dr; ++k) t = fma(U[s * cm + k], LW[s2 * cm + k], t);
+                rho[s * IMP_MAXD + s2] = t;
+            }
+            __syncthreads();
+            // normalise rho by its trace (p scales with the square, every quantity below is scale-free)
+            {
+                double tr = 0.0;
+                for (int s = 0; s < d; ++s) tr += rho[s * IMP_MAXD + s];
+                const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
+                __syncthreads();
+                for (int e = tid; e < d * d; e += IMP_T) rho[(e / d) * IMP_MAXD + (e % d)] *= sc;
+                __syncthreads();
+            }
+            // p_k = |rho phi_k|^2 on this thread's segment of the grid, segment sums, block-wide exclusive scan
+            double loc = 0.0, pmax = -1.0;
+            int kmax = 0;
+            for (int k = k0; k < k1; ++k) {
+                const double* ph = g.grid_phi + (int64_t)k * d;
+                double pk = 0.0;
+                for (int s = 0; s < d; ++s) {
+                    double q = 0.0;
+                    for (int s2 = 0; s2 < d; ++s2) q = fma(rho[s * IMP_MAXD + s2], ph[s2], q);
+                    pk = fma(q, q, pk);
+                }
+                p[k] = pk;
+                loc += pk;
+                if (pk > pmax) {
+                    pmax = pk;
+                    kmax = k;
+                }
+            }
+            segsum[tid] = loc;
+            __syncthreads();
+            double off = 0.0;
+            for (int t = 0; t < tid; ++t) off += segsum[t];       // same order for everybody: deterministic
+            double run = off;
+            for (int k = k0; k < k1; ++k) {
+                run += p[k];
+                S[k] = run;
+            }
+            __threadfence_block();
+            __syncthreads();
+            const double Stot = S[n - 1];
+            const double p0 = p[0];
+            auto cdf_at = [&](int k) { return k == 0 ? 0.0 : 0.5 * dx * ((S[k - 1] + S[k]) - p0); };   // cumulative trapezoid
+            const double Z = cdf_at(n - 1);
+            int ksel = 0;
+            if (g.method == 1) {
+                // mode: first maximum
+                const double gm = blk_max(pmax, red);
+                int cand = (pmax == gm) ? kmax : n;
+                cand = -(int)wave_max((double)(-cand));
+                __syncthreads();
+                if ((tid & 63) == 0) isel[tid >> 6] = cand;
+                __syncthreads();
+                ksel = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
+            } else {
+                // argmin_k |cdf_k / Z - target|: the cdf is non-decreasing, so the minimiser is the last k at or below
+                // the target or its successor
+                const double target = g.method == 0 ? 0.5 : g.u[i * T + j];
+                int klo = -1;
+                if (k0 < k1 && cdf_at(k0) / Z <= target) {
+                    klo = k0;
+                    for (int k = k0 + 1; k < k1; ++k) {
+                        if (cdf_at(k) / Z <= target) klo = k;
+                        else break;
+                    }
+                }
+                klo = (int)wave_max((double)klo);
+                __syncthreads();
+                if ((tid & 63) == 0) isel[tid >> 6] = klo;
+                __syncthreads();
+                klo = max(max(isel[0], isel[1]), max(isel[2], isel[3]));
+                if (klo < 0) klo = 0;
+                ksel = klo;
+                if (klo + 1 < n) {
+                    const double a0 = fabs(cdf_at(klo) / Z - target), a1 = fabs(cdf_at(klo + 1) / Z - target);
+                    if (a1 < a0) ksel = klo + 1;
+                }
+            }
+            const double xsel = g.grid_x[ksel];
+            double err = 0.0;
+            if (g.method == 0 && g.get_wmad) {
+                // StatsBase.median(|x - x*|, pweights(p / Z)): the deviations grow with the distance from ksel on the
+                // uniform grid; the cumulative weight of the window [ksel - jj, ksel + jj] comes from the prefix sums
+                const double mid = 0.5 * (Stot / Z);
+                const double gm = blk_max(pmax, red);
+                if (gm / Z > mid) {
+                    int cand = (pmax == gm) ? kmax : n;
+                    cand = -(int)wave_max((double)(-cand));
+                    __syncthreads();
+                    if ((tid & 63) == 0) isel[tid >> 6] = cand;
+                    __syncthreads();
+                    const int km = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
+                    err = fabs(g.grid_x[km] - xsel);
+                } else {
+                    int jhit = n;
+                    for (int jj = k0; jj < k1; ++jj) {          // jj doubles as the window half-width handled by this thread
+                        const int hi = min(n - 1, ksel + jj), lo = ksel - jj - 1;
+                        const double c = S[hi] - (lo >= 0 ? S[lo] : 0.0);
+                        if (c / Z > mid) {
+                            jhit = jj;
+                            break;
+                        }
+                    }
+                    jhit = -(int)wave_max((double)(-jhit));
+                    __syncthreads();
+                    if ((tid & 63) == 0) isel[tid >> 6] = jhit;
+                    __syncthreads();
+                    jhit = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
+                    // the element that tips the balance is the nearer of the two at distance jhit that exists
+                    const int lo = ksel - jhit, hi = ksel + jhit;
+                    err = (lo >= 0) ? fabs(g.grid_x[lo] - xsel) : fabs(g.grid_x[min(hi, n - 1)] - xsel);
+                    if (jhit >= n) err = 0.0;
+                }
+            }
+            if (tid == 0) {
+                g.x_out[i * T + j] = xsel;
+                g.err_out[i * T + j] = err;
+            }
+            // project onto the chosen state: L <- phi*^T (L W)
+            if (tid < d) ms[tid] = g.grid_phi[(int64_t)ksel * d + tid];
+            __syncthreads();
+            for (int b = tid; b < Dr; b += IMP_T) {
+                double t = 0.0;
+                for (int s = 0; s < d; ++s) t = fma(ms[s], LW[s * cm + b], t);
+                Ln[b] = t;
+            }
+            if (seen == nm) break;             // nothing right of the last missing site is needed
+        }
+        __syncthreads();
+        // rescale L by its largest magnitude
+        double mx = 0.0;
+        for (int b = tid; b < Dr; b += IMP_T) mx = fmax(mx, fabs(Ln[b]));
+        mx = blk_max(mx, red);
+        const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
+        for (int b = tid; b < Dr; b += IMP_T) L[b] = Ln[b] * sc;
+        __syncthreads();
+    }
+}
+
+hipError_t impute_init_attrs(int device) {
+    static unsigned long long done = 0;
+    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 8)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+    if (device >= 0 && device < 64) done |= 1ull << device;
+    return hipSuccess;
+}
+
+void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,
+                   int ngrid, int method, int get_wmad, const double* u, double* pbuf, double* sbuf, double* x_out, double* err_out,
+                   int64_t i0, int64_t count, hipStream_t s) {
+    const size_t lds_r = (size_t)4 * v.cap * v.cap * sizeof(double);
+    hipLaunchKernelGGL(k_imp_right, dim3((unsigned)count), dim3(IMP_T), lds_r, s, v, missing, Rbuf, max_missing, i0);
+    ImpArgs g{missing, Rbuf, grid_x, grid_phi, u, pbuf, sbuf, x_out, err_out, max_missing, ngrid, method, get_wmad, i0};
+    const size_t lds_l = (size_t)(2 * v.cap + 2 * IMP_MAXD * v.cap + IMP_MAXD) * sizeof(double);
+    hipLaunchKernelGGL(k_imp_left, dim3((unsigned)count), dim3(IMP_T), lds_l, s, v, g);
+}
+
+}  // namespace mpst

@@ -305,6 +305,11 @@ void launch_norm2(const View& v, double* out_norm2, double* gscratch /* 3*cap*ca
 void launch_scale_sites(const View& v, const double* norm2, hipStream_t s);
 void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s);
 
+// imputation engine (mpst_impute.hip)
+hipError_t impute_init_attrs(int device);
+void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,
+                   int ngrid, int method, int get_wmad, const double* u, double* pbuf, double* sbuf, double* x_out, double* err_out,
+                   int64_t i0, int64_t count, hipStream_t s);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);

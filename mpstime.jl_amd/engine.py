@@ -195,6 +195,24 @@ class SweepEngine:
                                          yh.ctypes.data_as(C.POINTER(C.c_double))))
         return (pred, yh) if return_overlaps else pred
 
+    def impute(self, which, missing, grid_x, grid_phi, method=0, get_wmad=True, u=None):
+        """mpst_impute: (x, err, seconds); x / err are (N, T) with the imputed value / WMAD at every missing site."""
+        m = np.ascontiguousarray(missing, dtype=np.uint8)
+        N, T = m.shape
+        gx = np.ascontiguousarray(grid_x, dtype=np.float64)
+        gp = np.ascontiguousarray(grid_phi, dtype=np.float64)
+        assert gp.shape == (len(gx), self.d) and N == self.N[which] and T == self.T
+        uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        x = np.zeros((N, T))
+        err = np.zeros((N, T))
+        sec = C.c_double()
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mpst_impute(self.ctx, which, m.ctypes.data_as(C.POINTER(C.c_uint8)), gx.ctypes.data_as(dp),
+                                       gp.ctypes.data_as(dp), len(gx), int(method), int(bool(get_wmad)),
+                                       uu.ctypes.data_as(dp) if uu is not None else None, x.ctypes.data_as(dp),
+                                       err.ctypes.data_as(dp), C.byref(sec)))
+        return x, err, sec.value
+
     def normalize(self):
         self._chk(self.lib.mpst_normalize(self.ctx))
 

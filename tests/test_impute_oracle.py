@@ -1,0 +1,76 @@
+"""The imputation oracle (oracle/impute_numpy.py, a line-by-line restatement of src/Imputation/MPS_methods.jl) against an
+independent definition of the same conditional densities: density-matrix environments over the full chain with every
+other missing site traced out, no preconditioning, no orthogonalisation."""
+import numpy as np
+import pytest
+
+from oracle import impute_numpy as I
+from oracle import ref_numpy as R
+
+
+def _setup(T=7, d=3, chi=4, seed=0, ngrid=201):
+    rng = np.random.default_rng(seed)
+    W = R.random_mps(T, d, chi, 2, rng)
+    mps = I.expand_label_index(W)[1]
+    xs = np.linspace(-1.0, 1.0, ngrid)
+    grid_phi = R.legendre_encode(xs, d)
+    x = rng.uniform(-1, 1, T)
+    enc = R.legendre_encode(x, d)
+    return mps, xs, grid_phi, enc, rng
+
+
+@pytest.mark.parametrize("missing", [[2], [0, 1], [3, 4, 5], [1, 3, 6], [0, 2, 4, 6], list(range(7))])
+@pytest.mark.parametrize("order", ["forwards", "backwards"])
+def test_median_path_equals_brute_force_conditionals(missing, order):
+    mps, xs, grid_phi, enc, rng = _setup(seed=len(missing))
+    T = len(mps)
+    xo, eo = I.impute(mps, enc, missing, xs, grid_phi, "median", order)
+    known = np.ones(T, dtype=bool)
+    known[missing] = False
+    fixed = {}
+    seq = sorted(missing) if order == "forwards" else sorted(missing, reverse=True)
+    pos = {j: k for k, j in enumerate(sorted(missing))}
+    for j in seq:
+        p = I.brute_force_conditional(mps, enc, known, j, fixed, grid_phi)
+        cdf = I.cumul_trapz_even(xs, p)
+        k = int(np.argmin(np.abs(cdf / cdf[-1] - 0.5)))
+        assert abs(xs[k] - xo[pos[j]]) <= (xs[1] - xs[0]) * 1.0000001, (j, xs[k], xo[pos[j]])
+        kk = int(np.argmin(np.abs(xs - xo[pos[j]])))
+        wm = I.weighted_median(np.abs(xs - xs[kk]), p / cdf[-1])
+        assert abs(wm - eo[pos[j]]) <= 1e-9
+        fixed[j] = grid_phi[kk]                    # condition on what the oracle chose (scale is irrelevant)
+
+
+def test_mode_and_quantile_paths():
+    mps, xs, grid_phi, enc, rng = _setup(T=6, seed=5)
+    missing = [1, 2, 4]
+    xm, _ = I.impute(mps, enc, missing, xs, grid_phi, "mode")
+    known = np.ones(6, dtype=bool)
+    known[missing] = False
+    fixed = {}
+    for k, j in enumerate(missing):
+        p = I.brute_force_conditional(mps, enc, known, j, fixed, grid_phi)
+        assert xs[int(np.argmax(p))] == xm[k]
+        fixed[j] = grid_phi[int(np.argmax(p))]
+    u = rng.uniform(0, 1, 3)
+    xq, _ = I.impute(mps, enc, missing, xs, grid_phi, "quantile", u=u)
+    fixed = {}
+    for k, j in enumerate(missing):
+        p = I.brute_force_conditional(mps, enc, known, j, fixed, grid_phi)
+        cdf = I.cumul_trapz_even(xs, p)
+        kk = int(np.argmin(np.abs(cdf / cdf[-1] - u[k])))
+        assert abs(xs[kk] - xq[k]) <= (xs[1] - xs[0]) * 1.0000001
+        fixed[j] = grid_phi[int(np.argmin(np.abs(xs - xq[k])))]
+
+
+def test_weighted_median_matches_definition():
+    rng = np.random.default_rng(1)
+    v = rng.uniform(0, 1, 101)
+    w = rng.uniform(0, 1, 101)
+    m = I.weighted_median(v, w)
+    o = np.argsort(v)
+    cw = np.cumsum(w[o])
+    assert m == v[o][np.argmax(cw > w.sum() / 2)]
+    w2 = np.zeros(5)
+    w2[3] = 1.0
+    assert I.weighted_median(np.arange(5.0), w2) == 3.0
