@@ -68,7 +68,8 @@ typedef struct {
     int32_t svd_alg;            /* MPST_SVD_* */
     int32_t rebuild_caches;     /* 1: redo both full cache rebuilds per sweep as the reference does
                                    (:770,:804); 0: skip them (bit-identical results) */
-    int32_t reserved0;
+    int32_t track_cost;         /* opts.track_cost (loss_functions.jl:50-52,80-82,181-184): record the loss before every
+                                   optimiser step and at the updated bond tensor; read them with mpst_get_loss_trace */
     double  eta;                /* opts.eta (:719) */
     double  cutoff;             /* opts.cutoff (:722) */
 } mpst_options;
@@ -176,6 +177,11 @@ int  mpst_build_caches(void* ctx);
 
 /* One full sweep = RealRealHighDimension.jl:727-808. */
 int  mpst_sweep(void* ctx, mpst_sweep_stats* out);
+
+/* opts.track_cost: the losses the reference prints during the last mpst_sweep, one row per bond in sweep order (backward
+ * half-sweep first): update_iters entries "Loss before step i" (loss_functions.jl:50-52 / :80-82) followed by the loss
+ * at the updated bond tensor, "Loss at site lid*rid" (:181-184).  out has 2(T-1) * (update_iters + 1) entries. */
+int  mpst_get_loss_trace(void* ctx, double* out);
 
 /* One bond update (:733-762 going left, :777-801 going right) - test hook. */
 int  mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* dbg);

@@ -23,7 +23,7 @@ KERNEL_CLASSES = ("yhat", "grad", "grad_reduce+update", "gram", "eig_tri", "spli
 class mpst_options(C.Structure):
     _fields_ = [("chi_max", C.c_int32), ("update_iters", C.c_int32), ("loss", C.c_int32), ("optimiser", C.c_int32),
                 ("rescale_before", C.c_int32), ("rescale_after", C.c_int32), ("train_classes_separately", C.c_int32),
-                ("svd_alg", C.c_int32), ("rebuild_caches", C.c_int32), ("reserved0", C.c_int32),
+                ("svd_alg", C.c_int32), ("rebuild_caches", C.c_int32), ("track_cost", C.c_int32),
                 ("eta", C.c_double), ("cutoff", C.c_double)]
 
 
@@ -69,6 +69,7 @@ SYMBOLS = {
     "mpst_get_mps": (C.c_int, [_vp, C.POINTER(_vp)]),
     "mpst_build_caches": (C.c_int, [_vp]),
     "mpst_sweep": (C.c_int, [_vp, C.POINTER(mpst_sweep_stats)]),
+    "mpst_get_loss_trace": (C.c_int, [_vp, _dp]),
     "mpst_bond_step": (C.c_int, [_vp, _i32, _i32, C.POINTER(mpst_bond_debug)]),
     "mpst_eval": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.POINTER(_i64)]),
     "mpst_classify": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _dp]),

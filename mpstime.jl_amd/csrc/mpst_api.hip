@@ -40,6 +40,7 @@ struct Ctx {
     double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
     double *gram = nullptr, *lam = nullptr, *E = nullptr, *eig_ws = nullptr;
     double *btn = nullptr, *norm_part = nullptr;
+    double* loss_trace = nullptr;   // track_cost: [2(T-1)][update_iters + 1]
     int n_norm_part = 0;
     bool fused = false;        // bond tensors <= MAX_DIM^2 and no rescale[1]: the 7-launch chain of mpst_fused.hip
     int64_t partial_elems = 0;
@@ -139,6 +140,7 @@ View make_view(Ctx* c, int which) {
     const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
     v.parts = s.parts[pk]; v.part_off = s.part_off[pk]; v.nparts = s.nparts[pk];
     v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
+    v.trace = nullptr; v.trace_it = 0; v.yhat_scaled = 0;
     return v;
 }
 
@@ -186,14 +188,17 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->tile_loss, std::max<int64_t>((int64_t)c->C * tr.ntiles, std::max(tr.nparts[0], tr.nparts[1])))) ) return rc;
     c->fused = dm <= MAX_DIM && !c->opt.rescale_before && getenv("MPST_NO_FUSED") == nullptr;
     const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
+    (void)pk;
     if (c->fused) {
-        c->partial_elems = (int64_t)tr.nparts[pk] * Lmax;        // independent of N: one partial per persistent workgroup
+        c->partial_elems = (int64_t)std::max(tr.nparts[0], tr.nparts[1]) * Lmax;   // independent of N: one partial per persistent workgroup
     } else {
-        c->partial_elems = (int64_t)(pk ? c->C : 1) * tr.nchunks * Lmax;
+        c->partial_elems = (int64_t)c->C * tr.nchunks * Lmax;    // sized for either loss: per-sweep loss functions switch without reallocating
     }
     if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
     if ((rc = dalloc(c, &c->btn, c->C * Lmax))) return rc;
     c->n_norm_part = (int)((c->C * Lmax + 63) / 64);      // RED_E entries per workgroup of k_fused_reduce
+    if ((rc = dalloc(c, &c->loss_trace, (int64_t)2 * (c->T - 1) * (c->opt.update_iters + 1)))) return rc;
+    HIPC(c, hipMemset(c->loss_trace, 0, (size_t)2 * (c->T - 1) * (c->opt.update_iters + 1) * sizeof(double)));
     if ((rc = dalloc(c, &c->norm_part, c->n_norm_part))) return rc;
     if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax))) return rc;
     HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax) * sizeof(double)));
@@ -298,8 +303,21 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
 // ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
 // have_bt: the bond tensor of this bond was already assembled by the previous bond's environment
 // kernel; next_bt_lid >= 0: assemble that bond's tensor inside this bond's environment kernel.
-int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = false, int next_bt_lid = -1) {
+int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt = false, int next_bt_lid = -1, int trace_row = -1) {
     hipStream_t s = c->stream;
+    View v = v_in;
+    const int n_it = c->opt.update_iters;
+    if (c->opt.track_cost && trace_row >= 0) v.trace = c->loss_trace + (int64_t)trace_row * (n_it + 1);
+    // track_cost: the loss at the updated (and, with rescale[2], normalised) bond tensor - one more forward pass over the batch
+    auto trace_final = [&](const double* bt_new) {
+        if (!v.trace) return;
+        View vy = v;
+        vy.bt = const_cast<double*>(bt_new);
+        vy.yhat_scaled = v.rescale_after;
+        vy.trace_it = n_it;
+        launch_yhat(vy, lid, s);
+        launch_trace_loss(vy, s);
+    };
     const int rid = lid + 1;
     if (c->fused) {
         const int iters = c->opt.update_iters;
@@ -315,12 +333,14 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
                 if (rc) return rc;
                 launch_grad_norm(v, lid, s);
             }
+            v.trace_it = it;
             if (it + 1 < iters) { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
         }
         { ProfScope p(c, K_GRAM); launch_gram_upd(v, lid, going_left, iters == 1, s); }   // last step + decomposeBT :756/:798
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
         { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
+        trace_final(c->btn);
         {
             ProfScope p(c, K_ENV);                                                // back-split + update_caches! :759/:799
             const int64_t cs = (int64_t)v.N * v.cap;
@@ -344,6 +364,7 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
             int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
             if (rc) return rc;
         }
+        v.trace_it = it;
         { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
     }
     { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
@@ -355,6 +376,7 @@ int enqueue_bond(Ctx* c, const View& v, int lid, int going_left, bool have_bt = 
         { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
     }
+    trace_final(c->bt);
     { ProfScope p(c, K_SPLIT); launch_split(v, lid, going_left, s); }
     {
         ProfScope p(c, K_ENV);                                                  // update_caches! :759/:799
@@ -460,7 +482,7 @@ void mpst_destroy(void* ctx) {
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
     if (c->big) big_eig_destroy(c->big);
-    dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part);
+    dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -565,7 +587,7 @@ int mpst_set_options(void* ctx, const mpst_options* o) {
         return fail(c, MPST_ERR_UNSUPPORTED, "no Loss_Grad_MSE method for TrainSeparate{true} (loss_functions.jl:561)");
     if (c->have_mps && o->chi_max > c->cap)
         return fail(c, MPST_ERR_INVALID, "chi_max %d exceeds the capacity %d fixed when the MPS was set; call mpst_set_options before mpst_set_mps", o->chi_max, c->cap);
-    const bool resize = !c->have_opt || o->loss != c->opt.loss || o->rescale_before != c->opt.rescale_before;
+    const bool resize = !c->have_opt || o->rescale_before != c->opt.rescale_before || o->update_iters != c->opt.update_iters;
     c->opt = *o;
     c->have_opt = true;
     c->epoch++;
@@ -907,7 +929,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             if (c->fused && k == nb) have = false;      // turning point: the same bond again, nothing was chained
             int next = -1;
             if (chain && k + 1 < 2 * nb && !boundary_after) next = (k + 1) < nb ? nb - 1 - (k + 1) : (k + 1) - nb;
-            if ((r = enqueue_bond(c, v, lid, left, have, next))) return r;
+            if ((r = enqueue_bond(c, v, lid, left, have, next, k))) return r;
             if (c->opt.rebuild_caches && k == nb - 1) enqueue_caches(c, v, 0);      // :770
         }
         if (c->opt.rebuild_caches) enqueue_caches(c, v, 1);                         // :804
@@ -969,6 +991,16 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         c->caches_valid = false;        // the state after a failed bond is unspecified: set_mps + build_caches to go on
         return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
     }
+    return 0;
+}
+
+int mpst_get_loss_trace(void* ctx, double* out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !out) return MPST_ERR_INVALID;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(out, c->loss_trace, (size_t)2 * (c->T - 1) * (c->opt.update_iters + 1) * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

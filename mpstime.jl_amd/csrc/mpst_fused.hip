@@ -384,9 +384,12 @@ __global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_lef
     }
     double nrm;
     const double step = step_from_parts(v, red, &nrm);
-    if (tile == 0 && threadIdx.x == 0 && first_iter) {
-        v.sc->loss = v.gradbuf[0];
-        v.sc->grad_norm = nrm;
+    if (tile == 0 && threadIdx.x == 0) {
+        if (first_iter) {
+            v.sc->loss = v.gradbuf[0];
+            v.sc->grad_norm = nrm;
+        }
+        if (v.trace) v.trace[v.trace_it] = v.gradbuf[0];      // "Loss before step i" of the last iteration
     }
     if (!live) return;
     d4 acc = {0, 0, 0, 0};

@@ -145,7 +145,6 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
     __shared__ double rho[IMP_MAXD * IMP_MAXD];
     __shared__ double segsum[IMP_T];
     __shared__ int isel[4];
-    __shared__ double dsel[4];
     const int64_t i = g.i0 + blockIdx.x;
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
     const uint8_t* mi = g.missing + i * T;

@@ -233,6 +233,9 @@ struct View {
     int32_t nparts, n_norm_part;
     double* norm_part;  // [n_norm_part] pieces of ||grad||^2
     double* btn;        // bt_new, written by k_gram_upd
+    double* trace;      // track_cost: this bond's row of the loss trace ([update_iters + 1]) or null
+    int32_t trace_it;   // which entry the launch at hand fills
+    int32_t yhat_scaled; // k_yhat: multiply yhat by sc->inv_norm (loss at the normalised bt_new)
     double* gradbuf;    // [2 + C*Lmax]: loss, pad, grad[c][x][y]
     double* gram;       // [MAX_DIM*MAX_DIM]
     double* lam;        // [MAX_DIM]
@@ -274,6 +277,7 @@ void launch_yhat(const View& v, int lid, hipStream_t s);
 void launch_grad(const View& v, int lid, hipStream_t s);
 void launch_grad_reduce(const View& v, int lid, hipStream_t s);
 void launch_update(const View& v, int lid, int first_iter, hipStream_t s);
+void launch_trace_loss(const View& v, hipStream_t s);   // track_cost: tile losses of the last launch_yhat -> v.trace[v.trace_it]
 void launch_gram(const View& v, int lid, int going_left, hipStream_t s);
 void launch_split(const View& v, int lid, int going_left, hipStream_t s);
 // env step: out[i][k] = sum_z Z_i[z] M[z][k], Z = (prev (x) phi_site) on the left

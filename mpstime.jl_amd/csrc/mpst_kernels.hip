@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     if (tid < 64) {
         double term = 0.0;
         if (tid < 16) {
-            const double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            if (v.yhat_scaled) yh *= v.sc->inv_norm;           // track_cost: loss at the normalised bt_new (loss_functions.jl:177-184)
             if (tid < tl.count) {
                 v.yhat[(int64_t)c * v.N + tl.start + tid] = yh;
                 if (mse) {
@@ -313,7 +314,8 @@ __global__ __launch_bounds__(256) void k_yhat_gen(View v, int lid) {
     if (tid < 64) {
         double term = 0.0;
         if (tid < 16) {
-            const double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+            if (v.yhat_scaled) yh *= v.sc->inv_norm;
             if (tid < tl.count) {
                 v.yhat[(int64_t)c * v.N + tl.start + tid] = yh;
                 if (mse) {
@@ -511,10 +513,28 @@ __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter)
     const double nrm = sqrt(nrm2);
     const double step = (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v.bt[i] -= step * g[i];
-    if (blockIdx.x == 0 && threadIdx.x == 0 && first_iter) {
-        v.sc->loss = v.gradbuf[0];
-        v.sc->grad_norm = nrm;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (first_iter) {
+            v.sc->loss = v.gradbuf[0];
+            v.sc->grad_norm = nrm;
+        }
+        if (v.trace) v.trace[v.trace_it] = v.gradbuf[0];      // "Loss before step i", loss_functions.jl:50-52 / :80-82
     }
+}
+
+// track_cost: loss from the per-tile terms k_yhat just wrote (same weighting as k_grad_reduce), one workgroup
+__global__ __launch_bounds__(256) void k_trace_loss(View v) {
+    __shared__ double red[4];
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    double s = 0.0;
+    if (mse) {
+        for (int i = threadIdx.x; i < v.C * v.ntiles; i += 256) s += v.tile_loss[i];
+        s *= v.invN;
+    } else {
+        for (int i = threadIdx.x; i < v.ntiles; i += 256) s += v.tile_loss[i] * (v.train_sep ? v.inv_count[v.tiles[i].cls] : v.invN);
+    }
+    const double tot = block_sum(s, red);
+    if (threadIdx.x == 0 && v.trace) v.trace[v.trace_it] = tot;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -876,6 +896,7 @@ void launch_grad_reduce(const View& v, int lid, hipStream_t s) {
 void launch_update(const View& v, int lid, int first_iter, hipStream_t s) {
     hipLaunchKernelGGL(k_update, dim3(32), dim3(256), 0, s, v, lid, first_iter);
 }
+void launch_trace_loss(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_trace_loss, dim3(1), dim3(256), 0, s, v); }
 void launch_gram(const View& v, int lid, int going_left, hipStream_t s) {
     const int dm = v.d * v.cap;
     const int tiles = cdiv(dm, 16) * cdiv(dm, 16);

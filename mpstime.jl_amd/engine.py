@@ -57,7 +57,7 @@ class SweepEngine:
 
     # -- configuration ----------------------------------------------------------------
     def set_options(self, chi_max, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO",
-                    rescale=(False, True), train_classes_separately=False, svd_alg=0, rebuild_caches=False):
+                    rescale=(False, True), train_classes_separately=False, svd_alg=0, rebuild_caches=False, track_cost=False):
         if str(loss).upper() not in L.LOSS:
             raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"loss {loss!r} unsupported by the array sweep")
         if str(bbopt).upper() not in L.OPT:
@@ -66,7 +66,8 @@ class SweepEngine:
                               "set 'use_legacy_ITensor=true' in MPSOptions to enable")
         o = L.mpst_options(int(chi_max), int(update_iters), L.LOSS[str(loss).upper()], L.OPT[str(bbopt).upper()],
                            int(bool(rescale[0])), int(bool(rescale[1])), int(bool(train_classes_separately)),
-                           int(svd_alg), int(bool(rebuild_caches)), 0, float(eta), float(cutoff))
+                           int(svd_alg), int(bool(rebuild_caches)), int(bool(track_cost)), float(eta), float(cutoff))
+        self._iters = int(update_iters)
         self._chk(self.lib.mpst_set_options(self.ctx, C.byref(o)))
 
     def set_dataset(self, which, phi, label_index, C_classes, global_counts=None):
@@ -173,6 +174,12 @@ class SweepEngine:
         self._chk(self.lib.mpst_sweep(self.ctx, C.byref(st)))
         return {"seconds": st.seconds, "max_chi": st.max_chi, "eig_sweeps_total": st.eig_sweeps_total,
                 "eig_fallbacks": st.eig_fallbacks}
+
+    def loss_trace(self):
+        """(2(T-1), update_iters + 1): losses before every optimiser step and at the updated bond tensor (track_cost)."""
+        out = np.zeros((2 * (self.T - 1), self._iters + 1))
+        self._chk(self.lib.mpst_get_loss_trace(self.ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
 
     def bond_step(self, lid, going_left):
         dbg = L.mpst_bond_debug()

@@ -71,8 +71,15 @@ class MPSOptions:
 
     def __post_init__(self):
         object.__setattr__(self, "encoding", _sym(self.encoding))
-        object.__setattr__(self, "loss_grad", _sym(self.loss_grad))
-        object.__setattr__(self, "bbopt", _sym(self.bbopt))
+        # a Symbol, or one per sweep (the reference's Options accepts arrays of length nsweeps, RealRealHighDimension.jl:691-713)
+        for name in ("loss_grad", "bbopt"):
+            v = getattr(self, name)
+            if isinstance(v, (list, tuple)):
+                if len(v) != self.nsweeps:
+                    raise AssertionError(f"{name} must be one value or a sequence of length nsweeps")
+                object.__setattr__(self, name, tuple(_sym(x) for x in v))
+            else:
+                object.__setattr__(self, name, _sym(v))
         canon, iscomplex, _, _ = encoding_info(self.encoding)
         if not self.dtype:
             object.__setattr__(self, "dtype", "ComplexF64" if iscomplex else "Float64")
@@ -96,9 +103,12 @@ def safe_options(opts) -> MPSOptions:
     raise TypeError("opts must be an MPSOptions")
 
 
-def engine_options(opts: MPSOptions) -> dict:
-    """Resolve the symbols the sweep consumes (model_loss_func :318-327, model_bbopt :298-311)
+def engine_options(opts: MPSOptions, sweep: int = 0) -> dict:
+    """Resolve the symbols sweep number `sweep` consumes (model_loss_func :318-327, model_bbopt :298-311)
     and reject what the array engine - like the reference's own array path - does not implement."""
+    lg = opts.loss_grad[sweep] if isinstance(opts.loss_grad, tuple) else opts.loss_grad
+    bbo = opts.bbopt[sweep] if isinstance(opts.bbopt, tuple) else opts.bbopt
+    opts = replace(opts, loss_grad=lg, bbopt=bbo)
     loss = opts.loss_grad.upper()
     if loss not in ("KLD", "MSE"):
         if loss == "MIXED":

@@ -84,7 +84,7 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
     own_engine = engine is None
     eng = engine or SweepEngine(device)
     try:
-        eng.set_options(rebuild_caches=False, **eopt)
+        eng.set_options(rebuild_caches=False, track_cost=opts.track_cost, **eopt)
         gcounts = None
         if shard is not None:
             tr_local, gcounts = shard.split(tr)
@@ -131,7 +131,18 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
             if verbosity > -1:
                 print(f"Using optimiser CustomGD with the \"{eopt['bbopt']}\" algorithm")
                 print(f"Starting backward sweeep: [{its + 1}/{opts.nsweeps}]")
+            if its > 0 and (isinstance(opts.loss_grad, tuple) or isinstance(opts.bbopt, tuple)):
+                eng.set_options(rebuild_caches=False, track_cost=opts.track_cost, **engine_options(opts, its))   # :727-728: this sweep's loss / optimiser
             st = eng.sweep()                                                     # :727-808
+            if opts.track_cost and verbosity >= 1:
+                # what custGD / TSGO (loss_functions.jl:50-52,80-82) and apply_update (:181-184) print, bond by bond
+                tr = eng.loss_trace()
+                nb = len(W) - 1
+                for q in range(2 * nb):
+                    lid = nb - 1 - q if q < nb else q - nb
+                    for it in range(opts.update_iters):
+                        print(f"Loss before step {it + 1}: {tr[q, it]}")
+                    print(f"Loss at site {lid + 1}*{lid + 2}: {tr[q, opts.update_iters]}")
             if verbosity > -1:
                 print(f"Finished sweep {its + 1}. Time for sweep: {round(st['seconds'], 2)}s")
             acc = log(st["seconds"])
@@ -277,3 +288,29 @@ def trendy_sine(T, n, period=None, slope=None, phase=None, sigma=0.0, rng=None):
     for i in range(n):
         X[i] = np.sin(2 * np.pi / per[i] * ts + pha[i]) + slo[i] * ts / T + sigma * rng.standard_normal(T)
     return X, {"period": per, "slope": slo, "phase": pha, "sigma": sigma, "T": T, "n": n}
+
+
+def save_trained_mps(path, trained: TrainedMPS):
+    """The counterpart of ``@save fpath mps`` (test/save_load.jl:17-24) for this package: the three fields of TrainedMPS
+    (src/Structs/options.jl:422-427) - site tensors, the MPSOptions, the EncodedTimeSeriesSet - in one .npz.  (JLD2 /
+    HDF5 cannot be written here: no HDF5 library in the image; the reference's own .jld2 fixture is read by
+    tests/golden/extract_jld2_fixture.py.)"""
+    import json
+    td = trained.train_data
+    opts = {k: (list(v) if isinstance(v, tuple) else v) for k, v in trained.opts.asdict().items()}
+    np.savez_compressed(path, n_sites=len(trained.mps), opts=json.dumps(opts), timeseries=td.phi, labels=td.labels,
+                        label_index=td.label_index, original_data=td.original_data, class_distribution=td.class_distribution,
+                        **{f"mps_{j}": t for j, t in enumerate(trained.mps)})
+
+
+def load_trained_mps(path) -> TrainedMPS:
+    import json
+    z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+    o = json.loads(str(z["opts"]))
+    for k in ("rescale", "data_bounds"):
+        o[k] = tuple(o[k])
+    for k in ("loss_grad", "bbopt"):
+        if isinstance(o[k], list):
+            o[k] = tuple(o[k])
+    td = EncodedTimeSeriesSet(z["timeseries"], z["labels"], z["label_index"], z["original_data"], z["class_distribution"])
+    return TrainedMPS([z[f"mps_{j}"] for j in range(int(z["n_sites"]))], MPSOptions(**o), td)

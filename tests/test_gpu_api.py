@@ -104,3 +104,20 @@ def test_exit_early_stops_at_perfect_training_accuracy():
     assert mps == mps_b
     mps_c, _, _ = mt.fitMPS(Xtr, ytr, opts=opts.set(eta=0.05))
     assert mps != mps_c
+
+
+def test_fitmps_with_per_sweep_loss_and_track_cost(capsys):
+    """loss_grad / bbopt given per sweep (RealRealHighDimension.jl:691-713) and track_cost's printed losses."""
+    Xtr, ytr = _toy(60, 12, 7)
+    base = mt.MPSOptions(d=3, chi_max=6, nsweeps=2, eta=0.05, verbosity=-1)
+    a, info_a, _ = mt.fitMPS(Xtr, ytr, opts=base)
+    b, info_b, _ = mt.fitMPS(Xtr, ytr, opts=base.set(loss_grad=["KLD", "KLD"], bbopt=["TSGO", "TSGO"]))
+    assert a.mps[0].shape == b.mps[0].shape and all(np.array_equal(x, y) for x, y in zip(a.mps, b.mps))
+    c, info_c, _ = mt.fitMPS(Xtr, ytr, opts=base.set(loss_grad=["KLD", "MSE"], bbopt=["TSGO", "GD"]))
+    assert info_c["train_KL_div"][1] == info_a["train_KL_div"][1]          # first sweep identical
+    assert info_c["train_KL_div"][2] != info_a["train_KL_div"][2]          # second one used the other loss / optimiser
+    capsys.readouterr()
+    mt.fitMPS(Xtr, ytr, opts=base.set(nsweeps=1, verbosity=1, track_cost=True))
+    out = capsys.readouterr().out
+    assert out.count("Loss before step 1:") == 2 * 11 and out.count("Loss at site") == 2 * 11
+    assert "Loss at site 11*12:" in out and "Loss at site 1*2:" in out

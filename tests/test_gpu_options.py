@@ -186,3 +186,39 @@ def test_call_order_is_enforced(eng):
         eng.sweep()
     with pytest.raises(mt.MPSTError, match="does not hold the label"):
         eng.bond_step(0, True)
+
+
+def test_track_cost_records_the_losses_the_reference_prints(eng):
+    """opts.track_cost (loss_functions.jl:50-52,80-82,181-184): per bond the loss before every optimiser step and the loss at
+    the updated, normalised bond tensor; checked against the oracle's loss function on the oracle's own trajectory."""
+    ds, W0 = make_problem(60, 6, 3, 3, 2, seed=51, balanced=False)
+    for loss, rescale in (("KLD", (False, True)), ("MSE", (False, False))):
+        opts = R.SweepOptions(nsweeps=1, chi_max=6, eta=0.05, update_iters=2, loss_grad=loss, rescale=rescale)
+        load_engine(eng, ds, W0, opts, track_cost=True)
+        eng.build_caches()
+        eng.sweep()
+        tr = eng.loss_trace()
+        T = ds.phi.shape[1]
+        assert tr.shape == (2 * (T - 1), 3)
+        W = [t.copy() for t in W0]
+        LE, RE = R.construct_caches(W, ds.phi, True)
+        q = 0
+        lg = R.LOSS_GRADS[loss]
+        for going_left, order in ((True, range(T - 2, -1, -1)), (False, range(0, T - 1))):
+            for lid in order:
+                bt, shape4 = R.flatten_bt(W[lid], W[lid + 1])
+                l0, g0 = lg(bt, LE, RE, ds, lid, lid + 1, False)
+                bt1 = bt - opts.eta * g0 / np.linalg.norm(g0)
+                l1, g1 = lg(bt1, LE, RE, ds, lid, lid + 1, False)
+                bt2 = bt1 - opts.eta * g1 / np.linalg.norm(g1)
+                if rescale[1]:
+                    bt2 = bt2 / np.linalg.norm(bt2)
+                l2, _ = lg(bt2, LE, RE, ds, lid, lid + 1, False)
+                assert np.allclose(tr[q], [l0, l1, l2], rtol=1e-9, atol=1e-12), (q, tr[q], l0, l1, l2)
+                R.bond_step(W, LE, RE, lid, ds, opts, going_left, {})
+                q += 1
+    # a sweep without track_cost leaves the trace alone and costs no extra launches
+    load_engine(eng, ds, W0, opts)
+    eng.build_caches()
+    eng.sweep()
+    assert np.all(eng.loss_trace() == 0.0)
