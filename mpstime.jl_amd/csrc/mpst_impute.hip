@@ -19,6 +19,7 @@
 //                 weighted median absolute deviation, L <- phi* (L W_j).
 // Real fp64; chi <= 64 (four chi x chi matrices in LDS), d <= 16.
 #include "mpst_internal.h"
+#include <type_traits>
 
 namespace mpst {
 
@@ -48,6 +49,32 @@ __device__ __forceinline__ const double* class_site(const View& v, int j, int cl
 }
 
 // ---- right environments ------------------------------------------------------------------------------------------------
+// C (M x N, row stride ld) (+)= A (M x K) * B, all in LDS, 16 x 16 tiles on the fp64 MFMA shared out over the 4 waves.
+// tb = false: B is K x N row-major; tb = true: B holds the transposed operand (N x K row-major), i.e. C += A * B^T.
+// Rows / columns beyond M / N / K must be zero in the operands (the buffers are kept zero-padded to multiples of 16).
+__device__ __forceinline__ void lds_mm(double* __restrict__ Cm, const double* __restrict__ A, const double* __restrict__ B, int M,
+                                       int N, int K, int ld, bool tb, bool accumulate) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, ks = (K + 3) >> 2;
+    for (int t = wave; t < tm * tn; t += 4) {
+        const int m0 = (t / tn) * 16, n0 = (t % tn) * 16;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = Cm[(m0 + kq + 4 * r) * ld + n0 + i16];
+        }
+        for (int u = 0; u < ks; ++u) {
+            const int k = 4 * u + kq;
+            const double av = A[(m0 + i16) * ld + k];
+            const double bv = tb ? B[(n0 + i16) * ld + k] : B[k * ld + n0 + i16];
+            acc = mfma_f64(av, bv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cm[(m0 + kq + 4 * r) * ld + n0 + i16] = acc[r];
+    }
+}
+
 __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __restrict__ missing, double* __restrict__ Rbuf,
                                                      int max_missing, int64_t i0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -59,10 +86,15 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
     for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
     if (nm == 0) return;
     const int cls = v.label[i];
-    double* Ra = smem;                 // [cm][cm] current R
-    double* Rb = Ra + cm * cm;         // [cm][cm] next R
-    double* Ms = Rb + cm * cm;         // [cm][cm] M_j or W_j[s]
-    double* T1 = Ms + cm * cm;         // [cm][cm] (M or W_s) * R
+    const int cp = (cm + 15) & ~15;            // matrices are kept zero-padded to a multiple of 16 rows / columns
+    const int ld = cp + 2;                     // + 2: the 16 rows an MFMA operand read touches land on different banks
+    const int msz = cp * ld;
+    double* Ra = smem;                 // current R
+    double* Rb = Ra + msz;             // next R
+    double* Ms = Rb + msz;             // M_j or W_j[s]
+    double* T1 = Ms + msz;             // (M or W_s) * R
+    for (int e = tid; e < 4 * msz; e += IMP_T) smem[e] = 0.0;
+    __syncthreads();
     double* R = Ra;
     double* Rn = Rb;
     if (tid == 0) R[0] = 1.0;
@@ -74,49 +106,61 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
         if (miss) {
             // the environment of the sites right of j is what site j's density matrix needs
             double* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm;
-            for (int e = tid; e < Dr * Dr; e += IMP_T) out[e] = R[(e / Dr) * cm + (e % Dr)];
+            for (int e = tid; e < Dr * Dr; e += IMP_T) out[e] = R[(e / Dr) * ld + (e % Dr)];
             ++slot;
             if (slot == nm) break;                 // nothing left of the first missing site needs a right environment
         }
         const double* W = class_site(v, j, cls, Dl, Dr);
         const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
-        for (int e = tid; e < Dl * Dl; e += IMP_T) Rn[(e / Dl) * cm + (e % Dl)] = 0.0;
         const int ns = miss ? d : 1;
         for (int s = 0; s < ns; ++s) {
-            // Ms = M_j (known) or W_j[s] (missing)
-            for (int e = tid; e < Dl * Dr; e += IMP_T) {
-                const int a = e / Dr, b = e - a * Dr;
-                double m;
+            // Ms = M_j (known) or W_j[s] (missing); 8 elements per thread per round trip, rows contiguous in b
+            for (int e0 = tid; e0 < Dl * Dr; e0 += 8 * IMP_T) {
+                double acc[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
                 if (miss) {
-                    m = W[((int64_t)a * d + s) * Dr + b];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int e = e0 + q * IMP_T;
+                        if (e < Dl * Dr) acc[q] = W[((int64_t)(e / Dr) * d + s) * Dr + (e % Dr)];
+                    }
                 } else {
-                    m = 0.0;
-                    for (int q = 0; q < d; ++q) m = fma(ph[q], W[((int64_t)a * d + q) * Dr + b], m);
+                    for (int qq = 0; qq < d; ++qq) {
+                        const double pq = ph[qq];
+                        double w[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int e = e0 + q * IMP_T;
+                            w[q] = (e < Dl * Dr) ? W[((int64_t)(e / Dr) * d + qq) * Dr + (e % Dr)] : 0.0;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q] = fma(pq, w[q], acc[q]);
+                    }
                 }
-                Ms[a * cm + b] = m;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * IMP_T;
+                    if (e < Dl * Dr) Ms[(e / Dr) * ld + (e % Dr)] = acc[q];
+                }
             }
             __syncthreads();
-            for (int e = tid; e < Dl * Dr; e += IMP_T) {           // T1 = Ms * R
-                const int a = e / Dr, b = e - a * Dr;
-                double t = 0.0;
-                for (int k = 0; k < Dr; ++k) t = fma(Ms[a * cm + k], R[k * cm + b], t);
-                T1[a * cm + b] = t;
-            }
+            lds_mm(T1, Ms, R, Dl, Dr, Dr, ld, false, false);          // T1 = Ms * R
             __syncthreads();
-            for (int e = tid; e < Dl * Dl; e += IMP_T) {           // Rn += T1 * Ms^T
-                const int a = e / Dl, a2 = e - a * Dl;
-                double t = 0.0;
-                for (int k = 0; k < Dr; ++k) t = fma(T1[a * cm + k], Ms[a2 * cm + k], t);
-                Rn[a * cm + a2] += t;
-            }
+            lds_mm(Rn, T1, Ms, Dl, Dl, Dr, ld, true, s > 0);           // Rn (+)= T1 * Ms^T
             __syncthreads();
         }
-        // rescale by the trace (every density below is scale-free) and swap
+        // rescale by the trace (every density below is scale-free), clear what the next site must find zero, swap
         double tr = 0.0;
-        for (int a = tid; a < Dl; a += IMP_T) tr += Rn[a * cm + a];
+        for (int a = tid; a < Dl; a += IMP_T) tr += Rn[a * ld + a];
         tr = blk_sum(tr, red);
         const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
-        for (int e = tid; e < Dl * Dl; e += IMP_T) Rn[(e / Dl) * cm + (e % Dl)] *= sc;
+        for (int e = tid; e < cp * cp; e += IMP_T) {
+            const int a = e / cp, b2 = e - a * cp;
+            Rn[a * ld + b2] = (a < Dl && b2 < Dl) ? Rn[a * ld + b2] * sc : 0.0;
+            Ms[a * ld + b2] = 0.0;
+            T1[a * ld + b2] = 0.0;
+        }
         __syncthreads();
         double* tmp = R;
         R = Rn;
@@ -170,40 +214,54 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
         const int Dl = v.chi[j], Dr = v.chi[j + 1];
         const bool miss = mi[j] != 0;
         const double* W = class_site(v, j, cls, Dl, Dr);
+        // LW[s][b] = sum_a L[a] W[a][s][b] for both kinds of site (consecutive threads = consecutive (s, b): every load of
+        // the 8 issued per round trip is coalesced); a known site then contracts s with its encoded value
+        for (int e = tid; e < d * Dr; e += IMP_T) {
+            const int s_ = e / Dr, b = e - s_ * Dr;
+            const double* wp = W + (int64_t)s_ * Dr + b;
+            const int64_t astr = (int64_t)d * Dr;
+            double t = 0.0;
+            for (int a0 = 0; a0 < Dl; a0 += 8) {
+                double w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = (a0 + q < Dl) ? wp[(int64_t)(a0 + q) * astr] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (a0 + q < Dl) t = fma(L[a0 + q], w[q], t);
+            }
+            LW[s_ * cm + b] = t;
+        }
+        __syncthreads();
         if (!miss) {
             const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
             for (int b = tid; b < Dr; b += IMP_T) {
                 double t = 0.0;
-                for (int a = 0; a < Dl; ++a) {
-                    const double la = L[a];
-                    for (int q = 0; q < d; ++q) t = fma(la * ph[q], W[((int64_t)a * d + q) * Dr + b], t);
-                }
+                for (int q = 0; q < d; ++q) t = fma(ph[q], LW[q * cm + b], t);
                 Ln[b] = t;
             }
         } else {
             const double* R = g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm;      // [Dr][Dr] compact
             ++seen;
-            // LW[s][b] = sum_a L[a] W[a][s][b]
-            for (int e = tid; e < d * Dr; e += IMP_T) {
-                const int s = e / Dr, b = e - s * Dr;
-                double t = 0.0;
-                for (int a = 0; a < Dl; ++a) t = fma(L[a], W[((int64_t)a * d + s) * Dr + b], t);
-                LW[s * cm + b] = t;
-            }
-            __syncthreads();
             // U = LW R;  rho = U LW^T
             for (int e = tid; e < d * Dr; e += IMP_T) {
-                const int s = e / Dr, b = e - s * Dr;
+                const int s_ = e / Dr, b = e - s_ * Dr;
                 double t = 0.0;
-                for (int k = 0; k < Dr; ++k) t = fma(LW[s * cm + k], R[(int64_t)k * Dr + b], t);
-                U[s * cm + b] = t;
+                for (int k0_ = 0; k0_ < Dr; k0_ += 8) {
+                    double r8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r8[q] = (k0_ + q < Dr) ? R[(int64_t)(k0_ + q) * Dr + b] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (k0_ + q < Dr) t = fma(LW[s_ * cm + k0_ + q], r8[q], t);
+                }
+                U[s_ * cm + b] = t;
             }
             __syncthreads();
             for (int e = tid; e < d * d; e += IMP_T) {
-                const int s = e / d, s2 = e - s * d;
+                const int s_ = e / d, s2 = e - s_ * d;
                 double t = 0.0;
-                for (int k = 0; k < Dr; ++k) t = fma(U[s * cm + k], LW[s2 * cm + k], t);
-                rho[s * IMP_MAXD + s2] = t;
+                for (int k = 0; k < Dr; ++k) t = fma(U[s_ * cm + k], LW[s2 * cm + k], t);
+                rho[s_ * IMP_MAXD + s2] = t;
             }
             __syncthreads();
             // normalise rho by its trace (p scales with the square, every quantity below is scale-free)
@@ -215,32 +273,100 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 for (int e = tid; e < d * d; e += IMP_T) rho[(e / d) * IMP_MAXD + (e % d)] *= sc;
                 __syncthreads();
             }
-            // p_k = |rho phi_k|^2 on this thread's segment of the grid, segment sums, block-wide exclusive scan
-            double loc = 0.0, pmax = -1.0;
+            // p_k = |rho phi_k|^2: grid values interleaved over the threads (consecutive lanes read consecutive encoded
+            // states: coalesced), rho in registers; then every thread sums its CONTIGUOUS segment for the block-wide scan
+            double pmax = -1.0;
             int kmax = 0;
-            for (int k = k0; k < k1; ++k) {
-                const double* ph = g.grid_phi + (int64_t)k * d;
-                double pk = 0.0;
-                for (int s = 0; s < d; ++s) {
-                    double q = 0.0;
-                    for (int s2 = 0; s2 < d; ++s2) q = fma(rho[s * IMP_MAXD + s2], ph[s2], q);
-                    pk = fma(q, q, pk);
+            {
+                double rr[IMP_MAXD * IMP_MAXD];
+#pragma unroll
+                for (int e = 0; e < IMP_MAXD * IMP_MAXD; ++e) rr[e] = (e / IMP_MAXD < d && e % IMP_MAXD < d) ? rho[e] : 0.0;
+                auto eval = [&](auto DD) {
+                    constexpr int D = decltype(DD)::value;
+                    for (int kb = tid; kb < n; kb += 4 * IMP_T) {          // 4 grid values per round trip
+                        double f[4][D];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int k = kb + q * IMP_T;
+                            const double* ph = g.grid_phi + (int64_t)(k < n ? k : 0) * D;
+#pragma unroll
+                            for (int s2 = 0; s2 < D; ++s2) f[q][s2] = ph[s2];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int k = kb + q * IMP_T;
+                            if (k < n) {
+                                double pk = 0.0;
+#pragma unroll
+                                for (int s = 0; s < D; ++s) {
+                                    double qq = 0.0;
+#pragma unroll
+                                    for (int s2 = 0; s2 < D; ++s2) qq = fma(rr[s * IMP_MAXD + s2], f[q][s2], qq);
+                                    pk = fma(qq, qq, pk);
+                                }
+                                p[k] = pk;
+                                if (pk > pmax) {      // strictly greater: within a thread k increases, so this keeps the first maximum
+                                    pmax = pk;
+                                    kmax = k;
+                                }
+                            }
+                        }
+                    }
+                };
+                switch (d) {
+                    case 2: eval(std::integral_constant<int, 2>{}); break;
+                    case 3: eval(std::integral_constant<int, 3>{}); break;
+                    case 4: eval(std::integral_constant<int, 4>{}); break;
+                    case 5: eval(std::integral_constant<int, 5>{}); break;
+                    case 6: eval(std::integral_constant<int, 6>{}); break;
+                    case 7: eval(std::integral_constant<int, 7>{}); break;
+                    case 8: eval(std::integral_constant<int, 8>{}); break;
+                    case 10: eval(std::integral_constant<int, 10>{}); break;
+                    case 12: eval(std::integral_constant<int, 12>{}); break;
+                    default:
+                        for (int k = tid; k < n; k += IMP_T) {
+                            const double* ph = g.grid_phi + (int64_t)k * d;
+                            double pk = 0.0;
+                            for (int s = 0; s < d; ++s) {
+                                double q = 0.0;
+                                for (int s2 = 0; s2 < d; ++s2) q = fma(rho[s * IMP_MAXD + s2], ph[s2], q);
+                                pk = fma(q, q, pk);
+                            }
+                            p[k] = pk;
+                            if (pk > pmax) {
+                                pmax = pk;
+                                kmax = k;
+                            }
+                        }
                 }
-                p[k] = pk;
-                loc += pk;
-                if (pk > pmax) {
-                    pmax = pk;
-                    kmax = k;
-                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            // every loop over a thread's segment below moves 8 values per round trip (the loops are latency-, not
+            // bandwidth-bound: one workgroup per instance)
+            double loc = 0.0;
+            for (int k = k0; k < k1; k += 8) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = (k + q < k1) ? p[k + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) loc += t[q];
             }
             segsum[tid] = loc;
             __syncthreads();
             double off = 0.0;
             for (int t = 0; t < tid; ++t) off += segsum[t];       // same order for everybody: deterministic
             double run = off;
-            for (int k = k0; k < k1; ++k) {
-                run += p[k];
-                S[k] = run;
+            for (int k = k0; k < k1; k += 8) {
+                double t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = (k + q < k1) ? p[k + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (k + q < k1) {
+                        run += t[q];
+                        S[k + q] = run;
+                    }
             }
             __threadfence_block();
             __syncthreads();
@@ -259,17 +385,24 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 __syncthreads();
                 ksel = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
             } else {
-                // argmin_k |cdf_k / Z - target|: the cdf is non-decreasing, so the minimiser is the last k at or below
-                // the target or its successor
+                // argmin_k |cdf_k / Z - target|: the cdf is non-decreasing, so the minimiser sits at the crossing.  Coarse
+                // position without divisions (cdf_k <= target * Z, counted per segment), then the reference's own
+                // expression |cdf_k / Z - target| on the handful of neighbours, first minimum wins (argmin).
                 const double target = g.method == 0 ? 0.5 : g.u[i * T + j];
-                int klo = -1;
-                if (k0 < k1 && cdf_at(k0) / Z <= target) {
-                    klo = k0;
-                    for (int k = k0 + 1; k < k1; ++k) {
-                        if (cdf_at(k) / Z <= target) klo = k;
-                        else break;
-                    }
+                const double tz = target * Z;
+                int below = 0;
+                for (int k = k0; k < k1; k += 8) {
+                    double t[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) t[q] = (k + q - 1 >= 0 && k + q - 1 < k1) ? S[k + q - 1] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (k + q < k1) {
+                            const double cv = (k + q == 0) ? 0.0 : 0.5 * dx * ((t[q] + t[q + 1]) - p0);
+                            below += cv <= tz ? 1 : 0;
+                        }
                 }
+                int klo = below > 0 ? k0 + below - 1 : -1;         // monotone: the points at or below the target form a prefix
                 klo = (int)wave_max((double)klo);
                 __syncthreads();
                 if ((tid & 63) == 0) isel[tid >> 6] = klo;
@@ -277,9 +410,13 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 klo = max(max(isel[0], isel[1]), max(isel[2], isel[3]));
                 if (klo < 0) klo = 0;
                 ksel = klo;
-                if (klo + 1 < n) {
-                    const double a0 = fabs(cdf_at(klo) / Z - target), a1 = fabs(cdf_at(klo + 1) / Z - target);
-                    if (a1 < a0) ksel = klo + 1;
+                double best = 1e300;
+                for (int k = max(0, klo - 2); k <= min(n - 1, klo + 3); ++k) {
+                    const double a = fabs(cdf_at(k) / Z - target);
+                    if (a < best) {
+                        best = a;
+                        ksel = k;
+                    }
                 }
             }
             const double xsel = g.grid_x[ksel];
@@ -299,14 +436,20 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                     err = fabs(g.grid_x[km] - xsel);
                 } else {
                     int jhit = n;
-                    for (int jj = k0; jj < k1; ++jj) {          // jj doubles as the window half-width handled by this thread
-                        const int hi = min(n - 1, ksel + jj), lo = ksel - jj - 1;
-                        const double c = S[hi] - (lo >= 0 ? S[lo] : 0.0);
-                        if (c / Z > mid) {
-                            jhit = jj;
-                            break;
+                    const double mz = mid * Z;
+                    for (int jj = k0; jj < k1 && jhit == n; jj += 8) {     // jj doubles as the window half-width handled by this thread
+                        double hi_[8], lo_[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const int hi = min(n - 1, ksel + jj + q), lo = ksel - (jj + q) - 1;
+                            hi_[q] = S[hi];
+                            lo_[q] = lo >= 0 ? S[lo] : 0.0;
                         }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            if (jj + q < k1 && jhit == n && (hi_[q] - lo_[q]) / Z > mid) jhit = jj + q;
                     }
+                    (void)mz;
                     jhit = -(int)wave_max((double)(-jhit));
                     __syncthreads();
                     if ((tid & 63) == 0) isel[tid >> 6] = jhit;
@@ -347,7 +490,7 @@ hipError_t impute_init_attrs(int device) {
     static unsigned long long done = 0;
     if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)k_imp_right, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 64 * 8)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 66 * 8)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_imp_left, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
@@ -356,7 +499,8 @@ hipError_t impute_init_attrs(int device) {
 void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,
                    int ngrid, int method, int get_wmad, const double* u, double* pbuf, double* sbuf, double* x_out, double* err_out,
                    int64_t i0, int64_t count, hipStream_t s) {
-    const size_t lds_r = (size_t)4 * v.cap * v.cap * sizeof(double);
+    const int cp = (v.cap + 15) & ~15;
+    const size_t lds_r = (size_t)4 * cp * (cp + 2) * sizeof(double);
     hipLaunchKernelGGL(k_imp_right, dim3((unsigned)count), dim3(IMP_T), lds_r, s, v, missing, Rbuf, max_missing, i0);
     ImpArgs g{missing, Rbuf, grid_x, grid_phi, u, pbuf, sbuf, x_out, err_out, max_missing, ngrid, method, get_wmad, i0};
     const size_t lds_l = (size_t)(2 * v.cap + 2 * IMP_MAXD * v.cap + IMP_MAXD) * sizeof(double);
