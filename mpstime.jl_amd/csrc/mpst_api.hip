@@ -52,7 +52,9 @@ struct Ctx {
     int64_t eval_N = 0;
     double* norm2 = nullptr;
     double* norm_scratch = nullptr;   // 3*cap*cap doubles for k_norm2 when they exceed its LDS
-    BigEig* big = nullptr;            // d*cap > MAX_DIM: library eigensolver at the capacity size
+    BigEig* big = nullptr;            // d*cap > MAX_DIM: library eigensolver at the capacity size (fallback of the blocked one)
+    BlockedEig* blk = nullptr;        // d*cap > MAX_DIM: hand-written blocked eigensolver
+    int64_t big_fallbacks = 0;        // bonds on which the blocked solver's verification asked for the library
     bool ws_ready = false;      // training workspace (caches, bond tensor, gradient, eigensolver) allocated for the current sizes
     bool eval_ready = false;    // evaluation scratch (chains, yeval, pred) allocated for max(N_train, N_test)
     bool caches_valid = false;  // LE / RE describe the current MPS: set by mpst_build_caches, cleared by whatever invalidates them
@@ -208,9 +210,13 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->E, (int64_t)dmx * c->cap))) return rc;
     if ((rc = dalloc(c, &c->norm_scratch, (int64_t)3 * c->cap * c->cap))) return rc;
     if (c->big) { big_eig_destroy(c->big); c->big = nullptr; }
+    if (c->blk) { blocked_eig_destroy(c->blk); c->blk = nullptr; }
     if (dm > MAX_DIM) {
         std::string e;
         if ((rc = big_eig_create(&c->big, dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        const char* sel = getenv("MPST_BIG_EIG");
+        if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, dm, &e)))
+            return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
     }
     if ((rc = dalloc(c, &c->eig_ws, (int64_t)eig_workspace_doubles()))) return rc;
     HIPC(c, hipMemset(c->eig_ws, 0, eig_workspace_doubles() * sizeof(double)));
@@ -370,7 +376,13 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
     { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
     if (c->big) {
         ProfScope p(c, K_EIG_TRI);
-        if (launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
+        int need_lib = 1;
+        if (c->blk) {
+            need_lib = launch_eig_blocked(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, c->blk, s);
+            if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
+            if (need_lib) c->big_fallbacks++;
+        }
+        if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
     } else {
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
         { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
@@ -482,6 +494,7 @@ void mpst_destroy(void* ctx) {
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
     if (c->big) big_eig_destroy(c->big);
+    if (c->blk) blocked_eig_destroy(c->blk);
     dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
@@ -1203,7 +1216,7 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[4] = c->cap;
     out[5] = c->nranks;
     out[6] = (c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
-    out[7] = 0;
+    out[7] = (int32_t)std::min<int64_t>(c->big_fallbacks, 1 << 30);
     return 0;
 }
 
@@ -1270,13 +1283,26 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
     HIPC(c, hipMemcpy(dG, G, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice));
     HIPC(c, hipMemset(dws, 0, eig_workspace_doubles() * sizeof(double)));
     if (n > MAX_DIM) {
-        BigEig* be = nullptr;
+        // alg 0: the hand-written blocked solver, library only if its verification asks for it; alg 2: the library alone
         std::string e;
-        if ((rc = big_eig_create(&be, n, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
-        rc = launch_eig_big_raw(dG, n, dl, dE, ds, be, c->stream);
-        (void)hipStreamSynchronize(c->stream);
-        big_eig_destroy(be);
-        if (rc) return fail(c, rc, "rocsolver_dsyevd failed");
+        int need_lib = 1;
+        if (alg != 2) {
+            BlockedEig* bl = nullptr;
+            if ((rc = blocked_eig_create(&bl, n, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+            HIPC(c, hipMemsetAsync(dl, 0, (size_t)n * sizeof(double), c->stream));
+            HIPC(c, hipMemsetAsync(dE, 0, (size_t)n * n * sizeof(double), c->stream));
+            need_lib = launch_eig_blocked(View{}, 0, 0, dG, n, dl, dE, ds, bl, c->stream);
+            blocked_eig_destroy(bl);
+            if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed");
+        }
+        if (need_lib && alg != 3) {
+            BigEig* be = nullptr;
+            if ((rc = big_eig_create(&be, n, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+            rc = launch_eig_big_raw(dG, n, dl, dE, ds, be, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            big_eig_destroy(be);
+            if (rc) return fail(c, rc, "rocsolver_dsyevd failed");
+        }
     } else {
         launch_eig_raw(dG, n, alg, dl, dE, ds, dws, c->stream);
     }

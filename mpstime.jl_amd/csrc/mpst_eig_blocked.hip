@@ -1,0 +1,650 @@
+// Symmetric eigensolver for Gram matrices beyond 128 x 128 (n = d*chi up to DIM_LIMIT): hand-written blocked Householder
+// tridiagonalisation spread over the chip, bisection + twisted factorisation per wanted eigenvalue, reflector
+// back-transformation, verification.  Stand-in for ITensors.svd -> LAPACK gesdd in decomposeBT
+// (src/Training/RealRealHighDimension.jl:166-169,185-188) at the sizes of the reference's documented runs
+// (d = 8..12, chi_max = 37..64: docs/src/hyperparameters.md:65,127,241-245).  rocSOLVER's dsyevd (mpst_eig.hip) stays
+// as the fallback when the on-device verification rejects the result (clustered kept eigenvalues).
+//
+// One dependent launch per Householder step instead of LAPACK's symv / dot / axpy / syr2 sequence (dsytd2):
+//   k_bt_step  (G workgroups) step j.  Every workgroup redundantly finishes the previous step's w (the one global
+//              reduction a step needs, alpha = -tau/2 y^T v, is deferred to here), applies that pending rank-2 update to
+//              row j and forms the reflector; then it updates ITS rows of the trailing matrix with the previous step's
+//              (v, w) and takes their products with the new v in the same pass: the matrix is read and written once per
+//              step, coalesced by rows, and no workgroup waits for another inside a launch.
+//   k_bt_vec   one workgroup per wanted eigenvalue: 256-way multisection Sturm bisection (sturm_count of the small
+//              solver), twisted factorisation (forward / backward pivots on two waves), back-transformation through the
+//              n-2 reflectors.
+//   k_bt_gram / k_bt_decide / k_bt_polish: Z^T Z - I on the MFMA, truncation rule + verdict (or the fallback flag),
+//              up to two Loewdin rounds E = Z (I - D/2) on the MFMA, publication.
+// The live size n is read on the device (bond dimensions never visit the host); launches are laid out for the capacity.
+#include "mpst_internal.h"
+#include <algorithm>
+
+namespace mpst {
+
+constexpr int BT_G = 128;          // workgroups of a Householder step
+constexpr int BT_T = 256;
+constexpr int BT_NMAX = DIM_LIMIT; // 1024
+
+struct BtProblem {
+    const double* G;
+    int n, rows, nspec, K0;
+};
+__device__ __forceinline__ BtProblem bt_resolve(const View& v, int lid, int going_left, const double* rawG, int rawn) {
+    BtProblem p;
+    if (rawn > 0) {
+        p.G = rawG;
+        p.n = rawn;
+        p.rows = rawn;
+        p.nspec = rawn;
+        p.K0 = rawn < CAP_LIMIT ? rawn : CAP_LIMIT;
+    } else {
+        const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
+        const int X = Dl * v.d, Y = v.d * Dr;
+        p.G = v.gram;
+        p.n = going_left ? Y : X;
+        p.rows = v.C * (going_left ? X : Y);
+        p.nspec = p.rows < p.n ? p.rows : p.n;
+        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;
+    }
+    return p;
+}
+
+struct BtBufs {
+    double* A;       // [ncap][ncap] working copy of G, full symmetric storage
+    double* Y;       // [ncap] y of the column just processed
+    double* Vall;    // [ncap][ncap] row j = reflector j
+    double* dd;      // [ncap] diagonal of T
+    double* ee;      // [ncap] off-diagonal of T
+    double* tau;     // [ncap]
+    double* Z;       // [CAP_LIMIT][ncap] eigenvectors of G (row k = vector k)
+    double* lam;     // [CAP_LIMIT]
+    double* res;     // [CAP_LIMIT]
+    double* D;       // [CAP_LIMIT][CAP_LIMIT] Z^T Z - I
+    int32_t* flag;   // [1] 0 ok, 1 = verification failed (host falls back to the library)
+    int32_t* ctl;    // [4] see k_bt_decide
+    int ncap;
+};
+
+__device__ __forceinline__ double bt_block_sum(double x, double* red) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(BT_T) void k_bt_prep(View v, int lid, int going_left, const double* rawG, int rawn, BtBufs b) {
+    const BtProblem pb = bt_resolve(v, lid, going_left, rawG, rawn);
+    const int n = pb.n, ld = b.ncap;
+    for (int64_t i = (int64_t)blockIdx.x * BT_T + threadIdx.x; i < (int64_t)n * n; i += (int64_t)gridDim.x * BT_T) {
+        const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+        b.A[(int64_t)r * ld + c] = pb.G[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *b.flag = 0;
+        if (n == 1) {
+            b.dd[0] = pb.G[0];
+            b.ee[0] = 0.0;
+        }
+    }
+}
+
+// One Householder step per launch (dsytd2 with the rank-2 update of step j-1 folded into step j's pass over the
+// trailing matrix, so the matrix is read and written once per step and the only global reductions are two block sums
+// that every workgroup repeats for itself):
+//   (a) every workgroup: alpha_{j-1} = -tau/2 y^T v, w = y + alpha v of the previous step (y, v complete in memory);
+//   (b) every workgroup: row j of the matrix with that pending update applied, d_j, the reflector v_j, tau_j, e_j;
+//   (c) its own rows r > j: A[r][:] -= v_prev[r] w^T + w[r] v_prev^T (full rows: both triangles stay consistent, and a
+//       row's product with v_j needs nothing from other workgroups), then y_r = tau_j A[r][:] v_j.
+__global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_left, int rawn, BtBufs b, int j) {
+    __shared__ double xs[BT_NMAX];      // row j with the pending update applied, then the reflector v_j
+    __shared__ double vl[BT_NMAX];      // v_{j-1}
+    __shared__ double wl[BT_NMAX];      // w_{j-1}
+    __shared__ double red[4];
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    const int n = pb.n, ld = b.ncap, tid = threadIdx.x;
+    if (j > n - 2) return;
+    // (a)
+    if (j > 0) {
+        const double* vprev = b.Vall + (int64_t)(j - 1) * ld;
+        double s = 0.0;
+        for (int r = j + tid; r < n; r += BT_T) {
+            const double vv = vprev[r];
+            vl[r] = vv;
+            s = fma(b.Y[r], vv, s);
+        }
+        s = bt_block_sum(s, red);
+        const double alpha = -0.5 * b.tau[j - 1] * s;
+        for (int r = j + tid; r < n; r += BT_T) wl[r] = fma(alpha, vl[r], b.Y[r]);
+    } else {
+        for (int r = tid; r < n; r += BT_T) vl[r] = wl[r] = 0.0;
+    }
+    __syncthreads();
+    // (b) row j (= column j: the trailing matrix is kept symmetric in full storage)
+    {
+        const double vj = vl[j], wj = wl[j];
+        const double* arow = b.A + (int64_t)j * ld;
+        for (int c = j + tid; c < n; c += BT_T) xs[c] = fma(-wj, vl[c], fma(-vj, wl[c], arow[c]));
+    }
+    __syncthreads();
+    const double dj = xs[j];
+    double tau = 0.0, beta;
+    {
+        double s = 0.0;
+        for (int r = j + 2 + tid; r < n; r += BT_T) s = fma(xs[r], xs[r], s);
+        s = bt_block_sum(s, red);
+        const double a0 = xs[j + 1];
+        beta = a0;
+        double scale = 0.0;
+        if (s > 0.0) {
+            beta = -copysign(sqrt(fma(a0, a0, s)), a0);
+            tau = (beta - a0) / beta;
+            scale = 1.0 / (a0 - beta);
+        }
+        __syncthreads();
+        for (int r = j + tid; r < n; r += BT_T) {
+            const double vr = r <= j ? 0.0 : (r == j + 1 ? 1.0 : xs[r] * scale);
+            xs[r] = vr;
+            if (blockIdx.x == 0) b.Vall[(int64_t)j * ld + r] = vr;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            b.tau[j] = tau;
+            b.dd[j] = dj;
+            b.ee[j] = beta;
+            if (j == n - 2) {
+                // the last diagonal entry, with the pending update of step n-3 applied
+                b.dd[n - 1] = b.A[(int64_t)(n - 1) * ld + (n - 1)] - 2.0 * vl[n - 1] * wl[n - 1];
+                b.ee[n - 1] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+    if (j == n - 2) return;
+    // (c) own rows: one wave per row, lanes along the row, 4 x 64 columns per round trip
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int m = n - (j + 1);
+        const int per = (m + gridDim.x - 1) / gridDim.x;
+        const int r0 = j + 1 + blockIdx.x * per, r1 = min(n, r0 + per);
+        for (int r = r0 + wave; r < r1; r += 4) {
+            double* arow = b.A + (int64_t)r * ld;
+            const double vr = vl[r], wr = wl[r];
+            double s = 0.0;
+            for (int c0 = j + 1 + lane; c0 < n; c0 += 64 * 4) {
+                double a4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a4[q] = (c0 + 64 * q < n) ? arow[c0 + 64 * q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = c0 + 64 * q;
+                    if (c < n) {
+                        const double a = fma(-wr, vl[c], fma(-vr, wl[c], a4[q]));
+                        arow[c] = a;
+                        s = fma(a, xs[c], s);
+                    }
+                }
+            }
+            s = wave_sum(s);
+            if (lane == 0) b.Y[r] = tau * s;
+        }
+    }
+}
+
+// # eigenvalues of T smaller than x (Sturm sequence, division-free with rescaling), T as (d_j, e_{j-1}^2) pairs in LDS
+__device__ __forceinline__ int bt_sturm(const double* __restrict__ de, int n, double x) {
+    double pp = 1.0, p = de[0] - x;
+    int cnt = p < 0.0 ? 1 : 0;
+    for (int j = 1; j < n; ++j) {
+        const double pn = fma(de[2 * j] - x, p, -de[2 * j + 1] * pp);
+        // sign change between p_{j-1} and p_j (a zero takes the sign opposite to its predecessor)
+        const bool neg_prev = p < 0.0 || (p == 0.0 && pp > 0.0);
+        const bool neg_now = pn < 0.0 || (pn == 0.0 && !neg_prev);
+        cnt += (neg_now != neg_prev) ? 1 : 0;
+        pp = p;
+        p = pn;
+        if ((j & 7) == 0) {
+            int e = __builtin_amdgcn_frexp_exp(p);
+            if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
+            p = __builtin_amdgcn_ldexp(p, -e);
+            pp = __builtin_amdgcn_ldexp(pp, -e);
+        }
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red[4];
+    __shared__ int cnt_s[4];
+    __shared__ int arg_s[4];
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x;
+    if (k >= pb.K0) return;
+    double* de = smem;                  // [n][2] (d_j, e_{j-1}^2)
+    double* es = de + 2 * BT_NMAX;      // [n]
+    double* Dp = es + BT_NMAX;          // [n] forward pivots
+    double* Dm = Dp + BT_NMAX;          // [n] backward pivots
+    double* z = Dm + BT_NMAX;           // [n]
+    for (int j = tid; j < n; j += BT_T) {
+        const double e = j > 0 ? b.ee[j - 1] : 0.0;
+        de[2 * j] = b.dd[j];
+        de[2 * j + 1] = e * e;
+        es[j] = b.ee[j];
+    }
+    __syncthreads();
+    // Gershgorin bounds
+    double gl = 1e300, gu = -1e300;
+    for (int j = tid; j < n; j += BT_T) {
+        const double a = j > 0 ? fabs(es[j - 1]) : 0.0, c = j < n - 1 ? fabs(es[j]) : 0.0;
+        gl = fmin(gl, de[2 * j] - a - c);
+        gu = fmax(gu, de[2 * j] + a + c);
+    }
+    gl = -wave_max(-gl);
+    gu = wave_max(gu);
+    if (lane == 0) {
+        red[wave] = gl;
+    }
+    __syncthreads();
+    gl = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    __syncthreads();
+    if (lane == 0) red[wave] = gu;
+    __syncthreads();
+    gu = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    const double pad = 2.0 * n * 2.3e-16 * tnorm + 1e-300;
+    double lo = gl - pad, hi = gu + pad;
+    // 256-way multisection for the k-th largest eigenvalue
+    const int target = n - 1 - k;
+    for (int it = 0; it < 7; ++it) {
+        const double h = (hi - lo) * (1.0 / (BT_T + 1));
+        const double xq = lo + h * (tid + 1);
+        const int cnt = bt_sturm(de, n, xq);
+        const unsigned long long bal = __ballot(cnt <= target);
+        if (lane == 0) cnt_s[wave] = __popcll(bal);
+        __syncthreads();
+        const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        __syncthreads();
+        const double nlo = jj > 0 ? lo + h * jj : lo;
+        const double nhi = jj < BT_T ? lo + h * (jj + 1) : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    const double lamk = 0.5 * (lo + hi);
+    // twisted factorisation (dlar1v): forward pivots on wave 0, backward pivots on wave 1, one lane each
+    const double pivmin = 1e-290 + 1e-30 * tnorm;
+    if (tid == 0) {
+        double dcur = de[0] - lamk;
+        if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
+        Dp[0] = dcur;
+        for (int j = 1; j < n; ++j) {
+            dcur = (de[2 * j] - lamk) - de[2 * j + 1] / dcur;
+            if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
+            Dp[j] = dcur;
+        }
+    } else if (tid == 64) {
+        double dcur = de[2 * (n - 1)] - lamk;
+        if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
+        Dm[n - 1] = dcur;
+        for (int j = n - 2; j >= 0; --j) {
+            dcur = (de[2 * j] - lamk) - de[2 * (j + 1) + 1] / dcur;
+            if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
+            Dm[j] = dcur;
+        }
+    }
+    __syncthreads();
+    // twist index: argmin |gamma_j|, gamma_j = D+_j + D-_j - (d_j - lambda)
+    double g = 1e300;
+    int gi = 0;
+    for (int j = tid; j < n; j += BT_T) {
+        const double gj = fabs(Dp[j] + Dm[j] - (de[2 * j] - lamk));
+        if (gj < g) {
+            g = gj;
+            gi = j;
+        }
+    }
+    {
+        const double gmin = -wave_max(-g);
+        const unsigned long long msk = __ballot(g == gmin);
+        const int first = __ffsll((long long)msk) - 1;
+        const int idx = __builtin_amdgcn_readlane(gi, first);
+        if (lane == 0) {
+            red[wave] = gmin;
+            arg_s[wave] = idx;
+        }
+    }
+    __syncthreads();
+    int rb = arg_s[0];
+    {
+        double gm = red[0];
+        for (int w = 1; w < 4; ++w)
+            if (red[w] < gm) {
+                gm = red[w];
+                rb = arg_s[w];
+            }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double zc = 1.0;
+        z[rb] = 1.0;
+        for (int j = rb - 1; j >= 0; --j) {
+            zc = -(es[j] / Dp[j]) * zc;
+            z[j] = zc;
+        }
+    } else if (tid == 64) {
+        double zc = 1.0;
+        for (int j = rb + 1; j < n; ++j) {
+            zc = -(es[j - 1] / Dm[j]) * zc;
+            z[j] = zc;
+        }
+    }
+    __syncthreads();
+    double nrm = 0.0;
+    for (int j = tid; j < n; j += BT_T) nrm = fma(z[j], z[j], nrm);
+    nrm = bt_block_sum(nrm, red);
+    const double sc = 1.0 / sqrt(nrm);
+    double ri = 0.0;
+    for (int j = tid; j < n; j += BT_T) {
+        const double zj = z[j] * sc, zp = j > 0 ? z[j - 1] * sc : 0.0, zn = j < n - 1 ? z[j + 1] * sc : 0.0;
+        ri = fmax(ri, fabs((de[2 * j] - lamk) * zj + (j > 0 ? es[j - 1] * zp : 0.0) + (j < n - 1 ? es[j] * zn : 0.0)));
+    }
+    ri = wave_max(ri);
+    __syncthreads();
+    if (lane == 0) red[wave] = ri;
+    __syncthreads();
+    ri = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    for (int j = tid; j < n; j += BT_T) z[j] *= sc;
+    __syncthreads();
+    // back-transformation: z <- H_0 H_1 ... H_{n-3} z, one reflector after the other (rows j+1 .. n-1 of Vall[j])
+    for (int j = n - 3; j >= 0; --j) {
+        const double* vj = b.Vall + (int64_t)j * ld;
+        double vv[4];
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = j + 1 + tid + BT_T * q;
+            vv[q] = r < n ? vj[r] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = j + 1 + tid + BT_T * q;
+            if (r < n) s = fma(vv[q], z[r], s);
+        }
+        s = bt_block_sum(s, red);
+        const double f = b.tau[j] * s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = j + 1 + tid + BT_T * q;
+            if (r < n) z[r] = fma(-f, vv[q], z[r]);
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < n; j += BT_T) b.Z[(int64_t)k * ld + j] = z[j];
+    if (tid == 0) {
+        b.lam[k] = lamk;
+        b.res[k] = tnorm > 0.0 ? ri / tnorm : ri;
+    }
+}
+
+// ---- verification, re-orthonormalisation, publication -------------------------------------------------------------------
+// D = Z^T Z - I for all K0 candidate vectors: one 16 x 16 tile per workgroup, the n rows split over its 4 waves.
+__global__ __launch_bounds__(BT_T) void k_bt_gram(View v, int lid, int going_left, int rawn, BtBufs b, int second) {
+    __shared__ double part[4][256];
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    if (second && !b.ctl[2]) return;
+    const int n = pb.n, ld = b.ncap, K0 = pb.K0;
+    const int tk = (K0 + 15) >> 4;
+    if ((int)blockIdx.x >= tk * tk) return;
+    const int a0 = ((int)blockIdx.x / tk) * 16, c0 = ((int)blockIdx.x % tk) * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int per = ((((n + 3) >> 2) + 3) >> 2) * 4;            // rows per wave, a multiple of 4
+    const int rbeg = wave * per, rend = min(n, rbeg + per);
+    const bool av = a0 + i16 < K0, cv = c0 + i16 < K0;
+    const double* za = b.Z + (int64_t)(a0 + i16) * ld;
+    const double* zc = b.Z + (int64_t)(c0 + i16) * ld;
+    d4 acc = {0, 0, 0, 0};
+    for (int r0 = rbeg; r0 < rend; r0 += 64) {
+        double x[16], y[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 4 * u + kq;
+            x[u] = (av && r < rend) ? za[r] : 0.0;
+            y[u] = (cv && r < rend) ? zc[r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (r0 + 4 * u < rend) acc = mfma_f64(x[u], y[u], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = a0 + kq + 4 * r, c = c0 + i16;
+            const double sum = (part[0][r * 64 + lane] + part[1][r * 64 + lane]) + (part[2][r * 64 + lane] + part[3][r * 64 + lane]);
+            if (a < K0 && c < K0) b.D[(int64_t)a * CAP_LIMIT + c] = sum - (a == c ? 1.0 : 0.0);
+        }
+    }
+}
+
+// truncation rule (as k_eig_fin / k_big_fin), verdict on the kept vectors, publication of the scalars.
+// ctl: [0] vectors to publish, [1] verdict ok, [2] a second Loewdin round is needed, [3] first round needed at all
+__global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_left, const double* rawG, int rawn, BtBufs b,
+                                                   double* rawlam, int32_t* rawinfo, int second) {
+    __shared__ double lam_s[CAP_LIMIT + 2];
+    __shared__ double red[16];
+    const BtProblem pb = bt_resolve(v, lid, going_left, rawG, rawn);
+    const bool raw = rawn > 0;
+    const int tid = threadIdx.x;
+    const int n = pb.n, nspec = pb.nspec, K0 = pb.K0;
+    if (second) {
+        // after the first polish: is the deviation of the polished vectors already at rounding?
+        if (!b.ctl[2]) return;
+        const int kout = b.ctl[0];
+        double emax = 0.0;
+        for (int e = tid; e < kout * kout; e += 512) emax = fmax(emax, fabs(b.D[(int64_t)(e / kout) * CAP_LIMIT + (e % kout)]));
+        emax = wave_max(emax);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = emax;
+        __syncthreads();
+        emax = 0.0;
+        for (int i = 0; i < 8; ++i) emax = fmax(emax, red[i]);
+        if (tid == 0 && !(emax < 1e-6)) {          // the first round should have squared it
+            b.ctl[1] = 0;
+            b.ctl[2] = 0;
+            *b.flag = 1;
+        }
+        return;
+    }
+    double part = 0.0;
+    for (int i = tid; i < n; i += 512) part += pb.G[(size_t)i * n + i];
+    double tr = wave_sum(part);
+    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    __syncthreads();
+    tr = 0.0;
+    for (int i = 0; i < 8; ++i) tr += red[i];
+    if (tid < K0) lam_s[tid] = fmax(b.lam[tid], 0.0);
+    __syncthreads();
+    const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
+    const double cutoff = raw ? -1.0 : v.cutoff;
+    const double inv2 = inv * inv;
+    const double scale0 = tr * inv2;
+    const double scale = scale0 == 0.0 ? 1.0 : scale0;
+    double kept = 0.0;
+    for (int i = 0; i < K0; ++i) kept += lam_s[i] * inv2;
+    int nk = K0;
+    double truncerr = scale0 - kept;
+    if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
+    if (nspec > 1) {
+        while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= cutoff * scale) {
+            truncerr += lam_s[nk - 1] * inv2;
+            --nk;
+        }
+    }
+    const int kout = raw ? K0 : nk;
+    double rmax = tid < kout ? b.res[tid] : 0.0;
+    rmax = wave_max(rmax);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = rmax;
+    __syncthreads();
+    rmax = 0.0;
+    for (int i = 0; i < 8; ++i) rmax = fmax(rmax, red[i]);
+    __syncthreads();
+    double emax = 0.0;
+    for (int e = tid; e < kout * kout; e += 512) emax = fmax(emax, fabs(b.D[(int64_t)(e / kout) * CAP_LIMIT + (e % kout)]));
+    emax = wave_max(emax);
+    if ((tid & 63) == 0) red[tid >> 6] = emax;
+    __syncthreads();
+    emax = 0.0;
+    for (int i = 0; i < 8; ++i) emax = fmax(emax, red[i]);
+    // vectors of eigenvalues close to the cutoff come out of the twisted factorisation orthogonal to ~1e-6 only (two
+    // Loewdin rounds take them to rounding); |D| > 1e-3 means a genuine cluster -> library solver
+    const bool ok = rmax < 1e-8 && rmax == rmax && emax < 1e-3 && emax == emax;
+    if (tid == 0) {
+        b.ctl[0] = kout;
+        b.ctl[1] = ok ? 1 : 0;
+        b.ctl[2] = (ok && emax >= 1e-8) ? 1 : 0;
+        b.ctl[3] = (ok && emax > 1e-14) ? 1 : 0;
+        *b.flag = ok ? 0 : 1;
+    }
+    if (raw) {
+        if (tid < K0) rawlam[tid] = lam_s[tid];
+        if (tid == 0) *rawinfo = ok ? -3 : -4;
+    } else if (ok) {
+        if (tid < K0) v.lam[tid] = lam_s[tid];
+        if (tid == 0) {
+            bool bad = !(tr == tr) || tr > 1e300;
+            for (int i = 0; i < K0; ++i) {
+                const double P = lam_s[i] * inv2;
+                if (!(P == P) || P > 1e300) bad = true;
+            }
+            v.sc->n_keep = nk;
+            v.sc->n_spec = K0;
+            v.sc->bt_norm2 = tr;
+            v.sc->inv_norm = inv;
+            v.sc->eig_sweeps = 0;
+            if (bad) v.sc->status = MPST_ERR_SVD;
+            v.chi[lid + 1] = nk;
+        }
+    }
+}
+
+// E = Z (I - D/2) over the kept vectors (Loewdin: squares the deviation from orthonormality without leaving the subspace):
+// 16 x 16 tiles of E on the MFMA, A operand = Z^T, B operand = -D/2 + I.  second = 1: the input is the first round's E.
+__global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_left, int rawn, BtBufs b, double* rawE, int second) {
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    if (!b.ctl[1] || (second && !b.ctl[2])) return;
+    const bool raw = rawn > 0;
+    const int n = pb.n, ld = b.ncap, kout = b.ctl[0];
+    const bool corr = second ? true : (b.ctl[3] != 0);
+    double* Eout = raw ? rawE : v.E;
+    const int ldE = raw ? n : v.cap;
+    const int tn = (n + 15) >> 4, tk = (kout + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    for (int t = blockIdx.x * 4 + wave; t < tn * tk; t += gridDim.x * 4) {
+        const int c0 = (t / tk) * 16, k0 = (t % tk) * 16;
+        const int c = c0 + i16, kk = k0 + i16;
+        d4 acc = {0, 0, 0, 0};
+        if (corr) {
+            for (int q0 = 0; q0 < kout; q0 += 64) {
+                double x[16], y[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k2 = q0 + 4 * u + kq;
+                    x[u] = (c < n && k2 < kout) ? b.Z[(int64_t)k2 * ld + c] : 0.0;
+                    y[u] = (kk < kout && k2 < kout) ? -0.5 * b.D[(int64_t)k2 * CAP_LIMIT + kk] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (q0 + 4 * u < kout) acc = mfma_f64(x[u], y[u], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int cr = c0 + kq + 4 * r, kc = k0 + i16;
+            if (cr < n && kc < kout) Eout[(size_t)cr * ldE + kc] = b.Z[(int64_t)kc * ld + cr] + acc[r];
+        }
+    }
+}
+
+// second round: the polished vectors become the input (Z <- E^T)
+__global__ __launch_bounds__(BT_T) void k_bt_copyback(View v, int lid, int going_left, int rawn, BtBufs b, const double* rawE) {
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    if (!b.ctl[2]) return;
+    const bool raw = rawn > 0;
+    const int n = pb.n, ld = b.ncap, kout = b.ctl[0];
+    const double* E = raw ? rawE : v.E;
+    const int ldE = raw ? n : v.cap;
+    for (int64_t e = (int64_t)blockIdx.x * BT_T + threadIdx.x; e < (int64_t)n * kout; e += (int64_t)gridDim.x * BT_T) {
+        const int kk = (int)(e / n), c = (int)(e - (int64_t)kk * n);
+        b.Z[(int64_t)kk * ld + c] = E[(size_t)c * ldE + kk];
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+struct BlockedEig {
+    BtBufs b{};
+    int32_t* host_flag = nullptr;
+};
+
+static size_t bt_vec_lds() { return (size_t)6 * BT_NMAX * sizeof(double); }
+
+int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
+    BlockedEig* e = new BlockedEig();
+    e->b.ncap = ncap;
+    auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess; };
+    const size_t n1 = ncap, n2 = (size_t)ncap * ncap;
+    bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, n1) && al(&e->b.Vall, n2) &&
+              al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
+              al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
+              hipHostMalloc((void**)&e->host_flag, sizeof(int32_t)) == hipSuccess;
+    if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, n1 * sizeof(double)) == hipSuccess;
+    if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
+                 true;
+    if (!ok) {
+        if (err) *err = "allocation of the blocked eigensolver's workspace failed";
+        blocked_eig_destroy(e);
+        return MPST_ERR_NOMEM;
+    }
+    *out = e;
+    return 0;
+}
+void blocked_eig_destroy(BlockedEig* e) {
+    if (!e) return;
+    double* ps[] = {e->b.A, e->b.D, e->b.Y, e->b.Vall, e->b.dd, e->b.ee, e->b.tau, e->b.Z, e->b.lam, e->b.res};
+    for (double* p : ps)
+        if (p) (void)hipFree(p);
+    if (e->b.flag) (void)hipFree(e->b.flag);
+    if (e->b.ctl) (void)hipFree(e->b.ctl);
+    if (e->host_flag) (void)hipHostFree(e->host_flag);
+    delete e;
+}
+
+// enqueue the whole solve; returns 1 if the on-device verification asks for the library fallback, 0 if E / lam / chi are
+// published, < 0 on a runtime error.  Synchronises the stream once (the verdict is read by the host).
+int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
+                       int32_t* rawinfo, BlockedEig* e, hipStream_t s) {
+    const BtBufs& b = e->b;
+    const int ncap = rawn > 0 ? rawn : b.ncap;
+    hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
+    for (int j = 0; j <= ncap - 2; ++j) hipLaunchKernelGGL(k_bt_step, dim3(BT_G), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
+    const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
+    hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
+    const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;
+    for (int second = 0; second < 2; ++second) {
+        if (second) hipLaunchKernelGGL(k_bt_copyback, dim3(64), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, (const double*)rawE);
+        hipLaunchKernelGGL(k_bt_gram, dim3(tk * tk), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, second);
+        hipLaunchKernelGGL(k_bt_decide, dim3(1), dim3(512), 0, s, v, lid, going_left, rawG, rawn, b, rawlam, rawinfo, second);
+        hipLaunchKernelGGL(k_bt_polish, dim3(std::max(1, std::min(256, (tn * tk + 3) / 4))), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, rawE, second);
+    }
+    if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+    if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
+    if (hipGetLastError() != hipSuccess) return MPST_ERR_DEVICE;
+    return *e->host_flag ? 1 : 0;
+}
+
+}  // namespace mpst

@@ -309,6 +309,13 @@ void launch_norm2(const View& v, double* out_norm2, double* gscratch /* 3*cap*ca
 void launch_scale_sites(const View& v, const double* norm2, hipStream_t s);
 void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hipStream_t s);
 
+// hand-written blocked eigensolver for d*chi_max > MAX_DIM (mpst_eig_blocked.hip); returns 1 when its on-device
+// verification asks for the library fallback
+struct BlockedEig;
+int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);
+void blocked_eig_destroy(BlockedEig* e);
+int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
+                       int32_t* rawinfo, BlockedEig* e, hipStream_t s);
 // imputation engine (mpst_impute.hip)
 hipError_t impute_init_attrs(int device);
 void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,

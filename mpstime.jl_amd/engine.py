@@ -238,7 +238,7 @@ class SweepEngine:
         out = (C.c_int32 * 8)()
         self._chk(self.lib.mpst_get_info(self.ctx, out))
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
-                "ranks": out[5], "graph": bool(out[6])}
+                "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7]}
 
     def eig_phases(self):
         us = np.zeros(6)
