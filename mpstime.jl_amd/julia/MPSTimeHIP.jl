@@ -19,7 +19,7 @@ const LIB = get(ENV, "MPSTIME_HIP_LIB", "libmpstime_hip.so")
 struct MpstOptions            # mpst_options, field for field
     chi_max::Int32; update_iters::Int32; loss::Int32; optimiser::Int32
     rescale_before::Int32; rescale_after::Int32; train_classes_separately::Int32
-    svd_alg::Int32; rebuild_caches::Int32; reserved0::Int32
+    svd_alg::Int32; rebuild_caches::Int32; track_cost::Int32
     eta::Float64; cutoff::Float64
 end
 struct MpstSweepStats
