@@ -19,6 +19,7 @@
 // The live size n is read on the device (bond dimensions never visit the host); launches are laid out for the capacity.
 #include "mpst_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace mpst {
 
@@ -631,7 +632,13 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     const BtBufs& b = e->b;
     const int ncap = rawn > 0 ? rawn : b.ncap;
     hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
-    for (int j = 0; j <= ncap - 2; ++j) hipLaunchKernelGGL(k_bt_step, dim3(BT_G), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
+    static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
+    for (int j = 0; j <= ncap - 2; ++j) {
+        // fewer workgroups once the trailing matrix is small: the redundant prologue is paid per workgroup
+        const int m = ncap - 1 - j;
+        const int g = std::max(1, std::min(bt_g, (m + 3) / 4));
+        hipLaunchKernelGGL(k_bt_step, dim3(g), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
+    }
     const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
     hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
     const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;

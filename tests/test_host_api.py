@@ -163,3 +163,40 @@ def test_per_sweep_loss_and_optimiser_and_save_load(tmp_path):
     mt.save_trained_mps(tmp_path / "m.npz", tm)
     back = mt.load_trained_mps(tmp_path / "m.npz")
     assert back == tm and back.opts == o and np.array_equal(back.train_data.phi, td.phi)
+
+
+def test_imputation_host_helpers():
+    """Host side of the imputation API: invert_test_transform undoes transform_test_data (utils.jl:202-334), the block
+    MAR mechanism (missing_data_mechanisms.jl:140-147), kNN_impute (imputation.jl:215-254), the grid of candidate values."""
+    import numpy as np
+    from mpstime_jl_amd.encodings import model_encoding, transform_test_data, transform_train_data
+    rng = np.random.default_rng(0)
+    Xtr = rng.normal(0.3, 2.0, (40, 12))
+    Xte = rng.normal(0.3, 2.5, (7, 12))
+    Xte[2, 5], Xte[4, 1] = 40.0, -40.0           # beyond anything in the training data: these series need the out-of-bounds rescale
+    opts = mt.MPSOptions(d=4, verbosity=-1)
+    enc = model_encoding(opts.encoding)
+    _, norms = transform_train_data(Xtr, opts, enc.range)
+    Xs, oob = transform_test_data(Xte, norms, opts, enc.range)
+    assert len(oob) > 0 and Xs.min() >= -1 and Xs.max() <= 1
+    back = mt.invert_test_transform(Xs, oob, norms, opts, enc.range)
+    ok = np.ones_like(Xte, dtype=bool)
+    ok[2, 5] = ok[4, 1] = False                  # saturated by the sigmoid: not invertible to 1e-9, everything else is
+    assert np.allclose(back[ok], Xte[ok], rtol=1e-7, atol=1e-7)
+    xc, idx = mt.mar(np.arange(20.0), 0.25, np.random.default_rng(1))
+    assert len(idx) == 5 and np.all(np.diff(idx) == 1) and np.all(np.isnan(xc[idx])) and np.isfinite(np.delete(xc, idx)).all()
+    with pytest.raises(ValueError):
+        mt.mar(np.arange(4.0), 1.5)
+    W = mt.generate_startingMPS(3, 12, 4, 2, 0)
+    ytr = np.array([0] * 20 + [1] * 20)
+    Xs_tr, _ = transform_train_data(Xtr, opts, enc.range)
+    td = mt.encode_dataset(Xtr, Xs_tr, ytr, enc, 4, {0: 0, 1: 1})
+    imp = mt.init_imputation_problem(mt.TrainedMPS(W, opts, td), Xte, np.array([0, 1, 0, 1, 0, 1, 0]), dx=1e-3, verbosity=0)
+    assert len(imp.x_guess_range.xvals) == 2001 and abs(imp.x_guess_range.xvals[-1] - 1.0) < 1e-12
+    assert imp.x_guess_range.xvals_enc.shape == (2001, 4) and imp.class_map == {0: 0, 1: 1}
+    nn = mt.kNN_impute(imp, 1, 0, [3, 4, 5], k=2)
+    known = np.setdiff1d(np.arange(12), [3, 4, 5])
+    d2 = np.mean((Xtr[20:][:, known] - Xte[1][known]) ** 2, axis=1)
+    assert np.array_equal(nn[0], Xtr[20:][np.argmin(d2)]) and len(nn) == 2
+    with pytest.raises(ValueError, match="Invalid method"):
+        mt.impute_dataset(imp, np.zeros((7, 12), dtype=bool), "bogus")
