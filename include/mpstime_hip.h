@@ -203,14 +203,35 @@ int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[
  *                   the encoded values the data set holds at those sites are ignored
  *   grid_x[ngrid]   the candidate values x_k (range(guess_range...; step = dx), imputation.jl:90) and
  *   grid_phi[ngrid][d]  their encoded states (time-independent encodings, :100-106)
- *   method          MPST_IMPUTE_MEDIAN (+ weighted median absolute deviation when get_wmad), MPST_IMPUTE_MODE,
- *                   MPST_IMPUTE_QUANTILE: inverse-transform sampling with the caller's uniform numbers u[N][T]
- *                   (impute_ITS without rejection; the reference draws them from a MersenneTwister)
- *   x_out[N][T]     imputed value at every missing site (in the encoding's domain; 0 elsewhere), err_out[N][T] the WMAD
- * Forward imputation order only; chi_max <= 64, d <= 16, real fp64. */
-enum { MPST_IMPUTE_MEDIAN = 0, MPST_IMPUTE_MODE = 1, MPST_IMPUTE_QUANTILE = 2 };
+ *   o->method       MPST_IMPUTE_MEDIAN (+ weighted median absolute deviation when get_err), MPST_IMPUTE_MODE,
+ *                   MPST_IMPUTE_QUANTILE: inverse-transform sampling with the caller's uniform numbers (impute_ITS with
+ *                   rejection_threshold = :none; the reference draws them from a MersenneTwister),
+ *                   MPST_IMPUTE_MEAN: expectation value (+ standard deviation when get_err), impute_mean :232-265 with
+ *                   get_mean_from_rdm, sampling_utils.jl:66-96; the state the chain is re-conditioned on is the encoding
+ *                   of the expectation value itself, evaluated on the device: Legendre bases only (mean_basis =
+ *                   MPST_BASIS_LEGENDRE / MPST_BASIS_LEGENDRE_NO_NORM),
+ *                   MPST_IMPUTE_ITS_REJECT: get_sample_from_rdm with a rejection threshold (:271-296): median and WMAD
+ *                   first, then up to max_trials inverse-transform samples, the first one within
+ *                   rejection_threshold * WMAD of the median is kept (the last one drawn if none is); err_out = WMAD
+ *   o->order        MPST_IMPUTE_FORWARDS / MPST_IMPUTE_BACKWARDS (impute_order, MPS_methods.jl:107-121): the missing
+ *                   sites are visited left to right / right to left, each conditioned on the ones already imputed
+ *   u[N][T][max_trials]  uniform numbers in [0, 1) for the two sampling methods (max_trials = 1 for QUANTILE), else NULL
+ *   x_out[N][T]     imputed value at every missing site (in the encoding's domain; 0 elsewhere), err_out[N][T] the
+ *                   uncertainty measure of the method (0 where there is none)
+ * chi_max <= 64, d <= 16, real fp64. */
+enum { MPST_IMPUTE_MEDIAN = 0, MPST_IMPUTE_MODE = 1, MPST_IMPUTE_QUANTILE = 2, MPST_IMPUTE_MEAN = 3, MPST_IMPUTE_ITS_REJECT = 4 };
+enum { MPST_IMPUTE_FORWARDS = 0, MPST_IMPUTE_BACKWARDS = 1 };
+typedef struct {
+    int32_t method;
+    int32_t order;
+    int32_t get_err;                /* get_wmad (median) / get_std (mean) */
+    int32_t max_trials;             /* ITS_REJECT only (reference default 10) */
+    int32_t mean_basis;             /* MEAN only */
+    int32_t reserved;
+    double  rejection_threshold;    /* ITS_REJECT only */
+} mpst_impute_opts;
 int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
-                 int32_t method, int32_t get_wmad, const double* u, double* x_out, double* err_out, double* seconds);
+                 const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds);
 
 /* normalize!(W), RealRealHighDimension.jl:852. */
 int  mpst_normalize(void* ctx);

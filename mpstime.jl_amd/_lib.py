@@ -49,6 +49,11 @@ BASIS = {"Legendre_Norm": 0, "Legendre_No_Norm": 1}      # canonical names (opti
 
 # every symbol include/mpstime_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
+class ImputeOpts(C.Structure):          # mpst_impute_opts
+    _fields_ = [("method", C.c_int32), ("order", C.c_int32), ("get_err", C.c_int32), ("max_trials", C.c_int32),
+                ("mean_basis", C.c_int32), ("reserved", C.c_int32), ("rejection_threshold", C.c_double)]
+
+
 SYMBOLS = {
     "mpst_version": (C.c_int, []),
     "mpst_last_error": (C.c_char_p, [_vp]),
@@ -74,7 +79,7 @@ SYMBOLS = {
     "mpst_eval": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, C.POINTER(_i64)]),
     "mpst_classify": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _dp]),
     "mpst_normalize": (C.c_int, [_vp]),
-    "mpst_impute": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint8), _dp, _dp, _i32, _i32, _i32, _dp, _dp, _dp, _dp]),
+    "mpst_impute": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint8), _dp, _dp, _i32, C.POINTER(ImputeOpts), _dp, _dp, _dp, _dp]),
     "mpst_selftest_mfma": (C.c_int, [_vp, _dp, _dp, _i32, _dp]),
     "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),

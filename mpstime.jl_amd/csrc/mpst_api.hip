@@ -1107,13 +1107,22 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
 }
 
 int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
-                int32_t method, int32_t get_wmad, const double* u, double* x_out, double* err_out, double* seconds) {
+                const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;
     if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
-    if (!missing || !grid_x || !grid_phi || !x_out || ngrid < 2) return fail(c, MPST_ERR_INVALID, "NULL argument or fewer than 2 grid values");
-    if (method < MPST_IMPUTE_MEDIAN || method > MPST_IMPUTE_QUANTILE) return fail(c, MPST_ERR_INVALID, "unknown imputation method");
-    if (method == MPST_IMPUTE_QUANTILE && !u) return fail(c, MPST_ERR_INVALID, "the quantile method needs the uniform numbers u[N][T]");
+    if (!missing || !grid_x || !grid_phi || !x_out || !o || ngrid < 2) return fail(c, MPST_ERR_INVALID, "NULL argument or fewer than 2 grid values");
+    const int method = o->method;
+    if (method < MPST_IMPUTE_MEDIAN || method > MPST_IMPUTE_ITS_REJECT) return fail(c, MPST_ERR_INVALID, "unknown imputation method");
+    if (o->order != MPST_IMPUTE_FORWARDS && o->order != MPST_IMPUTE_BACKWARDS) return fail(c, MPST_ERR_INVALID, "impute_order must be forwards (0) or backwards (1)");
+    const bool sampling = method == MPST_IMPUTE_QUANTILE || method == MPST_IMPUTE_ITS_REJECT;
+    if (sampling && !u) return fail(c, MPST_ERR_INVALID, "the sampling methods need the uniform numbers u[N][T][max_trials]");
+    const int ntrial = method == MPST_IMPUTE_ITS_REJECT ? o->max_trials : 1;
+    if (ntrial < 1) return fail(c, MPST_ERR_INVALID, "max_trials must be at least 1");
+    if (method == MPST_IMPUTE_ITS_REJECT && !(o->rejection_threshold >= 0.0)) return fail(c, MPST_ERR_INVALID, "rejection_threshold must be non-negative");
+    if (method == MPST_IMPUTE_MEAN && o->mean_basis != MPST_BASIS_LEGENDRE && o->mean_basis != MPST_BASIS_LEGENDRE_NO_NORM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "the mean method re-encodes on the device: Legendre bases only");
+    const int get_wmad = o->get_err;
     if (!c->have_mps || !c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options / mpst_set_mps must be called first");
     const DataSet& s = c->ds[which];
     if (s.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
@@ -1145,17 +1154,18 @@ int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid
         if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, chunk * maxm * c->cap * c->cap)) || (rc = dalloc(c, &dgx, ngrid)) ||
             (rc = dalloc(c, &dgp, (int64_t)ngrid * d)) || (rc = dalloc(c, &dp, chunk * ngrid)) || (rc = dalloc(c, &dS, chunk * ngrid)) ||
             (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
-        if (u && (rc = dalloc(c, &du, N * T))) return rc;
+        if (sampling && (rc = dalloc(c, &du, N * T * ntrial))) return rc;
         HIPC(c, hipMemcpy(dmiss, missing, (size_t)N * T, hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgx, grid_x, (size_t)ngrid * sizeof(double), hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgp, grid_phi, (size_t)ngrid * d * sizeof(double), hipMemcpyHostToDevice));
-        if (u) HIPC(c, hipMemcpy(du, u, (size_t)N * T * sizeof(double), hipMemcpyHostToDevice));
+        if (sampling) HIPC(c, hipMemcpy(du, u, (size_t)N * T * ntrial * sizeof(double), hipMemcpyHostToDevice));
         HIPC(c, hipMemset(dx, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
         View v = make_view(c, which);
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
-        for (int64_t i0 = 0; i0 < N; i0 += chunk)
-            launch_impute(v, dmiss, dR, maxm, dgx, dgp, ngrid, method, get_wmad, du, dp, dS, dx, de, i0, std::min(chunk, N - i0), c->stream);
+        const ImputeParams q{dmiss, dR, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, get_wmad, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
+                             ntrial, o->mean_basis, o->rejection_threshold};
+        for (int64_t i0 = 0; i0 < N; i0 += chunk) launch_impute(v, q, i0, std::min(chunk, N - i0), c->stream);
         HIPC(c, hipEventRecord(c->ev_stop, c->stream));
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventSynchronize(c->ev_stop));

@@ -17,6 +17,9 @@
 //                 reference computes: rdm is a plain Matrix there, so get_conditional_probability(state, rdm) takes the
 //                 (state, A::Matrix) method, sampling_utils.jl:19-41, and returns |state' * rdm|^2, not state' rdm state), block-wide prefix sums, selection,
 //                 weighted median absolute deviation, L <- phi* (L W_j).
+// Both imputation orders of the reference (impute_order = :forwards / :backwards, MPS_methods.jl:107-121): backwards is
+// the mirror image - the matrices come from the left, the vector from the right - and runs through the same kernels with
+// the two bond indices of every site tensor swapped (`rev`).
 // Real fp64; chi <= 64 (four chi x chi matrices in LDS), d <= 16.
 #include "mpst_internal.h"
 #include <type_traits>
@@ -47,6 +50,25 @@ __device__ __forceinline__ const double* class_site(const View& v, int j, int cl
     if (j == *v.label_site) W += (int64_t)cls * Dl * v.d * Dr;
     return W;
 }
+// A site as seen by a pass that enters through bond `in` and leaves through bond `out`: element (i, s, o).  Forwards the
+// left pass enters from the left (in = left bond), backwards from the right; the matrix pass is the opposite.
+struct SiteView {
+    const double* W;
+    int Din, Dout;
+    int64_t si, ss, so;      // strides of the (in, s, out) indices
+};
+__device__ __forceinline__ SiteView site_view(const View& v, int j, int cls, bool in_is_left) {
+    const int Dl = v.chi[j], Dr = v.chi[j + 1];
+    SiteView sv;
+    sv.W = class_site(v, j, cls, Dl, Dr);
+    sv.ss = Dr;
+    if (in_is_left) {
+        sv.Din = Dl; sv.Dout = Dr; sv.si = (int64_t)v.d * Dr; sv.so = 1;
+    } else {
+        sv.Din = Dr; sv.Dout = Dl; sv.si = 1; sv.so = (int64_t)v.d * Dr;
+    }
+    return sv;
+}
 
 // ---- right environments ------------------------------------------------------------------------------------------------
 // C (M x N, row stride ld) (+)= A (M x K) * B, all in LDS, 16 x 16 tiles on the fp64 MFMA shared out over the 4 waves.
@@ -76,7 +98,7 @@ __device__ __forceinline__ void lds_mm(double* __restrict__ Cm, const double* __
 }
 
 __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __restrict__ missing, double* __restrict__ Rbuf,
-                                                     int max_missing, int64_t i0) {
+                                                     int max_missing, int64_t i0, int rev) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
     const int64_t i = i0 + blockIdx.x;          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
@@ -89,10 +111,10 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
     const int cp = (cm + 15) & ~15;            // matrices are kept zero-padded to a multiple of 16 rows / columns
     const int ld = cp + 2;                     // + 2: the 16 rows an MFMA operand read touches land on different banks
     const int msz = cp * ld;
-    double* Ra = smem;                 // current R
-    double* Rb = Ra + msz;             // next R
-    double* Ms = Rb + msz;             // M_j or W_j[s]
-    double* T1 = Ms + msz;             // (M or W_s) * R
+    double* Ra = smem;                 // current environment matrix
+    double* Rb = Ra + msz;             // next one
+    double* Ms = Rb + msz;             // M_j or W_j[s] as an (out x in) matrix of this pass
+    double* T1 = Ms + msz;             // Ms * R
     for (int e = tid; e < 4 * msz; e += IMP_T) smem[e] = 0.0;
     __syncthreads();
     double* R = Ra;
@@ -100,64 +122,71 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
     if (tid == 0) R[0] = 1.0;
     __syncthreads();
     int slot = 0;
-    for (int j = T - 1; j >= 0; --j) {
-        const int Dl = v.chi[j], Dr = v.chi[j + 1];
+    for (int step = 0; step < T; ++step) {
+        // forwards imputation: this pass runs right to left and a site is entered through its RIGHT bond
+        const int j = rev ? step : T - 1 - step;
+        const SiteView sv = site_view(v, j, cls, rev != 0);
+        const int Di = sv.Din, Do = sv.Dout;        // R is Di x Di, the new one Do x Do
         const bool miss = mi[j] != 0;
         if (miss) {
-            // the environment of the sites right of j is what site j's density matrix needs
+            // the environment of the sites beyond j is what site j's density matrix needs
             double* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm;
-            for (int e = tid; e < Dr * Dr; e += IMP_T) out[e] = R[(e / Dr) * ld + (e % Dr)];
+            for (int e = tid; e < Di * Di; e += IMP_T) out[e] = R[(e / Di) * ld + (e % Di)];
             ++slot;
-            if (slot == nm) break;                 // nothing left of the first missing site needs a right environment
+            if (slot == nm) break;                 // nothing beyond the last missing site of this pass needs an environment
         }
-        const double* W = class_site(v, j, cls, Dl, Dr);
         const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
         const int ns = miss ? d : 1;
+        // consecutive threads walk the contiguous bond index of the stored tensor (its right bond)
+        const bool in_fast = sv.si == 1;
+        const int Df = in_fast ? Di : Do;
         for (int s = 0; s < ns; ++s) {
-            // Ms = M_j (known) or W_j[s] (missing); 8 elements per thread per round trip, rows contiguous in b
-            for (int e0 = tid; e0 < Dl * Dr; e0 += 8 * IMP_T) {
+            // Ms[o][i] = M_j (known) or W_j[s] (missing); 8 elements per thread per round trip
+            for (int e0 = tid; e0 < Di * Do; e0 += 8 * IMP_T) {
                 double acc[8];
+                int64_t off[8];
+                int dst[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * IMP_T;
+                    const int slow = e / Df, fast = e - slow * Df;
+                    const int ii = in_fast ? fast : slow, oo = in_fast ? slow : fast;
+                    off[q] = (int64_t)ii * sv.si + (int64_t)oo * sv.so;
+                    dst[q] = oo * ld + ii;
+                    acc[q] = 0.0;
+                }
                 if (miss) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int e = e0 + q * IMP_T;
-                        if (e < Dl * Dr) acc[q] = W[((int64_t)(e / Dr) * d + s) * Dr + (e % Dr)];
-                    }
+                    for (int q = 0; q < 8; ++q)
+                        if (e0 + q * IMP_T < Di * Do) acc[q] = sv.W[off[q] + (int64_t)s * sv.ss];
                 } else {
                     for (int qq = 0; qq < d; ++qq) {
                         const double pq = ph[qq];
                         double w[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int e = e0 + q * IMP_T;
-                            w[q] = (e < Dl * Dr) ? W[((int64_t)(e / Dr) * d + qq) * Dr + (e % Dr)] : 0.0;
-                        }
+                        for (int q = 0; q < 8; ++q) w[q] = (e0 + q * IMP_T < Di * Do) ? sv.W[off[q] + (int64_t)qq * sv.ss] : 0.0;
 #pragma unroll
                         for (int q = 0; q < 8; ++q) acc[q] = fma(pq, w[q], acc[q]);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = e0 + q * IMP_T;
-                    if (e < Dl * Dr) Ms[(e / Dr) * ld + (e % Dr)] = acc[q];
-                }
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q * IMP_T < Di * Do) Ms[dst[q]] = acc[q];
             }
             __syncthreads();
-            lds_mm(T1, Ms, R, Dl, Dr, Dr, ld, false, false);          // T1 = Ms * R
+            lds_mm(T1, Ms, R, Do, Di, Di, ld, false, false);          // T1 = Ms * R
             __syncthreads();
-            lds_mm(Rn, T1, Ms, Dl, Dl, Dr, ld, true, s > 0);           // Rn (+)= T1 * Ms^T
+            lds_mm(Rn, T1, Ms, Do, Do, Di, ld, true, s > 0);           // Rn (+)= T1 * Ms^T
             __syncthreads();
         }
         // rescale by the trace (every density below is scale-free), clear what the next site must find zero, swap
         double tr = 0.0;
-        for (int a = tid; a < Dl; a += IMP_T) tr += Rn[a * ld + a];
+        for (int a = tid; a < Do; a += IMP_T) tr += Rn[a * ld + a];
         tr = blk_sum(tr, red);
         const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
         for (int e = tid; e < cp * cp; e += IMP_T) {
             const int a = e / cp, b2 = e - a * cp;
-            Rn[a * ld + b2] = (a < Dl && b2 < Dl) ? Rn[a * ld + b2] * sc : 0.0;
+            Rn[a * ld + b2] = (a < Do && b2 < Do) ? Rn[a * ld + b2] * sc : 0.0;
             Ms[a * ld + b2] = 0.0;
             T1[a * ld + b2] = 0.0;
         }
@@ -168,20 +197,22 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
     }
 }
 
-// ---- left sweep with the imputation itself -------------------------------------------------------------------------------
+// ---- the sweep with the imputation itself ---------------------------------------------------------------------------------
 struct ImpArgs {
     const uint8_t* missing;     // [N][T]
-    const double* Rbuf;         // [N][max_missing][cap*cap]
+    const double* Rbuf;         // [chunk][max_missing][cap*cap]
     const double* grid_x;       // [ngrid]
     const double* grid_phi;     // [ngrid][d]
-    const double* u;            // [N][T] quantile targets (method 2) or null
-    double* pbuf;               // [N][ngrid] scratch: p_k
-    double* sbuf;               // [N][ngrid] scratch: prefix sums S_k
+    const double* u;            // [N][T][ntrial] uniform numbers (quantile / ITS) or null
+    double* pbuf;               // [chunk][ngrid] scratch: p_k
+    double* sbuf;               // [chunk][ngrid] scratch: prefix sums S_k
     double* x_out;              // [N][T]
     double* err_out;            // [N][T]
-    int max_missing, ngrid, method, get_wmad;
+    int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
+    double reject_thr;
     int64_t i0;                 // first instance of this chunk
 };
+enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 
 __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -210,64 +241,64 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
     if (tid == 0) L[0] = 1.0;
     __syncthreads();
     int seen = 0;
-    for (int j = 0; j < T; ++j) {
-        const int Dl = v.chi[j], Dr = v.chi[j + 1];
+    for (int step = 0; step < T; ++step) {
+        const int j = g.rev ? T - 1 - step : step;
+        const SiteView sv = site_view(v, j, cls, g.rev == 0);
+        const int Di = sv.Din, Do = sv.Dout;
         const bool miss = mi[j] != 0;
-        const double* W = class_site(v, j, cls, Dl, Dr);
-        // LW[s][b] = sum_a L[a] W[a][s][b] for both kinds of site (consecutive threads = consecutive (s, b): every load of
-        // the 8 issued per round trip is coalesced); a known site then contracts s with its encoded value
-        for (int e = tid; e < d * Dr; e += IMP_T) {
-            const int s_ = e / Dr, b = e - s_ * Dr;
-            const double* wp = W + (int64_t)s_ * Dr + b;
-            const int64_t astr = (int64_t)d * Dr;
+        // LW[s][o] = sum_i L[i] W(i, s, o) for both kinds of site; a known site then contracts s with its encoded value.
+        // Forwards consecutive threads are consecutive o (contiguous in memory), backwards the 8 loads of a thread are.
+        for (int e = tid; e < d * Do; e += IMP_T) {
+            const int s_ = e / Do, o = e - s_ * Do;
+            const double* wp = sv.W + (int64_t)s_ * sv.ss + (int64_t)o * sv.so;
             double t = 0.0;
-            for (int a0 = 0; a0 < Dl; a0 += 8) {
+            for (int a0 = 0; a0 < Di; a0 += 8) {
                 double w[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = (a0 + q < Dl) ? wp[(int64_t)(a0 + q) * astr] : 0.0;
+                for (int q = 0; q < 8; ++q) w[q] = (a0 + q < Di) ? wp[(int64_t)(a0 + q) * sv.si] : 0.0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (a0 + q < Dl) t = fma(L[a0 + q], w[q], t);
+                    if (a0 + q < Di) t = fma(L[a0 + q], w[q], t);
             }
-            LW[s_ * cm + b] = t;
+            LW[s_ * cm + o] = t;
         }
         __syncthreads();
         if (!miss) {
             const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
-            for (int b = tid; b < Dr; b += IMP_T) {
+            for (int o = tid; o < Do; o += IMP_T) {
                 double t = 0.0;
-                for (int q = 0; q < d; ++q) t = fma(ph[q], LW[q * cm + b], t);
-                Ln[b] = t;
+                for (int q = 0; q < d; ++q) t = fma(ph[q], LW[q * cm + o], t);
+                Ln[o] = t;
             }
         } else {
-            const double* R = g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm;      // [Dr][Dr] compact
+            const double* R = g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm;      // [Do][Do] compact
             ++seen;
             // U = LW R;  rho = U LW^T
-            for (int e = tid; e < d * Dr; e += IMP_T) {
-                const int s_ = e / Dr, b = e - s_ * Dr;
+            for (int e = tid; e < d * Do; e += IMP_T) {
+                const int s_ = e / Do, o = e - s_ * Do;
                 double t = 0.0;
-                for (int k0_ = 0; k0_ < Dr; k0_ += 8) {
+                for (int q0 = 0; q0 < Do; q0 += 8) {
                     double r8[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) r8[q] = (k0_ + q < Dr) ? R[(int64_t)(k0_ + q) * Dr + b] : 0.0;
+                    for (int q = 0; q < 8; ++q) r8[q] = (q0 + q < Do) ? R[(int64_t)(q0 + q) * Do + o] : 0.0;
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if (k0_ + q < Dr) t = fma(LW[s_ * cm + k0_ + q], r8[q], t);
+                        if (q0 + q < Do) t = fma(LW[s_ * cm + q0 + q], r8[q], t);
                 }
-                U[s_ * cm + b] = t;
+                U[s_ * cm + o] = t;
             }
             __syncthreads();
             for (int e = tid; e < d * d; e += IMP_T) {
                 const int s_ = e / d, s2 = e - s_ * d;
                 double t = 0.0;
-                for (int k = 0; k < Dr; ++k) t = fma(U[s_ * cm + k], LW[s2 * cm + k], t);
+                for (int k = 0; k < Do; ++k) t = fma(U[s_ * cm + k], LW[s2 * cm + k], t);
                 rho[s_ * IMP_MAXD + s2] = t;
             }
             __syncthreads();
             // normalise rho by its trace (p scales with the square, every quantity below is scale-free)
             {
                 double tr = 0.0;
-                for (int s = 0; s < d; ++s) tr += rho[s * IMP_MAXD + s];
+                for (int s_ = 0; s_ < d; ++s_) tr += rho[s_ * IMP_MAXD + s_];
                 const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
                 __syncthreads();
                 for (int e = tid; e < d * d; e += IMP_T) rho[(e / d) * IMP_MAXD + (e % d)] *= sc;
@@ -298,10 +329,10 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                             if (k < n) {
                                 double pk = 0.0;
 #pragma unroll
-                                for (int s = 0; s < D; ++s) {
+                                for (int s_ = 0; s_ < D; ++s_) {
                                     double qq = 0.0;
 #pragma unroll
-                                    for (int s2 = 0; s2 < D; ++s2) qq = fma(rr[s * IMP_MAXD + s2], f[q][s2], qq);
+                                    for (int s2 = 0; s2 < D; ++s2) qq = fma(rr[s_ * IMP_MAXD + s2], f[q][s2], qq);
                                     pk = fma(qq, qq, pk);
                                 }
                                 p[k] = pk;
@@ -327,9 +358,9 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                         for (int k = tid; k < n; k += IMP_T) {
                             const double* ph = g.grid_phi + (int64_t)k * d;
                             double pk = 0.0;
-                            for (int s = 0; s < d; ++s) {
+                            for (int s_ = 0; s_ < d; ++s_) {
                                 double q = 0.0;
-                                for (int s2 = 0; s2 < d; ++s2) q = fma(rho[s * IMP_MAXD + s2], ph[s2], q);
+                                for (int s2 = 0; s2 < d; ++s2) q = fma(rho[s_ * IMP_MAXD + s2], ph[s2], q);
                                 pk = fma(q, q, pk);
                             }
                             p[k] = pk;
@@ -374,21 +405,22 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
             const double p0 = p[0];
             auto cdf_at = [&](int k) { return k == 0 ? 0.0 : 0.5 * dx * ((S[k - 1] + S[k]) - p0); };   // cumulative trapezoid
             const double Z = cdf_at(n - 1);
-            int ksel = 0;
-            if (g.method == 1) {
-                // mode: first maximum
-                const double gm = blk_max(pmax, red);
-                int cand = (pmax == gm) ? kmax : n;
+            // first index of the block-wide maximum of p (mode; also the weighted median's "one weight above half" rule)
+            auto arg_pmax = [&](double& gmax) {
+                gmax = blk_max(pmax, red);
+                int cand = (pmax == gmax) ? kmax : n;
                 cand = -(int)wave_max((double)(-cand));
                 __syncthreads();
                 if ((tid & 63) == 0) isel[tid >> 6] = cand;
                 __syncthreads();
-                ksel = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
-            } else {
-                // argmin_k |cdf_k / Z - target|: the cdf is non-decreasing, so the minimiser sits at the crossing.  Coarse
-                // position without divisions (cdf_k <= target * Z, counted per segment), then the reference's own
-                // expression |cdf_k / Z - target| on the handful of neighbours, first minimum wins (argmin).
-                const double target = g.method == 0 ? 0.5 : g.u[i * T + j];
+                const int km = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
+                __syncthreads();
+                return km;
+            };
+            // argmin_k |cdf_k / Z - target|: the cdf is non-decreasing, so the minimiser sits at the crossing.  Coarse
+            // position without divisions (cdf_k <= target * Z, counted per segment), then the reference's own
+            // expression |cdf_k / Z - target| on the handful of neighbours, first minimum wins (argmin).
+            auto quantile = [&](double target) {
                 const double tz = target * Z;
                 int below = 0;
                 for (int k = k0; k < k1; k += 8) {
@@ -408,80 +440,153 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 if ((tid & 63) == 0) isel[tid >> 6] = klo;
                 __syncthreads();
                 klo = max(max(isel[0], isel[1]), max(isel[2], isel[3]));
+                __syncthreads();
                 if (klo < 0) klo = 0;
-                ksel = klo;
+                int ks = klo;
                 double best = 1e300;
                 for (int k = max(0, klo - 2); k <= min(n - 1, klo + 3); ++k) {
                     const double a = fabs(cdf_at(k) / Z - target);
                     if (a < best) {
                         best = a;
-                        ksel = k;
+                        ks = k;
+                    }
+                }
+                return ks;
+            };
+            // StatsBase.median(|x - x_c|, pweights(p / Z)): the deviations grow with the distance from kc on the uniform
+            // grid; the cumulative weight of the window [kc - jj, kc + jj] comes from the prefix sums
+            auto wmad = [&](int kc) {
+                const double xc = g.grid_x[kc];
+                const double mid = 0.5 * (Stot / Z);
+                double gm;
+                const int km = arg_pmax(gm);
+                if (gm / Z > mid) return fabs(g.grid_x[km] - xc);
+                int jhit = n;
+                for (int jj = k0; jj < k1 && jhit == n; jj += 8) {     // jj doubles as the window half-width handled by this thread
+                    double hi_[8], lo_[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int hi = min(n - 1, kc + jj + q), lo = kc - (jj + q) - 1;
+                        hi_[q] = S[hi];
+                        lo_[q] = lo >= 0 ? S[lo] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (jj + q < k1 && jhit == n && (hi_[q] - lo_[q]) / Z > mid) jhit = jj + q;
+                }
+                jhit = -(int)wave_max((double)(-jhit));
+                __syncthreads();
+                if ((tid & 63) == 0) isel[tid >> 6] = jhit;
+                __syncthreads();
+                jhit = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
+                __syncthreads();
+                if (jhit >= n) return 0.0;
+                // the element that tips the balance is one of the two at distance jhit (whichever exists)
+                const int lo = kc - jhit, hi = kc + jhit;
+                return (lo >= 0) ? fabs(g.grid_x[lo] - xc) : fabs(g.grid_x[min(hi, n - 1)] - xc);
+            };
+            const double* ui = g.u ? g.u + ((int64_t)i * T + j) * g.ntrial : nullptr;
+            int ksel = 0;
+            double xsel = 0.0, err = 0.0;
+            bool state_from_grid = true;
+            if (g.method == IMP_MODE) {
+                double gm;
+                ksel = arg_pmax(gm);                                         // get_mode_from_rdm, sampling_utils.jl:98-143
+            } else if (g.method == IMP_MEDIAN) {
+                ksel = quantile(0.5);                                        // get_median_from_rdm, :159-196
+                if (g.get_wmad) err = wmad(ksel);
+            } else if (g.method == IMP_QUANTILE) {
+                ksel = quantile(ui[0]);                                      // get_sample_from_rdm without rejection, :262-270
+            } else if (g.method == IMP_ITS_REJECT) {
+                // get_sample_from_rdm with a rejection threshold (:271-290): median and WMAD first, then up to max_trials
+                // inverse-transform samples, the first within threshold * WMAD of the median is kept (else the last drawn)
+                const int kmed = quantile(0.5);
+                const double w = wmad(kmed);
+                const double xm = g.grid_x[kmed];
+                ksel = kmed;
+                for (int t = 0; t < g.ntrial; ++t) {
+                    ksel = quantile(ui[t]);
+                    if (fabs(g.grid_x[ksel] - xm) < g.reject_thr * w) break;
+                }
+                err = w;
+            } else {
+                // get_mean_from_rdm (:60-96): E[x] = sum x p dx / Z, std from the same sums; the conditioning state is the
+                // encoding of E[x] itself, which is not a grid value
+                const double dxm = (g.grid_x[n - 1] - g.grid_x[0]) / (double)(n - 1);
+                double a = 0.0;
+                for (int k = k0; k < k1; k += 8) {
+                    double t[8], xx[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        t[q] = (k + q < k1) ? p[k + q] : 0.0;
+                        xx[q] = (k + q < k1) ? g.grid_x[k + q] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a = fma(xx[q], t[q], a);
+                }
+                const double ex = blk_sum(a, red) * dxm / Z;
+                __syncthreads();
+                if (g.get_wmad) {
+                    double b2 = 0.0;
+                    for (int k = k0; k < k1; k += 8) {
+                        double t[8], xx[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            t[q] = (k + q < k1) ? p[k + q] : 0.0;
+                            xx[q] = (k + q < k1) ? g.grid_x[k + q] : ex;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) b2 = fma((xx[q] - ex) * (xx[q] - ex), t[q], b2);
+                    }
+                    err = sqrt(blk_sum(b2, red) * dxm / Z);
+                    __syncthreads();
+                }
+                xsel = ex;
+                state_from_grid = false;
+                // Legendre states of E[x], same arithmetic as the encoder (k_encode; bases.jl:77-92,108)
+                if (tid == 0) {
+                    const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);
+                    double q0 = 1.0, q1 = ex;
+                    for (int k = 0; k < d; ++k) {
+                        double pk;
+                        if (k == 0) pk = 1.0;
+                        else if (k == 1) pk = ex;
+                        else {
+                            const int m = k - 1;
+                            pk = ((2 * m + 1) * ex * q1 - m * q0) / (m + 1);
+                            q0 = q1;
+                            q1 = pk;
+                        }
+                        double val = pk * sqrt((2.0 * k + 1.0) / 2.0);
+                        if (g.mean_basis == 0) val = val / nrm;
+                        ms[k] = val;
                     }
                 }
             }
-            const double xsel = g.grid_x[ksel];
-            double err = 0.0;
-            if (g.method == 0 && g.get_wmad) {
-                // StatsBase.median(|x - x*|, pweights(p / Z)): the deviations grow with the distance from ksel on the
-                // uniform grid; the cumulative weight of the window [ksel - jj, ksel + jj] comes from the prefix sums
-                const double mid = 0.5 * (Stot / Z);
-                const double gm = blk_max(pmax, red);
-                if (gm / Z > mid) {
-                    int cand = (pmax == gm) ? kmax : n;
-                    cand = -(int)wave_max((double)(-cand));
-                    __syncthreads();
-                    if ((tid & 63) == 0) isel[tid >> 6] = cand;
-                    __syncthreads();
-                    const int km = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
-                    err = fabs(g.grid_x[km] - xsel);
-                } else {
-                    int jhit = n;
-                    const double mz = mid * Z;
-                    for (int jj = k0; jj < k1 && jhit == n; jj += 8) {     // jj doubles as the window half-width handled by this thread
-                        double hi_[8], lo_[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const int hi = min(n - 1, ksel + jj + q), lo = ksel - (jj + q) - 1;
-                            hi_[q] = S[hi];
-                            lo_[q] = lo >= 0 ? S[lo] : 0.0;
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            if (jj + q < k1 && jhit == n && (hi_[q] - lo_[q]) / Z > mid) jhit = jj + q;
-                    }
-                    (void)mz;
-                    jhit = -(int)wave_max((double)(-jhit));
-                    __syncthreads();
-                    if ((tid & 63) == 0) isel[tid >> 6] = jhit;
-                    __syncthreads();
-                    jhit = min(min(isel[0], isel[1]), min(isel[2], isel[3]));
-                    // the element that tips the balance is the nearer of the two at distance jhit that exists
-                    const int lo = ksel - jhit, hi = ksel + jhit;
-                    err = (lo >= 0) ? fabs(g.grid_x[lo] - xsel) : fabs(g.grid_x[min(hi, n - 1)] - xsel);
-                    if (jhit >= n) err = 0.0;
-                }
+            if (state_from_grid) {
+                xsel = g.grid_x[ksel];
+                if (tid < d) ms[tid] = g.grid_phi[(int64_t)ksel * d + tid];
             }
             if (tid == 0) {
                 g.x_out[i * T + j] = xsel;
                 g.err_out[i * T + j] = err;
             }
-            // project onto the chosen state: L <- phi*^T (L W)
-            if (tid < d) ms[tid] = g.grid_phi[(int64_t)ksel * d + tid];
             __syncthreads();
-            for (int b = tid; b < Dr; b += IMP_T) {
+            // project onto the chosen state: L <- phi*^T (L W)
+            for (int o = tid; o < Do; o += IMP_T) {
                 double t = 0.0;
-                for (int s = 0; s < d; ++s) t = fma(ms[s], LW[s * cm + b], t);
-                Ln[b] = t;
+                for (int s_ = 0; s_ < d; ++s_) t = fma(ms[s_], LW[s_ * cm + o], t);
+                Ln[o] = t;
             }
-            if (seen == nm) break;             // nothing right of the last missing site is needed
+            if (seen == nm) break;             // nothing beyond the last missing site is needed
         }
         __syncthreads();
         // rescale L by its largest magnitude
         double mx = 0.0;
-        for (int b = tid; b < Dr; b += IMP_T) mx = fmax(mx, fabs(Ln[b]));
+        for (int o = tid; o < Do; o += IMP_T) mx = fmax(mx, fabs(Ln[o]));
         mx = blk_max(mx, red);
         const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
-        for (int b = tid; b < Dr; b += IMP_T) L[b] = Ln[b] * sc;
+        for (int o = tid; o < Do; o += IMP_T) L[o] = Ln[o] * sc;
         __syncthreads();
     }
 }
@@ -496,13 +601,12 @@ hipError_t impute_init_attrs(int device) {
     return hipSuccess;
 }
 
-void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,
-                   int ngrid, int method, int get_wmad, const double* u, double* pbuf, double* sbuf, double* x_out, double* err_out,
-                   int64_t i0, int64_t count, hipStream_t s) {
+void launch_impute(const View& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
     const int cp = (v.cap + 15) & ~15;
     const size_t lds_r = (size_t)4 * cp * (cp + 2) * sizeof(double);
-    hipLaunchKernelGGL(k_imp_right, dim3((unsigned)count), dim3(IMP_T), lds_r, s, v, missing, Rbuf, max_missing, i0);
-    ImpArgs g{missing, Rbuf, grid_x, grid_phi, u, pbuf, sbuf, x_out, err_out, max_missing, ngrid, method, get_wmad, i0};
+    hipLaunchKernelGGL(k_imp_right, dim3((unsigned)count), dim3(IMP_T), lds_r, s, v, q.missing, q.Rbuf, q.max_missing, i0, q.rev);
+    ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
+              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
     const size_t lds_l = (size_t)(2 * v.cap + 2 * IMP_MAXD * v.cap + IMP_MAXD) * sizeof(double);
     hipLaunchKernelGGL(k_imp_left, dim3((unsigned)count), dim3(IMP_T), lds_l, s, v, g);
 }

@@ -318,9 +318,15 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
                        int32_t* rawinfo, BlockedEig* e, hipStream_t s);
 // imputation engine (mpst_impute.hip)
 hipError_t impute_init_attrs(int device);
-void launch_impute(const View& v, const uint8_t* missing, double* Rbuf, int max_missing, const double* grid_x, const double* grid_phi,
-                   int ngrid, int method, int get_wmad, const double* u, double* pbuf, double* sbuf, double* x_out, double* err_out,
-                   int64_t i0, int64_t count, hipStream_t s);
+struct ImputeParams {
+    const uint8_t* missing;     // device [N][T]
+    double* Rbuf;               // device [chunk][max_missing][cap*cap]
+    const double *grid_x, *grid_phi, *u;
+    double *pbuf, *sbuf, *x_out, *err_out;
+    int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
+    double reject_thr;
+};
+void launch_impute(const View& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);

@@ -202,20 +202,26 @@ class SweepEngine:
                                          yh.ctypes.data_as(C.POINTER(C.c_double))))
         return (pred, yh) if return_overlaps else pred
 
-    def impute(self, which, missing, grid_x, grid_phi, method=0, get_wmad=True, u=None):
-        """mpst_impute: (x, err, seconds); x / err are (N, T) with the imputed value / WMAD at every missing site."""
+    def impute(self, which, missing, grid_x, grid_phi, method=0, get_wmad=True, u=None, order=0, max_trials=1,
+               rejection_threshold=0.0, mean_basis=1):
+        """mpst_impute: (x, err, seconds); x / err are (N, T) with the imputed value / its uncertainty at every missing
+        site.  method 0 median, 1 mode, 2 quantile of u (N, T), 3 mean, 4 inverse-transform sampling with rejection
+        (u (N, T, max_trials)); order 0 forwards, 1 backwards."""
         m = np.ascontiguousarray(missing, dtype=np.uint8)
         N, T = m.shape
         gx = np.ascontiguousarray(grid_x, dtype=np.float64)
         gp = np.ascontiguousarray(grid_phi, dtype=np.float64)
         assert gp.shape == (len(gx), self.d) and N == self.N[which] and T == self.T
         uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        if uu is not None:
+            assert uu.size == N * T * (int(max_trials) if int(method) == 4 else 1)
         x = np.zeros((N, T))
         err = np.zeros((N, T))
         sec = C.c_double()
         dp = C.POINTER(C.c_double)
+        o = L.ImputeOpts(int(method), int(order), int(bool(get_wmad)), int(max_trials), int(mean_basis), 0, float(rejection_threshold))
         self._chk(self.lib.mpst_impute(self.ctx, which, m.ctypes.data_as(C.POINTER(C.c_uint8)), gx.ctypes.data_as(dp),
-                                       gp.ctypes.data_as(dp), len(gx), int(method), int(bool(get_wmad)),
+                                       gp.ctypes.data_as(dp), len(gx), C.byref(o),
                                        uu.ctypes.data_as(dp) if uu is not None else None, x.ctypes.data_as(dp),
                                        err.ctypes.data_as(dp), C.byref(sec)))
         return x, err, sec.value

@@ -19,7 +19,8 @@ from .encodings import model_encoding, transform_test_data, transform_train_data
 from .engine import SweepEngine
 from .options import MPSOptions, engine_options, safe_options
 
-METHODS = {"median": 0, "mode": 1, "ITS": 2}
+METHODS = {"median": 0, "mode": 1, "ITS": 2, "mean": 3}
+ORDERS = {"forwards": 0, "backwards": 1}
 
 
 def invert_test_transform(X_scaled, oob_rescales, norms, opts: MPSOptions, enc_range):
@@ -118,14 +119,19 @@ def _scaled_instances(imp: ImputationProblem, rows, masks):
 
 
 def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median", rows=None, invert_transform: bool = True,
-                   get_wmad: bool = True, rng=None, engine: Optional[SweepEngine] = None, device: int = 0, return_seconds=False):
+                   get_wmad: bool = True, rng=None, engine: Optional[SweepEngine] = None, device: int = 0, return_seconds=False,
+                   impute_order: str = "forwards", rejection_threshold=None, max_trials: int = 10):
     """Impute every instance of ``imp.X_test[rows]`` (default: all) at the sites where ``missing_mask`` is True, each
     with the MPS of its class.  Returns (X_imputed, pred_err) in the original units (``invert_transform``) or in the
-    encoding's domain; pred_err is the weighted median absolute deviation for ``method="median"`` and None otherwise."""
+    encoding's domain; pred_err is the weighted median absolute deviation for ``method="median"``, the standard
+    deviation for ``"mean"`` and None otherwise.  ``"ITS"`` draws one trajectory per instance from ``rng``
+    (``rejection_threshold`` None is the reference's ``:none``)."""
     if method not in METHODS:
         raise ValueError("Invalid method. Choose :mean, :mode, :median, :kNearestNeighbour, :flatBaseline or :ITS"
-                         if method not in ("mean", "kNearestNeighbour", "flatBaseline") else
+                         if method not in ("kNearestNeighbour", "flatBaseline") else
                          f"method {method!r} is evaluated on the host in the reference and is not part of the device engine")
+    if impute_order not in ORDERS:
+        raise ValueError('impute_order must be either ":forwards" or ":backwards"')
     rows = np.arange(imp.X_test.shape[0]) if rows is None else np.asarray(rows)
     mask = np.asarray(missing_mask, dtype=bool)
     assert mask.shape == (len(rows), imp.X_test.shape[1])
@@ -136,8 +142,15 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
     m8 = np.ascontiguousarray(mask[order], dtype=np.uint8)
     N, T = m8.shape
     u = None
+    code, trials, thr, basis = METHODS[method], 1, 0.0, 1
     if method == "ITS":
-        u = np.ascontiguousarray((rng or np.random.default_rng()).uniform(0.0, 1.0, (N, T)))
+        if rejection_threshold is not None:
+            code, trials, thr = 4, int(max_trials), float(rejection_threshold)
+        u = np.ascontiguousarray((rng or np.random.default_rng()).uniform(0.0, 1.0, (N, T, trials)))
+    if method == "mean":
+        if enc.name not in ("Legendre_No_Norm", "Legendre_Norm"):
+            raise NotImplementedError("method 'mean' re-encodes the expectation value on the device: Legendre bases only")
+        basis = 0 if enc.name == "Legendre_Norm" else 1         # MPST_BASIS_LEGENDRE / MPST_BASIS_LEGENDRE_NO_NORM
     own = engine is None
     eng = engine or SweepEngine(device)
     try:
@@ -145,7 +158,8 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
         eng.set_options(**engine_options(imp.opts))
         eng.set_dataset(1, phi, lab[order], Cn)
         eng.set_mps(imp.mps)
-        x, err, secs = eng.impute(1, m8, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, METHODS[method], get_wmad, u)
+        x, err, secs = eng.impute(1, m8, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, code, get_wmad, u,
+                                  order=ORDERS[impute_order], max_trials=trials, rejection_threshold=thr, mean_basis=basis)
     finally:
         if own:
             eng.close()
@@ -153,7 +167,7 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
     inv[order] = np.arange(len(order))
     x, err = x[inv], err[inv]
     ts = np.where(mask, x, scaled)                               # x_samps: known values as given, imputed ones filled in
-    pred = err if method == "median" else None
+    pred = err if (method in ("median", "mean") and get_wmad) else None
     if invert_transform:
         hi = None
         if pred is not None:
@@ -188,8 +202,6 @@ def MPS_impute(imp: ImputationProblem, class_, instance: int, missing_sites, met
                engine: Optional[SweepEngine] = None, device: int = 0, **kw):
     """MPS_impute(imp, class, instance, missing_sites, method) (imputation.jl:467-550) without the plots:
     returns (ts, pred_err, target, metrics) with ``ts`` / ``pred_err`` lists of series as in the reference."""
-    if impute_order != "forwards":
-        raise NotImplementedError("the device engine imputes in forward order (the reference's default)")
     missing_sites = np.asarray(missing_sites, dtype=np.int64)
     cl = np.flatnonzero(np.asarray(imp.y_test) == class_)
     row = int(cl[instance])
@@ -205,7 +217,8 @@ def MPS_impute(imp: ImputationProblem, class_, instance: int, missing_sites, met
         ts, pred, target = [t], [None], imp.X_test[row]
     else:
         t, e = impute_dataset(imp, mask, method, rows=[row], invert_transform=invert_transform, engine=engine, device=device,
-                              **{k: v for k, v in kw.items() if k in ("get_wmad", "rng")})
+                              impute_order=impute_order,
+                              **{k: v for k, v in kw.items() if k in ("get_wmad", "rng", "rejection_threshold", "max_trials")})
         ts, pred = [t[0]], [None if e is None else e[0]]
         if invert_transform:
             target = imp.X_test[row]

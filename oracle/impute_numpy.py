@@ -136,10 +136,18 @@ def probs_from_rdm(A, grid_phi):
     return np.sum(np.abs(P) ** 2, axis=1)
 
 
-def impute_at(cond, xs, grid_phi, method="median", order="forwards", get_wmad=True, u=None):
+def impute_at(cond, xs, grid_phi, method="median", order="forwards", get_wmad=True, u=None, encode=None,
+              rejection_threshold=None, max_trials=10):
     """impute_at!, MPS_methods.jl:103-177, with get_median_from_rdm (:159-196 of sampling_utils.jl), get_mode_from_rdm
-    (:98-143) and the inverse-transform sample of get_sample_from_rdm without rejection (:262-275; the uniform numbers
-    `u[k]` for the k-th imputed site are supplied by the caller).  Returns (x, err) per conditioned site."""
+    (:98-143), get_mean_from_rdm (:66-96; `encode(x)` gives the state of the expectation value) and
+    get_sample_from_rdm (:262-296) with or without rejection; the uniform numbers `u[k]` (one, or max_trials with
+    rejection) for the k-th conditioned site are supplied by the caller.  Returns (x, err) per conditioned site.
+
+    Backwards order is restated as the mirror image of forwards (orthogonality centre on the last missing site, the
+    vector handed leftwards).  In the reference the re-conditioning step tests `order == :forwards` (:163) where
+    `order` is ITensors' function, not `impute_order`: the test is always false and the contraction is written for the
+    LAST index of the next tensor, which after orthogonalize! is the bond to the site just imputed in either order -
+    i.e. exactly this recursion."""
     n = len(cond)
     if order == "forwards":
         t = _right_orthogonalize(cond)              # orthogonalize!(mps, first_idx), :115
@@ -158,18 +166,36 @@ def impute_at(cond, xs, grid_phi, method="median", order="forwards", get_wmad=Tr
         p = probs_from_rdm(A, grid_phi)
         if method == "mode":
             k = int(np.argmax(p))
-            ms = grid_phi[k]
+            ms, xk = grid_phi[k], xs[k]
             err = 0.0
+        elif method == "mean":
+            dxs = xs[1] - xs[0]
+            Z = dxs * (np.sum(p) - 0.5 * (p[0] + p[-1]))        # integrate(x, y, TrapezoidalEvenFast())
+            dx = np.mean(np.abs(np.diff(xs)))                    # impute_mean, MPS_methods.jl:250
+            xk = float(np.sum(xs * p) * dx / Z)
+            ms = np.asarray(encode(xk)) / np.sqrt(Z)
+            err = float(np.sqrt(np.sum((xs - xk) ** 2 * p) * dx / Z)) if get_wmad else 0.0
         else:
             cdf = cumul_trapz_even(xs, p)
             Z = cdf[-1]
             cdf = cdf / Z
             pn = p / Z
-            target = 0.5 if method == "median" else float(u[ii])
-            k = int(np.argmin(np.abs(cdf - target)))
-            ms = grid_phi[k] / np.sqrt(Z)
-            err = weighted_median(np.abs(xs - xs[k]), pn) if (get_wmad and method == "median") else 0.0
-        xout[i], eout[i] = xs[k], err
+            if method == "median":
+                k = int(np.argmin(np.abs(cdf - 0.5)))
+                err = weighted_median(np.abs(xs - xs[k]), pn) if get_wmad else 0.0
+            elif rejection_threshold is None:                    # :none
+                k = int(np.argmin(np.abs(cdf - float(np.ravel(u[ii])[0]))))
+                err = 0.0
+            else:
+                km = int(np.argmin(np.abs(cdf - 0.5)))
+                err = weighted_median(np.abs(xs - xs[km]), pn)
+                k = km
+                for trial in range(max_trials):
+                    k = int(np.argmin(np.abs(cdf - float(u[ii][trial]))))
+                    if abs(xs[k] - xs[km]) < rejection_threshold * err:
+                        break
+            ms, xk = grid_phi[k] / np.sqrt(Z), xs[k]
+        xout[i], eout[i] = xk, err
         if ii != n - 1:
             Am = np.conj(ms) @ A                               # ms' * A
             nxt = t[idxs[ii + 1]]
@@ -181,12 +207,12 @@ def impute_at(cond, xs, grid_phi, method="median", order="forwards", get_wmad=Tr
     return xout, eout
 
 
-def impute(class_mps, enc, imputation_sites, xs, grid_phi, method="median", order="forwards", get_wmad=True, u=None):
-    """impute_median / impute_mode / impute_ITS (MPS_methods.jl:198-330) for one series.  `enc` (T, d): encoded states of
+def impute(class_mps, enc, imputation_sites, xs, grid_phi, method="median", order="forwards", get_wmad=True, u=None, **kw):
+    """impute_median / impute_mean / impute_mode / impute_ITS (MPS_methods.jl:198-345) for one series.  `enc` (T, d): encoded states of
     the KNOWN values (rows of missing sites are ignored).  Returns (x_imputed, err) at the imputation sites."""
     imp = sorted(int(j) for j in imputation_sites)
     cond = precondition(class_mps, enc, imp)
-    return impute_at(cond, xs, grid_phi, method, order, get_wmad, u)
+    return impute_at(cond, xs, grid_phi, method, order, get_wmad, u, **kw)
 
 
 def brute_force_conditional(class_mps, enc, known_mask, site, fixed, grid_phi):

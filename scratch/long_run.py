@@ -13,7 +13,7 @@ def run(name, phi, labels, C, chi, d, nsweeps, seed=1234):
     eng.set_mps(mt.generate_startingMPS(4, T, d, C, seed)); eng.build_caches()
     fb = 0; t0 = time.time(); hist = []
     for s in range(nsweeps):
-        st = eng.sweep(); fb = st["eig_fallbacks"]
+        st = eng.sweep(); fb += st["eig_fallbacks"]
         if s % 5 == 4 or s == nsweeps - 1:
             mse, kld, acc, _ = eng.eval(0); hist.append((s + 1, round(kld, 4), round(acc, 4)))
     eng.normalize()
@@ -28,3 +28,6 @@ run("config2 chi16", full.phi, full.label_index, 2, 16, 4, 20)
 z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "ref_ecg200_trained_mps.npz"))
 lab = np.repeat(np.arange(2), z["class_distribution"])
 run("ecg200 d5 chi25", z["pstates"], lab, 2, 25, 5, 20, seed=7)
+full2 = bench.make_inputs(240, 60, 8)
+run("d8 chi37 (blocked eigensolver)", full2.phi, full2.label_index, 2, 37, 8, 6)
+print("library fallbacks of the blocked solver are reported by eng.info() inside run() if needed")

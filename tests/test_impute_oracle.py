@@ -63,6 +63,55 @@ def test_mode_and_quantile_paths():
         fixed[j] = grid_phi[int(np.argmin(np.abs(xs - xq[k])))]
 
 
+@pytest.mark.parametrize("order", ["forwards", "backwards"])
+def test_mean_path_equals_brute_force_moments(order):
+    mps, xs, grid_phi, enc, rng = _setup(T=6, seed=9, ngrid=401)
+    d = grid_phi.shape[1]
+    missing = [0, 2, 3, 5]
+    f = lambda x: R.legendre_encode(x, d)
+    xo, so = I.impute(mps, enc, missing, xs, grid_phi, "mean", order, True, None, encode=f)
+    known = np.ones(6, dtype=bool)
+    known[missing] = False
+    fixed = {}
+    seq = missing if order == "forwards" else missing[::-1]
+    for j in seq:
+        p = I.brute_force_conditional(mps, enc, known, j, fixed, grid_phi)
+        # the reference's estimator (rectangle sums over a trapezoid normalisation, sampling_utils.jl:82-93) on the
+        # independently computed density
+        dx = xs[1] - xs[0]
+        Z = dx * (np.sum(p) - 0.5 * (p[0] + p[-1]))
+        ex = np.sum(xs * p) * dx / Z
+        k = missing.index(j)
+        assert abs(ex - xo[k]) < 1e-10
+        assert abs(np.sqrt(np.sum((xs - ex) ** 2 * p) * dx / Z) - so[k]) < 1e-10
+        fixed[j] = f(xo[k])
+
+
+def test_rejection_sampling_keeps_the_first_sample_inside_the_window():
+    mps, xs, grid_phi, enc, rng = _setup(T=6, seed=11, ngrid=401)
+    missing = [1, 2, 4]
+    u = rng.uniform(0, 1, (3, 8))
+    thr = 0.7
+    xr, wr = I.impute(mps, enc, missing, xs, grid_phi, "ITS", "forwards", True, u, rejection_threshold=thr, max_trials=8)
+    known = np.ones(6, dtype=bool)
+    known[missing] = False
+    fixed = {}
+    for k, j in enumerate(missing):
+        p = I.brute_force_conditional(mps, enc, known, j, fixed, grid_phi)
+        cdf = I.cumul_trapz_even(xs, p)
+        cdf /= cdf[-1]
+        med = xs[int(np.argmin(np.abs(cdf - 0.5)))]
+        draws = [xs[int(np.argmin(np.abs(cdf - t)))] for t in u[k]]
+        ok = [abs(x - med) < thr * wr[k] for x in draws]
+        expect = draws[ok.index(True)] if any(ok) else draws[-1]
+        assert abs(expect - xr[k]) <= (xs[1] - xs[0]) * 1.0000001
+        fixed[j] = grid_phi[int(np.argmin(np.abs(xs - xr[k])))]
+    # a threshold nothing can miss is plain inverse-transform sampling of the first number
+    x0, _ = I.impute(mps, enc, missing, xs, grid_phi, "ITS", "forwards", True, u, rejection_threshold=1e9, max_trials=8)
+    x1, _ = I.impute(mps, enc, missing, xs, grid_phi, "quantile", "forwards", True, u[:, 0])
+    assert np.array_equal(x0, x1)
+
+
 def test_weighted_median_matches_definition():
     rng = np.random.default_rng(1)
     v = rng.uniform(0, 1, 101)
