@@ -82,6 +82,103 @@ def host_cpu_model():
     return "unknown"
 
 
+def random_chain(T, d, chi, rng):
+    """Complex Gaussian site tensors in left-canonical form (the carried factor renormalised at every site), one class,
+    label index on the last site: the shape of a Fourier-encoded MPS out of the reference's legacy trainer."""
+    dims = [1] + [int(min(chi, d ** min(j, T - j, 30))) for j in range(1, T)] + [1]
+    t = [rng.standard_normal((dims[j], d, dims[j + 1])) + 1j * rng.standard_normal((dims[j], d, dims[j + 1])) for j in range(T)]
+    for j in range(T - 1):
+        l, d_, r = t[j].shape
+        q, rr = np.linalg.qr(t[j].reshape(l * d_, r))
+        t[j] = q.reshape(l, d_, q.shape[1])
+        t[j + 1] = np.einsum("kb,bsc->ksc", rr / np.linalg.norm(rr), t[j + 1])
+    t[-1] = t[-1] / np.linalg.norm(t[-1])
+    return [w if k < T - 1 else w[..., None] for k, w in enumerate(t)]
+
+
+def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
+    """BASELINE configs[4]: median imputation (+ WMAD) of a 50 % block of every instance on the reference's 20 001-value grid.
+    Instances are independent: every rank imputes its own N instances (weak scaling, no collective on the data path).  A
+    step is one pass over the rank's instances; the time of a step is the device time between the first and the last
+    kernel of the pass (operands resident), the PCIe-inclusive wall time is reported beside it."""
+    defaults = ap_defaults()
+    N = args.N if args.N != defaults["N"] else 8192
+    T = args.T if args.T != defaults["T"] else 200
+    chi = args.chi if args.chi != defaults["chi"] else 64
+    d = args.d if args.d != defaults["d"] else 8
+    rng = np.random.default_rng(100 + rank)
+    W = random_chain(T, d, chi, np.random.default_rng(7))
+    enc = mt.model_encoding("Fourier")
+    xs = -1.0 + 1e-4 * np.arange(20001)
+    gphi = np.ascontiguousarray(enc.encode(xs, d), dtype=np.complex128)
+    X = rng.uniform(-0.95, 0.95, (N, T))
+    phi = np.ascontiguousarray(enc.encode(X, d), dtype=np.complex128)
+    m = np.zeros((N, T), dtype=np.uint8)
+    for i in range(N):
+        s0 = rng.integers(0, T - T // 2 + 1)
+        m[i, s0:s0 + T // 2] = 1
+    lab = np.zeros(N, dtype=np.int32)
+    sites = int(m.sum())
+    eng = mt.SweepEngine(dev_index)
+    for _ in range(args.warmup):
+        eng.impute_model(W, phi, lab, m, xs, gphi, 0, True, compute="f32")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dev_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x, e, secs = eng.impute_model(W, phi, lab, m, xs, gphi, 0, True, compute="f32")
+        dev_s += secs
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        dev_s, wall = host_reduce([dev_s, wall], dist.ReduceOp.MAX)
+    eng.close()
+    ms_step = 1e3 * dev_s / args.steps
+    value = world * sites * args.steps / dev_s
+    # the density pass dominates: per missing site, ngrid x (d^2 complex MACs + d squares) fp64 VALU flops and the
+    # p / prefix-sum streams (write p, read p, write S, ~2 reads of S for the selections)
+    ngrid = len(xs)
+    flops = sites * ngrid * (8.0 * d * d + 4.0 * d)
+    bytes_ = sites * ngrid * 8.0 * 5.0
+    line = {"metric": "site-imputations/sec (imputation engine, BASELINE configs[4])", "value": value, "unit": "site-imputations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "c64 model; f32 chain contractions (MFMA f32 16x16x4), f64 densities",
+            "data": "synthetic",
+            "config": {"workload": f"median imputation + WMAD of a 50 % block, N={N} instances per GPU, T={T}, chi={chi}, d={d} Fourier "
+                                   f"(complex random canonical MPS), 20001-value grid", "parallelism": f"instances sharded over {world} GPU(s), no collective"},
+            "roofline": {"bound": "hbm", "achieved": bytes_ / dev_s * args.steps / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": bytes_ / dev_s * args.steps / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                         "note": "k_imp_left's density streams (5 x 8 B per grid value); the same pass does "
+                                 f"{flops / dev_s * args.steps / 1e12:.2f} TFLOP/s of fp64 VALU work (peak 78.6)"},
+            "wall_ms_per_step_incl_pcie_and_host_packing": 1e3 * wall / args.steps}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import impute_numpy as I         # the checker, timed as the CPU baseline on a bounded sample
+        cls = [w.reshape(w.shape[:3]) for w in W]
+        t1 = time.perf_counter()
+        done = 0
+        agree = []
+        for i in range(min(N, 64)):
+            s_ = np.flatnonzero(m[i])
+            xo, _ = I.impute(cls, phi[i], s_, xs, gphi, "median")
+            agree.append(np.mean(np.abs(x[i, s_] - xo) < 1e-12))
+            done += len(s_)
+            if time.perf_counter() - t1 > 15.0:
+                break
+        dt = time.perf_counter() - t1
+        line["cpu_baseline"] = {"value": done / dt, "unit": "site-imputations/s", "cores": 1, "kind": "port",
+                                "sample": f"{done} missing sites of the same instances with the NumPy complex128 restatement "
+                                          f"(oracle/impute_numpy.py) in {dt:.1f} s on {host_cpu_model()}",
+                                "fp32_chain_vs_numpy_c128_identical_frac": float(np.mean(agree))}
+    return line
+
+
+def ap_defaults():
+    return {"N": 4096, "T": 100, "chi": 32, "d": 4}
+
+
 def main():
     # Exactly one line may reach stdout: native libraries (the RCCL init banner, rocm-smi notices) write to fd 1
     # behind Python's back, so fd 1 is pointed at stderr for the whole run and the JSON line goes to the saved fd.
@@ -102,6 +199,9 @@ def main():
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
                          "and stream each (hyper-parameter search / CV folds); 0 = skip")
+    ap.add_argument("--workload", choices=["sweep", "impute"], default="sweep",
+                    help="sweep: the headline training sweep (BASELINE configs[2]).  impute: BASELINE configs[4], the imputation engine "
+                         "on a complex (Fourier) model with fp32 chain arithmetic; defaults N=8192 per GPU, T=200, chi=64, d=8")
     ap.add_argument("--allreduce", choices=["auto", "rccl", "oneshot"], default="auto",
                     help="collective of the sharded sweep: RCCL, the one-shot direct-write kernel, or whichever one trial sweep shows faster")
     args = ap.parse_args()
@@ -148,6 +248,13 @@ def main():
         return t.tolist()
 
     import mpstime_jl_amd as mt
+    if args.workload == "impute":
+        line = impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        if world > 1:
+            dist.destroy_process_group()
+        return
     N, T, d, chi, C = args.N, args.T, args.d, args.chi, 2
     full = make_inputs(N, T, d)
     W0 = mt.generate_startingMPS(4, T, d, C, 1234)

@@ -233,6 +233,34 @@ typedef struct {
 int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
                  const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds);
 
+/* The same engine on a model handed over in one call instead of through the context's data set and MPS - what an
+ * imputation-only caller has (init_imputation_problem, imputation.jl:143-190, takes a trained MPS and test data) - and
+ * the only door for the element types the sweep does not train:
+ *   dtype    MPST_DTYPE_C64: site tensors, encoded values and grid states are complex (interleaved re, im doubles) - the
+ *            reference's Fourier / Sahand bases (bases.jl:23-68), trained through its legacy ITensor path.  Known sites are
+ *            projected with the conjugate state (dag(timeseries_enc), MPS_methods.jl:17), densities are |rho phi|^2.
+ *   compute  MPST_COMPUTE_F32: the chain contractions (site tensors, environment matrices, boundary vectors) are stored
+ *            and multiplied in fp32 (MFMA f32 16x16x4); the density on the grid, its cumulative sums and every selection
+ *            stay fp64.  MPST_COMPUTE_F64: everything fp64.
+ * site[j]: (s, l, r) column-major, the label site (s, l, r, c), like mpst_set_mps; phi: [N][T][d]; label_idx[N] in [0, C)
+ * in any order.  chi_max <= 64 (complex fp64: 48), d <= 16.  mean_basis MPST_BASIS_FOURIER for complex models. */
+#define MPST_DTYPE_F64   0
+#define MPST_DTYPE_C64   1
+#define MPST_COMPUTE_F64 0
+#define MPST_COMPUTE_F32 1
+#define MPST_BASIS_FOURIER 2            /* fourier_encode, bases.jl:23-42 (mpst_impute_model_run's mean method only) */
+typedef struct {
+    int64_t N;
+    int32_t T, d, C, label_site;
+    int32_t dtype, compute;
+    const void* const* site;
+    const int32_t* chi;                 /* [T+1] */
+    const void* phi;
+    const int32_t* label_idx;
+} mpst_impute_model;
+int  mpst_impute_model_run(void* ctx, const mpst_impute_model* m, const uint8_t* missing, const double* grid_x, const void* grid_phi,
+                           int32_t ngrid, const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds);
+
 /* normalize!(W), RealRealHighDimension.jl:852. */
 int  mpst_normalize(void* ctx);
 

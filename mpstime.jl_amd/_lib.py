@@ -54,6 +54,12 @@ class ImputeOpts(C.Structure):          # mpst_impute_opts
                 ("mean_basis", C.c_int32), ("reserved", C.c_int32), ("rejection_threshold", C.c_double)]
 
 
+class ImputeModel(C.Structure):         # mpst_impute_model
+    _fields_ = [("N", C.c_int64), ("T", C.c_int32), ("d", C.c_int32), ("C", C.c_int32), ("label_site", C.c_int32),
+                ("dtype", C.c_int32), ("compute", C.c_int32), ("site", C.POINTER(C.c_void_p)), ("chi", C.POINTER(C.c_int32)),
+                ("phi", C.c_void_p), ("label_idx", C.POINTER(C.c_int32))]
+
+
 SYMBOLS = {
     "mpst_version": (C.c_int, []),
     "mpst_last_error": (C.c_char_p, [_vp]),
@@ -80,6 +86,8 @@ SYMBOLS = {
     "mpst_classify": (C.c_int, [_vp, C.c_int, C.POINTER(_i32), _dp]),
     "mpst_normalize": (C.c_int, [_vp]),
     "mpst_impute": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint8), _dp, _dp, _i32, C.POINTER(ImputeOpts), _dp, _dp, _dp, _dp]),
+    "mpst_impute_model_run": (C.c_int, [_vp, C.POINTER(ImputeModel), C.POINTER(C.c_uint8), _dp, _vp, _i32, C.POINTER(ImputeOpts), _dp, _dp,
+                                        _dp, _dp]),
     "mpst_selftest_mfma": (C.c_int, [_vp, _dp, _dp, _i32, _dp]),
     "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),

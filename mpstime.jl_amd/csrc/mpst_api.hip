@@ -1106,11 +1106,9 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
     return 0;
 }
 
-int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
-                const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
-    Ctx* c = (Ctx*)ctx;
-    if (!c) return MPST_ERR_INVALID;
-    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
+// shared tail of the two imputation entry points: option checks, scratch, launches, results
+static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const double* grid_x, const void* grid_phi, int32_t ngrid,
+                      const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
     if (!missing || !grid_x || !grid_phi || !x_out || !o || ngrid < 2) return fail(c, MPST_ERR_INVALID, "NULL argument or fewer than 2 grid values");
     const int method = o->method;
     if (method < MPST_IMPUTE_MEDIAN || method > MPST_IMPUTE_ITS_REJECT) return fail(c, MPST_ERR_INVALID, "unknown imputation method");
@@ -1120,52 +1118,53 @@ int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid
     const int ntrial = method == MPST_IMPUTE_ITS_REJECT ? o->max_trials : 1;
     if (ntrial < 1) return fail(c, MPST_ERR_INVALID, "max_trials must be at least 1");
     if (method == MPST_IMPUTE_ITS_REJECT && !(o->rejection_threshold >= 0.0)) return fail(c, MPST_ERR_INVALID, "rejection_threshold must be non-negative");
-    if (method == MPST_IMPUTE_MEAN && o->mean_basis != MPST_BASIS_LEGENDRE && o->mean_basis != MPST_BASIS_LEGENDRE_NO_NORM)
-        return fail(c, MPST_ERR_UNSUPPORTED, "the mean method re-encodes on the device: Legendre bases only");
-    const int get_wmad = o->get_err;
-    if (!c->have_mps || !c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options / mpst_set_mps must be called first");
-    const DataSet& s = c->ds[which];
-    if (s.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
-    if (c->cap > 64 || c->d > 16) return fail(c, MPST_ERR_UNSUPPORTED, "the imputation engine holds chi_max <= 64 and d <= 16 (got %d, %d)", c->cap, c->d);
-    HIPC(c, hipSetDevice(c->device));
+    if (method == MPST_IMPUTE_MEAN) {
+        const bool leg = o->mean_basis == MPST_BASIS_LEGENDRE || o->mean_basis == MPST_BASIS_LEGENDRE_NO_NORM;
+        if (!(m.is_complex ? o->mean_basis == MPST_BASIS_FOURIER : leg))
+            return fail(c, MPST_ERR_UNSUPPORTED, "the mean method re-encodes on the device: Legendre bases (real models) or Fourier (complex models) only");
+    }
+    const int lim = impute_chi_limit(m.is_complex != 0, m.compute_f32 != 0);
+    if (m.cap > lim || m.d > 16)
+        return fail(c, MPST_ERR_UNSUPPORTED, "the imputation engine holds chi_max <= %d (this element type) and d <= 16 (got %d, %d)", lim, m.cap, m.d);
     hipError_t ea = impute_init_attrs(c->device);
     if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
-    const int64_t N = s.N;
-    const int T = c->T, d = c->d;
+    const int64_t N = m.N;
+    const int T = m.T, d = m.d;
+    const int zw = m.is_complex ? 2 : 1;
+    const size_t esz = m.compute_f32 ? 4 : 8;
     int maxm = 0;
     for (int64_t i = 0; i < N; ++i) {
-        int m = 0;
-        for (int j = 0; j < T; ++j) m += missing[i * T + j] ? 1 : 0;
-        maxm = std::max(maxm, m);
+        int mm = 0;
+        for (int j = 0; j < T; ++j) mm += missing[i * T + j] ? 1 : 0;
+        maxm = std::max(maxm, mm);
     }
     std::vector<double> xo((size_t)N * T, 0.0), eo((size_t)N * T, 0.0);
     if (maxm > 0) {
-        // instances are processed in chunks so that the per-instance scratch (right environments of the missing sites,
-        // p_k and its prefix sums) stays below ~8 GB
-        const int64_t per = (int64_t)maxm * c->cap * c->cap + 2ll * ngrid;
+        // instances are processed in chunks so that the per-instance scratch (environments of the missing sites, p_k and
+        // its prefix sums) stays below ~8 GB
+        const int64_t per = (int64_t)maxm * m.cap * m.cap * zw + 2ll * ngrid;
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
-        uint8_t* dmiss = nullptr;
-        double *dR = nullptr, *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
+        uint8_t *dmiss = nullptr, *dR = nullptr;
+        double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
         struct Temps {
-            uint8_t** m; double **a, **b, **cc, **dd, **e, **f, **g, **h;
-            ~Temps() { dfree(m); dfree(a); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
+            uint8_t **m, **r; double **b, **cc, **dd, **e, **f, **g, **h;
+            ~Temps() { dfree(m); dfree(r); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
         } temps{&dmiss, &dR, &dgx, &dgp, &du, &dp, &dS, &dx, &de};
         int rc;
-        if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, chunk * maxm * c->cap * c->cap)) || (rc = dalloc(c, &dgx, ngrid)) ||
-            (rc = dalloc(c, &dgp, (int64_t)ngrid * d)) || (rc = dalloc(c, &dp, chunk * ngrid)) || (rc = dalloc(c, &dS, chunk * ngrid)) ||
-            (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
+        if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, (int64_t)(chunk * maxm * m.cap * m.cap * zw * esz))) ||
+            (rc = dalloc(c, &dgx, ngrid)) || (rc = dalloc(c, &dgp, (int64_t)ngrid * d * zw)) || (rc = dalloc(c, &dp, chunk * ngrid)) ||
+            (rc = dalloc(c, &dS, chunk * ngrid)) || (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
         if (sampling && (rc = dalloc(c, &du, N * T * ntrial))) return rc;
         HIPC(c, hipMemcpy(dmiss, missing, (size_t)N * T, hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgx, grid_x, (size_t)ngrid * sizeof(double), hipMemcpyHostToDevice));
-        HIPC(c, hipMemcpy(dgp, grid_phi, (size_t)ngrid * d * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(dgp, grid_phi, (size_t)ngrid * d * zw * sizeof(double), hipMemcpyHostToDevice));
         if (sampling) HIPC(c, hipMemcpy(du, u, (size_t)N * T * ntrial * sizeof(double), hipMemcpyHostToDevice));
         HIPC(c, hipMemset(dx, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
-        View v = make_view(c, which);
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
-        const ImputeParams q{dmiss, dR, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, get_wmad, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
+        const ImputeParams q{dmiss, dR, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
                              ntrial, o->mean_basis, o->rejection_threshold};
-        for (int64_t i0 = 0; i0 < N; i0 += chunk) launch_impute(v, q, i0, std::min(chunk, N - i0), c->stream);
+        for (int64_t i0 = 0; i0 < N; i0 += chunk) launch_impute(m, q, i0, std::min(chunk, N - i0), c->stream);
         HIPC(c, hipEventRecord(c->ev_stop, c->stream));
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventSynchronize(c->ev_stop));
@@ -1180,6 +1179,98 @@ int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid
     memcpy(x_out, xo.data(), xo.size() * sizeof(double));
     if (err_out) memcpy(err_out, eo.data(), eo.size() * sizeof(double));
     return 0;
+}
+
+int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid_x, const double* grid_phi, int32_t ngrid,
+                const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
+    if (!c->have_mps || !c->have_opt) return fail(c, MPST_ERR_INVALID, "mpst_set_options / mpst_set_mps must be called first");
+    const DataSet& s = c->ds[which];
+    if (s.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
+    HIPC(c, hipSetDevice(c->device));
+    const View v = make_view(c, which);
+    const ImpModel m{v.sites, v.site_stride, v.chi, v.label_site, v.phi, v.label, s.N, c->T, c->d, c->cap, 0, 0};
+    return run_impute(c, m, missing, grid_x, grid_phi, ngrid, o, u, x_out, err_out, seconds);
+}
+
+// Host arrays of a model in the boundary layouts (site: (s, l, r[, c]) column-major like mpst_set_mps; phi: [N][T][d]) to
+// the engine's layouts and element type.
+extern "C++" {
+template <typename R>
+static void pack_model(const mpst_impute_model* h, int cap, int64_t stride, bool cx, std::vector<R>& sites, std::vector<R>& phi) {
+    const int T = h->T, d = h->d, C = h->C, zw = cx ? 2 : 1;
+    sites.assign((size_t)stride * T * zw, R(0));
+    for (int j = 0; j < T; ++j) {
+        const int Dl = h->chi[j], Dr = h->chi[j + 1], Cj = (j == h->label_site) ? C : 1;
+        const double* src = (const double*)h->site[j];
+        R* dst = &sites[(size_t)j * stride * zw];
+        for (int cc = 0; cc < Cj; ++cc)
+            for (int r = 0; r < Dr; ++r)
+                for (int l = 0; l < Dl; ++l)
+                    for (int s = 0; s < d; ++s) {
+                        const size_t to = (((size_t)cc * Dl + l) * d + s) * Dr + r, from = s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc));
+                        for (int z = 0; z < zw; ++z) dst[to * zw + z] = (R)src[from * zw + z];
+                    }
+    }
+    const int64_t N = h->N;
+    phi.resize((size_t)N * T * d * zw);
+    const double* ps = (const double*)h->phi;
+    for (int64_t i = 0; i < N; ++i)
+        for (int j = 0; j < T; ++j)
+            for (int s = 0; s < d * zw; ++s) phi[((size_t)j * N + i) * d * zw + s] = (R)ps[((size_t)i * T + j) * d * zw + s];
+}
+}  // extern "C++"
+
+int mpst_impute_model_run(void* ctx, const mpst_impute_model* h, const uint8_t* missing, const double* grid_x, const void* grid_phi,
+                          int32_t ngrid, const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (!h || !h->site || !h->chi || !h->phi || !h->label_idx) return fail(c, MPST_ERR_INVALID, "NULL argument");
+    if (h->N <= 0 || h->T < 1 || h->d < 1 || h->C < 1) return fail(c, MPST_ERR_INVALID, "empty model or data");
+    if (h->dtype != MPST_DTYPE_F64 && h->dtype != MPST_DTYPE_C64) return fail(c, MPST_ERR_INVALID, "dtype must be MPST_DTYPE_F64 or MPST_DTYPE_C64");
+    if (h->compute != MPST_COMPUTE_F64 && h->compute != MPST_COMPUTE_F32) return fail(c, MPST_ERR_INVALID, "compute must be MPST_COMPUTE_F64 or MPST_COMPUTE_F32");
+    if (h->label_site < 0 || h->label_site >= h->T) return fail(c, MPST_ERR_INVALID, "label_site out of range");
+    if (h->chi[0] != 1 || h->chi[h->T] != 1) return fail(c, MPST_ERR_INVALID, "chi[0] and chi[T] must be 1");
+    int cap = 1;
+    for (int j = 0; j <= h->T; ++j) {
+        if (h->chi[j] < 1) return fail(c, MPST_ERR_INVALID, "chi[%d] < 1", j);
+        cap = std::max(cap, (int)h->chi[j]);
+    }
+    for (int j = 0; j < h->T; ++j)
+        if (!h->site[j]) return fail(c, MPST_ERR_INVALID, "site[%d] is NULL", j);
+    for (int64_t i = 0; i < h->N; ++i)
+        if (h->label_idx[i] < 0 || h->label_idx[i] >= h->C) return fail(c, MPST_ERR_INVALID, "label_idx[%lld] out of range", (long long)i);
+    const bool cx = h->dtype == MPST_DTYPE_C64, f32 = h->compute == MPST_COMPUTE_F32;
+    HIPC(c, hipSetDevice(c->device));
+    const int64_t stride = (int64_t)h->C * cap * h->d * cap;
+    const size_t esz = (f32 ? 4 : 8) * (cx ? 2 : 1);
+    uint8_t *dsites = nullptr, *dphi = nullptr;
+    int32_t *dchi = nullptr, *dls = nullptr, *dlab = nullptr;
+    struct Temps {
+        uint8_t **a, **b; int32_t **x, **y, **z;
+        ~Temps() { dfree(a); dfree(b); dfree(x); dfree(y); dfree(z); }
+    } temps{&dsites, &dphi, &dchi, &dls, &dlab};
+    int rc;
+    if ((rc = dalloc(c, &dsites, (int64_t)(stride * h->T * esz))) || (rc = dalloc(c, &dphi, (int64_t)(h->N * h->T * h->d * esz))) ||
+        (rc = dalloc(c, &dchi, h->T + 1)) || (rc = dalloc(c, &dls, 1)) || (rc = dalloc(c, &dlab, h->N))) return rc;
+    if (f32) {
+        std::vector<float> hs, hp;
+        pack_model<float>(h, cap, stride, cx, hs, hp);
+        HIPC(c, hipMemcpy(dsites, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(dphi, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        std::vector<double> hs, hp;
+        pack_model<double>(h, cap, stride, cx, hs, hp);
+        HIPC(c, hipMemcpy(dsites, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(dphi, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPC(c, hipMemcpy(dchi, h->chi, (size_t)(h->T + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(dls, &h->label_site, sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(dlab, h->label_idx, (size_t)h->N * sizeof(int32_t), hipMemcpyHostToDevice));
+    const ImpModel m{dsites, stride, dchi, dls, dphi, dlab, h->N, h->T, h->d, cap, cx ? 1 : 0, f32 ? 1 : 0};
+    return run_impute(c, m, missing, grid_x, grid_phi, ngrid, o, u, x_out, err_out, seconds);
 }
 
 int mpst_normalize(void* ctx) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ BtProblem bt_resolve(const View& v, int lid, int goin
 
 struct BtBufs {
     double* A;       // [ncap][ncap] working copy of G, full symmetric storage
-    double* Y;       // [ncap] y of the column just processed
+    double* Y;       // [2][ncap] y of the column just processed, indexed by the parity of the step
     double* Vall;    // [ncap][ncap] row j = reflector j
     double* dd;      // [ncap] diagonal of T
     double* ee;      // [ncap] off-diagonal of T
@@ -109,15 +109,18 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     // (a)
     if (j > 0) {
         const double* vprev = b.Vall + (int64_t)(j - 1) * ld;
+        // y is double-buffered by the parity of the step: a fast workgroup writes this step's y in (c) while a slow one is
+        // still reading the previous step's here
+        const double* yprev = b.Y + (int64_t)((j - 1) & 1) * ld;
         double s = 0.0;
         for (int r = j + tid; r < n; r += BT_T) {
             const double vv = vprev[r];
             vl[r] = vv;
-            s = fma(b.Y[r], vv, s);
+            s = fma(yprev[r], vv, s);
         }
         s = bt_block_sum(s, red);
         const double alpha = -0.5 * b.tau[j - 1] * s;
-        for (int r = j + tid; r < n; r += BT_T) wl[r] = fma(alpha, vl[r], b.Y[r]);
+        for (int r = j + tid; r < n; r += BT_T) wl[r] = fma(alpha, vl[r], yprev[r]);
     } else {
         for (int r = tid; r < n; r += BT_T) vl[r] = wl[r] = 0.0;
     }
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
                 }
             }
             s = wave_sum(s);
-            if (lane == 0) b.Y[r] = tau * s;
+            if (lane == 0) b.Y[(int64_t)(j & 1) * ld + r] = tau * s;
         }
     }
 }
@@ -599,11 +602,11 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     e->b.ncap = ncap;
     auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess; };
     const size_t n1 = ncap, n2 = (size_t)ncap * ncap;
-    bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, n1) && al(&e->b.Vall, n2) &&
+    bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
               al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&e->host_flag, sizeof(int32_t)) == hipSuccess;
-    if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, n1 * sizeof(double)) == hipSuccess;
+    if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
                  true;
     if (!ok) {

@@ -20,7 +20,13 @@
 // Both imputation orders of the reference (impute_order = :forwards / :backwards, MPS_methods.jl:107-121): backwards is
 // the mirror image - the matrices come from the left, the vector from the right - and runs through the same kernels with
 // the two bond indices of every site tensor swapped (`rev`).
-// Real fp64; chi <= 64 (four chi x chi matrices in LDS), d <= 16.
+// Element types.  The model (site tensors, encoded known values, grid states) is real or complex (the reference's
+// Fourier / Sahand bases give complex MPSs, trained through its legacy ITensor path); the chain contractions - site
+// tensors, environment matrices, the vector L - run in fp64 or in fp32 (MFMA f32 16x16x4, half the LDS and HBM bytes),
+// while the density on the grid, its prefix sums and every selection are always fp64.  Complex matrices live in LDS as
+// separate real and imaginary planes so that a complex product is four real MFMA chains.
+// Limits: d <= 16; the environment pass keeps 4 (real) / 8 (complex) padded chi x chi planes in LDS: chi <= 64, except
+// complex fp64: chi <= 48.
 #include "mpst_internal.h"
 #include <type_traits>
 
@@ -28,6 +34,44 @@ namespace mpst {
 
 constexpr int IMP_T = 256;
 constexpr int IMP_MAXD = 16;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename R> struct Mx;
+template <> struct Mx<double> {
+    using acc_t = d4;
+    using vec2 = double2;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return mfma_f64(a, b, c); }
+    static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
+};
+template <> struct Mx<float> {          // C/D map of the f32 16x16x4 form: row = 4 * (lane >> 4) + reg
+    using acc_t = f4;
+    using vec2 = float2;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
+
+// element e of an array of R (real) or of interleaved (re, im) pairs of R (complex)
+template <typename R, bool CX> __device__ __forceinline__ void zload(const R* __restrict__ p, int64_t e, R& re, R& im) {
+    if constexpr (CX) {
+        const typename Mx<R>::vec2 t = reinterpret_cast<const typename Mx<R>::vec2*>(p)[e];
+        re = t.x;
+        im = t.y;
+    } else {
+        re = p[e];
+        im = R(0);
+    }
+}
+template <typename R, bool CX> __device__ __forceinline__ void zstore(R* __restrict__ p, int64_t e, R re, R im) {
+    if constexpr (CX) {
+        typename Mx<R>::vec2 t;
+        t.x = re;
+        t.y = im;
+        reinterpret_cast<typename Mx<R>::vec2*>(p)[e] = t;
+    } else {
+        p[e] = re;
+    }
+}
 
 __device__ __forceinline__ double blk_sum(double x, double* red) {
     x = wave_sum(x);
@@ -44,23 +88,20 @@ __device__ __forceinline__ double blk_max(double x, double* red) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-// site tensor j of the class MPS of class `cls`: [a][s][b] with live dimensions
-__device__ __forceinline__ const double* class_site(const View& v, int j, int cls, int Dl, int Dr) {
-    const double* W = v.sites + (int64_t)j * v.site_stride;
-    if (j == *v.label_site) W += (int64_t)cls * Dl * v.d * Dr;
-    return W;
-}
-// A site as seen by a pass that enters through bond `in` and leaves through bond `out`: element (i, s, o).  Forwards the
+// A site as seen by a pass that enters through bond `in` and leaves through bond `out`: element (i, s, o) of the class
+// MPS of class `cls` ([a][s][b] with live dimensions; the label site holds one such block per class).  Forwards the
 // left pass enters from the left (in = left bond), backwards from the right; the matrix pass is the opposite.
-struct SiteView {
-    const double* W;
+template <typename R> struct SiteView {
+    const R* W;
     int Din, Dout;
-    int64_t si, ss, so;      // strides of the (in, s, out) indices
+    int64_t si, ss, so;      // strides of the (in, s, out) indices, in elements
 };
-__device__ __forceinline__ SiteView site_view(const View& v, int j, int cls, bool in_is_left) {
+template <typename R, bool CX> __device__ __forceinline__ SiteView<R> site_view(const ImpModel& v, int j, int cls, bool in_is_left) {
     const int Dl = v.chi[j], Dr = v.chi[j + 1];
-    SiteView sv;
-    sv.W = class_site(v, j, cls, Dl, Dr);
+    int64_t off = (int64_t)j * v.site_stride;
+    if (j == *v.label_site) off += (int64_t)cls * Dl * v.d * Dr;
+    SiteView<R> sv;
+    sv.W = (const R*)v.sites + (CX ? 2 : 1) * off;
     sv.ss = Dr;
     if (in_is_left) {
         sv.Din = Dl; sv.Dout = Dr; sv.si = (int64_t)v.d * Dr; sv.so = 1;
@@ -71,36 +112,58 @@ __device__ __forceinline__ SiteView site_view(const View& v, int j, int cls, boo
 }
 
 // ---- right environments ------------------------------------------------------------------------------------------------
-// C (M x N, row stride ld) (+)= A (M x K) * B, all in LDS, 16 x 16 tiles on the fp64 MFMA shared out over the 4 waves.
-// tb = false: B is K x N row-major; tb = true: B holds the transposed operand (N x K row-major), i.e. C += A * B^T.
-// Rows / columns beyond M / N / K must be zero in the operands (the buffers are kept zero-padded to multiples of 16).
-__device__ __forceinline__ void lds_mm(double* __restrict__ Cm, const double* __restrict__ A, const double* __restrict__ B, int M,
-                                       int N, int K, int ld, bool tb, bool accumulate) {
+// C (M x N, row stride ld) (+)= A (M x K) * B, all in LDS, 16 x 16 tiles on the MFMA shared out over the 4 waves.
+// tb = false: B is K x N row-major; tb = true: B holds the N x K operand whose conjugate transpose is meant, C += A * B^H.
+// Complex operands are (real plane, imaginary plane) pairs.  Rows / columns beyond M / N / K must be zero in the operands
+// (the buffers are kept zero-padded to multiples of 16).
+template <typename R> struct Plane {
+    R *r, *i;
+};
+template <typename R, bool CX>
+__device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int M, int N, int K, int ld, bool tb, bool accumulate) {
+    using acc_t = typename Mx<R>::acc_t;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, ks = (K + 3) >> 2;
     for (int t = wave; t < tm * tn; t += 4) {
         const int m0 = (t / tn) * 16, n0 = (t % tn) * 16;
-        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc_t accr = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
         if (accumulate) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = Cm[(m0 + kq + 4 * r) * ld + n0 + i16];
+            for (int r = 0; r < 4; ++r) {
+                accr[r] = Cm.r[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16];
+                if constexpr (CX) acci[r] = Cm.i[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16];
+            }
         }
         for (int u = 0; u < ks; ++u) {
             const int k = 4 * u + kq;
-            const double av = A[(m0 + i16) * ld + k];
-            const double bv = tb ? B[(n0 + i16) * ld + k] : B[k * ld + n0 + i16];
-            acc = mfma_f64(av, bv, acc);
+            const int ia = (m0 + i16) * ld + k;
+            const int ib = tb ? (n0 + i16) * ld + k : k * ld + n0 + i16;
+            const R ar = A.r[ia], br = B.r[ib];
+            accr = Mx<R>::mma(ar, br, accr);
+            if constexpr (CX) {
+                // plain: (ar + i ai)(br + i bi);  tb: (ar + i ai)(br - i bi)
+                const R ai = A.i[ia], bi = B.i[ib];
+                accr = Mx<R>::mma(tb ? ai : -ai, bi, accr);
+                acci = Mx<R>::mma(ai, br, acci);
+                acci = Mx<R>::mma(tb ? -ar : ar, bi, acci);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cm[(m0 + kq + 4 * r) * ld + n0 + i16] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+            Cm.r[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16] = accr[r];
+            if constexpr (CX) Cm.i[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16] = acci[r];
+        }
     }
 }
 
-__global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __restrict__ missing, double* __restrict__ Rbuf,
+template <typename R, bool CX>
+__global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
                                                      int max_missing, int64_t i0, int rev) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
+    constexpr int NP = CX ? 8 : 4, ZW = CX ? 2 : 1;
     const int64_t i = i0 + blockIdx.x;          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
     const uint8_t* mi = missing + i * T;
@@ -111,39 +174,41 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
     const int cp = (cm + 15) & ~15;            // matrices are kept zero-padded to a multiple of 16 rows / columns
     const int ld = cp + 2;                     // + 2: the 16 rows an MFMA operand read touches land on different banks
     const int msz = cp * ld;
-    double* Ra = smem;                 // current environment matrix
-    double* Rb = Ra + msz;             // next one
-    double* Ms = Rb + msz;             // M_j or W_j[s] as an (out x in) matrix of this pass
-    double* T1 = Ms + msz;             // Ms * R
-    for (int e = tid; e < 4 * msz; e += IMP_T) smem[e] = 0.0;
+    auto plane = [&](int k) { return Plane<R>{smem + (int64_t)(ZW * k) * msz, smem + (int64_t)(ZW * k + ZW - 1) * msz}; };
+    Plane<R> Rc = plane(0);            // current environment matrix
+    Plane<R> Rn = plane(1);            // next one
+    const Plane<R> Ms = plane(2);      // M_j or W_j[s] as an (out x in) matrix of this pass
+    const Plane<R> T1 = plane(3);      // Ms * R
+    for (int e = tid; e < NP * msz; e += IMP_T) smem[e] = R(0);
     __syncthreads();
-    double* R = Ra;
-    double* Rn = Rb;
-    if (tid == 0) R[0] = 1.0;
+    if (tid == 0) Rc.r[0] = R(1);
     __syncthreads();
     int slot = 0;
     for (int step = 0; step < T; ++step) {
         // forwards imputation: this pass runs right to left and a site is entered through its RIGHT bond
         const int j = rev ? step : T - 1 - step;
-        const SiteView sv = site_view(v, j, cls, rev != 0);
+        const SiteView<R> sv = site_view<R, CX>(v, j, cls, rev != 0);
         const int Di = sv.Din, Do = sv.Dout;        // R is Di x Di, the new one Do x Do
         const bool miss = mi[j] != 0;
         if (miss) {
             // the environment of the sites beyond j is what site j's density matrix needs
-            double* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm;
-            for (int e = tid; e < Di * Di; e += IMP_T) out[e] = R[(e / Di) * ld + (e % Di)];
+            R* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm * ZW;
+            for (int e = tid; e < Di * Di; e += IMP_T) {
+                const int at = (e / Di) * ld + (e % Di);
+                zstore<R, CX>(out, e, Rc.r[at], CX ? Rc.i[at] : R(0));
+            }
             ++slot;
             if (slot == nm) break;                 // nothing beyond the last missing site of this pass needs an environment
         }
-        const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
+        const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
         const int ns = miss ? d : 1;
         // consecutive threads walk the contiguous bond index of the stored tensor (its right bond)
         const bool in_fast = sv.si == 1;
         const int Df = in_fast ? Di : Do;
         for (int s = 0; s < ns; ++s) {
-            // Ms[o][i] = M_j (known) or W_j[s] (missing); 8 elements per thread per round trip
+            // Ms[o][i] = M_j = sum_q conj(phi_q) W_j[q] (known) or W_j[s] (missing); 8 elements per thread per round trip
             for (int e0 = tid; e0 < Di * Do; e0 += 8 * IMP_T) {
-                double acc[8];
+                R accr[8], acci[8];
                 int64_t off[8];
                 int dst[8];
 #pragma unroll
@@ -153,46 +218,68 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
                     const int ii = in_fast ? fast : slow, oo = in_fast ? slow : fast;
                     off[q] = (int64_t)ii * sv.si + (int64_t)oo * sv.so;
                     dst[q] = oo * ld + ii;
-                    acc[q] = 0.0;
+                    accr[q] = R(0);
+                    acci[q] = R(0);
                 }
                 if (miss) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if (e0 + q * IMP_T < Di * Do) acc[q] = sv.W[off[q] + (int64_t)s * sv.ss];
+                        if (e0 + q * IMP_T < Di * Do) zload<R, CX>(sv.W, off[q] + (int64_t)s * sv.ss, accr[q], acci[q]);
                 } else {
                     for (int qq = 0; qq < d; ++qq) {
-                        const double pq = ph[qq];
-                        double w[8];
+                        R pr, pi;
+                        zload<R, CX>(ph, qq, pr, pi);
+                        R wr[8], wi[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) w[q] = (e0 + q * IMP_T < Di * Do) ? sv.W[off[q] + (int64_t)qq * sv.ss] : 0.0;
+                        for (int q = 0; q < 8; ++q) {
+                            wr[q] = R(0);
+                            wi[q] = R(0);
+                            if (e0 + q * IMP_T < Di * Do) zload<R, CX>(sv.W, off[q] + (int64_t)qq * sv.ss, wr[q], wi[q]);
+                        }
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[q] = fma(pq, w[q], acc[q]);
+                        for (int q = 0; q < 8; ++q) {
+                            accr[q] = fma(pr, wr[q], accr[q]);
+                            if constexpr (CX) {
+                                accr[q] = fma(pi, wi[q], accr[q]);
+                                acci[q] = fma(pr, wi[q], acci[q]);
+                                acci[q] = fma(-pi, wr[q], acci[q]);
+                            }
+                        }
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (e0 + q * IMP_T < Di * Do) Ms[dst[q]] = acc[q];
+                    if (e0 + q * IMP_T < Di * Do) {
+                        Ms.r[dst[q]] = accr[q];
+                        if constexpr (CX) Ms.i[dst[q]] = acci[q];
+                    }
             }
             __syncthreads();
-            lds_mm(T1, Ms, R, Do, Di, Di, ld, false, false);          // T1 = Ms * R
+            lds_mm<R, CX>(T1, Ms, Rc, Do, Di, Di, ld, false, false);          // T1 = Ms * R
             __syncthreads();
-            lds_mm(Rn, T1, Ms, Do, Do, Di, ld, true, s > 0);           // Rn (+)= T1 * Ms^T
+            lds_mm<R, CX>(Rn, T1, Ms, Do, Do, Di, ld, true, s > 0);            // Rn (+)= T1 * Ms^H
             __syncthreads();
         }
         // rescale by the trace (every density below is scale-free), clear what the next site must find zero, swap
         double tr = 0.0;
-        for (int a = tid; a < Do; a += IMP_T) tr += Rn[a * ld + a];
+        for (int a = tid; a < Do; a += IMP_T) tr += (double)Rn.r[a * ld + a];
         tr = blk_sum(tr, red);
-        const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
+        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
         for (int e = tid; e < cp * cp; e += IMP_T) {
             const int a = e / cp, b2 = e - a * cp;
-            Rn[a * ld + b2] = (a < Do && b2 < Do) ? Rn[a * ld + b2] * sc : 0.0;
-            Ms[a * ld + b2] = 0.0;
-            T1[a * ld + b2] = 0.0;
+            const bool live = a < Do && b2 < Do;
+            Rn.r[a * ld + b2] = live ? Rn.r[a * ld + b2] * sc : R(0);
+            Ms.r[a * ld + b2] = R(0);
+            T1.r[a * ld + b2] = R(0);
+            if constexpr (CX) {
+                Rn.i[a * ld + b2] = live ? Rn.i[a * ld + b2] * sc : R(0);
+                Ms.i[a * ld + b2] = R(0);
+                T1.i[a * ld + b2] = R(0);
+            }
         }
         __syncthreads();
-        double* tmp = R;
-        R = Rn;
+        const Plane<R> tmp = Rc;
+        Rc = Rn;
         Rn = tmp;
     }
 }
@@ -200,9 +287,9 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(View v, const uint8_t* __re
 // ---- the sweep with the imputation itself ---------------------------------------------------------------------------------
 struct ImpArgs {
     const uint8_t* missing;     // [N][T]
-    const double* Rbuf;         // [chunk][max_missing][cap*cap]
+    const void* Rbuf;           // [chunk][max_missing][cap*cap] elements of the chain type
     const double* grid_x;       // [ngrid]
-    const double* grid_phi;     // [ngrid][d]
+    const double* grid_phi;     // [ngrid][d] doubles (real model) or (re, im) pairs (complex model)
     const double* u;            // [N][T][ntrial] uniform numbers (quantile / ITS) or null
     double* pbuf;               // [chunk][ngrid] scratch: p_k
     double* sbuf;               // [chunk][ngrid] scratch: prefix sums S_k
@@ -213,13 +300,17 @@ struct ImpArgs {
     int64_t i0;                 // first instance of this chunk
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
+enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2 };
 
-__global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_left(ImpModel v, ImpArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
-    __shared__ double rho[IMP_MAXD * IMP_MAXD];
+    __shared__ double rho[IMP_MAXD * IMP_MAXD];           // real part
+    __shared__ double rhoi[CX ? IMP_MAXD * IMP_MAXD : 1]; // imaginary part
     __shared__ double segsum[IMP_T];
     __shared__ int isel[4];
+    constexpr int ZW = CX ? 2 : 1;
     const int64_t i = g.i0 + blockIdx.x;
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
     const uint8_t* mi = g.missing + i * T;
@@ -227,72 +318,128 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
     for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
     if (nm == 0) return;
     const int cls = v.label[i];
-    double* L = smem;                      // [cm]
-    double* Ln = L + cm;                   // [cm]
-    double* LW = Ln + cm;                  // [d][cm]
-    double* U = LW + IMP_MAXD * cm;        // [d][cm]
-    double* ms = U + IMP_MAXD * cm;        // [d] chosen state
+    // vectors and d x chi panels as (real plane, imaginary plane) pairs
+    const int vsz = cm, psz = IMP_MAXD * cm;
+    const Plane<R> L{smem, smem + (ZW - 1) * vsz};
+    const Plane<R> Ln{smem + ZW * vsz, smem + ZW * vsz + (ZW - 1) * vsz};
+    R* pan = smem + 2 * ZW * vsz;
+    const Plane<R> LW{pan, pan + (ZW - 1) * psz};                               // [d][cm]
+    const Plane<R> U{pan + ZW * psz, pan + ZW * psz + (ZW - 1) * psz};          // [d][cm]
+    R* msp = pan + 2 * ZW * psz;
+    const Plane<R> ms{msp, msp + (ZW - 1) * IMP_MAXD};                          // [d] chosen state
     double* p = g.pbuf + (int64_t)blockIdx.x * g.ngrid;
     double* S = g.sbuf + (int64_t)blockIdx.x * g.ngrid;
     const int n = g.ngrid;
     const int seg = (n + IMP_T - 1) / IMP_T;
     const int k0 = min(n, tid * seg), k1 = min(n, k0 + seg);
     const double dx = g.grid_x[1] - g.grid_x[0];
-    if (tid == 0) L[0] = 1.0;
+    if (tid == 0) {
+        L.r[0] = R(1);
+        if constexpr (CX) L.i[0] = R(0);
+    }
     __syncthreads();
     int seen = 0;
     for (int step = 0; step < T; ++step) {
         const int j = g.rev ? T - 1 - step : step;
-        const SiteView sv = site_view(v, j, cls, g.rev == 0);
+        const SiteView<R> sv = site_view<R, CX>(v, j, cls, g.rev == 0);
         const int Di = sv.Din, Do = sv.Dout;
         const bool miss = mi[j] != 0;
         // LW[s][o] = sum_i L[i] W(i, s, o) for both kinds of site; a known site then contracts s with its encoded value.
         // Forwards consecutive threads are consecutive o (contiguous in memory), backwards the 8 loads of a thread are.
         for (int e = tid; e < d * Do; e += IMP_T) {
             const int s_ = e / Do, o = e - s_ * Do;
-            const double* wp = sv.W + (int64_t)s_ * sv.ss + (int64_t)o * sv.so;
-            double t = 0.0;
+            const int64_t w0 = (int64_t)s_ * sv.ss + (int64_t)o * sv.so;
+            R tr = R(0), ti = R(0);
             for (int a0 = 0; a0 < Di; a0 += 8) {
-                double w[8];
+                R wr[8], wi[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) w[q] = (a0 + q < Di) ? wp[(int64_t)(a0 + q) * sv.si] : 0.0;
+                for (int q = 0; q < 8; ++q) {
+                    wr[q] = R(0);
+                    wi[q] = R(0);
+                    if (a0 + q < Di) zload<R, CX>(sv.W, w0 + (int64_t)(a0 + q) * sv.si, wr[q], wi[q]);
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if (a0 + q < Di) t = fma(L[a0 + q], w[q], t);
+                    if (a0 + q < Di) {
+                        const R lr = L.r[a0 + q];
+                        tr = fma(lr, wr[q], tr);
+                        if constexpr (CX) {
+                            const R li = L.i[a0 + q];
+                            tr = fma(-li, wi[q], tr);
+                            ti = fma(lr, wi[q], ti);
+                            ti = fma(li, wr[q], ti);
+                        }
+                    }
             }
-            LW[s_ * cm + o] = t;
+            LW.r[s_ * cm + o] = tr;
+            if constexpr (CX) LW.i[s_ * cm + o] = ti;
         }
         __syncthreads();
         if (!miss) {
-            const double* ph = v.phi + ((int64_t)j * v.N + i) * d;
+            // L <- sum_s conj(phi_s) (L W)[s]   (condition_until_next!: class_mps[i] * dag(timeseries_enc[i]))
+            const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
             for (int o = tid; o < Do; o += IMP_T) {
-                double t = 0.0;
-                for (int q = 0; q < d; ++q) t = fma(ph[q], LW[q * cm + o], t);
-                Ln[o] = t;
+                R tr = R(0), ti = R(0);
+                for (int q = 0; q < d; ++q) {
+                    R pr, pi;
+                    zload<R, CX>(ph, q, pr, pi);
+                    tr = fma(pr, LW.r[q * cm + o], tr);
+                    if constexpr (CX) {
+                        tr = fma(pi, LW.i[q * cm + o], tr);
+                        ti = fma(pr, LW.i[q * cm + o], ti);
+                        ti = fma(-pi, LW.r[q * cm + o], ti);
+                    }
+                }
+                Ln.r[o] = tr;
+                if constexpr (CX) Ln.i[o] = ti;
             }
         } else {
-            const double* R = g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm;      // [Do][Do] compact
+            const R* Rm = (const R*)g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm * ZW;      // [Do][Do] compact
             ++seen;
-            // U = LW R;  rho = U LW^T
+            // U = LW R;  rho = U LW^H
             for (int e = tid; e < d * Do; e += IMP_T) {
                 const int s_ = e / Do, o = e - s_ * Do;
-                double t = 0.0;
+                R tr = R(0), ti = R(0);
                 for (int q0 = 0; q0 < Do; q0 += 8) {
-                    double r8[8];
+                    R rr8[8], ri8[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) r8[q] = (q0 + q < Do) ? R[(int64_t)(q0 + q) * Do + o] : 0.0;
+                    for (int q = 0; q < 8; ++q) {
+                        rr8[q] = R(0);
+                        ri8[q] = R(0);
+                        if (q0 + q < Do) zload<R, CX>(Rm, (int64_t)(q0 + q) * Do + o, rr8[q], ri8[q]);
+                    }
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if (q0 + q < Do) t = fma(LW[s_ * cm + q0 + q], r8[q], t);
+                        if (q0 + q < Do) {
+                            const R ar = LW.r[s_ * cm + q0 + q];
+                            tr = fma(ar, rr8[q], tr);
+                            if constexpr (CX) {
+                                const R ai = LW.i[s_ * cm + q0 + q];
+                                tr = fma(-ai, ri8[q], tr);
+                                ti = fma(ar, ri8[q], ti);
+                                ti = fma(ai, rr8[q], ti);
+                            }
+                        }
                 }
-                U[s_ * cm + o] = t;
+                U.r[s_ * cm + o] = tr;
+                if constexpr (CX) U.i[s_ * cm + o] = ti;
             }
             __syncthreads();
             for (int e = tid; e < d * d; e += IMP_T) {
                 const int s_ = e / d, s2 = e - s_ * d;
-                double t = 0.0;
-                for (int k = 0; k < Do; ++k) t = fma(U[s_ * cm + k], LW[s2 * cm + k], t);
-                rho[s_ * IMP_MAXD + s2] = t;
+                R tr = R(0), ti = R(0);
+                for (int k = 0; k < Do; ++k) {
+                    const R ur = U.r[s_ * cm + k], br = LW.r[s2 * cm + k];
+                    tr = fma(ur, br, tr);
+                    if constexpr (CX) {
+                        const R ui_ = U.i[s_ * cm + k], bi = LW.i[s2 * cm + k];
+                        tr = fma(ui_, bi, tr);
+                        ti = fma(ui_, br, ti);
+                        ti = fma(-ur, bi, ti);
+                    }
+                }
+                rho[s_ * IMP_MAXD + s2] = (double)tr;
+                if constexpr (CX) rhoi[s_ * IMP_MAXD + s2] = (double)ti;
             }
             __syncthreads();
             // normalise rho by its trace (p scales with the square, every quantity below is scale-free)
@@ -301,14 +448,90 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 for (int s_ = 0; s_ < d; ++s_) tr += rho[s_ * IMP_MAXD + s_];
                 const double sc = tr > 0.0 ? 1.0 / tr : 1.0;
                 __syncthreads();
-                for (int e = tid; e < d * d; e += IMP_T) rho[(e / d) * IMP_MAXD + (e % d)] *= sc;
+                for (int e = tid; e < d * d; e += IMP_T) {
+                    rho[(e / d) * IMP_MAXD + (e % d)] *= sc;
+                    if constexpr (CX) rhoi[(e / d) * IMP_MAXD + (e % d)] *= sc;
+                }
                 __syncthreads();
             }
             // p_k = |rho phi_k|^2: grid values interleaved over the threads (consecutive lanes read consecutive encoded
-            // states: coalesced), rho in registers; then every thread sums its CONTIGUOUS segment for the block-wide scan
+            // states: coalesced); then every thread sums its CONTIGUOUS segment for the block-wide scan
             double pmax = -1.0;
             int kmax = 0;
-            {
+            if constexpr (CX) {
+                // rho stays in LDS (every lane reads the same entry: broadcast), two grid values per round trip
+                const double2* gp = reinterpret_cast<const double2*>(g.grid_phi);
+                auto evalc = [&](auto DD) {
+                    constexpr int D = decltype(DD)::value;
+                    for (int kb = tid; kb < n; kb += 2 * IMP_T) {
+                        double2 f[2][D];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int k = kb + q * IMP_T;
+                            const double2* ph = gp + (int64_t)(k < n ? k : 0) * D;
+#pragma unroll
+                            for (int s2 = 0; s2 < D; ++s2) f[q][s2] = ph[s2];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int k = kb + q * IMP_T;
+                            if (k < n) {
+                                double pk = 0.0;
+#pragma unroll
+                                for (int s_ = 0; s_ < D; ++s_) {
+                                    double qr = 0.0, qi = 0.0;
+#pragma unroll
+                                    for (int s2 = 0; s2 < D; ++s2) {
+                                        const double ar = rho[s_ * IMP_MAXD + s2], ai = rhoi[s_ * IMP_MAXD + s2];
+                                        qr = fma(ar, f[q][s2].x, qr);
+                                        qr = fma(-ai, f[q][s2].y, qr);
+                                        qi = fma(ar, f[q][s2].y, qi);
+                                        qi = fma(ai, f[q][s2].x, qi);
+                                    }
+                                    pk = fma(qr, qr, pk);
+                                    pk = fma(qi, qi, pk);
+                                }
+                                p[k] = pk;
+                                if (pk > pmax) {
+                                    pmax = pk;
+                                    kmax = k;
+                                }
+                            }
+                        }
+                    }
+                };
+                switch (d) {
+                    case 2: evalc(std::integral_constant<int, 2>{}); break;
+                    case 3: evalc(std::integral_constant<int, 3>{}); break;
+                    case 4: evalc(std::integral_constant<int, 4>{}); break;
+                    case 5: evalc(std::integral_constant<int, 5>{}); break;
+                    case 6: evalc(std::integral_constant<int, 6>{}); break;
+                    case 8: evalc(std::integral_constant<int, 8>{}); break;
+                    default:
+                        for (int k = tid; k < n; k += IMP_T) {
+                            const double2* ph = gp + (int64_t)k * d;
+                            double pk = 0.0;
+                            for (int s_ = 0; s_ < d; ++s_) {
+                                double qr = 0.0, qi = 0.0;
+                                for (int s2 = 0; s2 < d; ++s2) {
+                                    const double ar = rho[s_ * IMP_MAXD + s2], ai = rhoi[s_ * IMP_MAXD + s2];
+                                    const double2 fv = ph[s2];
+                                    qr = fma(ar, fv.x, qr);
+                                    qr = fma(-ai, fv.y, qr);
+                                    qi = fma(ar, fv.y, qi);
+                                    qi = fma(ai, fv.x, qi);
+                                }
+                                pk = fma(qr, qr, pk);
+                                pk = fma(qi, qi, pk);
+                            }
+                            p[k] = pk;
+                            if (pk > pmax) {
+                                pmax = pk;
+                                kmax = k;
+                            }
+                        }
+                }
+            } else {
                 double rr[IMP_MAXD * IMP_MAXD];
 #pragma unroll
                 for (int e = 0; e < IMP_MAXD * IMP_MAXD; ++e) rr[e] = (e / IMP_MAXD < d && e % IMP_MAXD < d) ? rho[e] : 0.0;
@@ -543,72 +766,130 @@ __global__ __launch_bounds__(IMP_T) void k_imp_left(View v, ImpArgs g) {
                 }
                 xsel = ex;
                 state_from_grid = false;
-                // Legendre states of E[x], same arithmetic as the encoder (k_encode; bases.jl:77-92,108)
+                // state of E[x]: Legendre with the encoder's arithmetic (k_encode; bases.jl:77-92,108) or Fourier
+                // (bases.jl:23-42: cispi(f x) / sqrt(d), f = 0, 1, -1, 2, -2, ...)
                 if (tid == 0) {
-                    const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);
-                    double q0 = 1.0, q1 = ex;
-                    for (int k = 0; k < d; ++k) {
-                        double pk;
-                        if (k == 0) pk = 1.0;
-                        else if (k == 1) pk = ex;
-                        else {
-                            const int m = k - 1;
-                            pk = ((2 * m + 1) * ex * q1 - m * q0) / (m + 1);
-                            q0 = q1;
-                            q1 = pk;
+                    if (g.mean_basis == IMP_BASIS_FOURIER) {
+                        for (int k = 0; k < d; ++k) {
+                            const int f = (k + 1) / 2 * ((k & 1) ? 1 : -1);
+                            double sn, cs;
+                            sincospi((double)f * ex, &sn, &cs);
+                            ms.r[k] = (R)(cs / sqrt((double)d));
+                            if constexpr (CX) ms.i[k] = (R)(sn / sqrt((double)d));
                         }
-                        double val = pk * sqrt((2.0 * k + 1.0) / 2.0);
-                        if (g.mean_basis == 0) val = val / nrm;
-                        ms[k] = val;
+                    } else {
+                        const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);
+                        double q0 = 1.0, q1 = ex;
+                        for (int k = 0; k < d; ++k) {
+                            double pk;
+                            if (k == 0) pk = 1.0;
+                            else if (k == 1) pk = ex;
+                            else {
+                                const int m = k - 1;
+                                pk = ((2 * m + 1) * ex * q1 - m * q0) / (m + 1);
+                                q0 = q1;
+                                q1 = pk;
+                            }
+                            double val = pk * sqrt((2.0 * k + 1.0) / 2.0);
+                            if (g.mean_basis == IMP_BASIS_LEGENDRE) val = val / nrm;
+                            ms.r[k] = (R)val;
+                            if constexpr (CX) ms.i[k] = R(0);
+                        }
                     }
                 }
             }
             if (state_from_grid) {
                 xsel = g.grid_x[ksel];
-                if (tid < d) ms[tid] = g.grid_phi[(int64_t)ksel * d + tid];
+                if (tid < d) {
+                    ms.r[tid] = (R)g.grid_phi[((int64_t)ksel * d + tid) * ZW];
+                    if constexpr (CX) ms.i[tid] = (R)g.grid_phi[((int64_t)ksel * d + tid) * ZW + 1];
+                }
             }
             if (tid == 0) {
                 g.x_out[i * T + j] = xsel;
                 g.err_out[i * T + j] = err;
             }
             __syncthreads();
-            // project onto the chosen state: L <- phi*^T (L W)
+            // project onto the chosen state: L <- sum_s conj(ms_s) (L W)[s]   (Am = ms' * A, MPS_methods.jl:161)
             for (int o = tid; o < Do; o += IMP_T) {
-                double t = 0.0;
-                for (int s_ = 0; s_ < d; ++s_) t = fma(ms[s_], LW[s_ * cm + o], t);
-                Ln[o] = t;
+                R tr = R(0), ti = R(0);
+                for (int s_ = 0; s_ < d; ++s_) {
+                    const R mr = ms.r[s_];
+                    tr = fma(mr, LW.r[s_ * cm + o], tr);
+                    if constexpr (CX) {
+                        const R mi_ = ms.i[s_];
+                        tr = fma(mi_, LW.i[s_ * cm + o], tr);
+                        ti = fma(mr, LW.i[s_ * cm + o], ti);
+                        ti = fma(-mi_, LW.r[s_ * cm + o], ti);
+                    }
+                }
+                Ln.r[o] = tr;
+                if constexpr (CX) Ln.i[o] = ti;
             }
             if (seen == nm) break;             // nothing beyond the last missing site is needed
         }
         __syncthreads();
         // rescale L by its largest magnitude
         double mx = 0.0;
-        for (int o = tid; o < Do; o += IMP_T) mx = fmax(mx, fabs(Ln[o]));
+        for (int o = tid; o < Do; o += IMP_T) {
+            mx = fmax(mx, fabs((double)Ln.r[o]));
+            if constexpr (CX) mx = fmax(mx, fabs((double)Ln.i[o]));
+        }
         mx = blk_max(mx, red);
-        const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
-        for (int o = tid; o < Do; o += IMP_T) L[o] = Ln[o] * sc;
+        const R sc = mx > 0.0 ? (R)(1.0 / mx) : R(1);
+        for (int o = tid; o < Do; o += IMP_T) {
+            L.r[o] = Ln.r[o] * sc;
+            if constexpr (CX) L.i[o] = Ln.i[o] * sc;
+        }
         __syncthreads();
     }
 }
+
+static size_t right_lds_bytes(int cap, bool cx, bool f32) {
+    const int cp = (cap + 15) & ~15;
+    return (size_t)(cx ? 8 : 4) * cp * (cp + 2) * (f32 ? 4 : 8);
+}
+static size_t left_lds_bytes(int cap, bool cx, bool f32) {
+    return (size_t)(2 * cap + 2 * IMP_MAXD * cap + IMP_MAXD) * (cx ? 2 : 1) * (f32 ? 4 : 8);
+}
+int impute_chi_limit(bool cx, bool f32) { return (cx && !f32) ? 48 : 64; }
 
 hipError_t impute_init_attrs(int device) {
     static unsigned long long done = 0;
     if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)k_imp_right, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 66 * 8)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_imp_left, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)) != hipSuccess) return e;
+#define IMP_ATTR(R, CX, F32)                                                                                                       \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                      \
+                                 (int)right_lds_bytes(impute_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;               \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                       \
+                                 (int)left_lds_bytes(64, CX, F32))) != hipSuccess) return e;
+    IMP_ATTR(double, false, false)
+    IMP_ATTR(double, true, false)
+    IMP_ATTR(float, false, true)
+    IMP_ATTR(float, true, true)
+#undef IMP_ATTR
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
 }
 
-void launch_impute(const View& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
-    const int cp = (v.cap + 15) & ~15;
-    const size_t lds_r = (size_t)4 * cp * (cp + 2) * sizeof(double);
-    hipLaunchKernelGGL(k_imp_right, dim3((unsigned)count), dim3(IMP_T), lds_r, s, v, q.missing, q.Rbuf, q.max_missing, i0, q.rev);
+template <typename R, bool CX>
+static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
+    constexpr bool F32 = std::is_same<R, float>::value;
+    hipLaunchKernelGGL((k_imp_right<R, CX>), dim3((unsigned)count), dim3(IMP_T), right_lds_bytes(v.cap, CX, F32), s, v, q.missing,
+                       (R*)q.Rbuf, q.max_missing, i0, q.rev);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
-    const size_t lds_l = (size_t)(2 * v.cap + 2 * IMP_MAXD * v.cap + IMP_MAXD) * sizeof(double);
-    hipLaunchKernelGGL(k_imp_left, dim3((unsigned)count), dim3(IMP_T), lds_l, s, v, g);
+    hipLaunchKernelGGL((k_imp_left<R, CX>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+}
+
+void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
+    if (v.is_complex) {
+        if (v.compute_f32) launch_impute_t<float, true>(v, q, i0, count, s);
+        else launch_impute_t<double, true>(v, q, i0, count, s);
+    } else {
+        if (v.compute_f32) launch_impute_t<float, false>(v, q, i0, count, s);
+        else launch_impute_t<double, false>(v, q, i0, count, s);
+    }
 }
 
 }  // namespace mpst

@@ -318,15 +318,29 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
                        int32_t* rawinfo, BlockedEig* e, hipStream_t s);
 // imputation engine (mpst_impute.hip)
 hipError_t impute_init_attrs(int device);
+// what the engine reads of a model: site tensors [a][s][b] (label site: one block per class) at a uniform stride, live bond
+// dimensions, the encoded known values [T][N][d] and the class of every instance.  Elements are doubles / floats
+// (compute_f32) or interleaved (re, im) pairs of them (is_complex).
+struct ImpModel {
+    const void* sites;
+    int64_t site_stride;        // elements
+    const int32_t* chi;         // [T+1]
+    const int32_t* label_site;
+    const void* phi;
+    const int32_t* label;
+    int64_t N;
+    int32_t T, d, cap, is_complex, compute_f32;
+};
 struct ImputeParams {
     const uint8_t* missing;     // device [N][T]
-    double* Rbuf;               // device [chunk][max_missing][cap*cap]
-    const double *grid_x, *grid_phi, *u;
+    void* Rbuf;                 // device [chunk][max_missing][cap*cap] elements
+    const double *grid_x, *grid_phi, *u;    // grid_phi: [ngrid][d] doubles or (re, im) pairs
     double *pbuf, *sbuf, *x_out, *err_out;
     int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
     double reject_thr;
 };
-void launch_impute(const View& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s);
+int impute_chi_limit(bool cx, bool f32);
+void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);

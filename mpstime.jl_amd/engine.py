@@ -13,8 +13,8 @@ import numpy as np
 from . import _lib as L
 
 
-def _site_to_abi(t):
-    t = np.asarray(t, dtype=np.float64)
+def _site_to_abi(t, dtype=np.float64):
+    t = np.asarray(t, dtype=dtype)
     if t.ndim == 3:
         a = np.transpose(t, (1, 0, 2))          # (d, Dl, Dr)
     else:
@@ -224,6 +224,51 @@ class SweepEngine:
                                        gp.ctypes.data_as(dp), len(gx), C.byref(o),
                                        uu.ctypes.data_as(dp) if uu is not None else None, x.ctypes.data_as(dp),
                                        err.ctypes.data_as(dp), C.byref(sec)))
+        return x, err, sec.value
+
+    def impute_model(self, W, phi, label_index, missing, grid_x, grid_phi, method=0, get_wmad=True, u=None, order=0, max_trials=1,
+                     rejection_threshold=0.0, mean_basis=None, compute="f64", label_site=None):
+        """mpst_impute_model_run: the imputation engine on a model handed over in one call.  ``W``: site tensors
+        (Dl, d, Dr), the label site (Dl, d, Dr, C); ``phi`` (N, T, d) encoded known values; real or complex (then
+        ``grid_phi`` is complex too).  ``compute`` "f64" or "f32" (fp32 chain contractions, fp64 densities).
+        Returns (x, err, seconds)."""
+        cx = any(np.iscomplexobj(t) for t in W) or np.iscomplexobj(phi) or np.iscomplexobj(grid_phi)
+        dt = np.complex128 if cx else np.float64
+        T = len(W)
+        if label_site is None:
+            label_site = [j for j, t in enumerate(W) if np.ndim(t) == 4]
+            assert len(label_site) == 1, "exactly one site must carry the label index"
+            label_site = label_site[0]
+        Cn = int(W[label_site].shape[3])
+        d = int(W[0].shape[1])
+        chi = np.array([W[0].shape[0]] + [t.shape[2] for t in W], dtype=np.int32)
+        bufs = [_site_to_abi(t, dt) for t in W]
+        ptrs = (C.c_void_p * T)(*[b.ctypes.data for b in bufs])
+        ph = np.ascontiguousarray(phi, dtype=dt)
+        lab = np.ascontiguousarray(label_index, dtype=np.int32)
+        m = np.ascontiguousarray(missing, dtype=np.uint8)
+        N = ph.shape[0]
+        assert ph.shape == (N, T, d) and m.shape == (N, T) and lab.shape == (N,)
+        gx = np.ascontiguousarray(grid_x, dtype=np.float64)
+        gp = np.ascontiguousarray(grid_phi, dtype=dt)
+        assert gp.shape == (len(gx), d)
+        uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        if uu is not None:
+            assert uu.size == N * T * (int(max_trials) if int(method) == 4 else 1)
+        if mean_basis is None:
+            mean_basis = 2 if cx else 1
+        model = L.ImputeModel(N, T, d, Cn, int(label_site), 1 if cx else 0, {"f64": 0, "f32": 1}[compute],
+                              C.cast(ptrs, C.POINTER(C.c_void_p)), chi.ctypes.data_as(C.POINTER(C.c_int32)),
+                              ph.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.POINTER(C.c_int32)))
+        o = L.ImputeOpts(int(method), int(order), int(bool(get_wmad)), int(max_trials), int(mean_basis), 0, float(rejection_threshold))
+        x = np.zeros((N, T))
+        err = np.zeros((N, T))
+        sec = C.c_double()
+        dp = C.POINTER(C.c_double)
+        self._chk(self.lib.mpst_impute_model_run(self.ctx, C.byref(model), m.ctypes.data_as(C.POINTER(C.c_uint8)), gx.ctypes.data_as(dp),
+                                                 gp.ctypes.data_as(C.c_void_p), len(gx), C.byref(o),
+                                                 uu.ctypes.data_as(dp) if uu is not None else None, x.ctypes.data_as(dp),
+                                                 err.ctypes.data_as(dp), C.byref(sec)))
         return x, err, sec.value
 
     def normalize(self):

@@ -86,8 +86,6 @@ def init_imputation_problem(W, X_test, y_test=None, dx: float = 1e-4, guess_rang
     values ``range(guess_range...; step=dx)`` and their encoded states are tabulated once."""
     opts = safe_options(W.opts)
     enc = model_encoding(opts.encoding)
-    if np.iscomplexobj(enc.encode(np.zeros(1), opts.d)):
-        raise RuntimeError("the imputation engine is real-valued; complex encodings need the reference's ITensor path")
     if guess_range is None:
         guess_range = tuple(enc.range)
     X_test = np.asarray(X_test, dtype=np.float64)
@@ -96,7 +94,8 @@ def init_imputation_problem(W, X_test, y_test=None, dx: float = 1e-4, guess_rang
     xvals = guess_range[0] + dx * np.arange(n)
     td = W.train_data
     classes = np.unique(td.labels)
-    rng = EncodedDataRange(dx, guess_range, xvals, np.ascontiguousarray(enc.encode(xvals, opts.d), dtype=np.float64))
+    states = enc.encode(xvals, opts.d)
+    rng = EncodedDataRange(dx, guess_range, xvals, np.ascontiguousarray(states, dtype=np.complex128 if np.iscomplexobj(states) else np.float64))
     if verbosity > 0:
         print(f" - Dataset has {td.original_data.shape[0]} training samples and {X_test.shape[0]} testing samples.")
         print(f" - {len(classes)} class(es) were detected.")
@@ -120,12 +119,15 @@ def _scaled_instances(imp: ImputationProblem, rows, masks):
 
 def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median", rows=None, invert_transform: bool = True,
                    get_wmad: bool = True, rng=None, engine: Optional[SweepEngine] = None, device: int = 0, return_seconds=False,
-                   impute_order: str = "forwards", rejection_threshold=None, max_trials: int = 10):
+                   impute_order: str = "forwards", rejection_threshold=None, max_trials: int = 10, compute: str = "f64", shard=None):
     """Impute every instance of ``imp.X_test[rows]`` (default: all) at the sites where ``missing_mask`` is True, each
     with the MPS of its class.  Returns (X_imputed, pred_err) in the original units (``invert_transform``) or in the
     encoding's domain; pred_err is the weighted median absolute deviation for ``method="median"``, the standard
     deviation for ``"mean"`` and None otherwise.  ``"ITS"`` draws one trajectory per instance from ``rng``
-    (``rejection_threshold`` None is the reference's ``:none``)."""
+    (``rejection_threshold`` None is the reference's ``:none``).  Complex encodings (Fourier, Sahand) and
+    ``compute="f32"`` (fp32 chain contractions, fp64 densities) go through ``mpst_impute_model_run``.  With a ``shard``
+    (distributed.Shard) every rank imputes its slice of the rows - instances are independent, there is no collective on
+    the data path - and the results are gathered on every rank."""
     if method not in METHODS:
         raise ValueError("Invalid method. Choose :mean, :mode, :median, :kNearestNeighbour, :flatBaseline or :ITS"
                          if method not in ("kNearestNeighbour", "flatBaseline") else
@@ -135,10 +137,16 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
     rows = np.arange(imp.X_test.shape[0]) if rows is None else np.asarray(rows)
     mask = np.asarray(missing_mask, dtype=bool)
     assert mask.shape == (len(rows), imp.X_test.shape[1])
+    if shard is not None and shard.world > 1:
+        return _impute_sharded(imp, mask, method, rows, shard, invert_transform=invert_transform, get_wmad=get_wmad, rng=rng,
+                               engine=engine, device=device, return_seconds=return_seconds, impute_order=impute_order,
+                               rejection_threshold=rejection_threshold, max_trials=max_trials, compute=compute)
     enc, norms, raw, full, scaled, oob = _scaled_instances(imp, rows, mask)
     lab = np.array([imp.class_map[c] for c in np.asarray(imp.y_test)[rows].tolist()], dtype=np.int32)
     order = np.argsort(lab, kind="stable")                      # the engine wants class-sorted data sets
-    phi = np.ascontiguousarray(enc.encode(scaled[order], imp.opts.d), dtype=np.float64)
+    phi = enc.encode(scaled[order], imp.opts.d)
+    cx = np.iscomplexobj(phi) or np.iscomplexobj(imp.x_guess_range.xvals_enc) or any(np.iscomplexobj(t) for t in imp.mps)
+    phi = np.ascontiguousarray(phi, dtype=np.complex128 if cx else np.float64)
     m8 = np.ascontiguousarray(mask[order], dtype=np.uint8)
     N, T = m8.shape
     u = None
@@ -148,18 +156,22 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
             code, trials, thr = 4, int(max_trials), float(rejection_threshold)
         u = np.ascontiguousarray((rng or np.random.default_rng()).uniform(0.0, 1.0, (N, T, trials)))
     if method == "mean":
-        if enc.name not in ("Legendre_No_Norm", "Legendre_Norm"):
-            raise NotImplementedError("method 'mean' re-encodes the expectation value on the device: Legendre bases only")
-        basis = 0 if enc.name == "Legendre_Norm" else 1         # MPST_BASIS_LEGENDRE / MPST_BASIS_LEGENDRE_NO_NORM
+        if enc.name not in ("Legendre_No_Norm", "Legendre_Norm", "Fourier"):
+            raise NotImplementedError("method 'mean' re-encodes the expectation value on the device: Legendre and Fourier bases only")
+        basis = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2}[enc.name]         # MPST_BASIS_*
     own = engine is None
     eng = engine or SweepEngine(device)
     try:
-        Cn = int(imp.mps[-1].shape[3])
-        eng.set_options(**engine_options(imp.opts))
-        eng.set_dataset(1, phi, lab[order], Cn)
-        eng.set_mps(imp.mps)
-        x, err, secs = eng.impute(1, m8, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, code, get_wmad, u,
-                                  order=ORDERS[impute_order], max_trials=trials, rejection_threshold=thr, mean_basis=basis)
+        kw = dict(order=ORDERS[impute_order], max_trials=trials, rejection_threshold=thr, mean_basis=basis)
+        if cx or compute != "f64":
+            x, err, secs = eng.impute_model(imp.mps, phi, lab[order], m8, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, code,
+                                            get_wmad, u, compute=compute, **kw)
+        else:
+            Cn = int(imp.mps[-1].shape[3])
+            eng.set_options(**engine_options(imp.opts))
+            eng.set_dataset(1, phi, lab[order], Cn)
+            eng.set_mps(imp.mps)
+            x, err, secs = eng.impute(1, m8, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, code, get_wmad, u, **kw)
     finally:
         if own:
             eng.close()
@@ -177,6 +189,36 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
             pred = hi - ts
     out = (ts, pred)
     return out + (secs,) if return_seconds else out
+
+
+def _impute_sharded(imp, mask, method, rows, shard, return_seconds=False, rng=None, **kw):
+    """Rows i with i % world == rank on every rank (the classes stay balanced), results gathered with the host-side
+    process group; the uniform numbers of the sampling methods are drawn for the whole set on every rank from the same
+    generator, so a sharded run reproduces the single-process one."""
+    import torch.distributed as dist
+    mine = np.arange(shard.rank, len(rows), shard.world)
+    if rng is not None and method == "ITS":
+        raise NotImplementedError("sharded ITS: pass per-rank generators through a single-process call per shard")
+    ts = pred = None
+    secs = 0.0
+    if len(mine):
+        out = impute_dataset(imp, mask[mine], method, rows=np.asarray(rows)[mine], return_seconds=True, **kw)
+        ts, pred, secs = out
+    parts = [None] * shard.world
+    dist.all_gather_object(parts, (mine, ts, pred, secs), group=shard.group)
+    T = mask.shape[1]
+    full = np.zeros((len(rows), T))
+    perr = np.zeros((len(rows), T))
+    have_err = False
+    for idx, t, e, _ in parts:
+        if t is None:
+            continue
+        full[idx] = t
+        if e is not None:
+            perr[idx] = e
+            have_err = True
+    out = (full, perr if have_err else None)
+    return out + (max(p[3] for p in parts),) if return_seconds else out
 
 
 def kNN_impute(imp: ImputationProblem, class_, instance: int, missing_sites, k: int = 1):

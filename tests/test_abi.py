@@ -39,6 +39,9 @@ def test_struct_layouts_match_the_header():
 int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mpst_options), offsetof(mpst_options, eta), offsetof(mpst_options, cutoff),
          sizeof(mpst_sweep_stats), sizeof(mpst_bond_debug), offsetof(mpst_bond_debug, spectrum), offsetof(mpst_bond_debug, chi_new));
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mpst_impute_opts), offsetof(mpst_impute_opts, rejection_threshold),
+         sizeof(mpst_impute_model), offsetof(mpst_impute_model, dtype), offsetof(mpst_impute_model, site),
+         offsetof(mpst_impute_model, label_idx), sizeof(mpst_encode_opts));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -49,7 +52,10 @@ int main(void) {
     L = mt._lib
     assert vals == [ctypes.sizeof(L.mpst_options), L.mpst_options.eta.offset, L.mpst_options.cutoff.offset,
                     ctypes.sizeof(L.mpst_sweep_stats), ctypes.sizeof(L.mpst_bond_debug),
-                    L.mpst_bond_debug.spectrum.offset, L.mpst_bond_debug.chi_new.offset]
+                    L.mpst_bond_debug.spectrum.offset, L.mpst_bond_debug.chi_new.offset,
+                    ctypes.sizeof(L.ImputeOpts), L.ImputeOpts.rejection_threshold.offset, ctypes.sizeof(L.ImputeModel),
+                    L.ImputeModel.dtype.offset, L.ImputeModel.site.offset, L.ImputeModel.label_idx.offset,
+                    ctypes.sizeof(L.mpst_encode_opts)]
 
 
 def test_no_gpu_means_a_loud_error_not_a_fallback():

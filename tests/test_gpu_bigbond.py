@@ -178,3 +178,26 @@ def test_limits_are_reported(engine_cls):
             e.build_caches()
     finally:
         e.close()
+
+
+def test_blocked_tridiagonalisation_is_deterministic(eng):
+    """Regression: the Householder step kernel runs on many workgroups with no barrier between them inside a launch; the
+    vector y of a step used to share one buffer with the previous step's (a fast workgroup overwrote what a slow one was
+    still reading: 1 sweep in ~150 wrong).  Now double-buffered: 300 repetitions of a small sweep, bit-identical."""
+    N, T, d, chi0, chimax, C = 40, 3, 12, 10, 14, 1
+    ds, W0 = make_problem(N, T, d, chi0, C, seed=N + d)
+    opts = R.SweepOptions(nsweeps=1, chi_max=chimax, eta=0.05, loss_grad="KLD", bbopt="TSGO")
+    first = None
+    for rep in range(300):
+        load_engine(eng, ds, W0, opts)
+        eng.build_caches()
+        eng.sweep()
+        W = eng.get_mps()
+        if first is None:
+            first = W
+            Wo = [t.copy() for t in W0]
+            R.sweep(Wo, ds, opts)
+            yo, yg = R.contract_mps(Wo, ds.phi), R.contract_mps(W, ds.phi)
+            assert np.abs(yg - yo).max() <= 1e-8 * np.abs(yo).max()
+        else:
+            assert all(np.array_equal(a, b) for a, b in zip(first, W)), rep

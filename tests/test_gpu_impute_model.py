@@ -1,0 +1,199 @@
+"""mpst_impute_model_run: the imputation engine on a model handed over in one call - complex models (the reference's
+Fourier basis) and the fp32 chain arithmetic - against the NumPy restatement of src/Imputation/MPS_methods.jl
+(oracle/impute_numpy.py, complex-aware: dag(...) on the known states and on the re-conditioning state)."""
+import numpy as np
+import pytest
+
+from oracle import impute_numpy as I
+from oracle import ref_numpy as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _complex_mps(T, d, chi, C, rng):
+    Wr = R.random_mps(T, d, chi, C, rng)
+    Wi = R.random_mps(T, d, chi, C, rng)
+    return [a + 1j * b for a, b in zip(Wr, Wi)]
+
+
+def _problem(N, T, d, chi, C, seed, ngrid, cx):
+    rng = np.random.default_rng(seed)
+    W = _complex_mps(T, d, chi, C, rng) if cx else R.random_mps(T, d, chi, C, rng)
+    xs = -1.0 + (2.0 / (ngrid - 1)) * np.arange(ngrid)
+    enc = (lambda x: R.fourier_encode(x, d)) if cx else (lambda x: R.legendre_encode(x, d))
+    X = rng.uniform(-0.95, 0.95, (N, T))
+    y = rng.integers(0, C, N).astype(np.int32)              # any order: the model-run entry does not need sorted classes
+    m = (rng.uniform(size=(N, T)) < 0.4).astype(np.uint8)
+    m[0] = 1
+    m[1] = 0
+    m[2, :] = 0
+    m[2, T // 2] = 1
+    return W, xs, enc, enc(xs), X, y, enc(X), m, rng
+
+
+def _check(W, xs, grid_phi, phi, y, m, x_g, e_g, method, order="forwards", wmad=True, u=None, max_flips=2, **kw):
+    classes = I.expand_label_index(W)
+    dx = xs[1] - xs[0]
+    nflip = 0
+    for i in range(len(y)):
+        sites = np.flatnonzero(m[i])
+        assert np.all(x_g[i][m[i] == 0] == 0.0)
+        if len(sites) == 0:
+            continue
+        ui = None if u is None else (u[i, sites] if order == "forwards" else u[i, sites][::-1])
+        xo, eo = I.impute(classes[y[i]], phi[i], sites, xs, grid_phi, method, order, wmad, ui, **kw)
+        diff = np.abs(x_g[i, sites] - xo)
+        if order == "backwards":
+            diff = diff[::-1]
+        if np.any(diff > 1e-12):
+            first = int(np.argmax(diff > 1e-12))
+            assert diff[first] <= dx * 1.0000001, (i, sites, x_g[i, sites], xo)
+            assert np.all(diff[:first] <= 1e-12)
+            nflip += 1
+            continue
+        if method == "median" and wmad:
+            assert np.abs(e_g[i, sites] - eo).max() <= dx * 1.0000001
+    assert nflip <= max_flips, nflip
+
+
+@pytest.mark.parametrize("order", ["forwards", "backwards"])
+@pytest.mark.parametrize("cfg", [(14, 9, 3, 5, 2), (10, 12, 4, 9, 3), (6, 10, 8, 20, 1)], ids=["d3chi5", "d4chi9C3", "d8chi20"])
+def test_complex_fourier_model_fp64(engine_cls, cfg, order):
+    N, T, d, chi, C = cfg
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=5 * N + T, ngrid=1201, cx=True)
+    o = ["forwards", "backwards"].index(order)
+    u = rng.uniform(0.02, 0.98, (N, T))
+    eng = engine_cls(0)
+    try:
+        x_med, e_med, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True, order=o)
+        x_mode, _, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 1, False, order=o)
+        x_its, _, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u, order=o)
+        x_mean, e_mean, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, order=o)
+    finally:
+        eng.close()
+    _check(W, xs, grid_phi, phi, y, m, x_med, e_med, "median", order)
+    _check(W, xs, grid_phi, phi, y, m, x_mode, None, "mode", order)
+    _check(W, xs, grid_phi, phi, y, m, x_its, None, "quantile", order, u=u)
+    classes = I.expand_label_index(W)
+    for i in range(N):
+        sites = np.flatnonzero(m[i])
+        if len(sites) == 0:
+            continue
+        xo, eo = I.impute(classes[y[i]], phi[i], sites, xs, grid_phi, "mean", order, True, None, encode=enc)
+        assert np.abs(x_mean[i, sites] - xo).max() < 1e-9 and np.abs(e_mean[i, sites] - eo).max() < 1e-9
+
+
+def test_real_model_run_is_the_context_path(engine_cls):
+    """Same kernels, same operands: handing the model over in one call gives bit-identical results to the data set + MPS
+    of a context (class-sorted there, any order here)."""
+    N, T, d, chi, C = 18, 11, 4, 8, 2
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=7, ngrid=2001, cx=False)
+    order = np.argsort(y, kind="stable")
+    eng = engine_cls(0)
+    try:
+        x1, e1, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True)
+        eng.set_options(chi_max=chi)
+        eng.set_dataset(1, phi[order], y[order], C)
+        eng.set_mps(W)
+        x2, e2, _ = eng.impute(1, m[order], xs, grid_phi, 0, True)
+    finally:
+        eng.close()
+    assert np.array_equal(x1[order], x2) and np.array_equal(e1[order], e2)
+    _check(W, xs, grid_phi, phi, y, m, x1, e1, "median")
+
+
+@pytest.mark.parametrize("cx", [False, True], ids=["real", "complex"])
+def test_fp32_chain_arithmetic(engine_cls, cx):
+    """compute = fp32: the imputed values are the fp64 ones up to the grid value the density's quantile falls on - the
+    fp32 rounding of the chain (relative 1e-6 on rho) moves a quantile by much less than a grid step of 1e-3, so almost every
+    site agrees exactly and the rest by one step (before the difference propagates through the conditioning)."""
+    N, T, d, chi, C = 24, 14, 4, 10, 2
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=31, ngrid=2001, cx=cx)
+    eng = engine_cls(0)
+    try:
+        x64, e64, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True, compute="f64")
+        x32, e32, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True, compute="f32")
+        xm64, s64, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, compute="f64")
+        xm32, s32, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, compute="f32")
+    finally:
+        eng.close()
+    _check(W, xs, grid_phi, phi, y, m, x64, e64, "median")
+    mask = m.astype(bool)
+    dx = xs[1] - xs[0]
+    diff = np.abs(x32 - x64)[mask]
+    assert np.mean(diff == 0.0) > 0.9 and np.quantile(diff, 0.99) <= 3 * dx and diff.max() < 0.05
+    assert np.abs(xm32 - xm64)[mask].max() < 2e-4 and np.abs(s32 - s64)[mask].max() < 2e-4
+    assert not np.array_equal(xm32, xm64)                      # it really is a different arithmetic
+
+
+def test_model_run_error_paths(engine_cls):
+    import mpstime_jl_amd as mt
+    N, T, d, chi, C = 4, 6, 3, 4, 2
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=1, ngrid=101, cx=True)
+    eng = engine_cls(0)
+    try:
+        with pytest.raises(mt.MPSTError, match="Fourier"):
+            eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, mean_basis=1)
+        bad = y.copy()
+        bad[0] = C
+        with pytest.raises(mt.MPSTError, match="label_idx"):
+            eng.impute_model(W, phi, bad, m, xs, grid_phi, 0, True)
+        Tb = 14
+        Wbig = _complex_mps(Tb, 2, 50, 1, rng)
+        assert max(t.shape[2] for t in Wbig) == 50
+        Xb = rng.uniform(-0.9, 0.9, (N, Tb))
+        mb = (rng.uniform(size=(N, Tb)) < 0.5).astype(np.uint8)
+        args = (Wbig, R.fourier_encode(Xb, 2), np.zeros(N, dtype=np.int32), mb, xs, R.fourier_encode(xs, 2), 0, True)
+        with pytest.raises(mt.MPSTError, match="chi_max <= 48"):
+            eng.impute_model(*args)
+        x, e, _ = eng.impute_model(*args, compute="f32")
+        assert np.all(np.isfinite(x)) and np.all(x[mb == 0] == 0.0)
+    finally:
+        eng.close()
+
+
+def test_host_api_fourier_model_and_fp32(engine_cls):
+    """init_imputation_problem / impute_dataset / MPS_impute with the reference's Fourier encoding (a complex MPS, as its
+    legacy path trains) and with compute="f32"."""
+    import mpstime_jl_amd as mt
+    from mpstime_jl_amd.imputation import _scaled_instances
+    rng = np.random.default_rng(17)
+    T, d, chi, C, Ntr, Nte = 16, 5, 8, 2, 30, 10
+    W = _complex_mps(T, d, chi, C, rng)
+    opts = mt.MPSOptions(encoding="Fourier", d=d, chi_max=chi, verbosity=-1)
+    assert opts.dtype == "ComplexF64"
+    t = np.linspace(0, 1, T)
+    ytr = np.sort(rng.integers(0, C, Ntr))
+    Xtr = np.sin(2 * np.pi * (t[None, :] * (1 + ytr[:, None]) + rng.uniform(size=(Ntr, 1)))) + 0.1 * rng.normal(size=(Ntr, T))
+    yte = rng.integers(0, C, Nte)
+    Xte = np.sin(2 * np.pi * (t[None, :] * (1 + yte[:, None]) + rng.uniform(size=(Nte, 1)))) + 0.1 * rng.normal(size=(Nte, T))
+    td = mt.EncodedTimeSeriesSet(None, ytr, ytr.astype(np.int32), Xtr, np.bincount(ytr, minlength=C))
+    trained = mt.TrainedMPS(W, opts, td)
+    imp = mt.init_imputation_problem(trained, Xte, yte, dx=1e-3, verbosity=0)
+    assert np.iscomplexobj(imp.x_guess_range.xvals_enc)
+    mask = rng.uniform(size=(Nte, T)) < 0.35
+    ts, err = mt.impute_dataset(imp, mask, "median", invert_transform=False)
+    enc, norms, raw, full, scaled, oob = _scaled_instances(imp, np.arange(Nte), mask)
+    phi = enc.encode(scaled, d)
+    classes = I.expand_label_index(W)
+    nflip = 0
+    for k in range(Nte):
+        sites = np.flatnonzero(mask[k])
+        if len(sites) == 0:
+            continue
+        xo, eo = I.impute(classes[yte[k]], phi[k], sites, imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc, "median")
+        diff = np.abs(ts[k, sites] - xo)
+        if np.any(diff > 1e-12):
+            first = int(np.argmax(diff > 1e-12))
+            assert diff[first] <= 1.0000001e-3 and np.all(diff[:first] <= 1e-12)
+            nflip += 1
+        assert np.array_equal(ts[k][~mask[k]], scaled[k][~mask[k]])
+    assert nflip <= 1
+    ts32, _ = mt.impute_dataset(imp, mask, "median", invert_transform=False, compute="f32")
+    assert np.mean(ts32 == ts) > 0.9 and np.abs(ts32 - ts).max() < 0.05
+    ts_m, sd = mt.impute_dataset(imp, mask, "mean", impute_order="backwards")
+    assert np.all(np.isfinite(ts_m)) and np.all(sd[mask] >= 0)
+    cls = int(yte[0])
+    inst = int(np.flatnonzero(np.flatnonzero(yte == cls) == 0)[0])
+    t1, e1, target, metrics = mt.MPS_impute(imp, cls, inst, np.flatnonzero(mask[0]), "median", impute_order="backwards")
+    assert np.all(np.isfinite(t1[0])) and "MAE" in metrics[0]

@@ -163,3 +163,56 @@ def test_oneshot_allreduce_ranks_sharing_the_gpus(tmp_path, loss, world):
     yo = R.contract_mps(W1, ds.phi)
     ys = R.contract_mps([outs[0][f"W{j}"] for j in range(T)], ds.phi)
     assert np.abs(yo - ys).max() < 1e-8 * np.abs(yo).max()
+
+
+IMPUTE_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MPST_ROOT"])
+import numpy as np
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+import mpstime_jl_amd as mt
+z = np.load(os.environ["MPST_PROBLEM"])
+T = z["X"].shape[1]
+W = [z[f"W{j}"] for j in range(T)]
+opts = mt.MPSOptions(d=int(z["d"]), chi_max=int(z["chi"]), verbosity=-1)
+td = mt.EncodedTimeSeriesSet(None, z["ytr"], z["ytr"].astype(np.int32), z["Xtr"], np.bincount(z["ytr"]))
+imp = mt.init_imputation_problem(mt.TrainedMPS(W, opts, td), z["X"], z["y"], dx=1e-3, verbosity=0)
+sh = mt.Shard(rank, world, rccl=False)
+dev = rank % max(torch.cuda.device_count(), 1)
+ts, err = mt.impute_dataset(imp, z["mask"], "median", shard=sh, device=dev)
+np.savez(os.path.join(os.environ["MPST_OUT"], f"imp{rank}.npz"), ts=ts, err=err)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_imputation_equals_single_process(tmp_path, world):
+    """configs[4]'s multi-GPU shape: instances are independent, so the ranks impute disjoint rows with no collective on
+    the data path and gather the results on the host; rank r on GPU r mod #GPUs (all on one device on this pool)."""
+    import mpstime_jl_amd as mt
+    from oracle import ref_numpy as R
+    rng = np.random.default_rng(8)
+    T, d, chi, C, Ntr, N = 12, 4, 6, 2, 20, 11          # N not a multiple of the world size: ragged shards
+    W = R.random_mps(T, d, chi, C, rng)
+    ytr = np.sort(rng.integers(0, C, Ntr))
+    Xtr = rng.normal(size=(Ntr, T))
+    y = rng.integers(0, C, N)
+    X = rng.normal(size=(N, T))
+    mask = rng.uniform(size=(N, T)) < 0.4
+    prob = tmp_path / "problem.npz"
+    np.savez(prob, X=X, y=y, Xtr=Xtr, ytr=ytr, mask=mask, d=d, chi=chi, **{f"W{j}": t for j, t in enumerate(W)})
+    script = tmp_path / "worker.py"
+    script.write_text(IMPUTE_WORKER)
+    env = dict(os.environ, MPST_ROOT=ROOT, MPST_OUT=str(tmp_path), MPST_PROBLEM=str(prob))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), str(script)], check=True, env=env, timeout=600)
+    opts = mt.MPSOptions(d=d, chi_max=chi, verbosity=-1)
+    td = mt.EncodedTimeSeriesSet(None, ytr, ytr.astype(np.int32), Xtr, np.bincount(ytr))
+    imp = mt.init_imputation_problem(mt.TrainedMPS(W, opts, td), X, y, dx=1e-3, verbosity=0)
+    ts, err = mt.impute_dataset(imp, mask, "median")
+    for r in range(world):
+        o = np.load(tmp_path / f"imp{r}.npz")
+        assert np.array_equal(o["ts"], ts) and np.array_equal(o["err"], err)
