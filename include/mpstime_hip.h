@@ -262,6 +262,10 @@ int  mpst_impute_model_run(void* ctx, const mpst_impute_model* m, const uint8_t*
                            int32_t ngrid, const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds);
 
 /* normalize!(W), RealRealHighDimension.jl:852. */
+/* Device seconds of the last imputation call split into its two kernels: [0] the environment pass (k_imp_right, MFMA),
+ * [1] the sweep with the densities and selections (k_imp_left). */
+int  mpst_get_impute_phases(void* ctx, double* seconds_out /*[2]*/);
+
 int  mpst_normalize(void* ctx);
 
 /* Diagnostics used by bench.py / tests (no reference counterpart). */

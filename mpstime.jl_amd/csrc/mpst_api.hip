@@ -77,6 +77,7 @@ struct Ctx {
     std::vector<Rec> recs;
     size_t ev_used = 0;
     double prof_us[16] = {0};
+    double impute_phase_s[2] = {0, 0};   // last imputation call: environment pass, density sweep
     int64_t prof_cnt[16] = {0};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // one full sweep captured as a hipGraph (bond dimensions live on the device and every grid is sized
@@ -1164,13 +1165,35 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
         const ImputeParams q{dmiss, dR, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
                              ntrial, o->mean_basis, o->rejection_threshold};
-        for (int64_t i0 = 0; i0 < N; i0 += chunk) launch_impute(m, q, i0, std::min(chunk, N - i0), c->stream);
+        // one event between the two kernels of every chunk: the split of the pass into its environment and density halves
+        // (mpst_get_impute_phases) costs nothing against kernels of tens of milliseconds
+        struct Evs {
+            std::vector<hipEvent_t> e;
+            ~Evs() { for (auto x : e) (void)hipEventDestroy(x); }
+        } evs;
+        for (int64_t i0 = 0; i0 < N; i0 += chunk) {
+            hipEvent_t mid = nullptr, end = nullptr;
+            HIPC(c, hipEventCreate(&mid));
+            evs.e.push_back(mid);
+            HIPC(c, hipEventCreate(&end));
+            evs.e.push_back(end);
+            launch_impute(m, q, i0, std::min(chunk, N - i0), c->stream, mid);
+            HIPC(c, hipEventRecord(end, c->stream));
+        }
         HIPC(c, hipEventRecord(c->ev_stop, c->stream));
         HIPC(c, hipGetLastError());
         HIPC(c, hipEventSynchronize(c->ev_stop));
         float ms = 0.f;
         HIPC(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
         if (seconds) *seconds = 1e-3 * ms;
+        c->impute_phase_s[0] = c->impute_phase_s[1] = 0.0;
+        for (size_t k = 0; k < evs.e.size(); k += 2) {
+            float a = 0.f, b = 0.f;
+            HIPC(c, hipEventElapsedTime(&a, k == 0 ? c->ev_start : evs.e[k - 1], evs.e[k]));
+            HIPC(c, hipEventElapsedTime(&b, evs.e[k], evs.e[k + 1]));
+            c->impute_phase_s[0] += 1e-3 * a;
+            c->impute_phase_s[1] += 1e-3 * b;
+        }
         HIPC(c, hipMemcpy(xo.data(), dx, xo.size() * sizeof(double), hipMemcpyDeviceToHost));
         HIPC(c, hipMemcpy(eo.data(), de, eo.size() * sizeof(double), hipMemcpyDeviceToHost));
     } else if (seconds) {
@@ -1178,6 +1201,14 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
     }
     memcpy(x_out, xo.data(), xo.size() * sizeof(double));
     if (err_out) memcpy(err_out, eo.data(), eo.size() * sizeof(double));
+    return 0;
+}
+
+int mpst_get_impute_phases(void* ctx, double* seconds_out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !seconds_out) return MPST_ERR_INVALID;
+    seconds_out[0] = c->impute_phase_s[0];
+    seconds_out[1] = c->impute_phase_s[1];
     return 0;
 }
 

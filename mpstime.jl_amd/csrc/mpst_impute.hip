@@ -873,22 +873,23 @@ hipError_t impute_init_attrs(int device) {
 }
 
 template <typename R, bool CX>
-static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
+static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
     constexpr bool F32 = std::is_same<R, float>::value;
     hipLaunchKernelGGL((k_imp_right<R, CX>), dim3((unsigned)count), dim3(IMP_T), right_lds_bytes(v.cap, CX, F32), s, v, q.missing,
                        (R*)q.Rbuf, q.max_missing, i0, q.rev);
+    if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
     hipLaunchKernelGGL((k_imp_left<R, CX>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
 }
 
-void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s) {
+void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
     if (v.is_complex) {
-        if (v.compute_f32) launch_impute_t<float, true>(v, q, i0, count, s);
-        else launch_impute_t<double, true>(v, q, i0, count, s);
+        if (v.compute_f32) launch_impute_t<float, true>(v, q, i0, count, s, mid);
+        else launch_impute_t<double, true>(v, q, i0, count, s, mid);
     } else {
-        if (v.compute_f32) launch_impute_t<float, false>(v, q, i0, count, s);
-        else launch_impute_t<double, false>(v, q, i0, count, s);
+        if (v.compute_f32) launch_impute_t<float, false>(v, q, i0, count, s, mid);
+        else launch_impute_t<double, false>(v, q, i0, count, s, mid);
     }
 }
 

@@ -340,7 +340,7 @@ struct ImputeParams {
     double reject_thr;
 };
 int impute_chi_limit(bool cx, bool f32);
-void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s);
+void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);

@@ -271,6 +271,12 @@ class SweepEngine:
                                                  err.ctypes.data_as(dp), C.byref(sec)))
         return x, err, sec.value
 
+    def impute_phases(self):
+        """(environment pass, density sweep) device seconds of the last imputation call."""
+        out = np.zeros(2)
+        self._chk(self.lib.mpst_get_impute_phases(self.ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return float(out[0]), float(out[1])
+
     def normalize(self):
         self._chk(self.lib.mpst_normalize(self.ctx))
 
