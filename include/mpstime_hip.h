@@ -134,8 +134,10 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
  * class like mpst_set_dataset's input) goes through transform_train_data / transform_test_data
  * (src/utils.jl:161-275) and the Legendre basis (src/Encodings/bases.jl:70-108) on the GPU and becomes data set
  * `which`, instead of uploading the d times larger product states (encode_dataset,
- * src/Encodings/encodings.jl:120-150).  Order statistics stay on the host: `median`, `iqr` are the
- * RobustSigmoid parameters of the TRAINING set (Normalization.jl fit, utils.jl:171-176).  Training set
+ * src/Encodings/encodings.jl:120-150).  `median`, `iqr` are the
+ * RobustSigmoid parameters of the TRAINING set (Normalization.jl fit, utils.jl:171-176) - inputs, or, with
+ * fit_sigmoid = 1 on a training set, OUTPUTS fitted on the device (radix sort of the N T values, type-7
+ * quantiles).  Training set
  * (is_test = 0): the min / max of the sigmoid-transformed data are fitted on the device and returned in
  * lo / hi.  Test set (is_test = 1): lo / hi are inputs (the training fit); with rescale_out_of_bounds each
  * series is shifted / scaled into [0, 1] (utils.jl:243-266) and `oob_fix` ([N][2], may be NULL) receives the
@@ -149,8 +151,8 @@ typedef struct {
     int32_t minmax;                 /* MPSOptions.minmax */
     int32_t is_test;
     int32_t rescale_out_of_bounds;  /* test sets only */
-    int32_t reserved;
-    double  median, iqr;            /* in */
+    int32_t fit_sigmoid;            /* training sets only: fit median / iqr on the device */
+    double  median, iqr;            /* in, or out with fit_sigmoid */
     double  lo, hi;                 /* out for the training set, in for a test set */
     double  data_lb, data_ub;       /* MPSOptions.data_bounds */
     double  range_a, range_b;       /* the basis' input range (-1, 1 for Legendre) */

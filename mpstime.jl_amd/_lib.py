@@ -40,7 +40,7 @@ class mpst_bond_debug(C.Structure):
 
 class mpst_encode_opts(C.Structure):
     _fields_ = [("basis", C.c_int32), ("sigmoid_transform", C.c_int32), ("minmax", C.c_int32), ("is_test", C.c_int32),
-                ("rescale_out_of_bounds", C.c_int32), ("reserved", C.c_int32),
+                ("rescale_out_of_bounds", C.c_int32), ("fit_sigmoid", C.c_int32),
                 ("median", C.c_double), ("iqr", C.c_double), ("lo", C.c_double), ("hi", C.c_double),
                 ("data_lb", C.c_double), ("data_ub", C.c_double), ("range_a", C.c_double), ("range_b", C.c_double)]
 

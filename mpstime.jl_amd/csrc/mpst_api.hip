@@ -748,7 +748,10 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     if (!eo) return fail(c, MPST_ERR_INVALID, "NULL encode options");
     if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM)
         return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the real Legendre bases only (complex bases cannot be trained by the array sweep, loss_functions.jl:203-217)");
-    if (eo->sigmoid_transform && !(eo->iqr > 0.0)) return fail(c, MPST_ERR_INVALID, "robust sigmoid needs iqr > 0");
+    const bool fit_sig = eo->sigmoid_transform && eo->fit_sigmoid && !eo->is_test;
+    if (eo->fit_sigmoid && eo->is_test) return fail(c, MPST_ERR_INVALID, "fit_sigmoid: the RobustSigmoid is fitted on the training set only");
+    if (eo->sigmoid_transform && !fit_sig && !(eo->iqr > 0.0)) return fail(c, MPST_ERR_INVALID, "robust sigmoid needs iqr > 0");
+    if (fit_sig && N * (int64_t)T > 0x7fffffffll) return fail(c, MPST_ERR_UNSUPPORTED, "fit_sigmoid sorts at most 2^31 - 1 values");
     int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
     if (rc || N == 0) return rc;
     DataSet& s = c->ds[which];
@@ -761,6 +764,30 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     const bool test = eo->is_test != 0;
     if (test && eo->rescale_out_of_bounds && (rc = dalloc(c, &fix, 2 * N))) return rc;
     HIPC(c, hipMemcpy(dX, X, (size_t)N * T * sizeof(double), hipMemcpyHostToDevice));
+    double fit_seconds = 0.0;
+    if (fit_sig) {
+        // Normalization.fit(RobustSigmoid, X_train) (utils.jl:174): median and quartiles of all values from a device sort
+        double *sorted = nullptr, *q3 = nullptr;
+        uint8_t* tmp = nullptr;
+        struct T2 {
+            double **a, **b; uint8_t** t;
+            ~T2() { dfree(a); dfree(b); dfree(t); }
+        } t2{&sorted, &q3, &tmp};
+        const size_t tb = order_stats_temp_bytes(N * T);
+        if ((rc = dalloc(c, &sorted, N * T)) || (rc = dalloc(c, &q3, 3)) || (rc = dalloc(c, &tmp, (int64_t)tb))) return rc;
+        HIPC(c, hipEventRecord(c->ev_start, c->stream));
+        HIPC(c, launch_order_stats(dX, sorted, tmp, tb, N * T, q3, c->stream));
+        HIPC(c, hipEventRecord(c->ev_stop, c->stream));
+        HIPC(c, hipEventSynchronize(c->ev_stop));
+        float fms = 0.f;
+        HIPC(c, hipEventElapsedTime(&fms, c->ev_start, c->ev_stop));
+        fit_seconds = 1e-3 * fms;
+        double h3[3];
+        HIPC(c, hipMemcpy(h3, q3, sizeof h3, hipMemcpyDeviceToHost));
+        eo->median = h3[0];
+        eo->iqr = h3[2] - h3[1];
+        if (!(eo->iqr > 0.0)) return fail(c, MPST_ERR_INVALID, "robust sigmoid needs iqr > 0 (the training data has iqr = %g)", eo->iqr);
+    }
     if (test || !eo->minmax) {
         const double h[2] = {eo->lo, eo->hi};
         HIPC(c, hipMemcpy(lohi, h, sizeof h, hipMemcpyHostToDevice));
@@ -780,7 +807,7 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     HIPC(c, hipGetLastError());
     float ms = 0.f;
     HIPC(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
-    if (seconds) *seconds = 1e-3 * ms;
+    if (seconds) *seconds = 1e-3 * ms + fit_seconds;
     if (!test && eo->minmax) {
         double h[2];
         HIPC(c, hipMemcpy(h, lohi, sizeof h, hipMemcpyDeviceToHost));

@@ -4,11 +4,13 @@
 //   transform_train_data / transform_test_data  (src/utils.jl:161-275)
 //   legendre / legendre_no_norm                  (src/Encodings/bases.jl:70-108)
 //   the per-value encode loop of encode_dataset  (src/Encodings/encodings.jl:120-150)
-// so that a fit uploads the N x T raw matrix instead of the d times larger product states.  Order
-// statistics (median, quartiles of the training set) stay on the host: they are O(NT log NT) once.
+// so that a fit uploads the N x T raw matrix instead of the d times larger product states.  The order
+// statistics of the RobustSigmoid fit (median and quartiles of the training set, utils.jl:171-176) come from a
+// device radix sort of the N T values (hipCUB - a plain library sort, not a hot kernel) when asked for.
 // Every formula keeps the reference's order of operations; FMA contraction is off in this file so the
 // Bonnet recursion rounds like the host restatement (differences come from exp() only, ~1 ulp).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include "mpst_internal.h"
 
 #pragma clang fp contract(off)
@@ -119,6 +121,37 @@ __global__ __launch_bounds__(256) void k_encode(EncDev e, const double* __restri
         if (e.norm) v = v / e.nrm;
         out[k] = v;
     }
+}
+
+// ---- RobustSigmoid fit: median and inter-quartile range of all training values ---------------------------------
+// type-7 quantiles (Julia's / NumPy's default) of the sorted values; the interpolation is written as NumPy's _lerp so that
+// the host restatement and this kernel agree to the bit (Julia's a + g (b - a) differs from it by at most one ulp)
+__global__ void k_enc_quantiles(const double* __restrict__ xs, int64_t n, double* __restrict__ out /* median, q25, q75 */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto lerp = [](double a, double b, double t) {
+        const double dba = b - a;
+        return t >= 0.5 ? b - dba * (1.0 - t) : a + dba * t;
+    };
+    auto quant = [&](double q) {
+        const double pos = q * (double)(n - 1);
+        const int64_t lo = (int64_t)floor(pos);
+        const int64_t hi = lo + 1 < n ? lo + 1 : n - 1;
+        return lerp(xs[lo], xs[hi], pos - (double)lo);
+    };
+    out[0] = (n & 1) ? xs[n / 2] : 0.5 * (xs[n / 2 - 1] + xs[n / 2]);       // np.median / Statistics.median: mean of the middle pair
+    out[1] = quant(0.25);
+    out[2] = quant(0.75);
+}
+size_t order_stats_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, (const double*)nullptr, (double*)nullptr, (int)n);
+    return bytes;
+}
+hipError_t launch_order_stats(const double* X, double* sorted, void* temp, size_t temp_bytes, int64_t n, double* out3, hipStream_t s) {
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, X, sorted, (int)n, 0, 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_enc_quantiles, dim3(1), dim3(1), 0, s, (const double*)sorted, n, out3);
+    return hipGetLastError();
 }
 
 void launch_encode(const EncDev& e, const double* X, double* phi, double* part, double* lohi, double* fix, int fit_range,

@@ -298,6 +298,8 @@ struct EncDev {
     const double* lohi;     // device [2] min, max of the (sigmoid-transformed) training data
     const double* fix;      // device [N][2] per-series (shift, scale) of the out-of-bounds rescale, or null
 };
+size_t order_stats_temp_bytes(int64_t n);
+hipError_t launch_order_stats(const double* X, double* sorted, void* temp, size_t temp_bytes, int64_t n, double* out3, hipStream_t s);
 void launch_encode(const EncDev& e, const double* X, double* phi, double* part, double* lohi, double* fix, int fit_range,
                    hipStream_t s);
 // per-device opt-in to large dynamic LDS (hipFuncSetAttribute applies to the current device only)

@@ -85,7 +85,7 @@ class SweepEngine:
 
     def encode_dataset(self, which, X_sorted, label_index, C_classes, basis="Legendre_No_Norm", d=None, sigmoid_transform=True,
                        minmax=True, data_bounds=(0.0, 1.0), enc_range=(-1.0, 1.0), norms=None, rescale_out_of_bounds=True,
-                       global_counts=None):
+                       global_counts=None, sigmoid_fit=None):
         """Preprocess + encode the raw (N, T) matrix on the device (mpst_encode_dataset).  ``X_sorted`` must already be
         sorted by class.  ``norms=None`` fits a training set (median/IQR on the host, min/max on the device) and
         returns ``(norms, seconds)``; with ``norms`` from the training fit the data is treated as a test set and
@@ -108,8 +108,10 @@ class SweepEngine:
         eo.range_a, eo.range_b = map(float, enc_range)
         if norms is None:
             if sigmoid_transform:
-                q75, q25 = np.percentile(X, [75.0, 25.0])
-                eo.median, eo.iqr = float(np.median(X)), float(q75 - q25)
+                if sigmoid_fit is not None:             # (median, iqr) fitted elsewhere, e.g. over all shards
+                    eo.median, eo.iqr = map(float, sigmoid_fit)
+                else:
+                    eo.fit_sigmoid = 1                  # median / quartiles from a device sort of the values
         else:
             if norms.sigmoid is not None:
                 eo.median, eo.iqr = norms.sigmoid

@@ -95,3 +95,28 @@ def test_fitmps_with_device_encoding_matches_host_encoding():
     assert np.array_equal(a.train_data.original_data, b.train_data.original_data)
     assert abs(info_a["train_KL_div"][0] - info_b["train_KL_div"][0]) < 1e-10
     assert abs(info_a["test_KL_div"][0] - info_b["test_KL_div"][0]) < 1e-10
+
+
+@pytest.mark.parametrize("shape", [(97, 41), (64, 30), (1, 2), (3, 3), (500, 100)])
+def test_robust_sigmoid_fit_on_the_device(engine_cls, shape):
+    """Normalization.fit(RobustSigmoid, X_train) (utils.jl:174): median and inter-quartile range of ALL training values
+    from a device radix sort; type-7 quantiles written as NumPy's _lerp, so the host restatement is matched to the bit
+    (odd and even counts, the tiny cases where the quartiles interpolate between the only two values)."""
+    N, T = shape
+    rng = np.random.default_rng(N * 1000 + T)
+    X = rng.normal(size=(N, T)) * 3.0 + 0.5
+    y = np.zeros(N, dtype=np.int32)
+    eng = engine_cls(0)
+    try:
+        norms, sec = eng.encode_dataset(0, X, y, 1, d=3)
+        med = float(np.median(X))
+        q75, q25 = np.percentile(X, [75.0, 25.0])
+        assert norms.sigmoid[0] == med and norms.sigmoid[1] == float(q75 - q25)
+        # a fit handed in (e.g. computed over all shards) takes the other branch and gives the same encoding
+        phi = eng.get_encoded(0)
+        norms2, _ = eng.encode_dataset(0, X, y, 1, d=3, sigmoid_fit=norms.sigmoid)
+        assert norms2.sigmoid == norms.sigmoid and np.array_equal(eng.get_encoded(0), phi)
+        with pytest.raises(mt.MPSTError, match="iqr"):
+            eng.encode_dataset(0, np.ones((4, 5)), np.zeros(4, dtype=np.int32), 1, d=3)      # constant data: iqr = 0
+    finally:
+        eng.close()
