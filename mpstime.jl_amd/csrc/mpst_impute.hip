@@ -125,34 +125,65 @@ __device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, ks = (K + 3) >> 2;
-    for (int t = wave; t < tm * tn; t += 4) {
-        const int m0 = (t / tn) * 16, n0 = (t % tn) * 16;
-        acc_t accr = {0, 0, 0, 0}, acci = {0, 0, 0, 0};
-        if (accumulate) {
+    // a wave owns a 16-row block of C and up to 4 of its column tiles at a time: the A operand is read once for all of
+    // them and the independent accumulator chains keep the matrix pipe busy between dependent k-steps
+    // (as many as it takes to give each of the 4 waves one unit of work: small matrices keep one tile per wave)
+    constexpr int NT = 4;
+    const int nte = min(NT, max(1, (tm * tn + 3) >> 2));
+    const int ngrp = (tn + nte - 1) / nte;
+    for (int unit = wave; unit < tm * ngrp; unit += 4) {
+        const int m0 = (unit / ngrp) * 16;
+        const int nb = (unit % ngrp) * nte;
+        const int tn_hi = min(tn, nb + nte);
+        {
+            acc_t accr[NT], acci[NT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                accr[r] = Cm.r[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16];
-                if constexpr (CX) acci[r] = Cm.i[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16];
-            }
-        }
-        for (int u = 0; u < ks; ++u) {
-            const int k = 4 * u + kq;
-            const int ia = (m0 + i16) * ld + k;
-            const int ib = tb ? (n0 + i16) * ld + k : k * ld + n0 + i16;
-            const R ar = A.r[ia], br = B.r[ib];
-            accr = Mx<R>::mma(ar, br, accr);
-            if constexpr (CX) {
-                // plain: (ar + i ai)(br + i bi);  tb: (ar + i ai)(br - i bi)
-                const R ai = A.i[ia], bi = B.i[ib];
-                accr = Mx<R>::mma(tb ? ai : -ai, bi, accr);
-                acci = Mx<R>::mma(ai, br, acci);
-                acci = Mx<R>::mma(tb ? -ar : ar, bi, acci);
-            }
-        }
+            for (int t = 0; t < NT; ++t) {
+                accr[t] = acc_t{0, 0, 0, 0};
+                acci[t] = acc_t{0, 0, 0, 0};
+                if (accumulate && nb + t < tn_hi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            Cm.r[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16] = accr[r];
-            if constexpr (CX) Cm.i[(m0 + Mx<R>::row(kq, r)) * ld + n0 + i16] = acci[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
+                        accr[t][r] = Cm.r[at];
+                        if constexpr (CX) acci[t][r] = Cm.i[at];
+                    }
+                }
+            }
+            for (int u = 0; u < ks; ++u) {
+                const int k = 4 * u + kq;
+                const int ia = (m0 + i16) * ld + k;
+                const R ar = A.r[ia];
+                R ai = R(0);
+                if constexpr (CX) ai = A.i[ia];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (nb + t < tn_hi) {
+                        const int n0 = (nb + t) * 16;
+                        const int ib = tb ? (n0 + i16) * ld + k : k * ld + n0 + i16;
+                        const R br = B.r[ib];
+                        accr[t] = Mx<R>::mma(ar, br, accr[t]);
+                        if constexpr (CX) {
+                            // plain: (ar + i ai)(br + i bi);  tb: (ar + i ai)(br - i bi)
+                            const R bi = B.i[ib];
+                            accr[t] = Mx<R>::mma(tb ? ai : -ai, bi, accr[t]);
+                            acci[t] = Mx<R>::mma(ai, br, acci[t]);
+                            acci[t] = Mx<R>::mma(tb ? -ar : ar, bi, acci[t]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (nb + t < tn_hi) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
+                        Cm.r[at] = accr[t][r];
+                        if constexpr (CX) Cm.i[at] = acci[t][r];
+                    }
+                }
+            }
         }
     }
 }
