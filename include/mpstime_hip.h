@@ -220,7 +220,7 @@ int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[
  *   u[N][T][max_trials]  uniform numbers in [0, 1) for the two sampling methods (max_trials = 1 for QUANTILE), else NULL
  *   x_out[N][T]     imputed value at every missing site (in the encoding's domain; 0 elsewhere), err_out[N][T] the
  *                   uncertainty measure of the method (0 where there is none)
- * chi_max <= 64, d <= 16, real fp64. */
+ * chi_max <= 128, d <= 16, real fp64. */
 enum { MPST_IMPUTE_MEDIAN = 0, MPST_IMPUTE_MODE = 1, MPST_IMPUTE_QUANTILE = 2, MPST_IMPUTE_MEAN = 3, MPST_IMPUTE_ITS_REJECT = 4 };
 enum { MPST_IMPUTE_FORWARDS = 0, MPST_IMPUTE_BACKWARDS = 1 };
 typedef struct {
@@ -245,7 +245,7 @@ int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* gri
  *            and multiplied in fp32 (MFMA f32 16x16x4); the density on the grid, its cumulative sums and every selection
  *            stay fp64.  MPST_COMPUTE_F64: everything fp64.
  * site[j]: (s, l, r) column-major, the label site (s, l, r, c), like mpst_set_mps; phi: [N][T][d]; label_idx[N] in [0, C)
- * in any order.  chi_max <= 64 (complex fp64: 48), d <= 16.  mean_basis MPST_BASIS_FOURIER for complex models. */
+ * in any order.  chi_max <= 128, d <= 16.  mean_basis MPST_BASIS_FOURIER for complex models. */
 #define MPST_DTYPE_F64   0
 #define MPST_DTYPE_C64   1
 #define MPST_COMPUTE_F64 0

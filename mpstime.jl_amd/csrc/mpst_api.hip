@@ -1170,19 +1170,21 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
     if (maxm > 0) {
         // instances are processed in chunks so that the per-instance scratch (environments of the missing sites, p_k and
         // its prefix sums) stays below ~8 GB
-        const int64_t per = (int64_t)maxm * m.cap * m.cap * zw + 2ll * ngrid;
+        const int64_t welems = impute_work_elems(m.cap, m.is_complex != 0, m.compute_f32 != 0);
+        const int64_t per = (int64_t)maxm * m.cap * m.cap * zw + welems + 2ll * ngrid;
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
-        uint8_t *dmiss = nullptr, *dR = nullptr;
+        uint8_t *dmiss = nullptr, *dR = nullptr, *dW = nullptr;
         double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
         struct Temps {
-            uint8_t **m, **r; double **b, **cc, **dd, **e, **f, **g, **h;
-            ~Temps() { dfree(m); dfree(r); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
-        } temps{&dmiss, &dR, &dgx, &dgp, &du, &dp, &dS, &dx, &de};
+            uint8_t **m, **r, **w; double **b, **cc, **dd, **e, **f, **g, **h;
+            ~Temps() { dfree(m); dfree(r); dfree(w); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
+        } temps{&dmiss, &dR, &dW, &dgx, &dgp, &du, &dp, &dS, &dx, &de};
         int rc;
         if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, (int64_t)(chunk * maxm * m.cap * m.cap * zw * esz))) ||
             (rc = dalloc(c, &dgx, ngrid)) || (rc = dalloc(c, &dgp, (int64_t)ngrid * d * zw)) || (rc = dalloc(c, &dp, chunk * ngrid)) ||
             (rc = dalloc(c, &dS, chunk * ngrid)) || (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
         if (sampling && (rc = dalloc(c, &du, N * T * ntrial))) return rc;
+        if (welems && (rc = dalloc(c, &dW, (int64_t)(chunk * welems * esz)))) return rc;
         HIPC(c, hipMemcpy(dmiss, missing, (size_t)N * T, hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgx, grid_x, (size_t)ngrid * sizeof(double), hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgp, grid_phi, (size_t)ngrid * d * zw * sizeof(double), hipMemcpyHostToDevice));
@@ -1190,7 +1192,7 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         HIPC(c, hipMemset(dx, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
-        const ImputeParams q{dmiss, dR, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
+        const ImputeParams q{dmiss, dR, dW, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
                              ntrial, o->mean_basis, o->rejection_threshold};
         // one event between the two kernels of every chunk: the split of the pass into its environment and density halves
         // (mpst_get_impute_phases) costs nothing against kernels of tens of milliseconds

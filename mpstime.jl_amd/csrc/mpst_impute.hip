@@ -25,9 +25,10 @@
 // tensors, environment matrices, the vector L - run in fp64 or in fp32 (MFMA f32 16x16x4, half the LDS and HBM bytes),
 // while the density on the grid, its prefix sums and every selection are always fp64.  Complex matrices live in LDS as
 // separate real and imaginary planes so that a complex product is four real MFMA chains.
-// Limits: d <= 16; the environment pass keeps 4 (real) / 8 (complex) padded chi x chi planes in LDS: chi <= 64, except
-// complex fp64: chi <= 48.
+// Limits: d <= 16, chi <= 128.  The environment pass keeps 4 (real) / 8 (complex) padded chi x chi planes in LDS up to
+// chi = 64 (complex fp64: 48); beyond that k_imp_right_big works out of global scratch.
 #include "mpst_internal.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace mpst {
@@ -310,6 +311,202 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
         }
         __syncthreads();
         const Plane<R> tmp = Rc;
+        Rc = Rn;
+        Rn = tmp;
+    }
+}
+
+// ---- right environments beyond the LDS limit ---------------------------------------------------------------------------
+// chi up to CAP_LIMIT (128): the four chi x chi matrices of an instance live in global scratch (L2-resident: 4 x 128 KB
+// per workgroup) and the MFMA operands are read straight from there, 8 k-steps of loads in flight per wave.  A missing
+// site's W_j[s] is not even copied: the A / B operands walk the stored tensor with its own strides.  Slower per flop than
+// the LDS kernel (it costs speed, not capability).
+#ifndef GM_NT
+#define GM_NT 2
+#endif
+#ifndef GM_KU
+#define GM_KU 4
+#endif
+template <typename R> struct GMat {        // element (r, c) = p[(r * sr + c * sc) * ZW (+ 1)], rows x cols live
+    const R* p;
+    int64_t sr, sc;
+    int rows, cols;
+};
+template <typename R, bool CX> __device__ __forceinline__ void gload(const GMat<R>& m, int r, int c, R& re, R& im) {
+    re = R(0);
+    im = R(0);
+    if (r < m.rows && c < m.cols) zload<R, CX>(m.p, (int64_t)r * m.sr + (int64_t)c * m.sc, re, im);
+}
+// C (M x N row-major, leading dimension ldc) (+)= A * B  or  A * B^H (tb: B is the N x K operand)
+template <typename R, bool CX>
+__device__ __forceinline__ void gmem_mm(R* __restrict__ Cm, int ldc, GMat<R> A, GMat<R> B, int M, int N, int K, bool tb, bool accumulate) {
+    using acc_t = typename Mx<R>::acc_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
+    constexpr int NT = GM_NT, KU = GM_KU;     // column tiles per unit, k-steps per batch of loads
+    const int ngrp = (tn + NT - 1) / NT;
+    for (int unit = wave; unit < tm * ngrp; unit += 4) {
+        const int m0 = (unit / ngrp) * 16, nb = (unit % ngrp) * NT;
+        acc_t accr[NT], acci[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            accr[t] = acc_t{0, 0, 0, 0};
+            acci[t] = acc_t{0, 0, 0, 0};
+            if (accumulate && nb + t < tn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
+                    if (rr < M && cc < N) {
+                        R x, y;
+                        zload<R, CX>(Cm, (int64_t)rr * ldc + cc, x, y);
+                        accr[t][r] = x;
+                        acci[t][r] = y;
+                    }
+                }
+            }
+        }
+        for (int k0 = 0; k0 < K; k0 += 4 * KU) {
+            R ar[KU], ai[KU], br[NT][KU], bi[NT][KU];
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const int k = k0 + 4 * u + kq;
+                gload<R, CX>(A, m0 + i16, k < K ? k : A.cols, ar[u], ai[u]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int n = (nb + t) * 16 + i16;
+                    if (tb) gload<R, CX>(B, n, k < K ? k : B.cols, br[t][u], bi[t][u]);
+                    else gload<R, CX>(B, k < K ? k : B.rows, n, br[t][u], bi[t][u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (k0 + 4 * u < K) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if (nb + t < tn) {
+                            accr[t] = Mx<R>::mma(ar[u], br[t][u], accr[t]);
+                            if constexpr (CX) {
+                                accr[t] = Mx<R>::mma(tb ? ai[u] : -ai[u], bi[t][u], accr[t]);
+                                acci[t] = Mx<R>::mma(ai[u], br[t][u], acci[t]);
+                                acci[t] = Mx<R>::mma(tb ? -ar[u] : ar[u], bi[t][u], acci[t]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (nb + t < tn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
+                    if (rr < M && cc < N) zstore<R, CX>(Cm, (int64_t)rr * ldc + cc, accr[t][r], acci[t][r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename R, bool CX>
+__global__ __launch_bounds__(IMP_T) void k_imp_right_big(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
+                                                         R* __restrict__ work /* [chunk][4][cap*cap] */, int max_missing, int64_t i0, int rev) {
+    __shared__ double red[4];
+    constexpr int ZW = CX ? 2 : 1;
+    const int64_t i = i0 + blockIdx.x;
+    const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
+    const uint8_t* mi = missing + i * T;
+    int nm = 0;
+    for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
+    if (nm == 0) return;
+    const int cls = v.label[i];
+    const int64_t msz = (int64_t)cm * cm * ZW;
+    R* base = work + (int64_t)blockIdx.x * 4 * msz;
+    R* Rc = base;                  // current environment, compact [Di][Di]
+    R* Rn = base + msz;            // next one, compact [Do][Do]
+    R* Mb = base + 2 * msz;        // M_j of a known site, [Do][Di]
+    R* T1 = base + 3 * msz;        // [Do][Di]
+    if (tid == 0) zstore<R, CX>(Rc, 0, R(1), R(0));
+    __syncthreads();
+    int slot = 0;
+    for (int step = 0; step < T; ++step) {
+        const int j = rev ? step : T - 1 - step;
+        const SiteView<R> sv = site_view<R, CX>(v, j, cls, rev != 0);
+        const int Di = sv.Din, Do = sv.Dout;
+        const bool miss = mi[j] != 0;
+        if (miss) {
+            R* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm * ZW;
+            for (int e = tid; e < Di * Di * ZW; e += IMP_T) out[e] = Rc[e];
+            ++slot;
+            if (slot == nm) break;
+        }
+        const GMat<R> Rm{Rc, Di, 1, Di, Di};
+        if (miss) {
+            for (int s_ = 0; s_ < d; ++s_) {
+                // W_j[s] as the (out x in) matrix of this pass, read in place
+                const GMat<R> Ws{sv.W + (int64_t)s_ * sv.ss * ZW, sv.so, sv.si, Do, Di};
+                gmem_mm<R, CX>(T1, Di, Ws, Rm, Do, Di, Di, false, false);
+                __syncthreads();
+                gmem_mm<R, CX>(Rn, Do, GMat<R>{T1, Di, 1, Do, Di}, Ws, Do, Do, Di, true, s_ > 0);
+                __syncthreads();
+            }
+        } else {
+            const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
+            const bool in_fast = sv.si == 1;
+            const int Df = in_fast ? Di : Do;
+            for (int e0 = tid; e0 < Di * Do; e0 += 8 * IMP_T) {
+                R accr[8], acci[8];
+                int64_t off[8];
+                int dst[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int e = e0 + q * IMP_T;
+                    const int slow = e / Df, fast = e - slow * Df;
+                    const int ii = in_fast ? fast : slow, oo = in_fast ? slow : fast;
+                    off[q] = (int64_t)ii * sv.si + (int64_t)oo * sv.so;
+                    dst[q] = oo * Di + ii;
+                    accr[q] = R(0);
+                    acci[q] = R(0);
+                }
+                for (int qq = 0; qq < d; ++qq) {
+                    R pr, pi;
+                    zload<R, CX>(ph, qq, pr, pi);
+                    R wr[8], wi[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        wr[q] = R(0);
+                        wi[q] = R(0);
+                        if (e0 + q * IMP_T < Di * Do) zload<R, CX>(sv.W, off[q] + (int64_t)qq * sv.ss, wr[q], wi[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        accr[q] = fma(pr, wr[q], accr[q]);
+                        if constexpr (CX) {
+                            accr[q] = fma(pi, wi[q], accr[q]);
+                            acci[q] = fma(pr, wi[q], acci[q]);
+                            acci[q] = fma(-pi, wr[q], acci[q]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e0 + q * IMP_T < Di * Do) zstore<R, CX>(Mb, dst[q], accr[q], acci[q]);
+            }
+            __syncthreads();
+            const GMat<R> Mm{Mb, Di, 1, Do, Di};
+            gmem_mm<R, CX>(T1, Di, Mm, Rm, Do, Di, Di, false, false);
+            __syncthreads();
+            gmem_mm<R, CX>(Rn, Do, GMat<R>{T1, Di, 1, Do, Di}, Mm, Do, Do, Di, true, false);
+            __syncthreads();
+        }
+        double tr = 0.0;
+        for (int a_ = tid; a_ < Do; a_ += IMP_T) tr += (double)Rn[((int64_t)a_ * Do + a_) * ZW];
+        tr = blk_sum(tr, red);
+        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
+        for (int e = tid; e < Do * Do * ZW; e += IMP_T) Rn[e] *= sc;
+        __syncthreads();
+        R* tmp = Rc;
         Rc = Rn;
         Rn = tmp;
     }
@@ -883,7 +1080,13 @@ static size_t right_lds_bytes(int cap, bool cx, bool f32) {
 static size_t left_lds_bytes(int cap, bool cx, bool f32) {
     return (size_t)(2 * cap + 2 * IMP_MAXD * cap + IMP_MAXD) * (cx ? 2 : 1) * (f32 ? 4 : 8);
 }
-int impute_chi_limit(bool cx, bool f32) { return (cx && !f32) ? 48 : 64; }
+// the LDS kernel's limit; beyond it (or everywhere with MPST_IMPUTE_BIG=1, a test hook): k_imp_right_big
+static int impute_lds_chi_limit(bool cx, bool f32) {
+    static const bool force = getenv("MPST_IMPUTE_BIG") != nullptr;
+    return force ? 0 : ((cx && !f32) ? 48 : 64);
+}
+int impute_chi_limit(bool, bool) { return CAP_LIMIT; }
+int64_t impute_work_elems(int cap, bool cx, bool f32) { return cap > impute_lds_chi_limit(cx, f32) ? 4ll * cap * cap * (cx ? 2 : 1) : 0; }
 
 hipError_t impute_init_attrs(int device) {
     static unsigned long long done = 0;
@@ -891,9 +1094,9 @@ hipError_t impute_init_attrs(int device) {
     hipError_t e;
 #define IMP_ATTR(R, CX, F32)                                                                                                       \
     if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                      \
-                                 (int)right_lds_bytes(impute_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;               \
+                                 (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;           \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                       \
-                                 (int)left_lds_bytes(64, CX, F32))) != hipSuccess) return e;
+                                 (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;
     IMP_ATTR(double, false, false)
     IMP_ATTR(double, true, false)
     IMP_ATTR(float, false, true)
@@ -906,8 +1109,12 @@ hipError_t impute_init_attrs(int device) {
 template <typename R, bool CX>
 static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
     constexpr bool F32 = std::is_same<R, float>::value;
-    hipLaunchKernelGGL((k_imp_right<R, CX>), dim3((unsigned)count), dim3(IMP_T), right_lds_bytes(v.cap, CX, F32), s, v, q.missing,
-                       (R*)q.Rbuf, q.max_missing, i0, q.rev);
+    if (v.cap > impute_lds_chi_limit(CX, F32))
+        hipLaunchKernelGGL((k_imp_right_big<R, CX>), dim3((unsigned)count), dim3(IMP_T), 0, s, v, q.missing, (R*)q.Rbuf, (R*)q.work,
+                           q.max_missing, i0, q.rev);
+    else
+        hipLaunchKernelGGL((k_imp_right<R, CX>), dim3((unsigned)count), dim3(IMP_T), right_lds_bytes(v.cap, CX, F32), s, v, q.missing,
+                           (R*)q.Rbuf, q.max_missing, i0, q.rev);
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};

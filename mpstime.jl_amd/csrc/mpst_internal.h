@@ -336,12 +336,14 @@ struct ImpModel {
 struct ImputeParams {
     const uint8_t* missing;     // device [N][T]
     void* Rbuf;                 // device [chunk][max_missing][cap*cap] elements
+    void* work;                 // device [chunk][4][cap*cap] elements when the bond dimension exceeds the LDS kernel's, else null
     const double *grid_x, *grid_phi, *u;    // grid_phi: [ngrid][d] doubles or (re, im) pairs
     double *pbuf, *sbuf, *x_out, *err_out;
     int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
     double reject_thr;
 };
 int impute_chi_limit(bool cx, bool f32);
+int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scratch elements of the large-chi environment kernel
 void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin

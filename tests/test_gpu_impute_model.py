@@ -138,16 +138,10 @@ def test_model_run_error_paths(engine_cls):
         bad[0] = C
         with pytest.raises(mt.MPSTError, match="label_idx"):
             eng.impute_model(W, phi, bad, m, xs, grid_phi, 0, True)
-        Tb = 14
-        Wbig = _complex_mps(Tb, 2, 50, 1, rng)
-        assert max(t.shape[2] for t in Wbig) == 50
-        Xb = rng.uniform(-0.9, 0.9, (N, Tb))
-        mb = (rng.uniform(size=(N, Tb)) < 0.5).astype(np.uint8)
-        args = (Wbig, R.fourier_encode(Xb, 2), np.zeros(N, dtype=np.int32), mb, xs, R.fourier_encode(xs, 2), 0, True)
-        with pytest.raises(mt.MPSTError, match="chi_max <= 48"):
-            eng.impute_model(*args)
-        x, e, _ = eng.impute_model(*args, compute="f32")
-        assert np.all(np.isfinite(x)) and np.all(x[mb == 0] == 0.0)
+        with pytest.raises(mt.MPSTError, match="chi_max <= 128"):
+            Wh = R.random_mps(10, 16, 200, 1, rng)
+            eng.impute_model(Wh, R.legendre_encode(X[:, :1].repeat(10, 1), 16), np.zeros(N, dtype=np.int32), np.ones((N, 10), dtype=np.uint8),
+                             xs, R.legendre_encode(xs, 16), 0, True)
     finally:
         eng.close()
 
@@ -197,3 +191,37 @@ def test_host_api_fourier_model_and_fp32(engine_cls):
     inst = int(np.flatnonzero(np.flatnonzero(yte == cls) == 0)[0])
     t1, e1, target, metrics = mt.MPS_impute(imp, cls, inst, np.flatnonzero(mask[0]), "median", impute_order="backwards")
     assert np.all(np.isfinite(t1[0])) and "MAE" in metrics[0]
+
+
+@pytest.mark.parametrize("cx,compute,chi,d", [(True, "f64", 50, 2), (False, "f64", 72, 3), (True, "f32", 72, 3), (False, "f64", 128, 2)],
+                         ids=["complex_f64_chi50", "real_f64_chi72", "complex_f32_chi72", "real_f64_chi128"])
+def test_bond_dimensions_beyond_the_lds_kernel(engine_cls, cx, compute, chi, d):
+    """chi above 64 (complex fp64: 48): the environment pass works out of global scratch (k_imp_right_big)."""
+    N, C = 6, 1
+    T = {2: 16, 3: 12}[d]
+    rng = np.random.default_rng(chi)
+    W = _complex_mps(T, d, chi, C, rng) if cx else R.random_mps(T, d, chi, C, rng)
+    assert max(t.shape[2] for t in W) == min(chi, d ** (T // 2))
+    xs = -1.0 + (2.0 / 800) * np.arange(801)
+    enc = (lambda x: R.fourier_encode(x, d)) if cx else (lambda x: R.legendre_encode(x, d))
+    X = rng.uniform(-0.9, 0.9, (N, T))
+    y = np.zeros(N, dtype=np.int32)
+    m = (rng.uniform(size=(N, T)) < 0.5).astype(np.uint8)
+    m[0] = 1
+    eng = engine_cls(0)
+    try:
+        x_g, e_g, _ = eng.impute_model(W, enc(X), y, m, xs, enc(xs), 0, True, compute=compute)
+        x_b, e_b, _ = eng.impute_model(W, enc(X), y, m, xs, enc(xs), 0, True, compute=compute, order=1)
+    finally:
+        eng.close()
+    if compute == "f64":
+        _check(W, xs, enc(xs), enc(X), y, m, x_g, e_g, "median", max_flips=1)
+        _check(W, xs, enc(xs), enc(X), y, m, x_b, e_b, "median", "backwards", max_flips=1)
+    else:
+        classes = I.expand_label_index(W)
+        same = []
+        for i in range(N):
+            sites = np.flatnonzero(m[i])
+            xo, _ = I.impute(classes[0], enc(X)[i], sites, xs, enc(xs), "median")
+            same.append(np.abs(x_g[i, sites] - xo) < 1e-12)
+        assert np.mean(np.concatenate(same)) > 0.8
