@@ -1303,6 +1303,7 @@ void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int
 struct BigEig {
     rocblas_handle h = nullptr;
     int ncap = 0;
+    hipStream_t stream = nullptr;
     double *A = nullptr, *D = nullptr, *Ew = nullptr;
     rocblas_int* info = nullptr;
 };
@@ -1391,8 +1392,8 @@ int big_eig_create(BigEig** out, int ncap, hipStream_t s, std::string* err) {
         big_eig_destroy(b);
         return MPST_ERR_DEVICE;
     };
-    if (rocblas_create_handle(&b->h) != rocblas_status_success) return bail("rocblas_create_handle failed");
-    if (rocblas_set_stream(b->h, s) != rocblas_status_success) return bail("rocblas_set_stream failed");
+    // the rocBLAS handle (seconds of one-off initialisation) is created by the first bond that actually needs the library
+    b->stream = s;
     if (hipMalloc((void**)&b->A, sizeof(double) * (size_t)ncap * ncap) != hipSuccess || hipMalloc((void**)&b->D, sizeof(double) * ncap) != hipSuccess ||
         hipMalloc((void**)&b->Ew, sizeof(double) * ncap) != hipSuccess || hipMalloc((void**)&b->info, sizeof(rocblas_int)) != hipSuccess)
         return bail("hipMalloc of the rocSOLVER buffers failed");
@@ -1408,8 +1409,17 @@ void big_eig_destroy(BigEig* b) {
     if (b->h) rocblas_destroy_handle(b->h);
     delete b;
 }
+static bool big_eig_handle(BigEig* b) {
+    if (b->h) return true;
+    if (rocblas_create_handle(&b->h) != rocblas_status_success) {
+        b->h = nullptr;
+        return false;
+    }
+    return rocblas_set_stream(b->h, b->stream) == rocblas_status_success;
+}
 int launch_eig_big(const View& v, int lid, int going_left, BigEig* b, hipStream_t s) {
     const int ncap = b->ncap;
+    if (!big_eig_handle(b)) return MPST_ERR_DEVICE;
     hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->A, ncap);
     if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, ncap, b->A, ncap, b->D, b->Ew, b->info) != rocblas_status_success)
         return MPST_ERR_DEVICE;
@@ -1419,6 +1429,7 @@ int launch_eig_big(const View& v, int lid, int going_left, BigEig* b, hipStream_
 }
 int launch_eig_big_raw(const double* G, int n, double* lam, double* E, int32_t* info, BigEig* b, hipStream_t s) {
     View v{};
+    if (!big_eig_handle(b)) return MPST_ERR_DEVICE;
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
     hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, 0, 0, G, n, b->A, b->ncap);
     if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, b->ncap, b->A, b->ncap, b->D, b->Ew, b->info) != rocblas_status_success)

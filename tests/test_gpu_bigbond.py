@@ -183,12 +183,12 @@ def test_limits_are_reported(engine_cls):
 def test_blocked_tridiagonalisation_is_deterministic(eng):
     """Regression: the Householder step kernel runs on many workgroups with no barrier between them inside a launch; the
     vector y of a step used to share one buffer with the previous step's (a fast workgroup overwrote what a slow one was
-    still reading: 1 sweep in ~150 wrong).  Now double-buffered: 300 repetitions of a small sweep, bit-identical."""
+    still reading: 1 sweep in ~150 wrong).  Now double-buffered: 200 repetitions of a small sweep, bit-identical."""
     N, T, d, chi0, chimax, C = 40, 3, 12, 10, 14, 1
     ds, W0 = make_problem(N, T, d, chi0, C, seed=N + d)
     opts = R.SweepOptions(nsweeps=1, chi_max=chimax, eta=0.05, loss_grad="KLD", bbopt="TSGO")
     first = None
-    for rep in range(300):
+    for rep in range(200):
         load_engine(eng, ds, W0, opts)
         eng.build_caches()
         eng.sweep()
