@@ -195,28 +195,6 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     }
 }
 
-// # eigenvalues of T smaller than x (Sturm sequence, division-free with rescaling), T as (d_j, e_{j-1}^2) pairs in LDS
-__device__ __forceinline__ int bt_sturm(const double* __restrict__ de, int n, double x) {
-    double pp = 1.0, p = de[0] - x;
-    int cnt = p < 0.0 ? 1 : 0;
-    for (int j = 1; j < n; ++j) {
-        const double pn = fma(de[2 * j] - x, p, -de[2 * j + 1] * pp);
-        // sign change between p_{j-1} and p_j (a zero takes the sign opposite to its predecessor)
-        const bool neg_prev = p < 0.0 || (p == 0.0 && pp > 0.0);
-        const bool neg_now = pn < 0.0 || (pn == 0.0 && !neg_prev);
-        cnt += (neg_now != neg_prev) ? 1 : 0;
-        pp = p;
-        p = pn;
-        if ((j & 7) == 0) {
-            int e = __builtin_amdgcn_frexp_exp(p);
-            if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
-            p = __builtin_amdgcn_ldexp(p, -e);
-            pp = __builtin_amdgcn_ldexp(pp, -e);
-        }
-    }
-    return cnt;
-}
-
 __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
@@ -226,8 +204,8 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x;
     if (k >= pb.K0) return;
-    double* de = smem;                  // [n][2] (d_j, e_{j-1}^2)
-    double* es = de + 2 * BT_NMAX;      // [n]
+    double* de = smem;                  // [n + 8][2] (d_j, e_{j-1}^2), padded for sturm_count's groups of 8 rows
+    double* es = de + 2 * (BT_NMAX + 8);      // [n]
     double* Dp = es + BT_NMAX;          // [n] forward pivots
     double* Dm = Dp + BT_NMAX;          // [n] backward pivots
     double* z = Dm + BT_NMAX;           // [n]
@@ -260,12 +238,21 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     const double tnorm = fmax(fabs(gl), fabs(gu));
     const double pad = 2.0 * n * 2.3e-16 * tnorm + 1e-300;
     double lo = gl - pad, hi = gu + pad;
+    // pad T to 1 + a multiple of 8 rows with decoupled rows (e^2 = 0) whose diagonal lies above every abscissa: they add no
+    // sign change and let sturm_count run in whole groups of 8
+    {
+        const double dpad = hi + (hi - lo) + 1.0;
+        if (tid < 16) {
+            de[2 * n + tid] = (tid & 1) ? 0.0 : dpad;
+        }
+    }
+    __syncthreads();
     // 256-way multisection for the k-th largest eigenvalue
     const int target = n - 1 - k;
     for (int it = 0; it < 7; ++it) {
         const double h = (hi - lo) * (1.0 / (BT_T + 1));
         const double xq = lo + h * (tid + 1);
-        const int cnt = bt_sturm(de, n, xq);
+        const int cnt = sturm_count(de, n, xq);
         const unsigned long long bal = __ballot(cnt <= target);
         if (lane == 0) cnt_s[wave] = __popcll(bal);
         __syncthreads();
@@ -595,7 +582,7 @@ struct BlockedEig {
     int32_t* host_flag = nullptr;
 };
 
-static size_t bt_vec_lds() { return (size_t)6 * BT_NMAX * sizeof(double); }
+static size_t bt_vec_lds() { return (size_t)(6 * BT_NMAX + 16) * sizeof(double); }
 
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     BlockedEig* e = new BlockedEig();

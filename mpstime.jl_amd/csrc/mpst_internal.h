@@ -17,6 +17,57 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+__device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
+
+// # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free, rescaled by
+// a power of two every 8 steps.  (d_j, e_{j-1}^2) pairs are fetched 8 at a time so the LDS latency
+// is paid once per 8 steps.
+__device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n, double x) {
+    // One wave per SIMD runs this loop, so what counts is the number of instructions per step: 3 fp64
+    // ops (d - x, e^2 * p_{j-2}, fma) + 1 integer op that shifts the sign of p_j into a bit queue; the
+    // sign changes of 8 steps are counted with one popcount, the rescaling is a frexp/ldexp pair, and
+    // the 8 (d, e^2) pairs of the next group are requested from LDS before the current 8 are consumed.
+    // (The scalar data path was tried for T - it is wave-uniform - and lost: s_load latency per group.)
+    const double2* __restrict__ de2 = (const double2*)de;
+    double pp = 1.0, p = de[0] - x;
+    unsigned sb = ((unsigned)hi32(p)) >> 31;      // bit queue of signs, newest in bit 0
+    int cnt = (int)sb;
+    int j = 1;
+    double2 bufA[8], bufB[8];                     // ping-pong: no register copies
+    auto load8 = [&](double2 (&buf)[8], int j0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) buf[u] = de2[j0 + u];
+    };
+    auto run8 = [&](const double2 (&buf)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double t = buf[u].x - x;
+            const double pn = fma(t, p, -buf[u].y * pp);
+            sb = __builtin_amdgcn_alignbit(sb, (unsigned)hi32(pn), 31);   // (sb << 1) | sign(pn)
+            pp = p;
+            p = pn;
+        }
+        cnt += __popc((sb ^ (sb >> 1)) & 0xffu);
+        int e = __builtin_amdgcn_frexp_exp(p);
+        if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
+        p = __builtin_amdgcn_ldexp(p, -e);
+        pp = __builtin_amdgcn_ldexp(pp, -e);
+    };
+    // rows n .. n+7 are padding (k_eig_vec, k_bt_vec: T is padded with decoupled rows): whole groups only
+    if (j < n) load8(bufA, j);
+    while (j < n) {
+        if (j + 8 < n) load8(bufB, j + 8);
+        run8(bufA);
+        j += 8;
+        if (j >= n) break;
+        if (j + 8 < n) load8(bufA, j + 8);
+        run8(bufB);
+        j += 8;
+    }
+    return cnt;
+}
+
+
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute ------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, >100 cycles of dependent latency
 // per step); the reductions here sit on the critical path of single-workgroup kernels, so they
