@@ -3,7 +3,8 @@
 # The seam is the method the reference selects at src/Training/RealRealHighDimension.jl:556-560,
 #     fitMPS(W::MPS, training_states_meta, testing_states_meta, opts)        (:587-890)
 # next to the existing `use_legacy_ITensor` switch.  Everything above it (options, preprocessing,
-# encodings, generate_startingMPS) and below it (TrainedMPS, classify, imputation) stays Julia.
+# encodings, generate_startingMPS) and below it (TrainedMPS, classify) stays Julia; `impute_batch` at the end is the
+# device-side body of the imputation loop (get_predictions, src/Imputation/imputation.jl:264-410).
 #
 # Julia is not installed in the build container or on the GPU box (SURVEY.md fact 3), so this file
 # has been written to the C ABI in include/mpstime_hip.h but never executed; the Python mirror in
@@ -136,6 +137,58 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
             Wn[j] = itensor(reshape(outs[j], dim.(is)...), is...)
         end
         return TrainedMPS(Wn, MPSOptions(opts), train), info, test
+    finally
+        ccall((:mpst_destroy, LIB), Cvoid, (Ptr{Cvoid},), c)
+    end
+end
+
+# ---- imputation (src/Imputation/imputation.jl:264-410: the body of get_predictions' instance loop) ----------------------
+struct MpstImputeOpts            # mpst_impute_opts
+    method::Int32                # 0 median, 1 mode, 2 ITS (rejection_threshold = :none), 3 mean, 4 ITS with rejection
+    order::Int32                 # 0 :forwards, 1 :backwards
+    get_err::Int32               # get_wmad / get_std
+    max_trials::Int32
+    mean_basis::Int32            # 0 :Legendre_Norm, 1 :Legendre_No_Norm, 2 :Fourier
+    reserved::Int32
+    rejection_threshold::Float64
+end
+struct MpstImputeModel           # mpst_impute_model
+    N::Int64; T::Int32; d::Int32; C::Int32; label_site::Int32
+    dtype::Int32                 # 0 Float64, 1 ComplexF64 (site tensors, phi and the grid states alike)
+    compute::Int32               # 0 fp64, 1 fp32 chain contractions (densities stay fp64)
+    site::Ptr{Ptr{Cvoid}}; chi::Ptr{Int32}; phi::Ptr{Cvoid}; label_idx::Ptr{Int32}
+end
+
+"""
+    impute_batch(sites, chi, label_site, phi, label_idx, missing, xvals, xvals_enc; method, order, ...)
+
+Every instance of `phi` ((d, T, N), encoded known values; the columns of `missing` ((T, N), UInt8) mark what is to be imputed)
+with the class MPS of its label, on the GPU.  `sites[j]` is `Array(mps[j], s_j, l_{j-1}, l_j[, label])`, `xvals` /
+`xvals_enc` ((d, ngrid)) are `imp.x_guess_range`.  Returns `(x, err)`, both (T, N), in the encoding's domain;
+`invert_test_transform` (src/utils.jl:299) stays with the caller.
+"""
+function impute_batch(sites::Vector{<:Array}, chi::Vector{Int32}, label_site::Integer, phi::Array, label_idx::Vector{Int32},
+                      missing::Matrix{UInt8}, xvals::Vector{Float64}, xvals_enc::Matrix;
+                      method::Integer=0, order::Integer=0, get_err::Bool=true, max_trials::Integer=10, rejection_threshold::Float64=0.0,
+                      u::Union{Nothing,Array{Float64}}=nothing, compute::Integer=0, device::Integer=0)
+    d, T, N = size(phi)
+    cx = eltype(phi) <: Complex
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    check(C_NULL, ccall((:mpst_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), ctx, device))
+    c = ctx[]
+    try
+        ptrs = [Ptr{Cvoid}(pointer(a)) for a in sites]
+        x = zeros(Float64, T, N); err = zeros(Float64, T, N); secs = Ref(0.0)
+        GC.@preserve sites ptrs chi phi label_idx begin
+            model = Ref(MpstImputeModel(N, T, d, maximum(label_idx) + 1, label_site - 1, cx ? 1 : 0, compute,
+                                        pointer(ptrs), pointer(chi), Ptr{Cvoid}(pointer(phi)), pointer(label_idx)))
+            o = Ref(MpstImputeOpts(method, order, get_err ? 1 : 0, max_trials, cx ? 2 : 1, 0, rejection_threshold))
+            check(c, ccall((:mpst_impute_model_run, LIB), Cint,
+                           (Ptr{Cvoid}, Ref{MpstImputeModel}, Ptr{UInt8}, Ptr{Float64}, Ptr{Cvoid}, Int32, Ref{MpstImputeOpts}, Ptr{Float64},
+                            Ptr{Float64}, Ptr{Float64}, Ref{Float64}),
+                           c, model, missing, xvals, xvals_enc, length(xvals), o, u === nothing ? C_NULL : pointer(u), x, err, secs))
+        end
+        return x, err
     finally
         ccall((:mpst_destroy, LIB), Cvoid, (Ptr{Cvoid},), c)
     end
