@@ -159,6 +159,17 @@ __device__ __forceinline__ double dpp_bcast_add(double x, const int ctrl15_or_31
     }
     return x + __hiloint2double(hi, lo);
 }
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside the 16-lane rows (row_shr 1, 2, 4, 8 with zero fill), then
+// the last lane of row 0 / 2 into rows 1 / 3 (row_bcast:15) and of row 1 into rows 2 and 3 (row_bcast:31)
+__device__ __forceinline__ double wave_incl_scan(double x) {
+    x += dpp_mov<0x111>(x);
+    x += dpp_mov<0x112>(x);
+    x += dpp_mov<0x114>(x);
+    x += dpp_mov<0x118>(x);
+    x = dpp_bcast_add(x, 15);
+    x = dpp_bcast_add(x, 31);
+    return x;
+}
 // 64-lane sum on the matrix pipe: v_mfma_f64_4x4x4 (4 independent 4x4x4 products; A lane = 16k + 4b + i,
 // B lane = 16k + 4b + j, D lane = 16i + 4b + j - measured) with an all-ones partner first adds the four
 // 16-lane rows (k), then the four lanes of a quad group (i <-> k); two DPP rotations add the four groups b.
