@@ -530,7 +530,10 @@ struct ImpArgs {
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2 };
 
-template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_left(ImpModel v, ImpArgs g) {
+// Two workgroups per CU for real models (256 VGPRs: the latency-bound loops gain more from the second resident workgroup
+// than the ~300 B of spills cost - 45 -> 32 ms at chi = 32); complex models keep the whole register file (the spills of
+// their density loop cost more than residency gains at d = 8).
+template <typename R, bool CX> __global__ __launch_bounds__(IMP_T, CX ? 1 : 2) void k_imp_left(ImpModel v, ImpArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
@@ -759,22 +762,26 @@ template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_le
                         }
                 }
             } else {
-                double rr[IMP_MAXD * IMP_MAXD];
-#pragma unroll
-                for (int e = 0; e < IMP_MAXD * IMP_MAXD; ++e) rr[e] = (e / IMP_MAXD < d && e % IMP_MAXD < d) ? rho[e] : 0.0;
                 auto eval = [&](auto DD) {
                     constexpr int D = decltype(DD)::value;
-                    for (int kb = tid; kb < n; kb += 4 * IMP_T) {          // 4 grid values per round trip
-                        double f[4][D];
+                    constexpr int Q = D <= 4 ? 4 : 2;                      // grid values per batch of loads
+                    constexpr int DR = D <= 4 ? D : 1;                     // rho in registers for d <= 4, else read from LDS
+                    double rr[DR * DR];                                    // (every lane reads the same entry: a broadcast)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                    for (int e = 0; e < DR * DR; ++e) rr[e] = rho[(e / DR) * IMP_MAXD + (e % DR)];
+                    double fa[Q][D], fb[Q][D];                             // two batches: one in flight while the other is consumed
+                    auto loadf = [&](double (&f)[Q][D], int kb) {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
                             const int k = kb + q * IMP_T;
                             const double* ph = g.grid_phi + (int64_t)(k < n ? k : 0) * D;
 #pragma unroll
                             for (int s2 = 0; s2 < D; ++s2) f[q][s2] = ph[s2];
                         }
+                    };
+                    auto consume = [&](const double (&f)[Q][D], int kb) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < Q; ++q) {
                             const int k = kb + q * IMP_T;
                             if (k < n) {
                                 double pk = 0.0;
@@ -782,7 +789,7 @@ template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_le
                                 for (int s_ = 0; s_ < D; ++s_) {
                                     double qq = 0.0;
 #pragma unroll
-                                    for (int s2 = 0; s2 < D; ++s2) qq = fma(rr[s_ * IMP_MAXD + s2], f[q][s2], qq);
+                                    for (int s2 = 0; s2 < D; ++s2) qq = fma(D <= 4 ? rr[(s_ * DR + s2) % (DR * DR)] : rho[s_ * IMP_MAXD + s2], f[q][s2], qq);
                                     pk = fma(qq, qq, pk);
                                 }
                                 p[k] = pk;
@@ -792,6 +799,13 @@ template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_le
                                 }
                             }
                         }
+                    };
+                    loadf(fa, tid);
+                    for (int kb = tid; kb < n; kb += 2 * Q * IMP_T) {
+                        loadf(fb, kb + Q * IMP_T);
+                        consume(fa, kb);
+                        loadf(fa, kb + 2 * Q * IMP_T);
+                        consume(fb, kb + Q * IMP_T);
                     }
                 };
                 switch (d) {
@@ -802,8 +816,6 @@ template <typename R, bool CX> __global__ __launch_bounds__(IMP_T) void k_imp_le
                     case 6: eval(std::integral_constant<int, 6>{}); break;
                     case 7: eval(std::integral_constant<int, 7>{}); break;
                     case 8: eval(std::integral_constant<int, 8>{}); break;
-                    case 10: eval(std::integral_constant<int, 10>{}); break;
-                    case 12: eval(std::integral_constant<int, 12>{}); break;
                     default:
                         for (int k = tid; k < n; k += IMP_T) {
                             const double* ph = g.grid_phi + (int64_t)k * d;
