@@ -530,10 +530,10 @@ struct ImpArgs {
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2 };
 
-// Two workgroups per CU for real models (256 VGPRs: the latency-bound loops gain more from the second resident workgroup
-// than the ~300 B of spills cost - 45 -> 32 ms at chi = 32); complex models keep the whole register file (the spills of
-// their density loop cost more than residency gains at d = 8).
-template <typename R, bool CX> __global__ __launch_bounds__(IMP_T, CX ? 1 : 2) void k_imp_left(ImpModel v, ImpArgs g) {
+// OCC = workgroups per CU the kernel is compiled for.  Two (256 VGPRs) for real models and for complex ones with d <= 5: the
+// latency-bound loops gain more from the second resident workgroup than the ~300 B of spills cost (45 -> 32 ms at
+// chi = 32); complex models with larger d keep the whole register file (their density loop spills too much at 256).
+template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC) void k_imp_left(ImpModel v, ImpArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
@@ -1121,7 +1121,9 @@ hipError_t impute_init_attrs(int device) {
 #define IMP_ATTR(R, CX, F32)                                                                                                       \
     if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                      \
                                  (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;           \
-    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                       \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                 (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;                                \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
                                  (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;
     IMP_ATTR(double, false, false)
     IMP_ATTR(double, true, false)
@@ -1144,7 +1146,10 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
-    hipLaunchKernelGGL((k_imp_left<R, CX>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+    if (CX && v.d > 5)
+        hipLaunchKernelGGL((k_imp_left<R, CX, 1>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+    else
+        hipLaunchKernelGGL((k_imp_left<R, CX, 2>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
 }
 
 void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
