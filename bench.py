@@ -154,7 +154,7 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
                 "unit": "TFLOP/s", "frac": flops_env / t_env / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "avg_ms": 1e3 * t_env}
     roof_den = {"kernel": "k_imp_left<float, complex>", "bound": "hbm", "achieved": bytes_den / t_den / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": bytes_den / t_den / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_ms": 1e3 * t_den,
-                "note": f"latency-bound selection loops; the same kernel does {flops_den / t_den / 1e12:.2f} TFLOP/s of fp64 VALU work (vector peak 78.6)"}
+                "note": f"its density loop does {flops_den / t_den / 1e12:.2f} TFLOP/s of fp64 VALU work (vector peak 78.6) at one workgroup per CU; the p / prefix-sum streams are the HBM figure"}
     line = {"metric": "site-imputations/sec (imputation engine, BASELINE configs[4])", "value": value, "unit": "site-imputations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 model; f32 chain contractions (MFMA f32 16x16x4), f64 densities",
