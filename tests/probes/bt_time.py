@@ -1,6 +1,6 @@
 """Device time of the blocked eigensolver inside a sweep-like loop (bond_step at full bond dimension)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R

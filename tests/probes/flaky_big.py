@@ -1,6 +1,6 @@
 """Repeat the dchi168 sweep of tests/test_gpu_bigbond.py and count the runs whose result differs from the oracle's."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R

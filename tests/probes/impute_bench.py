@@ -5,7 +5,7 @@ unscaled NumPy restatement; the engine rescales at every site).  A model TRAINED
 the only kind the array path trains) gives the study its meaningful half: error against the held-out truth in both
 precisions.  Writes a JSON summary when --out is given."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R
