@@ -120,11 +120,67 @@ template <typename R, bool CX> __device__ __forceinline__ SiteView<R> site_view(
 template <typename R> struct Plane {
     R *r, *i;
 };
+// one unit of lds_mm: a 16-row block of C times NTE (compile-time) column tiles.  Nothing in the k-loop is predicated: a
+// runtime "is this tile live" test around every MFMA made the compiler shuttle the accumulators between VGPRs and AccVGPRs
+// and wait out every MFMA's latency (5.8 us for a 64^3 product whose matrix-pipe time is 1.7 us).
+template <typename R, bool CX, int NTE, bool TB>
+__device__ __forceinline__ void lds_mm_unit(Plane<R> Cm, Plane<R> A, Plane<R> B, int m0, int nb, int ks, int ld, bool accumulate) {
+    using acc_t = typename Mx<R>::acc_t;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    acc_t accr[NTE], acci[NTE];
+#pragma unroll
+    for (int t = 0; t < NTE; ++t) {
+        accr[t] = acc_t{0, 0, 0, 0};
+        acci[t] = acc_t{0, 0, 0, 0};
+    }
+    if (accumulate) {
+#pragma unroll
+        for (int t = 0; t < NTE; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
+                accr[t][r] = Cm.r[at];
+                if constexpr (CX) acci[t][r] = Cm.i[at];
+            }
+    }
+    const int ia0 = (m0 + i16) * ld + kq;
+    int ib0[NTE];
+#pragma unroll
+    for (int t = 0; t < NTE; ++t) ib0[t] = TB ? ((nb + t) * 16 + i16) * ld + kq : kq * ld + (nb + t) * 16 + i16;
+    const int bstep = TB ? 4 : 4 * ld;
+    for (int u = 0; u < ks; ++u) {
+        const R ar = A.r[ia0 + 4 * u];
+        R ai = R(0);
+        if constexpr (CX) ai = A.i[ia0 + 4 * u];
+        R br[NTE], bi[NTE];
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) {
+            br[t] = B.r[ib0[t] + bstep * u];
+            if constexpr (CX) bi[t] = B.i[ib0[t] + bstep * u];
+        }
+#pragma unroll
+        for (int t = 0; t < NTE; ++t) {
+            accr[t] = Mx<R>::mma(ar, br[t], accr[t]);
+            if constexpr (CX) {
+                // plain: (ar + i ai)(br + i bi);  TB: (ar + i ai)(br - i bi)
+                accr[t] = Mx<R>::mma(TB ? ai : -ai, bi[t], accr[t]);
+                acci[t] = Mx<R>::mma(ai, br[t], acci[t]);
+                acci[t] = Mx<R>::mma(TB ? -ar : ar, bi[t], acci[t]);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTE; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
+            Cm.r[at] = accr[t][r];
+            if constexpr (CX) Cm.i[at] = acci[t][r];
+        }
+}
 template <typename R, bool CX>
 __device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int M, int N, int K, int ld, bool tb, bool accumulate) {
-    using acc_t = typename Mx<R>::acc_t;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i16 = lane & 15, kq = lane >> 4;
+    const int wave = threadIdx.x >> 6;
     const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, ks = (K + 3) >> 2;
     // a wave owns a 16-row block of C and up to 4 of its column tiles at a time: the A operand is read once for all of
     // them and the independent accumulator chains keep the matrix pipe busy between dependent k-steps
@@ -135,55 +191,20 @@ __device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int 
     for (int unit = wave; unit < tm * ngrp; unit += 4) {
         const int m0 = (unit / ngrp) * 16;
         const int nb = (unit % ngrp) * nte;
-        const int tn_hi = min(tn, nb + nte);
-        {
-            acc_t accr[NT], acci[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                accr[t] = acc_t{0, 0, 0, 0};
-                acci[t] = acc_t{0, 0, 0, 0};
-                if (accumulate && nb + t < tn_hi) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
-                        accr[t][r] = Cm.r[at];
-                        if constexpr (CX) acci[t][r] = Cm.i[at];
-                    }
-                }
+        const int cnt = min(tn, nb + nte) - nb;
+        if (tb) {
+            switch (cnt) {
+                case 1: lds_mm_unit<R, CX, 1, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                case 2: lds_mm_unit<R, CX, 2, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                case 3: lds_mm_unit<R, CX, 3, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                default: lds_mm_unit<R, CX, 4, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
             }
-            for (int u = 0; u < ks; ++u) {
-                const int k = 4 * u + kq;
-                const int ia = (m0 + i16) * ld + k;
-                const R ar = A.r[ia];
-                R ai = R(0);
-                if constexpr (CX) ai = A.i[ia];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (nb + t < tn_hi) {
-                        const int n0 = (nb + t) * 16;
-                        const int ib = tb ? (n0 + i16) * ld + k : k * ld + n0 + i16;
-                        const R br = B.r[ib];
-                        accr[t] = Mx<R>::mma(ar, br, accr[t]);
-                        if constexpr (CX) {
-                            // plain: (ar + i ai)(br + i bi);  tb: (ar + i ai)(br - i bi)
-                            const R bi = B.i[ib];
-                            accr[t] = Mx<R>::mma(tb ? ai : -ai, bi, accr[t]);
-                            acci[t] = Mx<R>::mma(ai, br, acci[t]);
-                            acci[t] = Mx<R>::mma(tb ? -ar : ar, bi, acci[t]);
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (nb + t < tn_hi) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
-                        Cm.r[at] = accr[t][r];
-                        if constexpr (CX) Cm.i[at] = acci[t][r];
-                    }
-                }
+        } else {
+            switch (cnt) {
+                case 1: lds_mm_unit<R, CX, 1, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                case 2: lds_mm_unit<R, CX, 2, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                case 3: lds_mm_unit<R, CX, 3, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+                default: lds_mm_unit<R, CX, 4, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
             }
         }
     }
