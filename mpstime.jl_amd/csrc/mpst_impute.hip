@@ -342,9 +342,6 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
 // per workgroup) and the MFMA operands are read straight from there, 8 k-steps of loads in flight per wave.  A missing
 // site's W_j[s] is not even copied: the A / B operands walk the stored tensor with its own strides.  Slower per flop than
 // the LDS kernel (it costs speed, not capability).
-#ifndef GM_NT
-#define GM_NT 2
-#endif
 #ifndef GM_KU
 #define GM_KU 4
 #endif
@@ -358,74 +355,83 @@ template <typename R, bool CX> __device__ __forceinline__ void gload(const GMat<
     im = R(0);
     if (r < m.rows && c < m.cols) zload<R, CX>(m.p, (int64_t)r * m.sr + (int64_t)c * m.sc, re, im);
 }
-// C (M x N row-major, leading dimension ldc) (+)= A * B  or  A * B^H (tb: B is the N x K operand)
+// C (M x N row-major, leading dimension ldc) (+)= A * B  or  A * B^H (TB: B is the N x K operand); one unit = a 16-row
+// block times NTE column tiles, nothing in the k-loop predicated on the tile count (see lds_mm_unit)
+template <typename R, bool CX, int NTE, bool TB>
+__device__ __forceinline__ void gmem_mm_unit(R* __restrict__ Cm, int ldc, const GMat<R>& A, const GMat<R>& B, int M, int N, int K, int m0, int nb,
+                                             bool accumulate) {
+    using acc_t = typename Mx<R>::acc_t;
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    constexpr int KU = GM_KU;                 // k-steps per batch of loads
+    acc_t accr[NTE], acci[NTE];
+#pragma unroll
+    for (int t = 0; t < NTE; ++t) {
+        accr[t] = acc_t{0, 0, 0, 0};
+        acci[t] = acc_t{0, 0, 0, 0};
+        if (accumulate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
+                if (rr < M && cc < N) {
+                    R x, y;
+                    zload<R, CX>(Cm, (int64_t)rr * ldc + cc, x, y);
+                    accr[t][r] = x;
+                    acci[t][r] = y;
+                }
+            }
+        }
+    }
+    for (int k0 = 0; k0 < K; k0 += 4 * KU) {
+        R ar[KU], ai[KU], br[NTE][KU], bi[NTE][KU];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int k = k0 + 4 * u + kq;
+            gload<R, CX>(A, m0 + i16, k < K ? k : A.cols, ar[u], ai[u]);
+#pragma unroll
+            for (int t = 0; t < NTE; ++t) {
+                const int n = (nb + t) * 16 + i16;
+                if (TB) gload<R, CX>(B, n, k < K ? k : B.cols, br[t][u], bi[t][u]);
+                else gload<R, CX>(B, k < K ? k : B.rows, n, br[t][u], bi[t][u]);
+            }
+        }
+        // k-steps beyond K multiply zeros (gload returns 0 out of range): no test needed
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+#pragma unroll
+            for (int t = 0; t < NTE; ++t) {
+                accr[t] = Mx<R>::mma(ar[u], br[t][u], accr[t]);
+                if constexpr (CX) {
+                    accr[t] = Mx<R>::mma(TB ? ai[u] : -ai[u], bi[t][u], accr[t]);
+                    acci[t] = Mx<R>::mma(ai[u], br[t][u], acci[t]);
+                    acci[t] = Mx<R>::mma(TB ? -ar[u] : ar[u], bi[t][u], acci[t]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NTE; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
+            if (rr < M && cc < N) zstore<R, CX>(Cm, (int64_t)rr * ldc + cc, accr[t][r], acci[t][r]);
+        }
+    }
+}
 template <typename R, bool CX>
 __device__ __forceinline__ void gmem_mm(R* __restrict__ Cm, int ldc, GMat<R> A, GMat<R> B, int M, int N, int K, bool tb, bool accumulate) {
-    using acc_t = typename Mx<R>::acc_t;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i16 = lane & 15, kq = lane >> 4;
+    const int wave = threadIdx.x >> 6;
     const int tm = (M + 15) >> 4, tn = (N + 15) >> 4;
-    constexpr int NT = GM_NT, KU = GM_KU;     // column tiles per unit, k-steps per batch of loads
+    constexpr int NT = 2;                     // column tiles per unit
     const int ngrp = (tn + NT - 1) / NT;
     for (int unit = wave; unit < tm * ngrp; unit += 4) {
         const int m0 = (unit / ngrp) * 16, nb = (unit % ngrp) * NT;
-        acc_t accr[NT], acci[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            accr[t] = acc_t{0, 0, 0, 0};
-            acci[t] = acc_t{0, 0, 0, 0};
-            if (accumulate && nb + t < tn) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
-                    if (rr < M && cc < N) {
-                        R x, y;
-                        zload<R, CX>(Cm, (int64_t)rr * ldc + cc, x, y);
-                        accr[t][r] = x;
-                        acci[t][r] = y;
-                    }
-                }
-            }
-        }
-        for (int k0 = 0; k0 < K; k0 += 4 * KU) {
-            R ar[KU], ai[KU], br[NT][KU], bi[NT][KU];
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const int k = k0 + 4 * u + kq;
-                gload<R, CX>(A, m0 + i16, k < K ? k : A.cols, ar[u], ai[u]);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int n = (nb + t) * 16 + i16;
-                    if (tb) gload<R, CX>(B, n, k < K ? k : B.cols, br[t][u], bi[t][u]);
-                    else gload<R, CX>(B, k < K ? k : B.rows, n, br[t][u], bi[t][u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                if (k0 + 4 * u < K) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if (nb + t < tn) {
-                            accr[t] = Mx<R>::mma(ar[u], br[t][u], accr[t]);
-                            if constexpr (CX) {
-                                accr[t] = Mx<R>::mma(tb ? ai[u] : -ai[u], bi[t][u], accr[t]);
-                                acci[t] = Mx<R>::mma(ai[u], br[t][u], acci[t]);
-                                acci[t] = Mx<R>::mma(tb ? -ar[u] : ar[u], bi[t][u], acci[t]);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (nb + t < tn) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rr = m0 + Mx<R>::row(kq, r), cc = (nb + t) * 16 + i16;
-                    if (rr < M && cc < N) zstore<R, CX>(Cm, (int64_t)rr * ldc + cc, accr[t][r], acci[t][r]);
-                }
-            }
+        const bool two = nb + 1 < tn;
+        if (tb) {
+            if (two) gmem_mm_unit<R, CX, 2, true>(Cm, ldc, A, B, M, N, K, m0, nb, accumulate);
+            else gmem_mm_unit<R, CX, 1, true>(Cm, ldc, A, B, M, N, K, m0, nb, accumulate);
+        } else {
+            if (two) gmem_mm_unit<R, CX, 2, false>(Cm, ldc, A, B, M, N, K, m0, nb, accumulate);
+            else gmem_mm_unit<R, CX, 1, false>(Cm, ldc, A, B, M, N, K, m0, nb, accumulate);
         }
     }
 }
