@@ -145,6 +145,7 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
  * the device time of the encoding kernels. */
 #define MPST_BASIS_LEGENDRE         0   /* legendre(norm = true),  bases.jl:81-92 */
 #define MPST_BASIS_LEGENDRE_NO_NORM 1   /* legendre_no_norm,       bases.jl:108  (MPSOptions default) */
+#define MPST_BASIS_FOURIER          2   /* fourier_encode,         bases.jl:23-42 (mpst_encode_values; mean method of complex models) */
 typedef struct {
     int32_t basis;
     int32_t sigmoid_transform;      /* MPSOptions.sigmoid_transform */
@@ -160,6 +161,12 @@ typedef struct {
 int  mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* label_idx,
                          int64_t N, int32_t T, int32_t d, int32_t C, mpst_encode_opts* eo,
                          const int64_t* n_global_per_class, double* oob_fix, double* seconds);
+/* The same preprocessing + encoding kernels without a data set: X[N][T] in, the encoded states out to the host,
+ * phi_out[N][T][d] doubles for the Legendre bases or (re, im) pairs for MPST_BASIS_FOURIER (fourier_encode,
+ * bases.jl:23-42: cispi(f x) / sqrt(d), f = 0, 1, -1, 2, -2, ...) - what mpst_impute_model_run takes for a complex model.
+ * eo as for mpst_encode_dataset (fits returned in it); oob_fix [N][2] or NULL. */
+int  mpst_encode_values(void* ctx, const double* X, int64_t N, int32_t T, int32_t d, mpst_encode_opts* eo, void* phi_out,
+                        double* oob_fix, double* seconds);
 /* Encoded values of data set `which` back to the host, [N][T][d] (EncodedTimeSeriesSet.timeseries). */
 int  mpst_get_encoded(void* ctx, int which, double* phi_out);
 
@@ -250,7 +257,6 @@ int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* gri
 #define MPST_DTYPE_C64   1
 #define MPST_COMPUTE_F64 0
 #define MPST_COMPUTE_F32 1
-#define MPST_BASIS_FOURIER 2            /* fourier_encode, bases.jl:23-42 (mpst_impute_model_run's mean method only) */
 typedef struct {
     int64_t N;
     int32_t T, d, C, label_site;

@@ -45,7 +45,7 @@ class mpst_encode_opts(C.Structure):
                 ("data_lb", C.c_double), ("data_ub", C.c_double), ("range_a", C.c_double), ("range_b", C.c_double)]
 
 
-BASIS = {"Legendre_Norm": 0, "Legendre_No_Norm": 1}      # canonical names (options.jl:243-279; :Legendre == :Legendre_No_Norm)
+BASIS = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2}      # canonical names (options.jl:243-279; :Legendre == :Legendre_No_Norm)
 
 # every symbol include/mpstime_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)
@@ -73,6 +73,7 @@ SYMBOLS = {
     "mpst_set_dataset": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i32), _i64, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
     "mpst_encode_dataset": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i32), _i64, _i32, _i32, _i32, C.POINTER(mpst_encode_opts),
                                       C.POINTER(_i64), _dp, _dp]),
+    "mpst_encode_values": (C.c_int, [_vp, _dp, _i64, _i32, _i32, C.POINTER(mpst_encode_opts), _vp, _dp, _dp]),
     "mpst_get_encoded": (C.c_int, [_vp, C.c_int, _dp]),
     "mpst_set_options": (C.c_int, [_vp, C.POINTER(mpst_options)]),
     "mpst_set_mps": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_i32), _i32, _i32]),

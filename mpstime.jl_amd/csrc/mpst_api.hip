@@ -741,20 +741,16 @@ int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* labe
     return 0;
 }
 
-int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
-                        int32_t C, mpst_encode_opts* eo, const int64_t* n_global_per_class, double* oob_fix, double* seconds) {
-    Ctx* c = (Ctx*)ctx;
-    if (!c) return MPST_ERR_INVALID;
+// preprocessing + encoding of X[N][T] into dphi ([T][N][d] doubles, or (re, im) pairs for the Fourier basis): shared by
+// mpst_encode_dataset (dphi = the data set's product states) and mpst_encode_values (dphi = scratch, copied out)
+static int encode_core(Ctx* c, const double* X, int64_t N, int32_t T, int32_t d, mpst_encode_opts* eo, double* dphi, double* oob_fix,
+                       double* seconds) {
+    int rc;
     if (!eo) return fail(c, MPST_ERR_INVALID, "NULL encode options");
-    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM)
-        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the real Legendre bases only (complex bases cannot be trained by the array sweep, loss_functions.jl:203-217)");
     const bool fit_sig = eo->sigmoid_transform && eo->fit_sigmoid && !eo->is_test;
     if (eo->fit_sigmoid && eo->is_test) return fail(c, MPST_ERR_INVALID, "fit_sigmoid: the RobustSigmoid is fitted on the training set only");
     if (eo->sigmoid_transform && !fit_sig && !(eo->iqr > 0.0)) return fail(c, MPST_ERR_INVALID, "robust sigmoid needs iqr > 0");
     if (fit_sig && N * (int64_t)T > 0x7fffffffll) return fail(c, MPST_ERR_UNSUPPORTED, "fit_sigmoid sorts at most 2^31 - 1 values");
-    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
-    if (rc || N == 0) return rc;
-    DataSet& s = c->ds[which];
     double *dX = nullptr, *part = nullptr, *lohi = nullptr, *fix = nullptr;
     struct Temps {      // released on every exit path, the HIPC early returns included
         double **a, **b, **cc, **d;
@@ -795,13 +791,14 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     EncDev e{};
     e.N = N; e.T = T; e.d = d;
     e.norm = eo->basis == MPST_BASIS_LEGENDRE;
+    e.fourier = eo->basis == MPST_BASIS_FOURIER;
     e.sigmoid = eo->sigmoid_transform; e.minmax = eo->minmax; e.is_test = test;
     e.med = eo->median; e.s = eo->iqr / 1.35;
     e.lb = eo->data_lb; e.ub = eo->data_ub; e.a = eo->range_a; e.b = eo->range_b;
     e.nrm = std::sqrt(std::sqrt((2 * d + 1) / 2.0) * d);
     e.lohi = lohi; e.fix = fix;
     HIPC(c, hipEventRecord(c->ev_start, c->stream));
-    launch_encode(e, dX, s.phi, part, lohi, fix, !test && eo->minmax, c->stream);
+    launch_encode(e, dX, dphi, part, lohi, fix, !test && eo->minmax, c->stream);
     HIPC(c, hipEventRecord(c->ev_stop, c->stream));
     HIPC(c, hipEventSynchronize(c->ev_stop));
     HIPC(c, hipGetLastError());
@@ -815,6 +812,45 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
         eo->hi = h[1];
     }
     if (fix && oob_fix) HIPC(c, hipMemcpy(oob_fix, fix, (size_t)2 * N * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
+                        int32_t C, mpst_encode_opts* eo, const int64_t* n_global_per_class, double* oob_fix, double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (!eo) return fail(c, MPST_ERR_INVALID, "NULL encode options");
+    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "a data set holds real product states: Legendre bases only (complex bases cannot be trained by the array sweep, loss_functions.jl:203-217; mpst_encode_values encodes them for the imputation engine)");
+    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
+    if (rc || N == 0) return rc;
+    return encode_core(c, X, N, T, d, eo, c->ds[which].phi, oob_fix, seconds);
+}
+
+int mpst_encode_values(void* ctx, const double* X, int64_t N, int32_t T, int32_t d, mpst_encode_opts* eo, void* phi_out, double* oob_fix,
+                       double* seconds) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (!eo || !X || !phi_out) return fail(c, MPST_ERR_INVALID, "NULL argument");
+    if (N <= 0 || T < 1 || d < 1 || d > 64) return fail(c, MPST_ERR_INVALID, "bad dimensions");
+    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM && eo->basis != MPST_BASIS_FOURIER)
+        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the Legendre and Fourier bases");
+    HIPC(c, hipSetDevice(c->device));
+    const int zw = eo->basis == MPST_BASIS_FOURIER ? 2 : 1;
+    double* dphi = nullptr;
+    struct T1 {
+        double** a;
+        ~T1() { dfree(a); }
+    } t1{&dphi};
+    int rc;
+    if ((rc = dalloc(c, &dphi, N * T * d * zw))) return rc;
+    if ((rc = encode_core(c, X, N, T, d, eo, dphi, oob_fix, seconds))) return rc;
+    std::vector<double> tmp((size_t)N * T * d * zw);
+    HIPC(c, hipMemcpy(tmp.data(), dphi, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double* out = (double*)phi_out;
+    const size_t w = (size_t)d * zw;
+    for (int64_t i = 0; i < N; ++i)
+        for (int t = 0; t < T; ++t) memcpy(&out[((size_t)i * T + t) * w], &tmp[((size_t)t * N + i) * w], w * sizeof(double));
     return 0;
 }
 

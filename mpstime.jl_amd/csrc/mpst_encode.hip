@@ -104,6 +104,19 @@ __global__ __launch_bounds__(256) void k_encode(EncDev e, const double* __restri
         if (scale != 1.0) x /= scale;
     }
     x = (e.b - e.a) * x + e.a;
+    if (e.fourier) {
+        // fourier_encode (bases.jl:23-42): cispi(f x) / sqrt(d) with f = 0, 1, -1, 2, -2, ...
+        double* outc = phi + idx * e.d * 2;
+        const double inv = 1.0 / sqrt((double)e.d);
+        for (int k = 0; k < e.d; ++k) {
+            const int f = (k + 1) / 2 * ((k & 1) ? 1 : -1);
+            double sn, cs;
+            sincospi((double)f * x, &sn, &cs);
+            outc[2 * k] = cs * inv;
+            outc[2 * k + 1] = sn * inv;
+        }
+        return;
+    }
     double* out = phi + idx * e.d;
     // Bonnet recursion, then sqrt((2k+1)/2) (normalised Legendre), then the optional 1/nrm (bases.jl:77-92)
     double p0 = 1.0, p1 = x;

@@ -95,7 +95,7 @@ class SweepEngine:
             basis = model_encoding(basis).name           # canonical name; :Legendre is :Legendre_No_Norm (options.jl:245-246)
         except Exception:
             pass
-        if basis not in L.BASIS:
+        if basis not in ("Legendre_Norm", "Legendre_No_Norm"):
             raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the real Legendre bases only, not {basis!r}")
         X = np.ascontiguousarray(X_sorted, dtype=np.float64)
         lab = np.ascontiguousarray(label_index, dtype=np.int32)
@@ -133,6 +133,43 @@ class SweepEngine:
             return out, sec.value
         oob = [[i, float(fix[i, 0]), float(fix[i, 1])] for i in range(N) if fix[i, 0] != 0.0 or fix[i, 1] != 1.0]
         return oob, sec.value
+
+    def encode_values(self, X, basis="Legendre_No_Norm", d=4, sigmoid_transform=False, minmax=False, data_bounds=(0.0, 1.0),
+                      enc_range=None, norms=None, rescale_out_of_bounds=False):
+        """mpst_encode_values: the device preprocessing + encoding kernels on a raw (N, T) matrix, states back to the host -
+        (N, T, d) float64 for the Legendre bases, complex128 for "Fourier".  Defaults: X is already in the encoding's
+        domain (no transforms, identity range map); with transforms the [0, 1] data is mapped onto ``enc_range``
+        (default (-1, 1)).  ``norms`` as for encode_dataset (a test set) or None."""
+        from .encodings import model_encoding
+        try:
+            basis = model_encoding(basis).name
+        except Exception:
+            pass
+        if basis not in L.BASIS:
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the Legendre and Fourier bases, not {basis!r}")
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        N, T = X.shape
+        eo = L.mpst_encode_opts()
+        eo.basis, eo.sigmoid_transform, eo.minmax = L.BASIS[basis], int(bool(sigmoid_transform)), int(bool(minmax))
+        eo.is_test, eo.rescale_out_of_bounds = int(norms is not None), int(bool(rescale_out_of_bounds))
+        eo.data_lb, eo.data_ub = map(float, data_bounds)
+        if enc_range is None:
+            enc_range = (-1.0, 1.0) if (sigmoid_transform or minmax or norms is not None) else (0.0, 1.0)
+        eo.range_a, eo.range_b = map(float, enc_range)
+        if norms is None:
+            eo.fit_sigmoid = int(bool(sigmoid_transform))
+        else:
+            if norms.sigmoid is not None:
+                eo.median, eo.iqr = norms.sigmoid
+            eo.sigmoid_transform = int(norms.sigmoid is not None)
+            if norms.minmax is not None:
+                eo.lo, eo.hi = norms.minmax
+        cx = basis == "Fourier"
+        out = np.zeros((N, T, int(d)), dtype=np.complex128 if cx else np.float64)
+        sec = C.c_double()
+        self._chk(self.lib.mpst_encode_values(self.ctx, X.ctypes.data_as(C.POINTER(C.c_double)), N, T, int(d), C.byref(eo),
+                                              out.ctypes.data_as(C.c_void_p), None, C.byref(sec)))
+        return out, sec.value
 
     def get_encoded(self, which=0):
         phi = np.zeros((self.N[which], self.T, self.d))

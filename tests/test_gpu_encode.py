@@ -120,3 +120,27 @@ def test_robust_sigmoid_fit_on_the_device(engine_cls, shape):
             eng.encode_dataset(0, np.ones((4, 5)), np.zeros(4, dtype=np.int32), 1, d=3)      # constant data: iqr = 0
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("d", [2, 5, 8])
+def test_fourier_and_legendre_values_on_the_device(engine_cls, d):
+    """mpst_encode_values: fourier_encode (bases.jl:23-42: cispi(f x) / sqrt(d), f = 0, 1, -1, 2, -2, ...) and the Legendre
+    bases on the device without a data set - the states mpst_impute_model_run takes - against the host restatement."""
+    rng = np.random.default_rng(d)
+    X = rng.uniform(-1.0, 1.0, (37, 23))
+    eng = engine_cls(0)
+    try:
+        phi_f, sec = eng.encode_values(X, "Fourier", d)
+        phi_l, _ = eng.encode_values(X, "Legendre_No_Norm", d)
+        phi_n, _ = eng.encode_values(X, "Legendre_Norm", d)
+        # with the preprocessing of a training set in front (RobustSigmoid fitted on the device, MinMax)
+        Xr = rng.normal(size=(37, 23)) * 2.0
+        phi_p, _ = eng.encode_values(Xr, "Fourier", d, sigmoid_transform=True, minmax=True)
+    finally:
+        eng.close()
+    assert phi_f.dtype == np.complex128 and sec > 0
+    assert np.abs(phi_f - R.fourier_encode(X, d)).max() < 1e-14
+    assert np.abs(phi_l - R.legendre_encode(X, d)).max() < 1e-13
+    assert np.abs(phi_n - R.legendre_encode(X, d, norm=True)).max() < 1e-13
+    Xs, _ = R.transform_train_data(Xr, sigmoid_transform=True, minmax=True)
+    assert np.abs(phi_p - R.fourier_encode(Xs, d)).max() < 1e-12
