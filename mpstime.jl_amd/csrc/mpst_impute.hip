@@ -25,7 +25,7 @@
 // tensors, environment matrices, the vector L - run in fp64 or in fp32 (MFMA f32 16x16x4, half the LDS and HBM bytes),
 // while the density on the grid, its prefix sums and every selection are always fp64.  Complex matrices live in LDS as
 // separate real and imaginary planes so that a complex product is four real MFMA chains.
-// Limits: d <= 16, chi <= 128.  The environment pass keeps 4 (real) / 8 (complex) padded chi x chi planes in LDS up to
+// Limits: d <= 16, chi <= 128.  The environment pass keeps two padded chi x chi matrices (+ a 16-row block) in LDS up to
 // chi = 64 (complex fp64: 48); beyond that k_imp_right_big works out of global scratch.
 #include "mpst_internal.h"
 #include <cstdlib>
@@ -210,15 +210,42 @@ __device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int 
     }
 }
 
+// one 16 x 16 tile C(m0.., n0..) (+)= A[m0.. rows] * B  or  A * B^H (TB: B holds the N x K operand), operands in LDS planes
+// with leading dimension ld, the accumulator stays with the caller
+template <typename R, bool CX, bool TB>
+__device__ __forceinline__ void lds_tile(typename Mx<R>::acc_t& accr, typename Mx<R>::acc_t& acci, Plane<R> A, int a_row0, Plane<R> B, int n0,
+                                         int ks, int ld) {
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int ia0 = (a_row0 + i16) * ld + kq;
+    const int ib0 = TB ? (n0 + i16) * ld + kq : kq * ld + n0 + i16;
+    const int bstep = TB ? 4 : 4 * ld;
+    for (int u = 0; u < ks; ++u) {
+        const R ar = A.r[ia0 + 4 * u], br = B.r[ib0 + bstep * u];
+        accr = Mx<R>::mma(ar, br, accr);
+        if constexpr (CX) {
+            const R ai = A.i[ia0 + 4 * u], bi = B.i[ib0 + bstep * u];
+            accr = Mx<R>::mma(TB ? ai : -ai, bi, accr);
+            acci = Mx<R>::mma(ai, br, acci);
+            acci = Mx<R>::mma(TB ? -ar : ar, bi, acci);
+        }
+    }
+}
+
+// LDS holds the current environment R, the site matrix Ms and ONE 16-row block of T1 = Ms R; the new environment
+// R' = sum_s Ms R Ms^H never visits LDS while it is summed: wave w keeps column tile w of all (up to four) row blocks in
+// MFMA accumulators across the whole s loop.  2 x chi^2 + 16 chi elements instead of 4 x chi^2: two workgroups per CU at
+// chi = 64, which is what hides the site-tensor loads and the barriers of one workgroup behind the other's matrix work.
 template <typename R, bool CX>
 __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
                                                      int max_missing, int64_t i0, int rev) {
+    using acc_t = typename Mx<R>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
-    constexpr int NP = CX ? 8 : 4, ZW = CX ? 2 : 1;
+    constexpr int ZW = CX ? 2 : 1;
     const int64_t i = i0 + blockIdx.x;          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
-    const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
+    const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
     const uint8_t* mi = missing + i * T;
     int nm = 0;
     for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
@@ -226,13 +253,14 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
     const int cls = v.label[i];
     const int cp = (cm + 15) & ~15;            // matrices are kept zero-padded to a multiple of 16 rows / columns
     const int ld = cp + 2;                     // + 2: the 16 rows an MFMA operand read touches land on different banks
-    const int msz = cp * ld;
-    auto plane = [&](int k) { return Plane<R>{smem + (int64_t)(ZW * k) * msz, smem + (int64_t)(ZW * k + ZW - 1) * msz}; };
-    Plane<R> Rc = plane(0);            // current environment matrix
-    Plane<R> Rn = plane(1);            // next one
-    const Plane<R> Ms = plane(2);      // M_j or W_j[s] as an (out x in) matrix of this pass
-    const Plane<R> T1 = plane(3);      // Ms * R
-    for (int e = tid; e < NP * msz; e += IMP_T) smem[e] = R(0);
+    const int msz = cp * ld, bsz = 16 * ld;
+    const int tpr = cp >> 4;                                   // tiles per row of a padded matrix: 1, 2, 3 or 4
+    const int ngrp = tpr >= 3 ? 1 : (tpr == 2 ? 2 : 4);        // groups of waves that take row blocks in turn
+    const int grp = wave / (4 / ngrp), wc = wave % (4 / ngrp);  // this wave's group and column tile
+    const Plane<R> Rc{smem, smem + (ZW - 1) * msz};                                      // current environment matrix
+    const Plane<R> Ms{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};                // M_j or W_j[s] as an (out x in) matrix of this pass
+    const Plane<R> T1{smem + 2 * ZW * msz, smem + 2 * ZW * msz + (ZW - 1) * ngrp * bsz};  // one 16-row block of Ms * R per group
+    for (int e = tid; e < ZW * (2 * msz + ngrp * bsz); e += IMP_T) smem[e] = R(0);
     __syncthreads();
     if (tid == 0) Rc.r[0] = R(1);
     __syncthreads();
@@ -258,6 +286,13 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
         // consecutive threads walk the contiguous bond index of the stored tensor (its right bond)
         const bool in_fast = sv.si == 1;
         const int Df = in_fast ? Di : Do;
+        const int tmo = (Do + 15) >> 4, tni = (Di + 15) >> 4, ksi = (Di + 3) >> 2;
+        acc_t rnr[4], rni[4];                       // this wave's column tile of the new environment, its row blocks
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            rnr[rb] = acc_t{0, 0, 0, 0};
+            rni[rb] = acc_t{0, 0, 0, 0};
+        }
         for (int s = 0; s < ns; ++s) {
             // Ms[o][i] = M_j = sum_q conj(phi_q) W_j[q] (known) or W_j[s] (missing); 8 elements per thread per round trip
             for (int e0 = tid; e0 < Di * Do; e0 += 8 * IMP_T) {
@@ -308,32 +343,61 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
                     }
             }
             __syncthreads();
-            lds_mm<R, CX>(T1, Ms, Rc, Do, Di, Di, ld, false, false);          // T1 = Ms * R
-            __syncthreads();
-            lds_mm<R, CX>(Rn, T1, Ms, Do, Do, Di, ld, true, s > 0);            // Rn (+)= T1 * Ms^H
-            __syncthreads();
+            // row blocks are dealt out to `ngrp` groups of waves (4 / tiles-per-row groups: small matrices would leave
+            // most waves without a column tile); a group works on row block grp + it * ngrp in its own T1 block
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rb = grp + it * ngrp;
+                if (it * ngrp < tmo) {                      // uniform over the workgroup: every group takes the barriers
+                    const Plane<R> Tg{T1.r + grp * bsz, T1.i + grp * bsz};
+                    if (rb < tmo && wc < tni) {
+                        // T1 block = Ms[16 rb .. 16 rb + 15][:] * R: this wave's column tile (R is Di x Di)
+                        acc_t tr = {0, 0, 0, 0}, ti = {0, 0, 0, 0};
+                        lds_tile<R, CX, false>(tr, ti, Ms, 16 * rb, Rc, 16 * wc, ksi, ld);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int at = Mx<R>::row(kq, r) * ld + 16 * wc + i16;
+                            Tg.r[at] = tr[r];
+                            if constexpr (CX) Tg.i[at] = ti[r];
+                        }
+                    }
+                    __syncthreads();
+                    // R'[16 rb .., 16 wc ..] += T1 block * Ms[16 wc .. 16 wc + 15][:]^H
+                    if (rb < tmo && wc < tmo) lds_tile<R, CX, true>(rnr[it], rni[it], Tg, 0, Ms, 16 * wc, ksi, ld);
+                    __syncthreads();
+                }
+            }
         }
-        // rescale by the trace (every density below is scale-free), clear what the next site must find zero, swap
-        double tr = 0.0;
-        for (int a = tid; a < Do; a += IMP_T) tr += (double)Rn.r[a * ld + a];
-        tr = blk_sum(tr, red);
-        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
-        for (int e = tid; e < cp * cp; e += IMP_T) {
-            const int a = e / cp, b2 = e - a * cp;
-            const bool live = a < Do && b2 < Do;
-            Rn.r[a * ld + b2] = live ? Rn.r[a * ld + b2] * sc : R(0);
-            Ms.r[a * ld + b2] = R(0);
-            T1.r[a * ld + b2] = R(0);
-            if constexpr (CX) {
-                Rn.i[a * ld + b2] = live ? Rn.i[a * ld + b2] * sc : R(0);
-                Ms.i[a * ld + b2] = R(0);
-                T1.i[a * ld + b2] = R(0);
+        // the new environment replaces the old one in LDS (every read of R is behind the last barrier), rescaled by its trace
+        // (every density below is scale-free); rows / columns beyond Do must be zero for the next site
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rb = grp + it * ngrp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc + i16;
+                if (row < cp && col < cp) {
+                    const bool live = rb < tmo && wc < tmo && row < Do && col < Do;
+                    Rc.r[row * ld + col] = live ? rnr[it][r] : R(0);
+                    if constexpr (CX) Rc.i[row * ld + col] = live ? rni[it][r] : R(0);
+                }
             }
         }
         __syncthreads();
-        const Plane<R> tmp = Rc;
-        Rc = Rn;
-        Rn = tmp;
+        double tr = 0.0;
+        for (int a_ = tid; a_ < Do; a_ += IMP_T) tr += (double)Rc.r[a_ * ld + a_];
+        tr = blk_sum(tr, red);
+        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
+        for (int e = tid; e < cp * cp; e += IMP_T) {
+            const int a_ = e / cp, b2 = e - a_ * cp;
+            Rc.r[a_ * ld + b2] *= sc;
+            Ms.r[a_ * ld + b2] = R(0);
+            if constexpr (CX) {
+                Rc.i[a_ * ld + b2] *= sc;
+                Ms.i[a_ * ld + b2] = R(0);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1128,7 +1192,8 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
 
 static size_t right_lds_bytes(int cap, bool cx, bool f32) {
     const int cp = (cap + 15) & ~15;
-    return (size_t)(cx ? 8 : 4) * cp * (cp + 2) * (f32 ? 4 : 8);
+    const int ngrp = cp >= 48 ? 1 : (cp == 32 ? 2 : 4);
+    return (size_t)(cx ? 2 : 1) * (2 * cp + 16 * ngrp) * (cp + 2) * (f32 ? 4 : 8);
 }
 static size_t left_lds_bytes(int cap, bool cx, bool f32) {
     return (size_t)(2 * cap + 2 * IMP_MAXD * cap + IMP_MAXD) * (cx ? 2 : 1) * (f32 ? 4 : 8);
@@ -1136,7 +1201,7 @@ static size_t left_lds_bytes(int cap, bool cx, bool f32) {
 // the LDS kernel's limit; beyond it (or everywhere with MPST_IMPUTE_BIG=1, a test hook): k_imp_right_big
 static int impute_lds_chi_limit(bool cx, bool f32) {
     static const bool force = getenv("MPST_IMPUTE_BIG") != nullptr;
-    return force ? 0 : ((cx && !f32) ? 48 : 64);
+    return force ? 0 : ((cx && !f32) ? 48 : 64);     // complex fp64 above 48: one workgroup per CU in LDS loses to the global-scratch kernel (measured)
 }
 int impute_chi_limit(bool, bool) { return CAP_LIMIT; }
 int64_t impute_work_elems(int cap, bool cx, bool f32) { return cap > impute_lds_chi_limit(cx, f32) ? 4ll * cap * cap * (cx ? 2 : 1) : 0; }
