@@ -599,21 +599,64 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         glds16(ws + WS_VS + 2 * (tid + m * VEC_THREADS), Vd + 2 * (wave * 64 + m * VEC_THREADS));
     lds_barrier();
     VDBG(0);
-    // ---- 256-way multisection for the k-th largest eigenvalue -------------------------------------
+    // ---- multisection for the k-th largest eigenvalue ---------------------------------------------------
     const int target = n - 1 - k;       // ascending index
-    for (int it = 0; it < TRI_NSTEP; ++it) {
-        const double h = (hi - lo) * (1.0 / (VEC_THREADS + 1));
-        const double xq = lo + h * (tid + 1);
-        const int cnt = sturm_count(de, n, xq);
-        const unsigned long long b = __ballot(cnt <= target);
-        if (lane == 0) cnt_s[wave] = __popcll(b);
+    if (n >= 24) {
+        // Two-sided Sturm count: the inertia of T - x is that of its twisted factorisation - negative top-down pivots
+        // of rows 0..kk-1, negative bottom-up pivots of rows n-1..kk+1, and the sign of the twisted pivot at row kk.
+        // A pair of lanes runs the two halves of one abscissa (the same division-free recurrence on T and on the
+        // reversed T), so a round walks n/2 rows instead of n: 128 abscissae x 8 rounds cost 60 % of 256 x 7.
+        double* deR = Dm;                               // [n] pairs of the reversed matrix (the pivot arrays are free until the bisection is over)
+        const int kk = ((n >> 1) & ~7) + 1;             // top half: 1 + a multiple of 8 rows
+        for (int m = tid; m < n; m += VEC_THREADS) {
+            deR[2 * m] = de[2 * (n - 1 - m)];
+            deR[2 * m + 1] = m >= 1 ? de[2 * (n - m) + 1] : 0.0;
+        }
         lds_barrier();
-        const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
-        lds_barrier();
-        const double nlo = jj > 0 ? lo + h * jj : lo;
-        const double nhi = jj < VEC_THREADS ? lo + h * (jj + 1) : hi;
-        lo = nlo;
-        hi = nhi;
+        const bool bottom = tid & 1;
+        const double* arr = bottom ? deR : de;
+        const int rows = bottom ? n - 1 - kk : kk;
+        const double dk = de[2 * kk], e2a = de[2 * kk + 1], e2b = de[2 * (kk + 1) + 1];     // d_kk, e^2_{kk-1}, e^2_kk
+        constexpr int NPT = VEC_THREADS / 2;
+        for (int it = 0; it < 8; ++it) {
+            const double h = (hi - lo) * (1.0 / (NPT + 1));
+            const double xq = lo + h * ((tid >> 1) + 1);
+            double p1, p2;
+            int cnt = sturm_half(arr, rows, xq, p1, p2);
+            // the partner's count and end values (lane ^ 1): quad_perm [1, 0, 3, 2]
+            const int ocnt = __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, true);
+            const double o1 = dpp_mov<0xB1>(p1), o2 = dpp_mov<0xB1>(p2);
+            // top lane: (p1, p2) = (P_{kk-1}, P_{kk-2}), partner's = (Q_{kk+1}, Q_{kk+2}); bottom lane the other way round
+            const double P1 = bottom ? o1 : p1, P2 = bottom ? o2 : p2, Q1 = bottom ? p1 : o1, Q2 = bottom ? p2 : o2;
+            // gamma_kk = (d - x) - e2a P2 / P1 - e2b Q2 / Q1, signed through P1 Q1 (the two pairs carry their own scales)
+            const double g = fma(dk - xq, P1 * Q1, -fma(e2a * P2, Q1, e2b * Q2 * P1));
+            const int sg = ((hi32(g) ^ hi32(P1) ^ hi32(Q1)) >> 31) & 1;
+            cnt += ocnt + sg;
+            const unsigned long long bal = __ballot(cnt <= target) & 0x5555555555555555ull;
+            int* slot = cnt_s + 4 * (it & 1);                 // parity-indexed: one barrier per round
+            if (lane == 0) slot[wave] = __popcll(bal);
+            lds_barrier();
+            const int jj = slot[0] + slot[1] + slot[2] + slot[3];
+            const double nlo = jj > 0 ? lo + h * jj : lo;
+            const double nhi = jj < NPT ? lo + h * (jj + 1) : hi;
+            lo = nlo;
+            hi = nhi;
+        }
+    } else {
+        for (int it = 0; it < TRI_NSTEP; ++it) {
+            const double h = (hi - lo) * (1.0 / (VEC_THREADS + 1));
+            const double xq = lo + h * (tid + 1);
+            const int cnt = sturm_count(de, n, xq);
+            const unsigned long long b = __ballot(cnt <= target);
+            if (lane == 0) cnt_s[wave] = __popcll(b);
+            lds_barrier();
+            const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+            lds_barrier();
+            const double nlo = jj > 0 ? lo + h * jj : lo;
+            const double nhi = jj < VEC_THREADS ? lo + h * (jj + 1) : hi;
+            lo = nlo;
+            hi = nhi;
+        }
     }
     const double lamk = 0.5 * (lo + hi);
     VDBG(1);

@@ -68,6 +68,55 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ de, int n,
 }
 
 
+// One half of a two-sided Sturm count: the recurrence of sturm_count over `rows` rows of a (d, e^2) pair array that may be
+// the reversed matrix, without padding (whole groups of 8, then the remainder row by row).  Returns the number of negative
+// pivots among these rows and leaves the last two values of the sequence (rescaled together) in p, pp - what the caller
+// needs to evaluate the twisted pivot where the two halves meet.
+__device__ __forceinline__ int sturm_half(const double* __restrict__ arr, int rows, double x, double& p_out, double& pp_out) {
+    const double2* __restrict__ a2 = (const double2*)arr;
+    double pp = 1.0, p = arr[0] - x;
+    unsigned sb = ((unsigned)hi32(p)) >> 31;
+    int cnt = (int)sb;
+    int j = 1;
+    while (j + 8 <= rows) {               // (a ping-pong prefetch of the next group, as in sturm_count, measured slower here)
+        double2 buf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) buf[u] = a2[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double t = buf[u].x - x;
+            const double pn = fma(t, p, -buf[u].y * pp);
+            sb = __builtin_amdgcn_alignbit(sb, (unsigned)hi32(pn), 31);
+            pp = p;
+            p = pn;
+        }
+        cnt += __popc((sb ^ (sb >> 1)) & 0xffu);
+        int e = __builtin_amdgcn_frexp_exp(p);
+        if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
+        p = __builtin_amdgcn_ldexp(p, -e);
+        pp = __builtin_amdgcn_ldexp(pp, -e);
+        j += 8;
+    }
+    for (; j < rows; ++j) {
+        const double2 b = a2[j];
+        const double pn = fma(b.x - x, p, -b.y * pp);
+        sb = __builtin_amdgcn_alignbit(sb, (unsigned)hi32(pn), 31);
+        cnt += (int)((sb ^ (sb >> 1)) & 1u);
+        pp = p;
+        p = pn;
+    }
+    {
+        // hand the pair over at unit scale: the caller multiplies values of the two halves
+        int e = __builtin_amdgcn_frexp_exp(p);
+        if (p == 0.0) e = __builtin_amdgcn_frexp_exp(pp);
+        p = __builtin_amdgcn_ldexp(p, -e);
+        pp = __builtin_amdgcn_ldexp(pp, -e);
+    }
+    p_out = p;
+    pp_out = pp;
+    return cnt;
+}
+
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute ------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, >100 cycles of dependent latency
 // per step); the reductions here sit on the critical path of single-workgroup kernels, so they
