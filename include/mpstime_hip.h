@@ -294,8 +294,9 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * 128 x 128, 7 launches per bond), out[1] large-bond path (d*chi_max > 128), out[2] partial gradients per optimiser step
  * of the fused chain, out[3] 64-series chunks of the unfused chain, out[4] capacity bond dimension, out[5] ranks,
  * out[6] sweeps replayed from a hipGraph, out[7] bonds on which the blocked large-bond eigensolver handed over to the
- * library solver */
-int  mpst_get_info(void* ctx, int32_t* out /*[8]*/);
+ * library solver, out[8] bonds whose persistent tridiagonalisation gave up waiting for its peers and was redone one
+ * launch per step, out[9..11] reserved */
+int  mpst_get_info(void* ctx, int32_t* out /*[12]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */

@@ -195,6 +195,186 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     }
 }
 
+// ---- the same tridiagonalisation as ONE persistent launch -----------------------------------------------------------------
+// A Householder step per launch costs 6.4 us at n = 300-500: 1.5 us of launch and the rest because every
+// step rewrites the trailing matrix through memory (the eight XCDs have separate L2s).  Here the matrix never leaves the
+// chip's local memories: workgroup g keeps rows g, g+G, g+2G, ... in LDS for the whole factorisation and a step exchanges
+// only two length-n vectors through memory - y (every owner writes its entries) and the row the next step starts from -
+// with agent-scope loads / stores and one counting barrier (1.8 us per round across the XCDs, scratch/ubench/xcd_barrier.hip).
+// Every workgroup still repeats the cheap part (alpha, w, the reflector) for itself exactly as k_bt_step does, so the
+// arithmetic - and the bits - are those of the launch-per-step path, which remains the fallback when a workgroup's wait
+// runs out of patience (its peers not resident: other work holding the CUs).
+struct BtCoop {
+    double* ybuf;            // [2][ncap] y of a step, by parity
+    double* rowbuf;          // [2][ncap] the published row, by parity
+    unsigned int* counter;   // arrivals, monotonic within a solve
+    int32_t* abort_flag;     // set by a workgroup that gave up waiting: everybody leaves, the host falls back
+};
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every workgroup has arrived `target` times in total; false if the wait was abandoned
+__device__ __forceinline__ bool bt_coop_wait(const BtCoop& cp, unsigned int target, int* sh_ok) {
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        int spins = 0;
+        // relaxed polling: everything exchanged between workgroups is itself read and written with agent-scope operations,
+        // so no cache needs invalidating when the count is reached
+        while (__hip_atomic_load(cp.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023) == 0 &&
+                (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(cp.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
+}
+__device__ __forceinline__ void bt_coop_arrive(const BtCoop& cp) {
+    __syncthreads();            // waits for every thread's (write-through, agent-scope) stores of this step: nothing to flush
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cp.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_a[4], red_b[4], bc[2];
+    __shared__ int sh_ok;
+    constexpr int QV = BT_NMAX / BT_T;
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
+    const int n = pb.n, ld = b.ncap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int G = gridDim.x, g = blockIdx.x;
+    double* xs = smem;                   // [ncap] the reflector v_j (v_{j-1} when a step starts)
+    double* vl = xs + ld;                // [ncap] v_{j-1}
+    double* wl = vl + ld;                // [ncap] w_{j-1}
+    double* rows = wl + ld;              // [ceil(ncap / G)][ncap] this workgroup's rows g, g+G, ...
+    const int nown = g < n ? (n - 1 - g) / G + 1 : 0;
+    if (g == 0 && tid == 0) *b.flag = 0;
+    for (int k = 0; k < nown; ++k) {
+        const int r = g + k * G;
+        for (int c = tid; c < n; c += BT_T) rows[k * ld + c] = pb.G[(int64_t)r * n + c];
+    }
+    for (int c = tid; c < n; c += BT_T) xs[c] = vl[c] = wl[c] = 0.0;
+    __syncthreads();
+    if (n == 1) {
+        if (g == 0 && tid == 0) {
+            b.dd[0] = pb.G[0];
+            b.ee[0] = 0.0;
+        }
+        return;
+    }
+    if (g == 0)
+        for (int c = tid; c < n; c += BT_T) st_agent(cp.rowbuf + c, rows[c]);
+    bt_coop_arrive(cp);
+    double tau_prev = 0.0;
+    for (int j = 0; j <= n - 2; ++j) {
+        if (!bt_coop_wait(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+        // everything this step needs from the others, requested at once
+        const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * ld;
+        const double* rowj = cp.rowbuf + (int64_t)(j & 1) * ld;
+        double vp[QV], yp[QV], aj[QV];
+#pragma unroll
+        for (int q = 0; q < QV; ++q) {
+            const int idx = j + tid + BT_T * q;
+            const bool ok = idx < n;
+            yp[q] = (ok && j > 0) ? ld_agent(yprev + idx) : 0.0;
+            aj[q] = ok ? ld_agent(rowj + idx) : 0.0;
+            vp[q] = (ok && j > 0) ? xs[idx] : 0.0;
+        }
+        const double yj = j > 0 ? ld_agent(yprev + j) : 0.0;
+        // (a) alpha_{j-1}
+        double alpha;
+        {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < QV; ++q) s = fma(yp[q], vp[q], s);
+            s = wave_sum(s);
+            if (lane == 0) red_a[wave] = s;
+            __syncthreads();
+            alpha = -0.5 * tau_prev * ((red_a[0] + red_a[1]) + (red_a[2] + red_a[3]));
+        }
+        // (b) row j with the pending update applied (v_{j-1}[j] is the leading one of reflector j-1, w_{j-1}[j] = y_j + alpha)
+        const double vj = j > 0 ? 1.0 : 0.0, wj = j > 0 ? yj + alpha : 0.0;
+        double xr[QV];
+        double tau = 0.0, beta;
+        {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                const int idx = j + tid + BT_T * q;
+                yp[q] = j > 0 ? fma(alpha, vp[q], yp[q]) : 0.0;        // w_{j-1} from here on
+                xr[q] = fma(-wj, vp[q], fma(-vj, yp[q], aj[q]));
+                if (idx >= j + 2 && idx < n) s = fma(xr[q], xr[q], s);
+                if (idx < n) {
+                    vl[idx] = vp[q];
+                    wl[idx] = yp[q];
+                }
+            }
+            if (tid == 0) bc[0] = xr[0];               // d_j
+            if (tid == 1) bc[1] = xr[0];               // the leading entry of the column below the diagonal
+            s = wave_sum(s);
+            if (lane == 0) red_b[wave] = s;
+            __syncthreads();
+            s = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+            const double dj = bc[0], a0 = bc[1];
+            beta = a0;
+            double scale = 0.0;
+            if (s > 0.0) {
+                beta = -copysign(sqrt(fma(a0, a0, s)), a0);
+                tau = (beta - a0) / beta;
+                scale = 1.0 / (a0 - beta);
+            }
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                const int idx = j + tid + BT_T * q;
+                if (idx < n) {
+                    const double vr = idx <= j ? 0.0 : (idx == j + 1 ? 1.0 : xr[q] * scale);
+                    xs[idx] = vr;
+                    if (g == 0) b.Vall[(int64_t)j * ld + idx] = vr;
+                }
+            }
+            if (g == 0 && tid == 0) {
+                b.tau[j] = tau;
+                b.dd[j] = dj;
+                b.ee[j] = beta;
+            }
+            __syncthreads();
+        }
+        tau_prev = tau;
+        if (j == n - 2) {
+            // the last diagonal entry, with the pending update of step n-3 applied, from the row's owner
+            if ((n - 1) % G == g && tid == 0) {
+                const int k = (n - 1 - g) / G;
+                b.dd[n - 1] = rows[k * ld + (n - 1)] - 2.0 * vl[n - 1] * wl[n - 1];
+                b.ee[n - 1] = 0.0;
+            }
+            break;
+        }
+        // (c) own rows r > j: pending update, product with the new reflector; the owner of row j+1 publishes it
+        double* ynew = cp.ybuf + (int64_t)(j & 1) * ld;
+        double* rownext = cp.rowbuf + (int64_t)((j + 1) & 1) * ld;
+        for (int k = wave; k < nown; k += 4) {
+            const int r = g + k * G;
+            if (r <= j) continue;
+            double* arow = rows + k * ld;
+            const double vr = vl[r], wr = wl[r];
+            const bool pub = r == j + 1;
+            double s = 0.0;
+            for (int c = j + 1 + lane; c < n; c += 64) {
+                const double a_ = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
+                arow[c] = a_;
+                s = fma(a_, xs[c], s);
+                if (pub) st_agent(rownext + c, a_);
+            }
+            s = wave_sum(s);
+            if (lane == 0) st_agent(ynew + r, tau * s);
+        }
+        bt_coop_arrive(cp);
+    }
+}
+
 __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
@@ -579,8 +759,20 @@ __global__ __launch_bounds__(BT_T) void k_bt_copyback(View v, int lid, int going
 // ---- host side ----------------------------------------------------------------------------------------------------------
 struct BlockedEig {
     BtBufs b{};
-    int32_t* host_flag = nullptr;
+    BtCoop cp{};
+    int32_t* host_flag = nullptr;      // pinned: [0] verdict, [1] the persistent kernel gave up
+    int coop_aborts = 0;
 };
+static int coop_grid(int ncap) {
+    static const int gmax = [] { const char* e = getenv("MPST_BT_COOP_G"); return e ? std::max(1, atoi(e)) : 0; }();
+    // measured: four rows per workgroup up to n = 320 (80 workgroups), 64 workgroups beyond (8 rows each at n = 512: the
+    // barrier grows with the count faster than the row work shrinks), 128 when 64 would not fit the rows in LDS
+    return std::max(1, std::min(gmax ? gmax : (ncap > 768 ? 128 : (ncap <= 320 ? 80 : 64)), (ncap + 3) / 4));
+}
+static size_t coop_lds(int ncap) {
+    const int G = coop_grid(ncap);
+    return (size_t)(3 + (ncap + G - 1) / G) * ncap * sizeof(double);
+}
 
 static size_t bt_vec_lds() { return (size_t)(6 * BT_NMAX + 16) * sizeof(double); }
 
@@ -592,10 +784,11 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
               al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
-              hipHostMalloc((void**)&e->host_flag, sizeof(int32_t)) == hipSuccess;
+              hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 2 * n1) && al(&e->cp.rowbuf, 2 * n1) &&
+              hipMalloc((void**)&e->cp.counter, sizeof(unsigned int)) == hipSuccess && hipMalloc((void**)&e->cp.abort_flag, sizeof(int32_t)) == hipSuccess;
     if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
-                 true;
+                 hipFuncSetAttribute((const void*)k_bt_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds(BT_NMAX)) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -612,23 +805,17 @@ void blocked_eig_destroy(BlockedEig* e) {
     if (e->b.flag) (void)hipFree(e->b.flag);
     if (e->b.ctl) (void)hipFree(e->b.ctl);
     if (e->host_flag) (void)hipHostFree(e->host_flag);
+    if (e->cp.ybuf) (void)hipFree(e->cp.ybuf);
+    if (e->cp.rowbuf) (void)hipFree(e->cp.rowbuf);
+    if (e->cp.counter) (void)hipFree(e->cp.counter);
+    if (e->cp.abort_flag) (void)hipFree(e->cp.abort_flag);
     delete e;
 }
 
-// enqueue the whole solve; returns 1 if the on-device verification asks for the library fallback, 0 if E / lam / chi are
-// published, < 0 on a runtime error.  Synchronises the stream once (the verdict is read by the host).
-int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
-                       int32_t* rawinfo, BlockedEig* e, hipStream_t s) {
-    const BtBufs& b = e->b;
+// the launches that follow the tridiagonalisation: eigenvectors, verification, publication
+static void enqueue_after_tridiag(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
+                                  int32_t* rawinfo, const BtBufs& b, hipStream_t s) {
     const int ncap = rawn > 0 ? rawn : b.ncap;
-    hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
-    static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
-    for (int j = 0; j <= ncap - 2; ++j) {
-        // fewer workgroups once the trailing matrix is small: the redundant prologue is paid per workgroup
-        const int m = ncap - 1 - j;
-        const int g = std::max(1, std::min(bt_g, (m + 3) / 4));
-        hipLaunchKernelGGL(k_bt_step, dim3(g), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
-    }
     const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
     hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
     const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;
@@ -638,10 +825,45 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         hipLaunchKernelGGL(k_bt_decide, dim3(1), dim3(512), 0, s, v, lid, going_left, rawG, rawn, b, rawlam, rawinfo, second);
         hipLaunchKernelGGL(k_bt_polish, dim3(std::max(1, std::min(256, (tn * tk + 3) / 4))), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, rawE, second);
     }
-    if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
-    if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
-    if (hipGetLastError() != hipSuccess) return MPST_ERR_DEVICE;
+}
+
+// enqueue the whole solve; returns 1 if the on-device verification asks for the library fallback, 0 if E / lam / chi are
+// published, < 0 on a runtime error.  Synchronises the stream once (the verdict is read by the host).  Inside a sweep the
+// tridiagonalisation is the persistent kernel; if its workgroups could not all become resident within its patience it
+// gives up cleanly and the same bond is redone one launch per step.
+int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
+                       int32_t* rawinfo, BlockedEig* e, hipStream_t s) {
+    const BtBufs& b = e->b;
+    const int ncap = rawn > 0 ? rawn : b.ncap;
+    static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
+    bool coop = rawn == 0 && !no_coop;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (coop) {
+            if (hipMemsetAsync(e->cp.counter, 0, sizeof(unsigned int), s) != hipSuccess || hipMemsetAsync(e->cp.abort_flag, 0, sizeof(int32_t), s) != hipSuccess)
+                return MPST_ERR_DEVICE;
+            hipLaunchKernelGGL(k_bt_coop, dim3(coop_grid(ncap)), dim3(BT_T), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
+        } else {
+            hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
+            static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
+            for (int j = 0; j <= ncap - 2; ++j) {
+                // fewer workgroups once the trailing matrix is small: the redundant prologue is paid per workgroup
+                const int m = ncap - 1 - j;
+                const int g = std::max(1, std::min(bt_g, (m + 3) / 4));
+                hipLaunchKernelGGL(k_bt_step, dim3(g), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
+            }
+        }
+        enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, b, s);
+        e->host_flag[1] = 0;
+        if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (coop && hipMemcpyAsync(e->host_flag + 1, e->cp.abort_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (hipGetLastError() != hipSuccess) return MPST_ERR_DEVICE;
+        if (!(coop && e->host_flag[1])) break;
+        e->coop_aborts++;
+        coop = false;               // the persistent kernel gave up: the same bond again, one launch per step
+    }
     return *e->host_flag ? 1 : 0;
 }
+int blocked_eig_coop_aborts(const BlockedEig* e) { return e ? e->coop_aborts : 0; }
 
 }  // namespace mpst

@@ -426,6 +426,7 @@ void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hi
 // hand-written blocked eigensolver for d*chi_max > MAX_DIM (mpst_eig_blocked.hip); returns 1 when its on-device
 // verification asks for the library fallback
 struct BlockedEig;
+int blocked_eig_coop_aborts(const BlockedEig* e);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);
 void blocked_eig_destroy(BlockedEig* e);
 int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
