@@ -427,21 +427,60 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         }
     }
     __syncthreads();
-    // 256-way multisection for the k-th largest eigenvalue
+    // multisection for the k-th largest eigenvalue
     const int target = n - 1 - k;
-    for (int it = 0; it < 7; ++it) {
-        const double h = (hi - lo) * (1.0 / (BT_T + 1));
-        const double xq = lo + h * (tid + 1);
-        const int cnt = sturm_count(de, n, xq);
-        const unsigned long long bal = __ballot(cnt <= target);
-        if (lane == 0) cnt_s[wave] = __popcll(bal);
+    if (n >= 24) {
+        // two-sided Sturm count as in k_eig_vec: a pair of lanes runs the recurrence top-down over rows 0..kk-1 and
+        // bottom-up over rows n-1..kk+1, the sign of the twisted pivot at row kk completes the inertia; 128 abscissae x 8
+        // rounds of half the length instead of 256 x 7
+        double* deR = Dp;                               // [n] pairs of the reversed matrix (Dp, Dm are free until the bisection is over)
+        const int kk = ((n >> 1) & ~7) + 1;
+        for (int m = tid; m < n; m += BT_T) {
+            deR[2 * m] = de[2 * (n - 1 - m)];
+            deR[2 * m + 1] = m >= 1 ? de[2 * (n - m) + 1] : 0.0;
+        }
         __syncthreads();
-        const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+        const bool bottom = tid & 1;
+        const double* arr = bottom ? deR : de;
+        const int rows = bottom ? n - 1 - kk : kk;
+        const double dk = de[2 * kk], e2a = de[2 * kk + 1], e2b = de[2 * (kk + 1) + 1];
+        constexpr int NPT = BT_T / 2;
+        for (int it = 0; it < 8; ++it) {
+            const double h = (hi - lo) * (1.0 / (NPT + 1));
+            const double xq = lo + h * ((tid >> 1) + 1);
+            double p1, p2;
+            int cnt = sturm_half(arr, rows, xq, p1, p2);
+            const int ocnt = __builtin_amdgcn_update_dpp(0, cnt, 0xB1, 0xF, 0xF, true);     // the partner lane (lane ^ 1)
+            const double o1 = dpp_mov<0xB1>(p1), o2 = dpp_mov<0xB1>(p2);
+            const double P1 = bottom ? o1 : p1, P2 = bottom ? o2 : p2, Q1 = bottom ? p1 : o1, Q2 = bottom ? p2 : o2;
+            const double gq = fma(dk - xq, P1 * Q1, -fma(e2a * P2, Q1, e2b * Q2 * P1));
+            cnt += ocnt + (((hi32(gq) ^ hi32(P1) ^ hi32(Q1)) >> 31) & 1);
+            const unsigned long long bal = __ballot(cnt <= target) & 0x5555555555555555ull;
+            if (lane == 0) cnt_s[wave] = __popcll(bal);
+            __syncthreads();
+            const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+            __syncthreads();
+            const double nlo = jj > 0 ? lo + h * jj : lo;
+            const double nhi = jj < NPT ? lo + h * (jj + 1) : hi;
+            lo = nlo;
+            hi = nhi;
+        }
         __syncthreads();
-        const double nlo = jj > 0 ? lo + h * jj : lo;
-        const double nhi = jj < BT_T ? lo + h * (jj + 1) : hi;
-        lo = nlo;
-        hi = nhi;
+    } else {
+        for (int it = 0; it < 7; ++it) {
+            const double h = (hi - lo) * (1.0 / (BT_T + 1));
+            const double xq = lo + h * (tid + 1);
+            const int cnt = sturm_count(de, n, xq);
+            const unsigned long long bal = __ballot(cnt <= target);
+            if (lane == 0) cnt_s[wave] = __popcll(bal);
+            __syncthreads();
+            const int jj = cnt_s[0] + cnt_s[1] + cnt_s[2] + cnt_s[3];
+            __syncthreads();
+            const double nlo = jj > 0 ? lo + h * jj : lo;
+            const double nhi = jj < BT_T ? lo + h * (jj + 1) : hi;
+            lo = nlo;
+            hi = nhi;
+        }
     }
     const double lamk = 0.5 * (lo + hi);
     // twisted factorisation (dlar1v): forward pivots on wave 0, backward pivots on wave 1, one lane each
@@ -529,27 +568,61 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     __syncthreads();
     for (int j = tid; j < n; j += BT_T) z[j] *= sc;
     __syncthreads();
-    // back-transformation: z <- H_0 H_1 ... H_{n-3} z, one reflector after the other (rows j+1 .. n-1 of Vall[j])
-    for (int j = n - 3; j >= 0; --j) {
-        const double* vj = b.Vall + (int64_t)j * ld;
-        double vv[4];
-        double s = 0.0;
+    // back-transformation: z <- H_0 H_1 ... H_{n-3} z, one reflector after the other.  Every thread keeps its rows of z
+    // (r = tid + 256 q) in registers; the reflector rows are requested PD reflectors ahead (a load from L2 / the Infinity
+    // Cache takes ~1 us, a reflector's arithmetic ~0.2 us: one-ahead prefetching left the loop latency-bound at 0.5 us per
+    // reflector); the partial sums of the waves meet in a parity-indexed LDS slot, one barrier per reflector.
+    {
+        constexpr int QV = BT_NMAX / BT_T, PD = 6;
+        __shared__ double part[2][4];
+        double* taus = Dp;                          // the pivots are not needed any more
+        for (int j = tid; j < n; j += BT_T) taus[j] = b.tau[j];
+        double zr[QV], vb[PD][QV];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = j + 1 + tid + BT_T * q;
-            vv[q] = r < n ? vj[r] : 0.0;
+        for (int q = 0; q < QV; ++q) {
+            const int r = tid + BT_T * q;
+            zr[q] = r < n ? z[r] : 0.0;
+        }
+        auto fetch = [&](double (&dst)[QV], int j) {
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                const int r = tid + BT_T * q;
+                dst[q] = (j >= 0 && r < n) ? b.Vall[(int64_t)j * ld + r] : 0.0;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < PD; ++u) fetch(vb[u], n - 3 - u);
+        __syncthreads();
+        int par = 0;
+        for (int j0 = n - 3; j0 >= 0; j0 -= PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int j = j0 - u;
+                if (j >= 0) {                       // uniform
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < QV; ++q) {
+                        const int r = tid + BT_T * q;
+                        if (r > j && r < n) s = fma(vb[u][q], zr[q], s);      // rows <= j of reflector j are zero
+                    }
+                    s = wave_sum(s);
+                    if (lane == 0) part[par][wave] = s;
+                    __syncthreads();
+                    const double f = taus[j] * ((part[par][0] + part[par][1]) + (part[par][2] + part[par][3]));
+                    par ^= 1;
+#pragma unroll
+                    for (int q = 0; q < QV; ++q) {
+                        const int r = tid + BT_T * q;
+                        if (r > j && r < n) zr[q] = fma(-f, vb[u][q], zr[q]);
+                    }
+                    fetch(vb[u], j - PD);
+                }
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = j + 1 + tid + BT_T * q;
-            if (r < n) s = fma(vv[q], z[r], s);
-        }
-        s = bt_block_sum(s, red);
-        const double f = b.tau[j] * s;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = j + 1 + tid + BT_T * q;
-            if (r < n) z[r] = fma(-f, vv[q], z[r]);
+        for (int q = 0; q < QV; ++q) {
+            const int r = tid + BT_T * q;
+            if (r < n) z[r] = zr[q];
         }
         __syncthreads();
     }
