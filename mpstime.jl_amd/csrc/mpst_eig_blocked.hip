@@ -238,11 +238,13 @@ __device__ __forceinline__ void bt_coop_arrive(const BtCoop& cp) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cp.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+    constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double red_a[4], red_b[4], bc[2];
+    __shared__ double red_a[NW], red_b[NW], bc[2];
     __shared__ int sh_ok;
-    constexpr int QV = BT_NMAX / BT_T;
+    constexpr int QV = BT_NMAX / NT;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int G = gridDim.x, g = blockIdx.x;
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
     if (g == 0 && tid == 0) *b.flag = 0;
     for (int k = 0; k < nown; ++k) {
         const int r = g + k * G;
-        for (int c = tid; c < n; c += BT_T) rows[k * ld + c] = pb.G[(int64_t)r * n + c];
+        for (int c = tid; c < n; c += NT) rows[k * ld + c] = pb.G[(int64_t)r * n + c];
     }
-    for (int c = tid; c < n; c += BT_T) xs[c] = vl[c] = wl[c] = 0.0;
+    for (int c = tid; c < n; c += NT) xs[c] = vl[c] = wl[c] = 0.0;
     __syncthreads();
     if (n == 1) {
         if (g == 0 && tid == 0) {
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
         return;
     }
     if (g == 0)
-        for (int c = tid; c < n; c += BT_T) st_agent(cp.rowbuf + c, rows[c]);
+        for (int c = tid; c < n; c += NT) st_agent(cp.rowbuf + c, rows[c]);
     bt_coop_arrive(cp);
     double tau_prev = 0.0;
     for (int j = 0; j <= n - 2; ++j) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
         double vp[QV], yp[QV], aj[QV];
 #pragma unroll
         for (int q = 0; q < QV; ++q) {
-            const int idx = j + tid + BT_T * q;
+            const int idx = j + tid + NT * q;
             const bool ok = idx < n;
             yp[q] = (ok && j > 0) ? ld_agent(yprev + idx) : 0.0;
             aj[q] = ok ? ld_agent(rowj + idx) : 0.0;
@@ -293,7 +295,10 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
             s = wave_sum(s);
             if (lane == 0) red_a[wave] = s;
             __syncthreads();
-            alpha = -0.5 * tau_prev * ((red_a[0] + red_a[1]) + (red_a[2] + red_a[3]));
+            double sa = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sa += red_a[w];
+            alpha = -0.5 * tau_prev * sa;
         }
         // (b) row j with the pending update applied (v_{j-1}[j] is the leading one of reflector j-1, w_{j-1}[j] = y_j + alpha)
         const double vj = j > 0 ? 1.0 : 0.0, wj = j > 0 ? yj + alpha : 0.0;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
-                const int idx = j + tid + BT_T * q;
+                const int idx = j + tid + NT * q;
                 yp[q] = j > 0 ? fma(alpha, vp[q], yp[q]) : 0.0;        // w_{j-1} from here on
                 xr[q] = fma(-wj, vp[q], fma(-vj, yp[q], aj[q]));
                 if (idx >= j + 2 && idx < n) s = fma(xr[q], xr[q], s);
@@ -317,7 +322,9 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
             s = wave_sum(s);
             if (lane == 0) red_b[wave] = s;
             __syncthreads();
-            s = (red_b[0] + red_b[1]) + (red_b[2] + red_b[3]);
+            s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red_b[w];
             const double dj = bc[0], a0 = bc[1];
             beta = a0;
             double scale = 0.0;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
             }
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
-                const int idx = j + tid + BT_T * q;
+                const int idx = j + tid + NT * q;
                 if (idx < n) {
                     const double vr = idx <= j ? 0.0 : (idx == j + 1 ? 1.0 : xr[q] * scale);
                     xs[idx] = vr;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_coop(View v, int lid, int going_lef
         // (c) own rows r > j: pending update, product with the new reflector; the owner of row j+1 publishes it
         double* ynew = cp.ybuf + (int64_t)(j & 1) * ld;
         double* rownext = cp.rowbuf + (int64_t)((j + 1) & 1) * ld;
-        for (int k = wave; k < nown; k += 4) {
+        for (int k = wave; k < nown; k += NW) {
             const int r = g + k * G;
             if (r <= j) continue;
             double* arow = rows + k * ld;
@@ -836,11 +843,15 @@ struct BlockedEig {
     int32_t* host_flag = nullptr;      // pinned: [0] verdict, [1] the persistent kernel gave up
     int coop_aborts = 0;
 };
+static int coop_threads() {
+    static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
+    return nt == 256 ? 256 : 512;
+}
 static int coop_grid(int ncap) {
     static const int gmax = [] { const char* e = getenv("MPST_BT_COOP_G"); return e ? std::max(1, atoi(e)) : 0; }();
-    // measured: four rows per workgroup up to n = 320 (80 workgroups), 64 workgroups beyond (8 rows each at n = 512: the
-    // barrier grows with the count faster than the row work shrinks), 128 when 64 would not fit the rows in LDS
-    return std::max(1, std::min(gmax ? gmax : (ncap > 768 ? 128 : (ncap <= 320 ? 80 : 64)), (ncap + 3) / 4));
+    // measured: 512 threads and one row per wave (8 rows per workgroup): 37 workgroups at n = 296, 64 at n = 512 - fewer
+    // workgroups make the barrier cheaper, more threads keep the row work off the critical path
+    return std::max(1, std::min(gmax ? gmax : 128, (ncap + 7) / 8));
 }
 static size_t coop_lds(int ncap) {
     const int G = coop_grid(ncap);
@@ -861,7 +872,8 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
               hipMalloc((void**)&e->cp.counter, sizeof(unsigned int)) == hipSuccess && hipMalloc((void**)&e->cp.abort_flag, sizeof(int32_t)) == hipSuccess;
     if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop, hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds(BT_NMAX)) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -914,7 +926,10 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (coop) {
             if (hipMemsetAsync(e->cp.counter, 0, sizeof(unsigned int), s) != hipSuccess || hipMemsetAsync(e->cp.abort_flag, 0, sizeof(int32_t), s) != hipSuccess)
                 return MPST_ERR_DEVICE;
-            hipLaunchKernelGGL(k_bt_coop, dim3(coop_grid(ncap)), dim3(BT_T), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
+            if (coop_threads() == 512)
+                hipLaunchKernelGGL(k_bt_coop<512>, dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
+            else
+                hipLaunchKernelGGL(k_bt_coop<256>, dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
         } else {
             hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
             static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
