@@ -644,16 +644,21 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
 // beyond: the next bond's tensor (chain_bt_block)
 __global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_left, int site, int left_side,
                                                    const double* __restrict__ prev, int prev_bond, int out_bond,
-                                                   double* __restrict__ out, int nsplit) {
+                                                   double* __restrict__ out, int nsplit, int ntb, int tp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if ((int)blockIdx.x >= v.ntiles + nsplit) {
-        chain_bt_block(v, lid, going_left, (int)blockIdx.x - v.ntiles - nsplit, smem);
+    if ((int)blockIdx.x >= ntb + nsplit) {
+        chain_bt_block(v, lid, going_left, (int)blockIdx.x - ntb - nsplit, smem);
         return;
     }
-    if ((int)blockIdx.x >= v.ntiles) {
-        split_block(v, lid, going_left, (int)blockIdx.x - v.ntiles, nsplit);
+    if ((int)blockIdx.x >= ntb) {
+        split_block(v, lid, going_left, (int)blockIdx.x - ntb, nsplit);
         return;
     }
+    // new environment rows out_i = Z_i E.  A wave owns one 16-column tile of the output; with fewer than four column tiles
+    // (capacity <= 32) and enough tiles to go round, the workgroup takes two 16-series tiles at a time (tp, chosen by the
+    // launcher) so that no wave idles, and it keeps walking
+    // tiles (stride = number of tile blocks) with its E operand - 32 doubles per lane - loaded once: at N = 32768 one
+    // workgroup per tile spent its time launching and re-reading E (33 us for 17 MB of environment traffic).
     const int d = v.d;
     const int Dp = prev ? v.chi[prev_bond] : 1;
     const int Dout = v.chi[out_bond];
@@ -661,30 +666,40 @@ __global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_le
     const double* __restrict__ M = v.E;
     const int64_t sz = v.cap;
     const int ZP = (Z + 3) & ~3;
-    const Span tl = v.tiles[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* ph = v.phi + (int64_t)site * v.N * d;
-    stage16(smem, tl.start, tl.count, prev, Dp, ph, d, v.cap, left_side != 0, tid);
-    __syncthreads();
     const int i16 = lane & 15, kq = lane >> 4;
-    const int nt_out = (Dout + 15) >> 4;
-    for (int nt = wave; nt < nt_out; nt += 4) {
-        const int col = nt * 16 + i16;
-        const bool cv = col < Dout;
-        d4 acc = {0, 0, 0, 0};
-        double bv[32];
+    const double* ph = v.phi + (int64_t)site * v.N * d;
+    const int nt_out = (Dout + 15) >> 4;                    // <= 4 on this path (chi <= 64)
+    const int slot = wave / (4 / tp), nt = wave % (4 / tp);
+    const int col = nt * 16 + i16;
+    const bool cv = nt < nt_out && col < Dout;
+    double bv[32];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int z = 4 * u + kq;
-            bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
+    for (int u = 0; u < 32; ++u) {
+        const int z = 4 * u + kq;
+        bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
+    }
+    for (int t0 = (int)blockIdx.x * tp; t0 < v.ntiles; t0 += ntb * tp) {
+        if (t0 != (int)blockIdx.x * tp) __syncthreads();          // the previous pass has been consumed
+        for (int sl = 0; sl < tp; ++sl) {
+            if (t0 + sl < v.ntiles) {
+                const Span tl = v.tiles[t0 + sl];
+                stage16(smem + sl * 16 * FXS, tl.start, tl.count, prev, Dp, ph, d, v.cap, left_side != 0, tid);
+            }
         }
+        __syncthreads();
+        if (t0 + slot < v.ntiles && nt < nt_out) {
+            const Span tl = v.tiles[t0 + slot];
+            const double* Xs = smem + slot * 16 * FXS;
+            d4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
-            if (4 * u < ZP) acc = mfma_f64(smem[i16 * FXS + 4 * u + kq], bv[u], acc);
+            for (int u = 0; u < 32; ++u)
+                if (4 * u < ZP) acc = mfma_f64(Xs[i16 * FXS + 4 * u + kq], bv[u], acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = kq + 4 * r;
-            if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                const int i = kq + 4 * r;
+                if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+            }
         }
     }
 }
@@ -711,9 +726,12 @@ void launch_env_split(const View& v, int lid, int going_left, int site, int left
     const int dm = v.d * v.cap;
     const int nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
     const int nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
-    const size_t lds = std::max((size_t)16 * FXS, chain ? (size_t)4 * CHAIN_J * 256 : (size_t)0) * sizeof(double);
-    hipLaunchKernelGGL(k_env_split, dim3(v.ntiles + nsplit + nchain), dim3(256), lds, s, v, lid, going_left,
-                       site, left_side, prev, prev_bond, out_bond, out, nsplit);
+    const int tp = (v.cap <= 32 && v.ntiles >= 512) ? 2 : 1;      // tiles a workgroup stages per pass
+    const size_t lds = std::max((size_t)tp * 16 * FXS, chain ? (size_t)4 * CHAIN_J * 256 : (size_t)0) * sizeof(double);
+    // tile blocks: at most two per CU; each walks the tiles with that stride (one pass covers one or two tiles, see the kernel)
+    const int ntb = std::max(1, std::min(v.ntiles, 512));
+    hipLaunchKernelGGL(k_env_split, dim3(ntb + nsplit + nchain), dim3(256), lds, s, v, lid, going_left,
+                       site, left_side, prev, prev_bond, out_bond, out, nsplit, ntb, tp);
 }
 
 }  // namespace mpst
