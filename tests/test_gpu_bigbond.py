@@ -201,3 +201,7 @@ def test_blocked_tridiagonalisation_is_deterministic(eng):
             assert np.abs(yg - yo).max() <= 1e-8 * np.abs(yo).max()
         else:
             assert all(np.array_equal(a, b) for a, b in zip(first, W)), rep
+    info = eng.info()
+    # the persistent tridiagonalisation carried every bond (it hands a bond back only when its workgroups cannot all
+    # become resident), and nothing needed the library solver
+    assert info["large_bond"] and info["persistent_tridiag_aborts"] == 0 and info["library_eig_fallbacks"] == 0
