@@ -144,3 +144,24 @@ def test_fourier_and_legendre_values_on_the_device(engine_cls, d):
     assert np.abs(phi_n - R.legendre_encode(X, d, norm=True)).max() < 1e-13
     Xs, _ = R.transform_train_data(Xr, sigmoid_transform=True, minmax=True)
     assert np.abs(phi_p - R.fourier_encode(Xs, d)).max() < 1e-12
+
+
+def test_encode_values_test_set_path_equals_the_data_set_path(engine_cls):
+    """mpst_encode_values with a training fit handed in (a test set: train-fitted sigmoid / min-max) gives the states
+    mpst_encode_dataset stores for the same data (out-of-bounds rescale off in both)."""
+    Xtr, ytr = _data(64, 30, 1)
+    Xte, yte = _data(40, 30, 2, spread=1.2)
+    eng = engine_cls(0)
+    try:
+        norms, _ = eng.encode_dataset(0, Xtr, ytr, 3, d=4)
+        eng.encode_dataset(1, Xte, yte, 3, d=4, norms=norms, rescale_out_of_bounds=False)
+        ref = eng.get_encoded(1)
+        phi, _ = eng.encode_values(Xte, "Legendre_No_Norm", 4, norms=norms, minmax=True)
+        assert np.array_equal(phi, ref)
+        # the scaled values themselves from the second Legendre state (sqrt(3/2) x), then Fourier on the host
+        xs = ref[:, :, 1] / np.sqrt(1.5)
+        phi_f, _ = eng.encode_values(Xte, "Fourier", 4, norms=norms, minmax=True)
+        assert np.abs(phi_f - R.fourier_encode(xs, 4)).max() < 1e-12
+    finally:
+        eng.close()
+
