@@ -214,13 +214,6 @@ __device__ __forceinline__ TriShared tri_carve(double* smem) {
 }
 __device__ __forceinline__ int voff(int i, int n) { return i * (n - 1) - (i * (i - 1)) / 2; }
 
-// reciprocal to full double precision from the hardware seed (2 Newton steps)
-__device__ __forceinline__ double frcp(double b) {
-    double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
-    r = fma(fma(-b, r, 1.0), r, r);
-    return r;
-}
 
 // ---- global workspace shared by the three kernels (doubles) ----------------------------------
 constexpr int WS_DE = 0;        // [128][2]  (d_j, e_{j-1}^2)

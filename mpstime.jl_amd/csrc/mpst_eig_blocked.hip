@@ -497,7 +497,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
         Dp[0] = dcur;
         for (int j = 1; j < n; ++j) {
-            dcur = (de[2 * j] - lamk) - de[2 * j + 1] / dcur;
+            dcur = (de[2 * j] - lamk) - de[2 * j + 1] * frcp(dcur);
             if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
             Dp[j] = dcur;
         }
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
         Dm[n - 1] = dcur;
         for (int j = n - 2; j >= 0; --j) {
-            dcur = (de[2 * j] - lamk) - de[2 * (j + 1) + 1] / dcur;
+            dcur = (de[2 * j] - lamk) - de[2 * (j + 1) + 1] * frcp(dcur);
             if (!(fabs(dcur) >= pivmin)) dcur = -pivmin;
             Dm[j] = dcur;
         }
@@ -547,13 +547,13 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         double zc = 1.0;
         z[rb] = 1.0;
         for (int j = rb - 1; j >= 0; --j) {
-            zc = -(es[j] / Dp[j]) * zc;
+            zc = -(es[j] * frcp(Dp[j])) * zc;
             z[j] = zc;
         }
     } else if (tid == 64) {
         double zc = 1.0;
         for (int j = rb + 1; j < n; ++j) {
-            zc = -(es[j - 1] / Dm[j]) * zc;
+            zc = -(es[j - 1] * frcp(Dm[j])) * zc;
             z[j] = zc;
         }
     }

@@ -117,6 +117,14 @@ __device__ __forceinline__ int sturm_half(const double* __restrict__ arr, int ro
     return cnt;
 }
 
+// reciprocal to full double precision from the hardware seed (2 Newton steps)
+__device__ __forceinline__ double frcp(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+
 // ---- cross-lane reductions on the VALU (DPP) instead of ds_bpermute ------------------------
 // hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, >100 cycles of dependent latency
 // per step); the reductions here sit on the critical path of single-workgroup kernels, so they
