@@ -195,7 +195,8 @@ int ensure_workspace(Ctx* c) {
     if (c->fused) {
         c->partial_elems = (int64_t)std::max(tr.nparts[0], tr.nparts[1]) * Lmax;   // independent of N: one partial per persistent workgroup
     } else {
-        c->partial_elems = (int64_t)c->C * tr.nchunks * Lmax;    // sized for either loss: per-sweep loss functions switch without reallocating
+        const int nbcap = ((dm + GB - 1) / GB) * ((dm + GB - 1) / GB);
+        c->partial_elems = (int64_t)c->C * grad_nsplit(tr.nchunks, nbcap, c->C) * Lmax;    // one partial per k_grad workgroup share, independent of N
     }
     if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
     if ((rc = dalloc(c, &c->btn, c->C * Lmax))) return rc;

@@ -284,6 +284,14 @@ constexpr int PARTS_TARGET = 128;   // persistent workgroups of the fused gradie
 constexpr int TILE_S = 16;    // series per yhat/env tile (one MFMA M-tile)
 constexpr int CHUNK_S = 64;   // series per gradient chunk (the GEMM K extent of one partial)
 constexpr int GB = 64;        // gradient output block edge per workgroup
+// k_grad (unfused path): workgroups that share the chunks of one (class, output block); each walks its share with the
+// accumulators in registers and writes one partial block.  Enough workgroups to fill the chip (GRAD_WG_TARGET over all
+// blocks and classes), never more than there are chunks: the partial count is independent of N.
+constexpr int GRAD_WG_TARGET = 512;
+inline int grad_nsplit(int nchunks, int nblocks, int C) {
+    const int per = (GRAD_WG_TARGET + nblocks * C - 1) / (nblocks * C);
+    return per < 1 ? 1 : (per > nchunks ? (nchunks > 0 ? nchunks : 1) : per);
+}
 constexpr int MAX_DIM = 128;  // d*chi_max limit of the register/LDS-resident eigensolver and of the single-pass bond kernels
 constexpr int DIM_LIMIT = 1024;  // d*chi_max limit of the engine (LDS tile of 16 series x d*chi doubles)
 constexpr int CAP_LIMIT = 128;   // largest bond dimension (environment rows are staged 16 lanes x 8 values)

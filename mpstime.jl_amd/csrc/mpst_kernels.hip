@@ -234,112 +234,181 @@ __global__ __launch_bounds__(256) void k_yhat(View v, int lid) {
     }
 }
 
-// Same contraction for bond tensors beyond 128 x 128 (d*chi_max up to DIM_LIMIT): the X tile stays in LDS, the B_c panel
-// of a pair of 16-column tiles streams through registers 128 rows at a time, and Y_i[y] = phi_i[s] * RE_i[b] is applied
-// from its factors ([16][d] and [16][Dr] in LDS) instead of a staged Khatri-Rao tile.
-__global__ __launch_bounds__(256) void k_yhat_gen(View v, int lid) {
+// Same contraction for bond tensors beyond 128 x 128 (d*chi_max up to DIM_LIMIT).  A workgroup of 16 waves takes MT tiles
+// of 16 series: every B_c fragment a wave pulls from L2 feeds 2*MT MFMAs (MT tiles x a pair of adjacent 16-column tiles),
+// and the 16 waves split the (column pair, K range) space, so 4 waves per SIMD hide the L2 latency of the streamed
+// panel.  Neither Khatri-Rao tile is staged: X_i[x] = LE_i[a] * phi_i[s] is formed from its factors in LDS on the way
+// into the MFMA (one multiply per 2 MFMAs), Y_i[y] = phi_i[s] * RE_i[b] is applied to the accumulators.  The partial
+// sums of the 16 waves meet in LDS in a fixed order.
+template <int MT>
+__global__ __launch_bounds__(1024) void k_yhat_gen(View v, int lid) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const BondDims b = bond_dims(v, lid);
     const int d = v.d, rid = lid + 1;
-    const Span tl = v.tiles[blockIdx.x];
     const bool mse = v.loss == MPST_LOSS_MSE;
-    const int c = mse ? (int)blockIdx.y : tl.cls;
-    const int XP = (b.X + 3) & ~3, XS = XP + 2;
-    double* Xs = smem;                      // [16][XS]
-    double* Pr = Xs + 16 * XS;              // [16][d]     phi of the right site
-    double* Rr = Pr + 16 * d;               // [16][Dr+1]  right environment rows
-    double* red = Rr + 16 * (b.Dr + 1);     // [4][16]
+    const int t0 = blockIdx.x * MT;
+    const int ntl = min(MT, v.ntiles - t0);
+    const int LS = (b.Dl + 2) | 1, PS = d | 1, RS = (b.Dr + 1) | 1;
+    double* Lf = smem;                      // [MT][16][LS]  left environment rows (zero beyond Dl)
+    double* Pl = Lf + MT * 16 * LS;         // [MT][16][PS]  phi of the left site
+    double* Pr = Pl + MT * 16 * PS;         // [MT][16][PS]  phi of the right site
+    double* Rr = Pr + MT * 16 * PS;         // [MT][16][RS]  right environment rows
+    double* red = Rr + MT * 16 * RS;        // [16 waves][MT][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
     const double* phl = v.phi + (int64_t)lid * v.N * d;
     const double* phr = v.phi + (int64_t)rid * v.N * d;
-    stage_tile16(Xs, XS, tl, LEp, b.Dl, phl, d, v.cap, true);
     {
-        const int i = tid >> 4, j = tid & 15;
-        const bool valid = i < tl.count;
-        const int64_t smp = tl.start + (valid ? i : 0);
-        for (int s = j; s < d; s += 16) Pr[i * d + s] = valid ? phr[smp * d + s] : 0.0;
-        for (int a = j; a < b.Dr; a += 16) Rr[i * (b.Dr + 1) + a] = valid ? (REn ? REn[smp * v.cap + a] : 1.0) : 0.0;
+        const int m = tid >> 8, i = (tid >> 4) & 15, j = tid & 15;
+        if (m < MT) {
+            bool valid = false;
+            int64_t smp = 0;
+            if (m < ntl) {
+                const Span tl = v.tiles[t0 + m];
+                valid = i < tl.count;
+                smp = tl.start + (valid ? i : 0);
+            }
+            double* lf = Lf + (m * 16 + i) * LS;
+            for (int a = j; a < LS; a += 16) lf[a] = (valid && a < b.Dl) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
+            double* rr = Rr + (m * 16 + i) * RS;
+            for (int a = j; a < b.Dr; a += 16) rr[a] = valid ? (REn ? REn[smp * v.cap + a] : 1.0) : 0.0;
+            for (int s = j; s < d; s += 16) {
+                Pl[(m * 16 + i) * PS + s] = valid ? phl[smp * d + s] : 0.0;
+                Pr[(m * 16 + i) * PS + s] = valid ? phr[smp * d + s] : 0.0;
+            }
+        }
     }
     __syncthreads();
-    const double* Bc = v.bt + (int64_t)c * b.L;
     const int i16 = lane & 15, kq = lane >> 4;
-    double p[4] = {0, 0, 0, 0};
-    const int nty = (b.Y + 15) >> 4;
-    for (int nt0 = wave; nt0 < nty; nt0 += 8) {
-        d4 acc[2] = {d4{0, 0, 0, 0}, d4{0, 0, 0, 0}};
-        for (int kb = 0; kb < XP; kb += 128) {
-            double bv[2][32];
+    const int XP = (b.X + 3) & ~3;
+    const int nty = (b.Y + 15) >> 4, npair = (nty + 1) >> 1;
+    const int KS = npair >= 16 ? 1 : 16 / npair;                   // K ranges per column pair: 16 wave tasks or more
+    constexpr int UB = MT == 4 ? 4 : 8;                            // k-steps whose B fragments are in flight together (register budget: 128)
+    const int Kc = ((XP + KS - 1) / KS + 4 * UB - 1) / (4 * UB) * (4 * UB);
+    const int da = 4 / d, ds = 4 - da * d;
+    double p[MT][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int col = (nt0 + 4 * h) * 16 + i16;
-                const bool cv = col < b.Y;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int u = 0; u < 32; ++u) {
+        for (int r = 0; r < 4; ++r) p[m][r] = 0.0;
+    // KLD: the tiles of a group may belong to two classes at a class boundary; each run of equal class is one pass
+    for (int rs = 0, re; rs < ntl; rs = re) {
+        int c;
+        if (mse) {
+            c = blockIdx.y;
+            re = ntl;
+        } else {
+            c = v.tiles[t0 + rs].cls;
+            re = rs + 1;
+            while (re < ntl && v.tiles[t0 + re].cls == c) ++re;
+        }
+        const double* Bc = v.bt + (int64_t)c * b.L;
+        for (int task = wave; task < npair * KS; task += 16) {
+            const int pr2 = task % npair, ks = task / npair;
+            const int kbeg = ks * Kc, kend = min(XP, kbeg + Kc);
+            if (kbeg >= kend) continue;
+            const int col0 = (2 * pr2) * 16 + i16, col1 = col0 + 16;
+            d4 acc[MT][2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][0] = acc[m][1] = d4{0, 0, 0, 0};
+            int ka = (kbeg + kq) / d, ksx = (kbeg + kq) - ka * d;     // x = ka * d + ksx: the A operand's factor indices
+            for (int kb = kbeg; kb < kend; kb += 4 * UB) {
+                double bv[2][UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
                     const int kx = kb + 4 * u + kq;
-                    bv[h][u] = (cv && kx < b.X) ? Bc[(int64_t)kx * b.Y + col] : 0.0;
+                    const double* row = Bc + (int64_t)kx * b.Y;
+                    bv[0][u] = (col0 < b.Y && kx < b.X) ? row[col0] : 0.0;
+                    bv[1][u] = (col1 < b.Y && kx < b.X) ? row[col1] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (kb + 4 * u < kend) {
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+                            const double am = Lf[(m * 16 + i16) * LS + ka] * Pl[(m * 16 + i16) * PS + ksx];
+                            acc[m][0] = mfma_f64(am, bv[0][u], acc[m][0]);
+                            acc[m][1] = mfma_f64(am, bv[1][u], acc[m][1]);
+                        }
+                    }
+                    ksx += ds;
+                    ka += da;
+                    if (ksx >= d) {
+                        ksx -= d;
+                        ++ka;
+                    }
                 }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (nt0 + 4 * h < nty) {
+                const int col = h ? col1 : col0;
+                if (col < b.Y) {
+                    const int sy = col / b.Dr, bb = col - sy * b.Dr;
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) {
-                        const int k0 = kb + 4 * u;
-                        if (k0 < XP) acc[h] = mfma_f64(Xs[i16 * XS + k0 + kq], bv[h][u], acc[h]);
+                    for (int m = 0; m < MT; ++m) {
+                        if (m >= rs && m < re) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int i = m * 16 + kq + 4 * r;
+                                p[m][r] += acc[m][h][r] * (Pr[i * PS + sy] * Rr[i * RS + bb]);
+                            }
+                        }
                     }
                 }
             }
         }
+    }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col = (nt0 + 4 * h) * 16 + i16;
-            if (col < b.Y) {
-                const int sy = col / b.Dr, bb = col - sy * b.Dr;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = kq + 4 * r;
-                    p[r] += acc[h][r] * (Pr[i * d + sy] * Rr[i * (b.Dr + 1) + bb]);
-                }
-            }
+        for (int r = 0; r < 4; ++r) {
+            const double x = sum16(p[m][r]);
+            if (i16 == 0) red[(wave * MT + m) * 16 + kq + 4 * r] = x;
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const double x = sum16(p[r]);
-        if (i16 == 0) red[wave * 16 + kq + 4 * r] = x;
-    }
     __syncthreads();
     if (tid < 64) {
+        const int m = tid >> 4, i = tid & 15;
         double term = 0.0;
-        if (tid < 16) {
-            double yh = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
+        int c = 0;
+        if (m < ntl) {
+            const Span tl = v.tiles[t0 + m];
+            c = mse ? (int)blockIdx.y : tl.cls;
+            double yh = 0.0;
+            for (int w = 0; w < 16; ++w) yh += red[(w * MT + m) * 16 + i];
             if (v.yhat_scaled) yh *= v.sc->inv_norm;
-            if (tid < tl.count) {
-                v.yhat[(int64_t)c * v.N + tl.start + tid] = yh;
+            if (i < tl.count) {
+                v.yhat[(int64_t)c * v.N + tl.start + i] = yh;
                 if (mse) {
-                    const double m = (tl.cls == c) ? 1.0 : 0.0;
-                    term = 0.5 * (yh - m) * (yh - m);
+                    const double mm = (tl.cls == c) ? 1.0 : 0.0;
+                    term = 0.5 * (yh - mm) * (yh - mm);
                 } else {
                     term = -log(yh * yh);
                 }
             }
         }
         term = sum16(term);
-        if (tid == 0) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + blockIdx.x] = term;
+        if (i == 0 && m < ntl) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + t0 + m] = term;
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// gradient partials: P[chunk] (64x64 block) = sum_{i in chunk} w_i X_i Y_i^T
-//   KLD: w_i = 1/yhat_i                      (loss_functions.jl:258, :367)
-//   MSE: w_i = yhat_i^c - [label_i == c]     (:489, :608)
+// gradient partials: P[c][j] (64x64 block) = sum_{i in the j-th share of class c's chunks} w_i X_i Y_i^T
+//   KLD: w_i = 1/yhat_i over the series of class c      (loss_functions.jl:258, :367)
+//   MSE: w_i = yhat_i^c - [label_i == c] over all series (:489, :608)
+// A workgroup walks its share of the chunks with the accumulators in registers and writes ONE partial block, so the
+// partial count (C * nsplit) and the workspace do not grow with N; the next chunk's operands are in flight (registers)
+// while the MFMAs of the current one run out of LDS.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_grad(View v, int lid) {
+struct GradStage {
+    double le[16], pl[16], re[16], pr[16];
+};
+__global__ __launch_bounds__(256, 2) void k_grad(View v, int lid, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int XS = GB + 16;  // row stride: lanes 16-31 land on the other half of the bank row
-    double* Xs = smem;           // [64 series][XS]
+    // [64 series][64 columns], unpadded (two workgroups per CU): odd rows hold their 16-column groups pairwise swapped, so
+    // the rows k and k + 1 a half-wave reads together land on different halves of the banks
+    constexpr int XS = GB;
+    double* Xs = smem;
     double* Ys = smem + CHUNK_S * XS;
     const BondDims b = bond_dims(v, lid);
     const int d = v.d, rid = lid + 1;
@@ -347,9 +416,11 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
     const int blk = blockIdx.y;
     if (blk >= nbx * nby) return;
     const int bx = blk / nby, by = blk - bx * nby;
-    const Span ch = v.chunks[blockIdx.x];
     const bool mse = v.loss == MPST_LOSS_MSE;
-    const int c = mse ? (int)blockIdx.z : ch.cls;
+    const int c = blockIdx.z;
+    const int kc0 = mse ? 0 : v.cls_chunk_off[c], kc1 = mse ? v.nchunks : v.cls_chunk_off[c + 1];
+    const int ka = kc0 + (int)(((int64_t)(kc1 - kc0) * blockIdx.x) / nsplit);
+    const int kb = kc0 + (int)(((int64_t)(kc1 - kc0) * (blockIdx.x + 1)) / nsplit);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
@@ -360,7 +431,7 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
 
     // index tables: one integer division per column of the block instead of one per element
     __shared__ int xa_[GB], xs_[GB], yb_[GB], ys_[GB];
-    __shared__ double w_[CHUNK_S];       // per-series weight: one IEEE division per series, not one per thread
+    __shared__ double w_[2][CHUNK_S];    // per-series weight: one IEEE division per series, not one per thread
     if (tid < GB) {
         const int x = bx * GB + tid;
         const int a = x / d;
@@ -371,56 +442,80 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
         const int sy = y / b.Dr;
         yb_[tid - GB] = y < b.Y ? y - sy * b.Dr : -1;
         ys_[tid - GB] = sy;
-    } else if (tid < 2 * GB + CHUNK_S) {
-        const int i = tid - 2 * GB;
-        const double yv = i < ch.count ? yh[ch.start + i] : 1.0;
-        w_[i] = mse ? (yv - ((ch.cls == c) ? 1.0 : 0.0)) : 1.0 / yv;
     }
     __syncthreads();
-    {
-        // thread -> column xx = tid & 63 of the block, series i = (tid >> 6) + 4m; every load of
-        // the 16 series is issued before the first product is formed
-        const int xx = tid & 63, i0 = tid >> 6;
-        const int a = xa_[xx], sx = xs_[xx], bb = yb_[xx], sy = ys_[xx];
-        double le[16], pl[16], re[16], pr[16], w[16];
+    // thread -> column xx = tid & 63 of the block, series i = (tid >> 6) + 4m
+    const int xx = tid & 63, i0 = tid >> 6;
+    const int a_ = xa_[xx], sx = xs_[xx], bb = yb_[xx], sy = ys_[xx];
+    GradStage g;
+    Span nxt = v.chunks[ka < kb ? ka : 0];   // the chunk descriptor is read one chunk ahead of its use
+    int cnt_cur = 0, cls_cur = 0;
+    double yv = 1.0;
+    auto fetch = [&](int k) {
+        const Span ch = nxt;
+        cnt_cur = ch.count;
+        cls_cur = ch.cls;
+        if (k + 1 < kb) nxt = v.chunks[k + 1];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             const int i = i0 + 4 * m;
             const bool ok = i < ch.count;
             const int64_t smp = ch.start + (ok ? i : 0);
-            le[m] = (ok && a >= 0) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
-            pl[m] = (ok && a >= 0) ? phl[smp * d + sx] : 0.0;
-            re[m] = (ok && bb >= 0) ? (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
-            pr[m] = (ok && bb >= 0) ? phr[smp * d + sy] : 0.0;
-            w[m] = w_[i];
+            g.le[m] = (ok && a_ >= 0) ? (LEp ? LEp[smp * v.cap + a_] : 1.0) : 0.0;
+            g.pl[m] = (ok && a_ >= 0) ? phl[smp * d + sx] : 0.0;
+            g.re[m] = (ok && bb >= 0) ? (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
+            g.pr[m] = (ok && bb >= 0) ? phr[smp * d + sy] : 0.0;
         }
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            const int i = i0 + 4 * m;
-            Xs[i * XS + xx] = le[m] * pl[m];
-            Ys[i * XS + xx] = w[m] * pr[m] * re[m];
-        }
-    }
-    __syncthreads();
-
+        if (tid < CHUNK_S) yv = tid < ch.count ? yh[ch.start + tid] : 1.0;
+    };
+    // the weights of the fetched chunk: after the MFMAs, so that nobody waits on the yhat load before them
+    auto publish_w = [&](int k) {
+        if (tid < CHUNK_S) w_[k & 1][tid] = mse ? (yv - ((cls_cur == c) ? 1.0 : 0.0)) : 1.0 / yv;
+    };
     const int i16 = lane & 15, kq = lane >> 4;
     const int mt = wave;  // 16 x-rows of the block per wave
     d4 acc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[nt] = d4{0, 0, 0, 0};
-    const int kmax = (ch.count + 3) & ~3;
-    if (bx * GB + mt * 16 < b.X) {
-        for (int k0 = 0; k0 < kmax; k0 += 4) {
-            const double a = Xs[(k0 + kq) * XS + mt * 16 + i16];
+    const bool rows_live = bx * GB + mt * 16 < b.X;
+    if (ka < kb) {
+        fetch(ka);
+        publish_w(ka);
+    }
+    for (int k = ka; k < kb; ++k) {
+        const int kmax = (cnt_cur + 3) & ~3;
+        __syncthreads();               // w_[k & 1] written; the previous chunk's MFMAs are done with Xs / Ys
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const double bv = Ys[(k0 + kq) * XS + nt * 16 + i16];
-                acc[nt] = mfma_f64(a, bv, acc[nt]);
+        for (int m = 0; m < 16; ++m) {
+            const int i = i0 + 4 * m;
+            const int xw = xx ^ ((i & 1) << 4);
+            Xs[i * XS + xw] = g.le[m] * g.pl[m];
+            Ys[i * XS + xw] = w_[k & 1][i] * g.pr[m] * g.re[m];
+        }
+        __syncthreads();
+        if (k + 1 < kb) fetch(k + 1);
+        if (rows_live) {
+            const int sw = (kq & 1) << 4;                       // row k0 + kq is odd iff kq is
+            const double* xr = Xs + kq * XS + ((mt * 16) ^ sw) + i16;
+            const double* yr = Ys + kq * XS + i16;
+            if (kmax == CHUNK_S) {                              // full chunk: straight-line, LDS reads run ahead of the MFMAs
+#pragma unroll
+                for (int k0 = 0; k0 < CHUNK_S; k0 += 4) {
+                    const double a = xr[k0 * XS];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma_f64(a, yr[k0 * XS + ((nt * 16) ^ sw)], acc[nt]);
+                }
+            } else {
+                for (int k0 = 0; k0 < kmax; k0 += 4) {
+                    const double a = xr[k0 * XS];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[nt] = mfma_f64(a, yr[k0 * XS + ((nt * 16) ^ sw)], acc[nt]);
+                }
             }
         }
+        if (k + 1 < kb) publish_w(k + 1);
     }
-    const int64_t pc = mse ? (int64_t)c * v.nchunks + blockIdx.x : blockIdx.x;
-    double* out = v.partial + pc * (int64_t)b.L;
+    double* out = v.partial + ((int64_t)c * nsplit + blockIdx.x) * (int64_t)b.L;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int col = by * GB + nt * 16 + i16;
@@ -434,7 +529,7 @@ __global__ __launch_bounds__(256) void k_grad(View v, int lid) {
 
 // grad[c] = scale_c * sum_chunks P ; loss = scaled sum of the tile terms.
 // gradbuf = [loss, 0, grad[c][x][y] ...] is the buffer the multi-GPU all-reduce sums.
-__global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid) {
+__global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid, int nsplit) {
     __shared__ double red[4];
     const BondDims b = bond_dims(v, lid);
     const bool mse = v.loss == MPST_LOSS_MSE;
@@ -444,25 +539,14 @@ __global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid) {
         const int c = (int)(idx / b.L);
         const int64_t e = idx - (int64_t)c * b.L;
         // fixed association order: 8 interleaved partial sums, then a fixed tree
-        const double* p;
-        int k0, k1;
-        double scale;
-        if (mse) {
-            p = v.partial + (int64_t)c * v.nchunks * b.L + e;
-            k0 = 0;
-            k1 = v.nchunks;
-            scale = v.invN;                                        // :608
-        } else {
-            p = v.partial + e;
-            k0 = v.cls_chunk_off[c];
-            k1 = v.cls_chunk_off[c + 1];
-            scale = -(v.train_sep ? v.inv_count[c] : v.invN);      // :367 / :424
-        }
+        const double* p = v.partial + (int64_t)c * nsplit * b.L + e;
+        const double scale = mse ? v.invN                                       // :608
+                                 : -(v.train_sep ? v.inv_count[c] : v.invN);    // :367 / :424
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = k0; k < k1; k += 16) {                       // 16 loads in flight; same association as 8 + 8
+        for (int k = 0; k < nsplit; k += 16) {                    // 16 loads in flight; same association as 8 + 8
             double t[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) t[u] = (k + u < k1) ? p[(int64_t)(k + u) * b.L] : 0.0;
+            for (int u = 0; u < 16; ++u) t[u] = (k + u < nsplit) ? p[(int64_t)(k + u) * b.L] : 0.0;
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc[u & 7] += t[u];
         }
@@ -878,20 +962,27 @@ void launch_yhat(const View& v, int lid, hipStream_t s) {
         const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * (((dm + 15) & ~15) + 2) + 64) * sizeof(double);
         hipLaunchKernelGGL(k_yhat, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
     } else {
-        const size_t lds = (size_t)(16 * (((dm + 3) & ~3) + 2) + 16 * v.d + 16 * (v.cap + 1) + 64) * sizeof(double);
-        hipLaunchKernelGGL(k_yhat_gen, dim3(v.ntiles, gy), dim3(256), lds, s, v, lid);
+        // tiles per workgroup: as many as still leave a workgroup per CU
+        const int mt = (v.ntiles >= 1024 && v.cap <= 64) ? 4 : (v.ntiles >= 512 ? 2 : 1);
+        const size_t lds = (size_t)(mt * 16 * (((v.cap + 2) | 1) + 2 * (v.d | 1) + ((v.cap + 1) | 1)) + 16 * mt * 16) * sizeof(double);
+        const dim3 grid(cdiv(v.ntiles, mt), gy);
+        if (mt == 4) hipLaunchKernelGGL(k_yhat_gen<4>, grid, dim3(1024), lds, s, v, lid);
+        else if (mt == 2) hipLaunchKernelGGL(k_yhat_gen<2>, grid, dim3(1024), lds, s, v, lid);
+        else hipLaunchKernelGGL(k_yhat_gen<1>, grid, dim3(1024), lds, s, v, lid);
     }
 }
 void launch_grad(const View& v, int lid, hipStream_t s) {
     const int dm = v.d * v.cap;
     const int nb = cdiv(dm, GB) * cdiv(dm, GB);
-    const size_t lds = (size_t)2 * CHUNK_S * (GB + 16) * sizeof(double);
-    const int gz = v.loss == MPST_LOSS_MSE ? v.C : 1;
-    hipLaunchKernelGGL(k_grad, dim3(v.nchunks, nb, gz), dim3(256), lds, s, v, lid);
+    const size_t lds = (size_t)2 * CHUNK_S * GB * sizeof(double);
+    const int nsplit = grad_nsplit(v.nchunks, nb, v.C);
+    hipLaunchKernelGGL(k_grad, dim3(nsplit, nb, v.C), dim3(256), lds, s, v, lid, nsplit);
 }
 void launch_grad_reduce(const View& v, int lid, hipStream_t s) {
-    const int64_t tot = (int64_t)v.C * v.d * v.cap * v.d * v.cap;
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, lid);
+    const int dm = v.d * v.cap;
+    const int64_t tot = (int64_t)v.C * dm * dm;
+    const int nsplit = grad_nsplit(v.nchunks, cdiv(dm, GB) * cdiv(dm, GB), v.C);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, lid, nsplit);
 }
 void launch_update(const View& v, int lid, int first_iter, hipStream_t s) {
     hipLaunchKernelGGL(k_update, dim3(32), dim3(256), 0, s, v, lid, first_iter);
@@ -921,10 +1012,12 @@ hipError_t init_kernel_attrs(int device) {
     if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)(2 * CHUNK_S * (GB + 16) * sizeof(double)))) != hipSuccess) return e;
+                                 (int)(2 * CHUNK_S * GB * sizeof(double)))) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_env, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_gen, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_gen<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_gen<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_gen<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
