@@ -574,25 +574,16 @@ __global__ __launch_bounds__(256) void k_grad_reduce(View v, int lid, int nsplit
 }
 
 // TSGO: bt -= eta * grad/||grad||  (loss_functions.jl:79);  GD: bt -= eta * grad (:49).
-// Every workgroup recomputes ||grad|| in the same fixed order, so all see the same bits.
+// ||grad|| comes from the pieces k_grad_norm wrote, summed by every workgroup in the same fixed order.
 __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter) {
     __shared__ double red[4];
     const BondDims b = bond_dims(v, lid);
     const int n = v.C * b.L;
     const double* g = v.gradbuf + 2;
-    // ||grad||^2: every workgroup sums the whole (L2-resident) gradient in the same order
-    // 16 independent 16-byte loads in flight per thread: 4 round trips to L2 for the 256 KB of config 3
-    double s4[4] = {0, 0, 0, 0};
-    const int n4 = n & ~7;
-    for (int i = threadIdx.x * 2; i < n4; i += 8192) {
-        double2 t[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) t[u] = (i + 512 * u < n4) ? *(const double2*)&g[i + 512 * u] : make_double2(0.0, 0.0);
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s4[u & 3] += t[u].x * t[u].x + t[u].y * t[u].y;
-    }
-    double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    for (int i = n4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    // ||grad||^2 from the pieces k_grad_norm wrote (64 entries each): every workgroup sums them in the same order, so
+    // all see the same bits - and none re-reads the whole gradient (4 MB at d*chi = 512)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < v.n_norm_part; i += 256) s += v.norm_part[i];
     const double nrm2 = block_sum(s, red);
     const double nrm = sqrt(nrm2);
     const double step = (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
@@ -985,7 +976,10 @@ void launch_grad_reduce(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, v, lid, nsplit);
 }
 void launch_update(const View& v, int lid, int first_iter, hipStream_t s) {
-    hipLaunchKernelGGL(k_update, dim3(32), dim3(256), 0, s, v, lid, first_iter);
+    launch_grad_norm(v, lid, s);
+    const int64_t tot = (int64_t)v.C * v.d * v.cap * v.d * v.cap;
+    const int grid = (int)std::min<int64_t>(512, std::max<int64_t>(32, (tot + 1023) / 1024));
+    hipLaunchKernelGGL(k_update, dim3(grid), dim3(256), 0, s, v, lid, first_iter);
 }
 void launch_trace_loss(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_trace_loss, dim3(1), dim3(256), 0, s, v); }
 void launch_gram(const View& v, int lid, int going_left, hipStream_t s) {
