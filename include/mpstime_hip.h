@@ -295,7 +295,8 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * of the fused chain, out[3] 64-series chunks of the unfused chain, out[4] capacity bond dimension, out[5] ranks,
  * out[6] sweeps replayed from a hipGraph, out[7] bonds on which the blocked large-bond eigensolver handed over to the
  * library solver, out[8] bonds whose persistent tridiagonalisation gave up waiting for its peers and was redone one
- * launch per step, out[9..11] reserved */
+ * launch per step, out[9] bonds whose XCD-local tridiagonalisation found its workgroups on more than one XCD and was
+ * redone with the cross-XCD exchange, out[10..11] reserved */
 int  mpst_get_info(void* ctx, int32_t* out /*[12]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader

@@ -1416,7 +1416,8 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[6] = (c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
     out[7] = (int32_t)std::min<int64_t>(c->big_fallbacks, 1 << 30);
     out[8] = blocked_eig_coop_aborts(c->blk);      // bonds the persistent tridiagonalisation handed back to the launch-per-step path
-    out[9] = out[10] = out[11] = 0;
+    out[9] = blocked_eig_xcd_misplaced(c->blk);    // bonds whose XCD-local attempt found its workgroups on several XCDs (redone across the XCDs)
+    out[10] = out[11] = 0;
     return 0;
 }
 

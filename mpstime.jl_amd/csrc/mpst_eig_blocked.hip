@@ -209,21 +209,63 @@ struct BtCoop {
     double* rowbuf;          // [2][ncap] the published row, by parity
     unsigned int* counter;   // arrivals, monotonic within a solve
     int32_t* abort_flag;     // set by a workgroup that gave up waiting: everybody leaves, the host falls back
+    unsigned long long* roll;  // roll call of the XCD-local variant: low byte = workgroups present, 7 bits per XCD above it
 };
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Two variants of the exchange.  SC_AGENT: relaxed agent-scope atomics (sc1: served by memory, correct wherever the
+// workgroups run).  SC_XCD: plain stores (the L1 writes through; the store is acknowledged by the L2), an L2 atomic for
+// the count and NON-TEMPORAL loads (never kept in the reader's L1, so always served by the L2): coherent exactly when
+// every participant sits on the SAME XCD, which the kernel checks with a roll call (HW_REG_XCC_ID) before the first
+// such operation - it gives up otherwise.  scratch/ubench/xcd_exchange.hip: 1.33 us per round of 32 workgroups against
+// 2.1-2.4 us with agent scope (and what does NOT work: sc0 loads with 32 workgroups, with or without buffer_inv sc0).
+constexpr int SC_AGENT = __HIP_MEMORY_SCOPE_AGENT, SC_XCD = __HIP_MEMORY_SCOPE_WORKGROUP;
+constexpr int ABORT_PATIENCE = 1, ABORT_PLACEMENT = 2;
+template <int SC> __device__ __forceinline__ void st_sc(double* p, double x) {
+    if (SC == SC_XCD) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(x) : "memory");
+    else __hip_atomic_store(p, x, __ATOMIC_RELAXED, SC);
+}
+template <int SC> __device__ __forceinline__ unsigned int ld_count(const unsigned int* p) {
+    if (SC == SC_XCD) {
+        unsigned int v;
+        asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, SC);
+}
+// the five values a step needs from the others (two each of y and of the published row, and y_j), requested together
+template <int SC> __device__ __forceinline__ void ld5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4,
+                                                      double& v0, double& v1, double& v2, double& v3, double& v4) {
+    if (SC == SC_XCD) {
+        asm volatile("global_load_dwordx2 %0, %5, off nt\n\t"
+                     "global_load_dwordx2 %1, %6, off nt\n\t"
+                     "global_load_dwordx2 %2, %7, off nt\n\t"
+                     "global_load_dwordx2 %3, %8, off nt\n\t"
+                     "global_load_dwordx2 %4, %9, off nt\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4)
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4)
+                     : "memory");
+    } else {
+        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, SC);
+        v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, SC);
+        v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, SC);
+        v3 = __hip_atomic_load(p3, __ATOMIC_RELAXED, SC);
+        v4 = __hip_atomic_load(p4, __ATOMIC_RELAXED, SC);
+    }
+}
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF; }   // HW_REG_XCC_ID[3:0]
 // every workgroup has arrived `target` times in total; false if the wait was abandoned
+template <int SC>
 __device__ __forceinline__ bool bt_coop_wait(const BtCoop& cp, unsigned int target, int* sh_ok) {
     if (threadIdx.x == 0) {
         int ok = 1;
         int spins = 0;
-        // relaxed polling: everything exchanged between workgroups is itself read and written with agent-scope operations,
-        // so no cache needs invalidating when the count is reached
-        while (__hip_atomic_load(cp.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        // relaxed polling: everything exchanged between workgroups is itself read and written with operations of the
+        // same scope, so no cache needs invalidating when the count is reached
+        while (ld_count<SC>(cp.counter) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023) == 0 &&
                 (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-                __hip_atomic_store(cp.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
             }
@@ -233,13 +275,47 @@ __device__ __forceinline__ bool bt_coop_wait(const BtCoop& cp, unsigned int targ
     __syncthreads();
     return *sh_ok != 0;
 }
+template <int SC>
 __device__ __forceinline__ void bt_coop_arrive(const BtCoop& cp) {
-    __syncthreads();            // waits for every thread's (write-through, agent-scope) stores of this step: nothing to flush
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cp.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's (write-through) stores of the step have left the CU
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cp.counter, 1u, __ATOMIC_RELAXED, SC);
+}
+// XCD-local variant only: everybody announces itself and its XCD (agent scope, one word), waits for the G participants
+// and checks that exactly one XCD field is populated
+__device__ __forceinline__ bool bt_coop_roll_call(const BtCoop& cp, int G, int* sh_ok) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cp.roll, 1ull | (1ull << (8 + 7 * (xcc_id() & 7))), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1, spins = 0;
+        unsigned long long r;
+        while (((r = __hip_atomic_load(cp.roll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffull) < (unsigned long long)G) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023) == 0 &&
+                (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        if (ok) {
+            int fields = 0;
+            for (int x = 0; x < 8; ++x) fields += ((r >> (8 + 7 * x)) & 0x7full) != 0;
+            if (fields != 1) {                    // every participant reads the same final word: all leave together
+                __hip_atomic_fetch_or(cp.abort_flag, ABORT_PLACEMENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+            }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+// stride: only the workgroups blockIdx.x = 0 mod stride take part (the dispatcher deals consecutive workgroups round-robin
+// over the 8 XCDs, so stride 8 puts the participants on one XCD - the roll call verifies it); the others leave at once.
+template <int NT, int SC>
+__global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride) {
+    if ((int)blockIdx.x % stride != 0) return;
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_a[NW], red_b[NW], bc[2];
@@ -247,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
     constexpr int QV = BT_NMAX / NT;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int G = gridDim.x, g = blockIdx.x;
+    const int G = ((int)gridDim.x + stride - 1) / stride, g = (int)blockIdx.x / stride;
     double* xs = smem;                   // [ncap] the reflector v_j (v_{j-1} when a step starts)
     double* vl = xs + ld;                // [ncap] v_{j-1}
     double* wl = vl + ld;                // [ncap] w_{j-1}
@@ -267,25 +343,40 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
         }
         return;
     }
+    if (SC == SC_XCD && !bt_coop_roll_call(cp, G, &sh_ok)) return;
     if (g == 0)
-        for (int c = tid; c < n; c += NT) st_agent(cp.rowbuf + c, rows[c]);
-    bt_coop_arrive(cp);
+        for (int c = tid; c < n; c += NT) st_sc<SC>(cp.rowbuf + c, rows[c]);
+    bt_coop_arrive<SC>(cp);
     double tau_prev = 0.0;
     for (int j = 0; j <= n - 2; ++j) {
-        if (!bt_coop_wait(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+        if (!bt_coop_wait<SC>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
         // everything this step needs from the others, requested at once
         const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * ld;
         const double* rowj = cp.rowbuf + (int64_t)(j & 1) * ld;
-        double vp[QV], yp[QV], aj[QV];
+        double vp[QV], yp[QV], aj[QV], yj;
+        if constexpr (QV == 2) {
+            const int i0 = j + tid, i1 = j + tid + NT;
+            const int c0 = i0 < n ? i0 : j, c1 = i1 < n ? i1 : j;        // out-of-range lanes read entry j and drop it
+            ld5<SC>(yprev + c0, rowj + c0, yprev + c1, rowj + c1, yprev + j, yp[0], aj[0], yp[1], aj[1], yj);
+            yp[0] = (i0 < n && j > 0) ? yp[0] : 0.0;
+            yp[1] = (i1 < n && j > 0) ? yp[1] : 0.0;
+            aj[0] = i0 < n ? aj[0] : 0.0;
+            aj[1] = i1 < n ? aj[1] : 0.0;
+            yj = j > 0 ? yj : 0.0;
+            vp[0] = (i0 < n && j > 0) ? xs[i0] : 0.0;
+            vp[1] = (i1 < n && j > 0) ? xs[i1] : 0.0;
+        } else {
+            static_assert(SC == SC_AGENT, "the XCD-local exchange is written for 512 threads");
 #pragma unroll
-        for (int q = 0; q < QV; ++q) {
-            const int idx = j + tid + NT * q;
-            const bool ok = idx < n;
-            yp[q] = (ok && j > 0) ? ld_agent(yprev + idx) : 0.0;
-            aj[q] = ok ? ld_agent(rowj + idx) : 0.0;
-            vp[q] = (ok && j > 0) ? xs[idx] : 0.0;
+            for (int q = 0; q < QV; ++q) {
+                const int idx = j + tid + NT * q;
+                const bool ok = idx < n;
+                yp[q] = (ok && j > 0) ? __hip_atomic_load(yprev + idx, __ATOMIC_RELAXED, SC) : 0.0;
+                aj[q] = ok ? __hip_atomic_load(rowj + idx, __ATOMIC_RELAXED, SC) : 0.0;
+                vp[q] = (ok && j > 0) ? xs[idx] : 0.0;
+            }
+            yj = j > 0 ? __hip_atomic_load(yprev + j, __ATOMIC_RELAXED, SC) : 0.0;
         }
-        const double yj = j > 0 ? ld_agent(yprev + j) : 0.0;
         // (a) alpha_{j-1}
         double alpha;
         {
@@ -373,12 +464,12 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
                 const double a_ = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
                 arow[c] = a_;
                 s = fma(a_, xs[c], s);
-                if (pub) st_agent(rownext + c, a_);
+                if (pub) st_sc<SC>(rownext + c, a_);
             }
             s = wave_sum(s);
-            if (lane == 0) st_agent(ynew + r, tau * s);
+            if (lane == 0) st_sc<SC>(ynew + r, tau * s);
         }
-        bt_coop_arrive(cp);
+        bt_coop_arrive<SC>(cp);
     }
 }
 
@@ -842,6 +933,7 @@ struct BlockedEig {
     BtCoop cp{};
     int32_t* host_flag = nullptr;      // pinned: [0] verdict, [1] the persistent kernel gave up
     int coop_aborts = 0;
+    int xcd_misplaced = 0;             // solves whose XCD-local attempt found its workgroups on more than one XCD
 };
 static int coop_threads() {
     static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
@@ -857,6 +949,13 @@ static size_t coop_lds(int ncap) {
     const int G = coop_grid(ncap);
     return (size_t)(3 + (ncap + G - 1) / G) * ncap * sizeof(double);
 }
+// XCD-local variant: one workgroup per CU of one XCD (32), every 8th workgroup of the launch
+constexpr int XCD_G = 32, XCD_STRIDE = 8;
+static size_t xcd_lds(int ncap) { return (size_t)(3 + (ncap + XCD_G - 1) / XCD_G) * ncap * sizeof(double); }
+static bool xcd_usable(int ncap) {
+    static const bool off = getenv("MPST_BT_NO_XCD") != nullptr;
+    return !off && coop_threads() == 512 && xcd_lds(ncap) <= 150 * 1024;
+}
 
 static size_t bt_vec_lds() { return (size_t)(6 * BT_NMAX + 16) * sizeof(double); }
 
@@ -869,11 +968,16 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
               al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 2 * n1) && al(&e->cp.rowbuf, 2 * n1) &&
-              hipMalloc((void**)&e->cp.counter, sizeof(unsigned int)) == hipSuccess && hipMalloc((void**)&e->cp.abort_flag, sizeof(int32_t)) == hipSuccess;
+              hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
+    if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
+        e->cp.abort_flag = (int32_t*)(e->cp.counter + 1);
+        e->cp.roll = (unsigned long long*)(e->cp.counter + 2);
+    }
     if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop<256, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop<512, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -893,7 +997,6 @@ void blocked_eig_destroy(BlockedEig* e) {
     if (e->cp.ybuf) (void)hipFree(e->cp.ybuf);
     if (e->cp.rowbuf) (void)hipFree(e->cp.rowbuf);
     if (e->cp.counter) (void)hipFree(e->cp.counter);
-    if (e->cp.abort_flag) (void)hipFree(e->cp.abort_flag);
     delete e;
 }
 
@@ -921,15 +1024,17 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     const BtBufs& b = e->b;
     const int ncap = rawn > 0 ? rawn : b.ncap;
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
-    bool coop = rawn == 0 && !no_coop;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (coop) {
-            if (hipMemsetAsync(e->cp.counter, 0, sizeof(unsigned int), s) != hipSuccess || hipMemsetAsync(e->cp.abort_flag, 0, sizeof(int32_t), s) != hipSuccess)
-                return MPST_ERR_DEVICE;
-            if (coop_threads() == 512)
-                hipLaunchKernelGGL(k_bt_coop<512>, dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
+    // mode 2: persistent kernel confined to one XCD; 1: persistent kernel across the XCDs; 0: one launch per step
+    int mode = (rawn == 0 && !no_coop) ? (xcd_usable(ncap) ? 2 : 1) : 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (mode) {
+            if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
+            if (mode == 2)
+                hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE);
+            else if (coop_threads() == 512)
+                hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1);
             else
-                hipLaunchKernelGGL(k_bt_coop<256>, dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, b, e->cp);
+                hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1);
         } else {
             hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
             static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
@@ -943,15 +1048,23 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, b, s);
         e->host_flag[1] = 0;
         if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
-        if (coop && hipMemcpyAsync(e->host_flag + 1, e->cp.abort_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (mode && hipMemcpyAsync(e->host_flag + 1, e->cp.abort_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
         if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
         if (hipGetLastError() != hipSuccess) return MPST_ERR_DEVICE;
-        if (!(coop && e->host_flag[1])) break;
-        e->coop_aborts++;
-        coop = false;               // the persistent kernel gave up: the same bond again, one launch per step
+        if (!(mode && e->host_flag[1])) break;
+        // the persistent kernel gave up: the same bond again - across the XCDs if only the placement was wrong (its
+        // workgroups were all there), else one launch per step
+        if (mode == 2 && e->host_flag[1] == ABORT_PLACEMENT) {
+            e->xcd_misplaced++;
+            mode = 1;
+        } else {
+            e->coop_aborts++;
+            mode = 0;
+        }
     }
     return *e->host_flag ? 1 : 0;
 }
 int blocked_eig_coop_aborts(const BlockedEig* e) { return e ? e->coop_aborts : 0; }
+int blocked_eig_xcd_misplaced(const BlockedEig* e) { return e ? e->xcd_misplaced : 0; }
 
 }  // namespace mpst

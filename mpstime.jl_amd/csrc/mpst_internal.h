@@ -443,6 +443,7 @@ void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hi
 // verification asks for the library fallback
 struct BlockedEig;
 int blocked_eig_coop_aborts(const BlockedEig* e);
+int blocked_eig_xcd_misplaced(const BlockedEig* e);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);
 void blocked_eig_destroy(BlockedEig* e);
 int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,

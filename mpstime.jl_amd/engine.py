@@ -334,7 +334,8 @@ class SweepEngine:
         out = (C.c_int32 * 12)()
         self._chk(self.lib.mpst_get_info(self.ctx, out))
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
-                "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8]}
+                "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
+                "xcd_local_misplaced": out[9]}
 
     def eig_phases(self):
         us = np.zeros(6)
