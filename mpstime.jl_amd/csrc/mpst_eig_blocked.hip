@@ -212,45 +212,55 @@ struct BtCoop {
     unsigned long long* roll;  // roll call of the XCD-local variant: low byte = workgroups present, 7 bits per XCD above it
 };
 // Two variants of the exchange.  SC_AGENT: relaxed agent-scope atomics (sc1: served by memory, correct wherever the
-// workgroups run).  SC_XCD: plain stores (the L1 writes through; the store is acknowledged by the L2), an L2 atomic for
-// the count and NON-TEMPORAL loads (never kept in the reader's L1, so always served by the L2): coherent exactly when
-// every participant sits on the SAME XCD, which the kernel checks with a roll call (HW_REG_XCC_ID) before the first
-// such operation - it gives up otherwise.  scratch/ubench/xcd_exchange.hip: 1.33 us per round of 32 workgroups against
-// 2.1-2.4 us with agent scope (and what does NOT work: sc0 loads with 32 workgroups, with or without buffer_inv sc0).
+// workgroups run) and a counting barrier.  SC_XCD: plain stores (the L1 writes through to the L2) and NON-TEMPORAL loads
+// (never kept in the reader's L1, so always served by the L2): coherent exactly when every participant sits on the SAME
+// XCD, which the kernel checks with a roll call (HW_REG_XCC_ID) before the first such operation - it gives up
+// otherwise.  scratch/ubench/xcd_exchange.hip: 1.33 us per counted round of 32 workgroups against 2.1-2.4 us with agent
+// scope (and what does NOT work: sc0 loads with 32 workgroups, with or without buffer_inv sc0).  On top of that the
+// XCD-local variant drops the counter: its entries validate themselves (below).
 constexpr int SC_AGENT = __HIP_MEMORY_SCOPE_AGENT, SC_XCD = __HIP_MEMORY_SCOPE_WORKGROUP;
 constexpr int ABORT_PATIENCE = 1, ABORT_PLACEMENT = 2;
-template <int SC> __device__ __forceinline__ void st_sc(double* p, double x) {
-    if (SC == SC_XCD) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(x) : "memory");
-    else __hip_atomic_store(p, x, __ATOMIC_RELAXED, SC);
+template <int SC> __device__ __forceinline__ void st_sc(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, SC); }
+// ---- XCD-local exchange: self-validating entries, no counter ----------------------------------------------------------
+// An entry is 16 bytes {value, key ^ bits(value)}; key = (solve sequence number, kind, step).  The producer just stores
+// it - no s_waitcnt, no barrier, no atomic on its side - and every consumer polls the entries it needs until they carry
+// the key of the step: the poll IS the load.  A torn or stale read cannot validate (an old value under a new tag word
+// fails the xor unless the value is the same anyway), so nothing depends on the two halves arriving together.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long tag_key(unsigned int seq, int kind, int step) {
+    return ((unsigned long long)seq << 32) | ((unsigned long long)kind << 20) | (unsigned long long)(step + 1);
 }
-template <int SC> __device__ __forceinline__ unsigned int ld_count(const unsigned int* p) {
-    if (SC == SC_XCD) {
-        unsigned int v;
-        asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-        return v;
-    }
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, SC);
+__device__ __forceinline__ void st_tag(double* base, int idx, double x, unsigned long long key) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x), t = key ^ bits;
+    const u32x4 q = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)t, (unsigned int)(t >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(base + 2 * idx), "v"(q) : "memory");
 }
-// the five values a step needs from the others (two each of y and of the published row, and y_j), requested together
-template <int SC> __device__ __forceinline__ void ld5(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4,
-                                                      double& v0, double& v1, double& v2, double& v3, double& v4) {
-    if (SC == SC_XCD) {
-        asm volatile("global_load_dwordx2 %0, %5, off nt\n\t"
-                     "global_load_dwordx2 %1, %6, off nt\n\t"
-                     "global_load_dwordx2 %2, %7, off nt\n\t"
-                     "global_load_dwordx2 %3, %8, off nt\n\t"
-                     "global_load_dwordx2 %4, %9, off nt\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4)
-                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4)
-                     : "memory");
-    } else {
-        v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, SC);
-        v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, SC);
-        v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, SC);
-        v3 = __hip_atomic_load(p3, __ATOMIC_RELAXED, SC);
-        v4 = __hip_atomic_load(p4, __ATOMIC_RELAXED, SC);
-    }
+__device__ __forceinline__ bool tag_ok(const u32x4 q, unsigned long long key, double& x) {
+    const unsigned long long bits = (unsigned long long)q.x | ((unsigned long long)q.y << 32);
+    const unsigned long long t = (unsigned long long)q.z | ((unsigned long long)q.w << 32);
+    x = __longlong_as_double((long long)bits);
+    return (t ^ bits) == key;
+}
+// the five entries a step needs from the others, requested together with non-temporal loads; true if all carry their key
+__device__ __forceinline__ bool ld5_tag(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4,
+                                        unsigned long long k0, unsigned long long k1, unsigned long long k2, unsigned long long k3,
+                                        unsigned long long k4, double& v0, double& v1, double& v2, double& v3, double& v4) {
+    u32x4 q0, q1, q2, q3, q4;
+    asm volatile("global_load_dwordx4 %0, %5, off nt\n\t"
+                 "global_load_dwordx4 %1, %6, off nt\n\t"
+                 "global_load_dwordx4 %2, %7, off nt\n\t"
+                 "global_load_dwordx4 %3, %8, off nt\n\t"
+                 "global_load_dwordx4 %4, %9, off nt\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4)
+                 : "memory");
+    bool ok = tag_ok(q0, k0, v0);
+    ok = tag_ok(q1, k1, v1) && ok;
+    ok = tag_ok(q2, k2, v2) && ok;
+    ok = tag_ok(q3, k3, v3) && ok;
+    ok = tag_ok(q4, k4, v4) && ok;
+    return ok;
 }
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF; }   // HW_REG_XCC_ID[3:0]
 // every workgroup has arrived `target` times in total; false if the wait was abandoned
@@ -261,7 +271,7 @@ __device__ __forceinline__ bool bt_coop_wait(const BtCoop& cp, unsigned int targ
         int spins = 0;
         // relaxed polling: everything exchanged between workgroups is itself read and written with operations of the
         // same scope, so no cache needs invalidating when the count is reached
-        while (ld_count<SC>(cp.counter) < target) {
+        while (__hip_atomic_load(cp.counter, __ATOMIC_RELAXED, SC) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 1023) == 0 &&
                 (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
@@ -314,7 +324,7 @@ __device__ __forceinline__ bool bt_coop_roll_call(const BtCoop& cp, int G, int* 
 // stride: only the workgroups blockIdx.x = 0 mod stride take part (the dispatcher deals consecutive workgroups round-robin
 // over the 8 XCDs, so stride 8 puts the participants on one XCD - the roll call verifies it); the others leave at once.
 template <int NT, int SC>
-__global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride) {
+__global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
     if ((int)blockIdx.x % stride != 0) return;
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -343,21 +353,45 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
         }
         return;
     }
-    if (SC == SC_XCD && !bt_coop_roll_call(cp, G, &sh_ok)) return;
-    if (g == 0)
-        for (int c = tid; c < n; c += NT) st_sc<SC>(cp.rowbuf + c, rows[c]);
-    bt_coop_arrive<SC>(cp);
+    constexpr bool TAGGED = SC == SC_XCD;
+    if (TAGGED && !bt_coop_roll_call(cp, G, &sh_ok)) return;          // leaves sh_ok = 1
+    if (g == 0) {
+        for (int c = tid; c < n; c += NT) {
+            if constexpr (TAGGED) st_tag(cp.rowbuf, c, rows[c], tag_key(seq, 2, 0));
+            else st_sc<SC>(cp.rowbuf + c, rows[c]);
+        }
+    }
+    if constexpr (!TAGGED) bt_coop_arrive<SC>(cp);
     double tau_prev = 0.0;
+#ifdef MPST_COOP_PROF
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_amdgcn_s_memrealtime(), t1;
+#define PSTAMP(i) do { t1 = __builtin_amdgcn_s_memrealtime(); pt[i] += t1 - t0; t0 = t1; } while (0)
+#else
+#define PSTAMP(i) do { } while (0)
+#endif
     for (int j = 0; j <= n - 2; ++j) {
-        if (!bt_coop_wait<SC>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
-        // everything this step needs from the others, requested at once
-        const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * ld;
-        const double* rowj = cp.rowbuf + (int64_t)(j & 1) * ld;
+        PSTAMP(5);
         double vp[QV], yp[QV], aj[QV], yj;
-        if constexpr (QV == 2) {
+        if constexpr (TAGGED) {
+            static_assert(QV == 2 || !TAGGED, "the XCD-local exchange is written for 512 threads");
+            // entries are 16 bytes; y of step j-1 sits in the buffer of parity (j+1)&1, the published row j in j&1
+            const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * 2 * ld;
+            const double* rowj = cp.rowbuf + (int64_t)(j & 1) * 2 * ld;
+            const unsigned long long kr = tag_key(seq, 2, j), ky = j > 0 ? tag_key(seq, 1, j - 1) : kr;
+            const double* ysrc = j > 0 ? yprev : rowj;            // step 0 has no y: poll the row entries twice
             const int i0 = j + tid, i1 = j + tid + NT;
-            const int c0 = i0 < n ? i0 : j, c1 = i1 < n ? i1 : j;        // out-of-range lanes read entry j and drop it
-            ld5<SC>(yprev + c0, rowj + c0, yprev + c1, rowj + c1, yprev + j, yp[0], aj[0], yp[1], aj[1], yj);
+            const int c0 = i0 < n ? i0 : j, c1 = i1 < n ? i1 : j;        // out-of-range lanes poll entry j and drop it
+            int spins = 0;
+            while (!ld5_tag(ysrc + 2 * c0, rowj + 2 * c0, ysrc + 2 * c1, rowj + 2 * c1, ysrc + 2 * j, ky, kr, ky, kr, ky,
+                            yp[0], aj[0], yp[1], aj[1], yj)) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 255) == 0 &&
+                    (spins > (1 << 19) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh_ok = 0;                                     // seen by everybody after the next barrier
+                    break;
+                }
+            }
             yp[0] = (i0 < n && j > 0) ? yp[0] : 0.0;
             yp[1] = (i1 < n && j > 0) ? yp[1] : 0.0;
             aj[0] = i0 < n ? aj[0] : 0.0;
@@ -366,7 +400,11 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             vp[0] = (i0 < n && j > 0) ? xs[i0] : 0.0;
             vp[1] = (i1 < n && j > 0) ? xs[i1] : 0.0;
         } else {
-            static_assert(SC == SC_AGENT, "the XCD-local exchange is written for 512 threads");
+            if (!bt_coop_wait<SC>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+            PSTAMP(0);
+            // everything this step needs from the others, requested at once
+            const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * ld;
+            const double* rowj = cp.rowbuf + (int64_t)(j & 1) * ld;
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
                 const int idx = j + tid + NT * q;
@@ -377,24 +415,27 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             }
             yj = j > 0 ? __hip_atomic_load(yprev + j, __ATOMIC_RELAXED, SC) : 0.0;
         }
+        PSTAMP(1);
         // (a) alpha_{j-1}
         double alpha;
         {
             double s = 0.0;
 #pragma unroll
             for (int q = 0; q < QV; ++q) s = fma(yp[q], vp[q], s);
-            s = wave_sum(s);
+            s = wave_sum_fast(s);
             if (lane == 0) red_a[wave] = s;
             __syncthreads();
+            if (TAGGED && sh_ok == 0) return;          // somebody's poll ran out of patience: all leave together
             double sa = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sa += red_a[w];
             alpha = -0.5 * tau_prev * sa;
         }
+        PSTAMP(2);
         // (b) row j with the pending update applied (v_{j-1}[j] is the leading one of reflector j-1, w_{j-1}[j] = y_j + alpha)
         const double vj = j > 0 ? 1.0 : 0.0, wj = j > 0 ? yj + alpha : 0.0;
         double xr[QV];
-        double tau = 0.0, beta;
+        double tau = 0.0, beta, dj;
         {
             double s = 0.0;
 #pragma unroll
@@ -410,13 +451,14 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             }
             if (tid == 0) bc[0] = xr[0];               // d_j
             if (tid == 1) bc[1] = xr[0];               // the leading entry of the column below the diagonal
-            s = wave_sum(s);
+            s = wave_sum_fast(s);
             if (lane == 0) red_b[wave] = s;
             __syncthreads();
             s = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += red_b[w];
-            const double dj = bc[0], a0 = bc[1];
+            const double a0 = bc[1];
+            dj = bc[0];
             beta = a0;
             double scale = 0.0;
             if (s > 0.0) {
@@ -427,21 +469,25 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
                 const int idx = j + tid + NT * q;
-                if (idx < n) {
-                    const double vr = idx <= j ? 0.0 : (idx == j + 1 ? 1.0 : xr[q] * scale);
-                    xs[idx] = vr;
-                    if (g == 0) b.Vall[(int64_t)j * ld + idx] = vr;
-                }
+                if (idx < n) xs[idx] = idx <= j ? 0.0 : (idx == j + 1 ? 1.0 : xr[q] * scale);
             }
-            if (g == 0 && tid == 0) {
+            __syncthreads();
+        }
+        // what only the later kernels read (the stored reflector, tau, d_j, e_j) is written off the critical path, after the
+        // step's exchange has been issued, every workgroup a share
+        auto bookkeeping = [&]() {
+            const int per = (n + G - 1) / G, idx = g * per + tid;      // every workgroup a contiguous share of the reflector
+            if (tid < per && idx >= j && idx < n) b.Vall[(int64_t)j * ld + idx] = xs[idx];
+            if (g == j % G && tid == 0) {
                 b.tau[j] = tau;
                 b.dd[j] = dj;
                 b.ee[j] = beta;
             }
-            __syncthreads();
-        }
+        };
         tau_prev = tau;
+        PSTAMP(3);
         if (j == n - 2) {
+            bookkeeping();
             // the last diagonal entry, with the pending update of step n-3 applied, from the row's owner
             if ((n - 1) % G == g && tid == 0) {
                 const int k = (n - 1 - g) / G;
@@ -451,26 +497,92 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             break;
         }
         // (c) own rows r > j: pending update, product with the new reflector; the owner of row j+1 publishes it
-        double* ynew = cp.ybuf + (int64_t)(j & 1) * ld;
-        double* rownext = cp.rowbuf + (int64_t)((j + 1) & 1) * ld;
-        for (int k = wave; k < nown; k += NW) {
-            const int r = g + k * G;
-            if (r <= j) continue;
-            double* arow = rows + k * ld;
-            const double vr = vl[r], wr = wl[r];
-            const bool pub = r == j + 1;
-            double s = 0.0;
-            for (int c = j + 1 + lane; c < n; c += 64) {
-                const double a_ = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
-                arow[c] = a_;
-                s = fma(a_, xs[c], s);
-                if (pub) st_sc<SC>(rownext + c, a_);
+        double* ynew = cp.ybuf + (int64_t)(j & 1) * (TAGGED ? 2 : 1) * ld;
+        double* rownext = cp.rowbuf + (int64_t)((j + 1) & 1) * (TAGGED ? 2 : 1) * ld;
+        const unsigned long long key_y = tag_key(seq, 1, j), key_r = tag_key(seq, 2, j + 1);
+        auto put_row = [&](int c, double x) {
+            if constexpr (TAGGED) st_tag(rownext, c, x, key_r);
+            else st_sc<SC>(rownext + c, x);
+        };
+        auto put_y = [&](int r, double x) {
+            if constexpr (TAGGED) st_tag(ynew, r, x, key_y);
+            else st_sc<SC>(ynew + r, x);
+        };
+        // two rows per pass (k and k + NW): they share the LDS reads of v, w and the new reflector, and their two
+        // reductions overlap; per row the arithmetic is that of the one-row loop
+        for (int k = wave; k < nown; k += 2 * NW) {
+            const int k2 = k + NW;
+            const int r1 = g + k * G, r2 = g + k2 * G;
+            const bool live1 = r1 > j, live2 = k2 < nown && r2 > j;
+            if (!live2) {
+                if (!live1) continue;
+                double* arow = rows + k * ld;
+                const double vr = vl[r1], wr = wl[r1];
+                const bool pub = r1 == j + 1;
+                double s = 0.0;
+                for (int c = j + 1 + lane; c < n; c += 64) {
+                    const double a_ = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
+                    arow[c] = a_;
+                    s = fma(a_, xs[c], s);
+                    if (pub) put_row(c, a_);
+                }
+                s = wave_sum_fast(s);
+                if (lane == 0) put_y(r1, tau * s);
+                continue;
             }
-            s = wave_sum(s);
-            if (lane == 0) st_sc<SC>(ynew + r, tau * s);
+            double* arow1 = rows + k * ld;
+            double* arow2 = rows + k2 * ld;
+            const double vr1 = vl[r1], wr1 = wl[r1], vr2 = vl[r2], wr2 = wl[r2];
+            const bool pub1 = live1 && r1 == j + 1, pub2 = r2 == j + 1;
+            double s1 = 0.0, s2 = 0.0;
+            // 4 x 64 columns per pass, every LDS operand requested before the first use: the loop is bound by the
+            // LDS latency of a pass, not by its bytes (per lane the columns are still accumulated in ascending order)
+            for (int cb = j + 1 + lane; cb < n + lane; cb += 256) {
+                double vc[4], wc[4], xc[4], r1v[4], r2v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = cb + 64 * u, cc = c < n ? c : n - 1;
+                    vc[u] = vl[cc];
+                    wc[u] = wl[cc];
+                    xc[u] = xs[cc];
+                    r1v[u] = arow1[cc];
+                    r2v[u] = arow2[cc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = cb + 64 * u;
+                    if (c < n) {
+                        if (live1) {
+                            const double a1 = fma(-wr1, vc[u], fma(-vr1, wc[u], r1v[u]));
+                            arow1[c] = a1;
+                            s1 = fma(a1, xc[u], s1);
+                            if (pub1) put_row(c, a1);
+                        }
+                        const double a2 = fma(-wr2, vc[u], fma(-vr2, wc[u], r2v[u]));
+                        arow2[c] = a2;
+                        s2 = fma(a2, xc[u], s2);
+                        if (pub2) put_row(c, a2);
+                    }
+                }
+            }
+            PSTAMP(0);
+            s1 = wave_sum_fast(s1);
+            s2 = wave_sum_fast(s2);
+            if (lane == 0) {
+                if (live1) put_y(r1, tau * s1);
+                put_y(r2, tau * s2);
+            }
         }
-        bt_coop_arrive<SC>(cp);
+        PSTAMP(4);
+        if constexpr (!TAGGED) bt_coop_arrive<SC>(cp);
+        bookkeeping();
     }
+#ifdef MPST_COOP_PROF
+    if (g == 0 && tid == 0) {
+        unsigned long long* st = v.sc->eig_stamps;
+        st[0] = 0; st[1] = pt[0]; st[2] = 0; st[3] = pt[1]; st[4] = pt[1] + pt[2]; st[5] = pt[1] + pt[2] + pt[3]; st[8] = 0; st[9] = pt[4]; st[6] = 0; st[7] = pt[5];
+    }
+#endif
 }
 
 __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
@@ -933,6 +1045,7 @@ struct BlockedEig {
     BtCoop cp{};
     int32_t* host_flag = nullptr;      // pinned: [0] verdict, [1] the persistent kernel gave up
     int coop_aborts = 0;
+    unsigned int seq = 0;              // solve sequence number: part of the key of the XCD-local exchange's entries
     int xcd_misplaced = 0;             // solves whose XCD-local attempt found its workgroups on more than one XCD
 };
 static int coop_threads() {
@@ -967,7 +1080,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
               al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
-              hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 2 * n1) && al(&e->cp.rowbuf, 2 * n1) &&
+              hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 4 * n1) && al(&e->cp.rowbuf, 4 * n1) &&
               hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
     if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
         e->cp.abort_flag = (int32_t*)(e->cp.counter + 1);
@@ -1030,11 +1143,11 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
             if (mode == 2)
-                hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE);
+                hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (coop_threads() == 512)
-                hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1);
+                hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
             else
-                hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1);
+                hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
         } else {
             hipLaunchKernelGGL(k_bt_prep, dim3(256), dim3(BT_T), 0, s, v, lid, going_left, rawG, rawn, b);
             static const int bt_g = [] { const char* e = getenv("MPST_BT_G"); return e ? std::max(1, atoi(e)) : BT_G; }();
