@@ -91,6 +91,26 @@ __global__ __launch_bounds__(BT_T) void k_bt_prep(View v, int lid, int going_lef
     }
 }
 
+// beta, tau and 1/(alpha - beta) of dlarfg from alpha = a0 and the squared norm s of the rest of the column, for both the
+// launch-per-step and the persistent kernels (same code = same bits).  The chain sits on every step's critical path in
+// every workgroup, so it is the branch-free form of k_eig_tri: v_rsq_f64 + two Heron steps instead of the IEEE square
+// root, hardware reciprocal seed + Newton steps (frcp) instead of the two IEEE divisions.  A column whose tail is zero
+// or below 1e-140 in norm is treated as already reduced (tau = 0), as dlarfg's s == 0 branch.
+__device__ __forceinline__ void bt_reflector_scalars(double a0, double s, double& beta, double& tau, double& scale) {
+    const double xx = fma(a0, a0, s);
+    const bool nz = s > 0.0 && xx > 1e-280;
+    const double rs = __builtin_amdgcn_rsq(nz ? xx : 1.0);
+    double nrm = xx * rs;
+    const double hrs = 0.5 * rs;
+    nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
+    nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
+    const double bneg = copysign(nrm, a0);                 // -beta
+    const double ib = frcp(bneg), is = frcp(a0 + bneg);
+    beta = nz ? -bneg : a0;
+    tau = nz ? (bneg + a0) * ib : 0.0;                     // (beta - alpha) / beta
+    scale = nz ? is : 0.0;                                 // 1 / (alpha - beta)
+}
+
 // One Householder step per launch (dsytd2 with the rank-2 update of step j-1 folded into step j's pass over the
 // trailing matrix, so the matrix is read and written once per step and the only global reductions are two block sums
 // that every workgroup repeats for itself):
@@ -141,11 +161,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
         const double a0 = xs[j + 1];
         beta = a0;
         double scale = 0.0;
-        if (s > 0.0) {
-            beta = -copysign(sqrt(fma(a0, a0, s)), a0);
-            tau = (beta - a0) / beta;
-            scale = 1.0 / (a0 - beta);
-        }
+        bt_reflector_scalars(a0, s, beta, tau, scale);
         __syncthreads();
         for (int r = j + tid; r < n; r += BT_T) {
             const double vr = r <= j ? 0.0 : (r == j + 1 ? 1.0 : xs[r] * scale);
@@ -461,11 +477,7 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             dj = bc[0];
             beta = a0;
             double scale = 0.0;
-            if (s > 0.0) {
-                beta = -copysign(sqrt(fma(a0, a0, s)), a0);
-                tau = (beta - a0) / beta;
-                scale = 1.0 / (a0 - beta);
-            }
+            bt_reflector_scalars(a0, s, beta, tau, scale);
 #pragma unroll
             for (int q = 0; q < QV; ++q) {
                 const int idx = j + tid + NT * q;
