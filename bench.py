@@ -61,8 +61,14 @@ def kernel_model(N, d, chi, C, info):
         "split": ("mfma", 2.0 * m * n * chi),
         "bt_assemble": ("mfma", 2.0 * C * X * chi * Y),
         "env": ("hbm", 8.0 * N * (chi + d + chi)),         # read env row + site vector, write new env row
-        "grad_reduce+update": ("hbm", 8.0 * (N / 64.0 + 3.0) * C * X * Y),
     }
+    # unfused chain: k_grad_reduce reads C * nsplit partial blocks and writes the gradient; k_grad_norm + k_update read it
+    # twice and read + write the bond tensor.  The profile slot holds two scopes per optimiser step (reduce | norm + update),
+    # so the per-scope average is half of the sum.  nsplit as in csrc/mpst_internal.h: grad_nsplit.
+    dm = d * chi
+    nb = ((dm + 63) // 64) ** 2
+    nsplit = min(max(1, info.get("nchunks", 1)), max(1, -(-512 // (nb * C))))
+    model["grad_reduce+update"] = ("hbm", 0.5 * 8.0 * (nsplit + 5.0) * C * X * Y)
     if info.get("fused"):
         P = info["nparts"]
         model["grad"] = ("mfma", 4.0 * N * X * Y)           # k_bond_fused: yhat AND the gradient partials
