@@ -815,19 +815,58 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
 #pragma unroll
         for (int u = 0; u < PD; ++u) fetch(vb[u], n - 3 - u);
         __syncthreads();
+        // Two reflectors per round: H_{j-1} H_j z = z - f_j v_j - f_{j-1} v_{j-1} with f_j = tau_j v_j^T z and
+        // f_{j-1} = tau_{j-1} (v_{j-1}^T z - f_j v_{j-1}^T v_j): the three dot products share one reduction round and one
+        // barrier (the loop is bound by those, not by its arithmetic).
+        static_assert(PD % 2 == 0, "reflectors are applied in pairs");
+        __shared__ double part3[2][4][3];
         int par = 0;
         for (int j0 = n - 3; j0 >= 0; j0 -= PD) {
 #pragma unroll
-            for (int u = 0; u < PD; ++u) {
+            for (int u = 0; u < PD; u += 2) {
                 const int j = j0 - u;
-                if (j >= 0) {                       // uniform
+                if (j >= 1) {                       // uniform: the pair (j, j-1)
+                    double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < QV; ++q) {
+                        const int r = tid + BT_T * q;
+                        if (r > j && r < n) {                                     // rows <= j of reflector j are zero
+                            sa = fma(vb[u][q], zr[q], sa);
+                            sc = fma(vb[u + 1][q], vb[u][q], sc);
+                        }
+                        if (r > j - 1 && r < n) sb = fma(vb[u + 1][q], zr[q], sb);
+                    }
+                    sa = wave_sum_fast(sa);
+                    sb = wave_sum_fast(sb);
+                    sc = wave_sum_fast(sc);
+                    if (lane == 0) {
+                        part3[par][wave][0] = sa;
+                        part3[par][wave][1] = sb;
+                        part3[par][wave][2] = sc;
+                    }
+                    __syncthreads();
+                    const double ta = (part3[par][0][0] + part3[par][1][0]) + (part3[par][2][0] + part3[par][3][0]);
+                    const double tb = (part3[par][0][1] + part3[par][1][1]) + (part3[par][2][1] + part3[par][3][1]);
+                    const double tc = (part3[par][0][2] + part3[par][1][2]) + (part3[par][2][2] + part3[par][3][2]);
+                    par ^= 1;
+                    const double fj = taus[j] * ta;
+                    const double fm = taus[j - 1] * fma(-fj, tc, tb);
+#pragma unroll
+                    for (int q = 0; q < QV; ++q) {
+                        const int r = tid + BT_T * q;
+                        if (r > j && r < n) zr[q] = fma(-fj, vb[u][q], zr[q]);
+                        if (r > j - 1 && r < n) zr[q] = fma(-fm, vb[u + 1][q], zr[q]);
+                    }
+                    fetch(vb[u], j - PD);
+                    fetch(vb[u + 1], j - 1 - PD);
+                } else if (j == 0) {                // uniform: a last single reflector
                     double s = 0.0;
 #pragma unroll
                     for (int q = 0; q < QV; ++q) {
                         const int r = tid + BT_T * q;
-                        if (r > j && r < n) s = fma(vb[u][q], zr[q], s);      // rows <= j of reflector j are zero
+                        if (r > j && r < n) s = fma(vb[u][q], zr[q], s);
                     }
-                    s = wave_sum(s);
+                    s = wave_sum_fast(s);
                     if (lane == 0) part[par][wave] = s;
                     __syncthreads();
                     const double f = taus[j] * ((part[par][0] + part[par][1]) + (part[par][2] + part[par][3]));
@@ -837,7 +876,6 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
                         const int r = tid + BT_T * q;
                         if (r > j && r < n) zr[q] = fma(-f, vb[u][q], zr[q]);
                     }
-                    fetch(vb[u], j - PD);
                 }
             }
         }
