@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_prep(View v, int lid, int going_lef
 }
 
 // beta, tau and 1/(alpha - beta) of dlarfg from alpha = a0 and the squared norm s of the rest of the column, for both the
-// launch-per-step and the persistent kernels (same code = same bits).  The chain sits on every step's critical path in
+// launch-per-step and the persistent kernels.  The chain sits on every step's critical path in
 // every workgroup, so it is the branch-free form of k_eig_tri: v_rsq_f64 + two Heron steps instead of the IEEE square
 // root, hardware reciprocal seed + Newton steps (frcp) instead of the two IEEE divisions.  A column whose tail is zero
 // or below 1e-140 in norm is treated as already reduced (tau = 0), as dlarfg's s == 0 branch.
@@ -217,9 +217,10 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
 // chip's local memories: workgroup g keeps rows g, g+G, g+2G, ... in LDS for the whole factorisation and a step exchanges
 // only two length-n vectors through memory - y (every owner writes its entries) and the row the next step starts from -
 // with agent-scope loads / stores and one counting barrier (1.8 us per round across the XCDs, scratch/ubench/xcd_barrier.hip).
-// Every workgroup still repeats the cheap part (alpha, w, the reflector) for itself exactly as k_bt_step does, so the
-// arithmetic - and the bits - are those of the launch-per-step path, which remains the fallback when a workgroup's wait
-// runs out of patience (its peers not resident: other work holding the CUs).
+// Every workgroup still repeats the cheap part (alpha, w, the reflector) for itself as k_bt_step does (the same arithmetic;
+// the block reductions run over 512 instead of 256 threads, so the two agree to rounding, not to the bit).  The
+// launch-per-step path remains the fallback when a workgroup's wait runs out of patience (its peers not resident: other
+// work holding the CUs).  The two persistent variants below give identical bits (tests/probes/path_hash.py).
 struct BtCoop {
     double* ybuf;            // [2][ncap] y of a step, by parity
     double* rowbuf;          // [2][ncap] the published row, by parity
