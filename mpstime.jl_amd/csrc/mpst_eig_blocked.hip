@@ -67,6 +67,22 @@ struct BtBufs {
     int ncap;
 };
 
+// the sum a 512-thread workgroup (8 waves, added in wave order) forms, from 256 threads that each carry the partial sums of
+// two of its threads (t and t + 256)
+__device__ __forceinline__ double bt_block_sum512(double sA, double sB, double* red8) {
+    sA = wave_sum_fast(sA);
+    sB = wave_sum_fast(sB);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red8[threadIdx.x >> 6] = sA;
+        red8[4 + (threadIdx.x >> 6)] = sB;
+    }
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red8[w];
+    return s;
+}
 __device__ __forceinline__ double bt_block_sum(double x, double* red) {
     x = wave_sum(x);
     __syncthreads();
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     __shared__ double xs[BT_NMAX];      // row j with the pending update applied, then the reflector v_j
     __shared__ double vl[BT_NMAX];      // v_{j-1}
     __shared__ double wl[BT_NMAX];      // w_{j-1}
-    __shared__ double red[4];
+    __shared__ double red[8];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x;
     if (j > n - 2) return;
@@ -132,13 +148,14 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
         // y is double-buffered by the parity of the step: a fast workgroup writes this step's y in (c) while a slow one is
         // still reading the previous step's here
         const double* yprev = b.Y + (int64_t)((j - 1) & 1) * ld;
-        double s = 0.0;
-        for (int r = j + tid; r < n; r += BT_T) {
-            const double vv = vprev[r];
-            vl[r] = vv;
-            s = fma(yprev[r], vv, s);
-        }
-        s = bt_block_sum(s, red);
+        // the two block sums of a step are formed exactly as the persistent kernel forms them with 512 threads (thread t
+        // there owns the entries j + t + 512 q; thread t here plays t and t + 256): the paths then agree to the bit, and a
+        // bond that falls back to this path mid-sweep does not perturb the result
+        double sA = 0.0, sB = 0.0;
+        for (int r = j + tid; r < n; r += BT_T) vl[r] = vprev[r];
+        for (int r = j + tid; r < n; r += 2 * BT_T) sA = fma(yprev[r], vprev[r], sA);
+        for (int r = j + tid + BT_T; r < n; r += 2 * BT_T) sB = fma(yprev[r], vprev[r], sB);
+        const double s = bt_block_sum512(sA, sB, red);
         const double alpha = -0.5 * b.tau[j - 1] * s;
         for (int r = j + tid; r < n; r += BT_T) wl[r] = fma(alpha, vl[r], yprev[r]);
     } else {
@@ -155,9 +172,11 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     const double dj = xs[j];
     double tau = 0.0, beta;
     {
-        double s = 0.0;
-        for (int r = j + 2 + tid; r < n; r += BT_T) s = fma(xs[r], xs[r], s);
-        s = bt_block_sum(s, red);
+        double sA = 0.0, sB = 0.0;
+        for (int r = j + tid; r < n; r += 2 * BT_T)
+            if (r >= j + 2) sA = fma(xs[r], xs[r], sA);
+        for (int r = j + tid + BT_T; r < n; r += 2 * BT_T) sB = fma(xs[r], xs[r], sB);
+        const double s = bt_block_sum512(sA, sB, red);
         const double a0 = xs[j + 1];
         beta = a0;
         double scale = 0.0;
@@ -217,10 +236,10 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
 // chip's local memories: workgroup g keeps rows g, g+G, g+2G, ... in LDS for the whole factorisation and a step exchanges
 // only two length-n vectors through memory - y (every owner writes its entries) and the row the next step starts from -
 // with agent-scope loads / stores and one counting barrier (1.8 us per round across the XCDs, scratch/ubench/xcd_barrier.hip).
-// Every workgroup still repeats the cheap part (alpha, w, the reflector) for itself as k_bt_step does (the same arithmetic;
-// the block reductions run over 512 instead of 256 threads, so the two agree to rounding, not to the bit).  The
+// Every workgroup still repeats the cheap part (alpha, w, the reflector) for itself as k_bt_step does - the same arithmetic
+// in the same association (bt_block_sum512) - so all paths give identical bits (tests/probes/path_hash.py).  The
 // launch-per-step path remains the fallback when a workgroup's wait runs out of patience (its peers not resident: other
-// work holding the CUs).  The two persistent variants below give identical bits (tests/probes/path_hash.py).
+// work holding the CUs).
 struct BtCoop {
     double* ybuf;            // [2][ncap] y of a step, by parity
     double* rowbuf;          // [2][ncap] the published row, by parity
