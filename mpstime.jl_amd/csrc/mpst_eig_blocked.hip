@@ -17,6 +17,7 @@
 //   k_bt_gram / k_bt_decide / k_bt_polish: Z^T Z - I on the MFMA, truncation rule + verdict (or the fallback flag),
 //              up to two Loewdin rounds E = Z (I - D/2) on the MFMA, publication.
 // The live size n is read on the device (bond dimensions never visit the host); launches are laid out for the capacity.
+#include <atomic>
 #include "mpst_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -246,6 +247,8 @@ struct BtCoop {
     unsigned int* counter;   // arrivals, monotonic within a solve
     int32_t* abort_flag;     // set by a workgroup that gave up waiting: everybody leaves, the host falls back
     unsigned long long* roll;  // roll call of the XCD-local variant: low byte = workgroups present, 7 bits per XCD above it
+    int xsel;                // which workgroups of a strided launch take part (blockIdx % stride): the context's ordinal, so that
+                             // concurrent fits on one GPU confine their solves to different XCDs
 };
 // Two variants of the exchange.  SC_AGENT: relaxed agent-scope atomics (sc1: served by memory, correct wherever the
 // workgroups run) and a counting barrier.  SC_XCD: plain stores (the L1 writes through to the L2) and NON-TEMPORAL loads
@@ -336,8 +339,9 @@ __device__ __forceinline__ bool bt_coop_roll_call(const BtCoop& cp, int G, int* 
         unsigned long long r;
         while (((r = __hip_atomic_load(cp.roll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffull) < (unsigned long long)G) {
             __builtin_amdgcn_s_sleep(1);
+            // (about 30 ms: peers that are not resident by then are waiting for CUs other work holds)
             if ((++spins & 1023) == 0 &&
-                (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                (spins > (1 << 15) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                 __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -357,11 +361,11 @@ __device__ __forceinline__ bool bt_coop_roll_call(const BtCoop& cp, int G, int* 
     return *sh_ok != 0;
 }
 
-// stride: only the workgroups blockIdx.x = 0 mod stride take part (the dispatcher deals consecutive workgroups round-robin
+// stride: only the workgroups blockIdx.x = cp.xsel mod stride take part (the dispatcher deals consecutive workgroups round-robin
 // over the 8 XCDs, so stride 8 puts the participants on one XCD - the roll call verifies it); the others leave at once.
 template <int NT, int SC>
 __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
-    if ((int)blockIdx.x % stride != 0) return;
+    if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_a[NW], red_b[NW], bc[2];
@@ -1153,8 +1157,10 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
               hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 4 * n1) && al(&e->cp.rowbuf, 4 * n1) &&
               hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
     if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
+        static std::atomic<int> ordinal{0};
         e->cp.abort_flag = (int32_t*)(e->cp.counter + 1);
         e->cp.roll = (unsigned long long*)(e->cp.counter + 2);
+        e->cp.xsel = ordinal.fetch_add(1) & 7;
     }
     if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
