@@ -6,7 +6,7 @@ import pytest
 
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R
-from tests.helpers import load_engine, make_problem, teacher_forced_segment
+from tests.helpers import load_engine, make_problem, teacher_forced_segment, teacher_forced_sweep
 
 pytestmark = pytest.mark.gpu
 
@@ -63,11 +63,8 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES, ids=[f"dchi{c[2] * c[4]}" for c in CASES])
-def test_big_bond_sweep_bond_by_bond(eng, case):
-    N, T, d, chi0, chimax, C, loss, bbopt = case
-    ds, W0 = make_problem(N, T, d, chi0, C, seed=N + d)
-    opts = R.SweepOptions(nsweeps=1, chi_max=chimax, eta=0.05, loss_grad=loss, bbopt=bbopt)
+def _bond_by_bond(eng, ds, W0, opts, T):
+    """One sweep, every bond update compared with the restatement's on the same inputs; returns the oracle's final MPS."""
     load_engine(eng, ds, W0, opts)
     eng.build_caches()
     W = [t.copy() for t in W0]
@@ -86,6 +83,15 @@ def test_big_bond_sweep_bond_by_bond(eng, case):
             assert np.abs(np.asarray(tr_g["S"])[:len(So)] - So).max() <= 1e-9 * So[0]
             yo, yg = R.contract_mps(W, ds.phi), R.contract_mps(eng.get_mps(), ds.phi)
             assert np.abs(yg - yo).max() <= 1e-9 * np.abs(yo).max()
+    return W
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"dchi{c[2] * c[4]}" for c in CASES])
+def test_big_bond_sweep_bond_by_bond(eng, case):
+    N, T, d, chi0, chimax, C, loss, bbopt = case
+    ds, W0 = make_problem(N, T, d, chi0, C, seed=N + d)
+    opts = R.SweepOptions(nsweeps=1, chi_max=chimax, eta=0.05, loss_grad=loss, bbopt=bbopt)
+    W = _bond_by_bond(eng, ds, W0, opts, T)
     mse, kld, acc, conf = eng.eval(0)
     mo, ko, ao, co = R.mse_loss_acc(W, ds, conf=True)
     assert abs(mse - mo) < 1e-9 and abs(kld - ko) < 1e-9 * max(1, abs(ko)) and acc == ao and np.array_equal(conf, co)
@@ -100,6 +106,34 @@ def test_big_bond_sweep_bond_by_bond(eng, case):
     yo, yg = R.contract_mps(Wo, ds.phi), R.contract_mps(eng.get_mps(), ds.phi)
     assert np.abs(yg - yo).max() <= 1e-8 * np.abs(yo).max()
     assert abs(R.mps_norm(eng.get_mps()) - 1.0) < 1e-12
+
+
+MANY = [
+    # enough series for the 4-tiles-per-workgroup form of k_yhat_gen (from 1024 tiles of 16 series; the 2-tile form is what
+    # test_config5_shape_chi64_d8_teacher_forced runs) and for k_grad workgroups that walk many chunks; three classes
+    # whose sizes are no multiple of the tile group, so that groups straddle class boundaries
+    (16550, 4, 9, 10, 15, 3, "KLD", "TSGO"),
+    (16550, 4, 9, 10, 15, 3, "MSE", "GD"),
+]
+
+
+@pytest.mark.parametrize("case", MANY, ids=[f"N{c[0]}_{c[6]}" for c in MANY])
+def test_big_bond_many_series(eng, case):
+    """Every bond of one sweep, each update started from the C oracle's state (free-running trajectories drift apart:
+    a 1e-9 difference in one bond's gradient - a sum with heavy cancellation over 16 k series - is amplified bond by
+    bond)."""
+    from oracle.c_oracle import COracle
+    N, T, d, chi0, chimax, C, loss, bbopt = case
+    ds, W0 = make_problem(N, T, d, chi0, C, seed=N + d)
+    opts = R.SweepOptions(nsweeps=1, chi_max=chimax, eta=0.05, loss_grad=loss, bbopt=bbopt)
+    load_engine(eng, ds, W0, opts)
+    assert np.bincount(ds.label_index).tolist() == [5517, 5517, 5516]       # 345 tiles per class: 345 % 4 != 0
+    co = COracle(W0, ds.phi, ds.label_index, ds.class_distribution, chimax, eta=0.05, loss=loss, bbopt=bbopt, rebuild_caches=False)
+    co.build_caches(around_label=True)
+    worst, flips = teacher_forced_sweep(eng, co, ds.phi, T, overlap_every=2)
+    assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, worst
+    assert flips <= 1
+    assert eng.info()["large_bond"]
 
 
 def _trendy(N, T, d, C):
