@@ -424,7 +424,7 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             int spins = 0;
             while (!ld5_tag(ysrc + 2 * c0, rowj + 2 * c0, ysrc + 2 * c1, rowj + 2 * c1, ysrc + 2 * j, ky, kr, ky, kr, ky,
                             yp[0], aj[0], yp[1], aj[1], yj)) {
-                __builtin_amdgcn_s_sleep(1);
+                // (no s_sleep: a poll is an L2 round trip, there is nothing else for the wave to do)
                 if ((++spins & 255) == 0 &&
                     (spins > (1 << 19) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                     __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
