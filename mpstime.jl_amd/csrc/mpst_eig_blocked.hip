@@ -1121,6 +1121,7 @@ struct BlockedEig {
     int coop_aborts = 0;
     unsigned int seq = 0;              // solve sequence number: part of the key of the XCD-local exchange's entries
     int xcd_misplaced = 0;             // solves whose XCD-local attempt found its workgroups on more than one XCD
+    int cooldown = 0;                  // solves left that skip the persistent kernels after one of them gave up waiting
 };
 static int coop_threads() {
     static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
@@ -1215,6 +1216,12 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
     // mode 2: persistent kernel confined to one XCD; 1: persistent kernel across the XCDs; 0: one launch per step
     int mode = (rawn == 0 && !no_coop) ? (xcd_usable(ncap) ? 2 : 1) : 0;
+    // after a persistent kernel ran out of patience (its workgroups could not all become resident: the GPU is shared with
+    // other work) the next solves go straight to the launch-per-step path instead of each paying the wait again
+    if (mode && e->cooldown > 0) {
+        e->cooldown--;
+        mode = 0;
+    }
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
@@ -1248,6 +1255,7 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
             mode = 1;
         } else {
             e->coop_aborts++;
+            e->cooldown = 32;
             mode = 0;
         }
     }
