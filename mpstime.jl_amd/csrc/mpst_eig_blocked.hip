@@ -782,17 +782,24 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
             }
     }
     __syncthreads();
+    // the multipliers of the two substitutions do not depend on the running product: all threads form them first (the
+    // reciprocals leave the serial chains, which are then one multiply per row), in place of the pivots they replace
+    for (int j = tid; j < n; j += BT_T) {
+        if (j < rb) Dp[j] = -(es[j] * frcp(Dp[j]));
+        else if (j > rb) Dm[j] = -(es[j - 1] * frcp(Dm[j]));
+    }
+    __syncthreads();
     if (tid == 0) {
         double zc = 1.0;
         z[rb] = 1.0;
         for (int j = rb - 1; j >= 0; --j) {
-            zc = -(es[j] * frcp(Dp[j])) * zc;
+            zc = Dp[j] * zc;
             z[j] = zc;
         }
     } else if (tid == 64) {
         double zc = 1.0;
         for (int j = rb + 1; j < n; ++j) {
-            zc = -(es[j - 1] * frcp(Dm[j])) * zc;
+            zc = Dm[j] * zc;
             z[j] = zc;
         }
     }
