@@ -40,6 +40,12 @@ struct Ctx {
     double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
     double *gram = nullptr, *lam = nullptr, *E = nullptr, *eig_ws = nullptr;
     double *btn = nullptr, *norm_part = nullptr;
+    // sliced bond GEMMs (k_yhat_s / k_grad_s): slice contributions to yhat, loss pieces, arrival tickets
+    double *b2_ypart = nullptr, *b2_lossp = nullptr;
+    unsigned int* b2_tick = nullptr;
+    unsigned long long* b2_dbg = nullptr;   // bring-up stamps of the sliced kernels (MPST_B2_DEBUG builds)
+    int b2_ksplit = 0, b2_norm_parts = 0;
+    bool b2 = false;            // the fused chain uses k_yhat_s + k_grad_s instead of k_bond_fused + k_fused_reduce
     double* loss_trace = nullptr;   // track_cost: [2(T-1)][update_iters + 1]
     int n_norm_part = 0;
     bool fused = false;        // bond tensors <= MAX_DIM^2 and no rescale[1]: the 7-launch chain of mpst_fused.hip
@@ -120,7 +126,7 @@ void dfree(T** p) {
 }
 
 void free_dataset(DataSet& s) {
-    dfree(&s.phi); dfree(&s.label); dfree(&s.tiles); dfree(&s.chunks); dfree(&s.cls_chunk_off); dfree(&s.inv_count);
+    dfree(&s.phi); dfree(&s.label); dfree(&s.tiles); dfree(&s.chunks); dfree(&s.cls_chunk_off); dfree(&s.cls_off); dfree(&s.inv_count);
     for (int k = 0; k < 2; ++k) { dfree(&s.parts[k]); dfree(&s.part_off[k]); }
     s = DataSet();
 }
@@ -144,6 +150,7 @@ View make_view(Ctx* c, int which) {
     v.parts = s.parts[pk]; v.part_off = s.part_off[pk]; v.nparts = s.nparts[pk];
     v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
     v.trace = nullptr; v.trace_it = 0; v.yhat_scaled = 0;
+    v.cls_off = s.cls_off; v.ypart = c->b2_ypart; v.lossp = c->b2_lossp; v.tick = c->b2_tick; v.b2_ksplit = c->b2_ksplit; v.dbg = c->b2_dbg;
     return v;
 }
 
@@ -192,8 +199,25 @@ int ensure_workspace(Ctx* c) {
     c->fused = dm <= MAX_DIM && !c->opt.rescale_before && getenv("MPST_NO_FUSED") == nullptr;
     const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
     (void)pk;
+    c->b2 = c->fused && c->d >= 2 && c->d <= 16 && getenv("MPST_NO_B2") == nullptr;
     if (c->fused) {
         c->partial_elems = (int64_t)std::max(tr.nparts[0], tr.nparts[1]) * Lmax;   // independent of N: one partial per persistent workgroup
+        if (c->b2) {
+            View gv{};
+            gv.C = c->C; gv.d = c->d; gv.cap = c->cap;
+            const int64_t max_pass = tr.N;                  // MSE walks every series in every pass; KLD at most that
+            c->b2_ksplit = b2_ksplit(gv, max_pass);
+            c->b2_norm_parts = c->C * b2_blocks_cap(gv);
+            c->partial_elems = std::max(c->partial_elems, b2_partial_elems(gv, max_pass));
+            if ((rc = dalloc(c, &c->b2_ypart, (int64_t)2 * c->C * tr.N))) return rc;
+            if ((rc = dalloc(c, &c->b2_lossp, (int64_t)c->C * 64))) return rc;
+            if ((rc = dalloc(c, &c->b2_tick, (int64_t)c->b2_norm_parts + 1))) return rc;
+            HIPC(c, hipMemset(c->b2_tick, 0, (size_t)(c->b2_norm_parts + 1) * sizeof(unsigned int)));
+#ifdef MPST_B2_DEBUG
+            if ((rc = dalloc(c, &c->b2_dbg, 8192 * 8))) return rc;
+            HIPC(c, hipMemset(c->b2_dbg, 0, 8192 * 8 * sizeof(unsigned long long)));
+#endif
+        }
     } else {
         const int nbcap = ((dm + GB - 1) / GB) * ((dm + GB - 1) / GB);
         c->partial_elems = (int64_t)c->C * grad_nsplit(tr.nchunks, nbcap, c->C) * Lmax;    // one partial per k_grad workgroup share, independent of N
@@ -203,7 +227,7 @@ int ensure_workspace(Ctx* c) {
     c->n_norm_part = (int)((c->C * Lmax + 63) / 64);      // RED_E entries per workgroup of k_fused_reduce
     if ((rc = dalloc(c, &c->loss_trace, (int64_t)2 * (c->T - 1) * (c->opt.update_iters + 1)))) return rc;
     HIPC(c, hipMemset(c->loss_trace, 0, (size_t)2 * (c->T - 1) * (c->opt.update_iters + 1) * sizeof(double)));
-    if ((rc = dalloc(c, &c->norm_part, c->n_norm_part))) return rc;
+    if ((rc = dalloc(c, &c->norm_part, std::max(c->n_norm_part, c->b2_norm_parts)))) return rc;
     if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax))) return rc;
     HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax) * sizeof(double)));
     const int dmx = std::max(dm, MAX_DIM);
@@ -333,8 +357,13 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         const int chain = (next_bt_lid >= 0 && next_bt_lid == (going_left ? lid - 1 : lid + 1)) ? 1 : 0;
         if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }   // flatten_bt :733/:777
         for (int it = 0; it < iters; ++it) {                                     // TSGO/custGD :44,:75
-            { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }        // yhat + gradient partials
-            { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
+            if (c->b2) {
+                { ProfScope p(c, K_YHAT); launch_yhat_s(v, lid, s); }           // yhat, by column slices of B_c
+                { ProfScope p(c, K_GRAD); launch_grad_s(v, lid, s); }           // gradient blocks, reduced by their last arriver
+            } else {
+                { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }    // yhat + gradient partials
+                { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
+            }
             if (c->nranks > 1) {
                 ProfScope p(c, K_ALLREDUCE);
                 int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
@@ -344,7 +373,13 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             v.trace_it = it;
             if (it + 1 < iters) { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
         }
-        { ProfScope p(c, K_GRAM); launch_gram_upd(v, lid, going_left, iters == 1, s); }   // last step + decomposeBT :756/:798
+        {
+            ProfScope p(c, K_GRAM);                                               // last step + decomposeBT :756/:798
+            View vg = v;
+            // pieces of ||grad||^2: one per gradient block from k_grad_s; after an all-reduce k_grad_norm has rewritten them
+            if (c->b2 && c->nranks == 1) vg.n_norm_part = c->b2_norm_parts;
+            launch_gram_upd(vg, lid, going_left, iters == 1, s);
+        }
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
         { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
@@ -498,6 +533,7 @@ void mpst_destroy(void* ctx) {
     if (c->big) big_eig_destroy(c->big);
     if (c->blk) blocked_eig_destroy(c->blk);
     dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
+    dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -671,6 +707,12 @@ static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N
     HIPC(c, hipMemcpy(s.chunks, chunks.data(), chunks.size() * sizeof(Span), hipMemcpyHostToDevice));
     if ((rc = dalloc(c, &s.cls_chunk_off, C + 1))) return rc;
     HIPC(c, hipMemcpy(s.cls_chunk_off, coff.data(), (size_t)(C + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> soff(C + 1, 0);
+        for (int k = 0; k < C; ++k) soff[k + 1] = soff[k] + (int32_t)s.counts[k];
+        if ((rc = dalloc(c, &s.cls_off, C + 1))) return rc;
+        HIPC(c, hipMemcpy(s.cls_off, soff.data(), (size_t)(C + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     // parts of the fused gradient kernel: class-pure runs of whole 16-series tiles, about PARTS_TARGET of them
     {
         int64_t tiles_total = 0;
@@ -1435,6 +1477,16 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     us[3] = 0.01 * (double)(t[5] - t[4]);                     //                    back-transformation
     us[4] = 0.01 * (double)(t[9] - t[8]);                     // k_eig_fin: truncation, verification, Loewdin
     us[5] = (double)(t[7] - t[6]);                            // shader cycles spent in the tridiagonalisation
+    return 0;
+}
+
+// not part of the ABI: stamps of the sliced bond kernels (-DMPST_B2_DEBUG builds), 8192 x 8 slots
+int mpst_debug_b2(void* ctx, unsigned long long* out) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->b2_dbg || !out) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(out, c->b2_dbg, 8192 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

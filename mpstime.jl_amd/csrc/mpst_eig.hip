@@ -401,6 +401,9 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         dslot = (stamps && i == 60 && lane == 0) ? (wave == 12 ? 16 : wave == 6 ? 24 : wave == 7 ? 32 : -1) : -1;
 #endif
         DBG(0);
+#ifdef MPST_TRI_STEPPROF
+        if (stamps && tid == 0) stamps[64 + i] = __builtin_readcyclecounter();
+#endif
         if (!live) flush_reflector();              // a helper wave is idle in this phase
         if (live) {
 #pragma unroll

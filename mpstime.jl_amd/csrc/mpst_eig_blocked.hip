@@ -66,7 +66,10 @@ struct BtBufs {
     int32_t* flag;   // [1] 0 ok, 1 = verification failed (host falls back to the library)
     int32_t* ctl;    // [4] see k_bt_decide
     int ncap;
+    const int32_t* abort;   // persistent tridiagonalisation's abort word (null on the launch-per-step path): when it is set,
+                            // dd / ee / Vall are stale or partial and every kernel after it must leave without publishing
 };
+__device__ __forceinline__ bool bt_aborted(const BtBufs& b) { return b.abort && *(const volatile int32_t*)b.abort != 0; }
 
 // the sum a 512-thread workgroup (8 waves, added in wave order) forms, from 256 threads that each carry the partial sums of
 // two of its threads (t and t + 256)
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x;
-    if (k >= pb.K0) return;
+    if (k >= pb.K0 || bt_aborted(b)) return;
     double* de = smem;                  // [n + 8][2] (d_j, e_{j-1}^2), padded for sturm_count's groups of 8 rows
     double* es = de + 2 * (BT_NMAX + 8);      // [n]
     double* Dp = es + BT_NMAX;          // [n] forward pivots
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
 __global__ __launch_bounds__(BT_T) void k_bt_gram(View v, int lid, int going_left, int rawn, BtBufs b, int second) {
     __shared__ double part[4][256];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
-    if (second && !b.ctl[2]) return;
+    if (bt_aborted(b) || (second && !b.ctl[2])) return;
     const int n = pb.n, ld = b.ncap, K0 = pb.K0;
     const int tk = (K0 + 15) >> 4;
     if ((int)blockIdx.x >= tk * tk) return;
@@ -976,6 +979,10 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     const bool raw = rawn > 0;
     const int tid = threadIdx.x;
     const int n = pb.n, nspec = pb.nspec, K0 = pb.K0;
+    if (bt_aborted(b)) {                // nothing is published; the host redoes the bond (it reads the abort word first)
+        if (tid == 0) *b.flag = 1;
+        return;
+    }
     if (second) {
         // after the first polish: is the deviation of the polished vectors already at rounding?
         if (!b.ctl[2]) return;
@@ -995,13 +1002,26 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
         }
         return;
     }
-    double part = 0.0;
-    for (int i = tid; i < n; i += 512) part += pb.G[(size_t)i * n + i];
-    double tr = wave_sum(part);
-    if ((tid & 63) == 0) red[tid >> 6] = tr;
+    double part = 0.0, partT = 0.0;
+    for (int i = tid; i < n; i += 512) {
+        part += pb.G[(size_t)i * n + i];
+        partT += b.dd[i];
+    }
+    double tr = wave_sum(part), trT = wave_sum(partT);
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = tr;
+        red[8 + (tid >> 6)] = trT;
+    }
     __syncthreads();
     tr = 0.0;
-    for (int i = 0; i < 8; ++i) tr += red[i];
+    trT = 0.0;
+    for (int i = 0; i < 8; ++i) {
+        tr += red[i];
+        trT += red[8 + i];
+    }
+    // the one check of T against G itself (residuals and orthonormality below are relative to T): an orthogonal
+    // similarity keeps the trace, so a tridiagonal matrix that belongs to another bond does not pass
+    const bool trace_ok = fabs(trT - tr) <= 1e-9 * fabs(tr) + 1e-300;
     if (tid < K0) lam_s[tid] = fmax(b.lam[tid], 0.0);
     __syncthreads();
     const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
@@ -1038,7 +1058,7 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     for (int i = 0; i < 8; ++i) emax = fmax(emax, red[i]);
     // vectors of eigenvalues close to the cutoff come out of the twisted factorisation orthogonal to ~1e-6 only (two
     // Loewdin rounds take them to rounding); |D| > 1e-3 means a genuine cluster -> library solver
-    const bool ok = rmax < 1e-8 && rmax == rmax && emax < 1e-3 && emax == emax;
+    const bool ok = rmax < 1e-8 && rmax == rmax && emax < 1e-3 && emax == emax && trace_ok;
     if (tid == 0) {
         b.ctl[0] = kout;
         b.ctl[1] = ok ? 1 : 0;
@@ -1072,7 +1092,7 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
 // 16 x 16 tiles of E on the MFMA, A operand = Z^T, B operand = -D/2 + I.  second = 1: the input is the first round's E.
 __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_left, int rawn, BtBufs b, double* rawE, int second) {
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
-    if (!b.ctl[1] || (second && !b.ctl[2])) return;
+    if (bt_aborted(b) || !b.ctl[1] || (second && !b.ctl[2])) return;
     const bool raw = rawn > 0;
     const int n = pb.n, ld = b.ncap, kout = b.ctl[0];
     const bool corr = second ? true : (b.ctl[3] != 0);
@@ -1109,7 +1129,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_l
 // second round: the polished vectors become the input (Z <- E^T)
 __global__ __launch_bounds__(BT_T) void k_bt_copyback(View v, int lid, int going_left, int rawn, BtBufs b, const double* rawE) {
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
-    if (!b.ctl[2]) return;
+    if (bt_aborted(b) || !b.ctl[2]) return;
     const bool raw = rawn > 0;
     const int n = pb.n, ld = b.ncap, kout = b.ctl[0];
     const double* E = raw ? rawE : v.E;
@@ -1248,7 +1268,9 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
                 hipLaunchKernelGGL(k_bt_step, dim3(g), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, j);
             }
         }
-        enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, b, s);
+        BtBufs bt = b;
+        bt.abort = mode ? e->cp.abort_flag : nullptr;
+        enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, bt, s);
         e->host_flag[1] = 0;
         if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
         if (mode && hipMemcpyAsync(e->host_flag + 1, e->cp.abort_flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;

@@ -704,6 +704,338 @@ __global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_le
     }
 }
 
+// =====================================================================================================================
+// Sliced bond GEMMs (round 3): k_yhat_s + k_grad_s replace k_bond_fused + k_fused_reduce.
+//
+// k_bond_fused keeps a whole B_c (128 KB) per workgroup and writes a whole partial gradient (128 KB) per workgroup: at
+// N = 4096 both transfers cost more than the matrix work between them, and the partials (16.8 MB written, then re-read by
+// k_fused_reduce) are 14x the algorithmic bytes of the bond.  Here no workgroup moves more than ~50 KB either way:
+//   k_yhat_s   yhat_i = X_i^T B_c Y_i split over 64-column slices of B_c: one workgroup = 32 series x 64 columns, the
+//              slices' contributions go to ypart[slice][.] and are added in slice order by whoever reads them.
+//   k_grad_s   output-stationary gradient: one workgroup = one (class, 32 x 32 block of G_c, share of the class' series);
+//              a block is (a range of the left bond) x (all left site states) by (all right site states) x (a range of
+//              the right bond), so a series contributes 2 (32/d + d) numbers to it instead of a whole environment row.
+//              The shares of a block meet through memory: write-through partials (8 KB each), a ticket per block, and the
+//              LAST arriver adds them in share order - a fixed order, so the result does not depend on who was last -
+//              scales, writes the gradient and the block's piece of ||grad||^2.  The last block to finish adds the loss
+//              pieces.  loss_functions.jl:248-262,353-369 (KLD), :489-531,600-612 (MSE).
+// =====================================================================================================================
+struct B2 {
+    int Dl, Dr, X, Y;
+    int64_t L;
+    int aw, bw;         // bond entries per x / y block: aw*d <= 32 rows, d*bw <= 32 columns
+    int nbx, nby;       // live blocks
+};
+__device__ __forceinline__ B2 b2_dims(const View& v, int lid) {
+    B2 b;
+    b.Dl = v.chi[lid];
+    b.Dr = v.chi[lid + 2];
+    b.X = b.Dl * v.d;
+    b.Y = v.d * b.Dr;
+    b.L = (int64_t)b.X * b.Y;
+    b.aw = max(1, 32 / v.d);
+    b.bw = b.aw;
+    b.nbx = (b.Dl + b.aw - 1) / b.aw;
+    b.nby = (b.Dr + b.bw - 1) / b.bw;
+    return b;
+}
+__device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int YS_T = 512;        // 8 waves: wave = (tile 0..1 of the group, 16-column tile 0..3 of the slice)
+constexpr int YS_COLS = 64;      // columns of B_c per slice
+
+// grid.x = 8 * nslc * ghc (see launch_yhat_s): workgroup id -> (group g = 8 gh + gl, slice sl); grid.y = passes (MSE: C)
+template <int DM>
+__global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ghc) {
+    __shared__ __attribute__((aligned(16))) double Xs[2][16 * FXS];
+    __shared__ double red[2][4][16];
+    const B2 b = b2_dims(v, lid);
+    const int d = v.d, rid = lid + 1;
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int id = blockIdx.x, gl = id & 7, rest = id >> 3, sl = rest % nslc, gh = rest / nslc;
+    if (sl * YS_COLS >= b.Y) return;
+    const int pass = mse ? (int)blockIdx.y : 0;
+    const int tsel = wave >> 2, ct = wave & 3;
+    const int col = sl * YS_COLS + ct * 16 + i16;
+    const bool cv = col < b.Y;
+    const int sp = cv ? col / b.Dr : 0, bb = cv ? col - sp * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+    const int ngroups = (v.ntiles + 1) >> 1;
+    const int half = tid >> 8, st = tid & 255;             // threads 0..255 stage tile 2g, 256..511 tile 2g + 1
+    const int XP = (b.X + 3) & ~3;
+    double* ypart = v.ypart + ((int64_t)sl * (mse ? v.C : 1) + pass) * v.N;
+
+    d4 bq[8];
+    int cur_cls = -1;
+    int g = gh * 8 + gl;
+    if (g >= ngroups) return;
+#ifdef MPST_B2_DEBUG
+    unsigned long long* dbg = (v.dbg && tid == 0) ? v.dbg + (4096 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+    int dbi = 0;
+#define YSTAMP() do { if (dbg && dbi < 8) dbg[dbi++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define YSTAMP() do { } while (0)
+#endif
+    YSTAMP();
+    StageRegs<DM> sr;
+    Span tst = (2 * g + half < v.ntiles) ? v.tiles[2 * g + half] : Span{0, 0, 0, 0};
+    stage16_load(sr, tst.start, tst.count, LEp, b.Dl, phl, d, v.cap, st);
+    for (; g < ngroups; g += 8 * ghc) {
+        const Span tl = (2 * g + tsel < v.ntiles) ? v.tiles[2 * g + tsel] : Span{0, 0, 0, 0};
+        const int cls = mse ? pass : tl.cls;
+        if (cls != cur_cls) {                              // (wave-uniform) B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
+            const double* Bc = v.bt + (int64_t)cls * b.L;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int x = 16 * mt + kq + 4 * r;
+                    bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
+                }
+            cur_cls = cls;
+        }
+        double yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = kq + 4 * r;
+            const int64_t smp = tl.start + (i < tl.count ? i : 0);
+            yv[r] = (cv && i < tl.count) ? phr[smp * d + sp] * (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
+        }
+        YSTAMP();
+        __syncthreads();                                   // the previous group's tiles are consumed
+        stage16_store(sr, Xs[half], tst.start, tst.count, b.Dl, phl, d, true, st);
+        __syncthreads();
+        YSTAMP();
+        if (g + 8 * ghc < ngroups) {                       // the next group's rows fly during this group's matrix work
+            const int gn = g + 8 * ghc;
+            tst = (2 * gn + half < v.ntiles) ? v.tiles[2 * gn + half] : Span{0, 0, 0, 0};
+            stage16_load(sr, tst.start, tst.count, LEp, b.Dl, phl, d, v.cap, st);
+        }
+        const double* Xt = Xs[tsel];
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 32; u += 2) {
+            if (4 * u < XP) acc0 = mfma_f64(Xt[i16 * FXS + 4 * u + kq], bq[u >> 2][u & 3], acc0);
+            if (4 * u + 4 < XP) acc1 = mfma_f64(Xt[i16 * FXS + 4 * u + 4 + kq], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+            if ((u & 7) == 6) asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double x = sum16((acc0[r] + acc1[r]) * yv[r]);
+            if (i16 == 0) red[tsel][ct][kq + 4 * r] = x;
+        }
+        YSTAMP();
+        __syncthreads();
+        if (tid < 32) {
+            const int ts = tid >> 4, j = tid & 15;
+            if (2 * g + ts < v.ntiles) {
+                const Span tt = v.tiles[2 * g + ts];
+                if (j < tt.count) ypart[tt.start + j] = (red[ts][0][j] + red[ts][1][j]) + (red[ts][2][j] + red[ts][3][j]);
+            }
+        }
+    }
+}
+
+constexpr int GS_T = 512;        // 8 waves: wave = (MFMA tile 0..3 of the 32 x 32 block, half of a stage's series)
+constexpr int GS_KC = 64;        // series per stage
+constexpr int GS_LS = 17;        // LDS row stride of the staged factors (<= 16 entries per series and factor)
+
+// grid.x = ksplit * nbxc * nbyc (capacity), grid.y = C.  Workgroup id -> (ks = id % ksplit, block = id / ksplit).
+__global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbxc, int nbyc) {
+    __shared__ double As[GS_KC * GS_LS], Pl[GS_KC * GS_LS], Bs[GS_KC * GS_LS], Pr[GS_KC * GS_LS];
+    __shared__ double comb[4][256];
+    __shared__ double redl[8];
+    __shared__ int last_s;
+    const B2 b = b2_dims(v, lid);
+    const int d = v.d, rid = lid + 1;
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int c = blockIdx.y;
+    const int ks = (int)blockIdx.x % ksplit, blk = (int)blockIdx.x / ksplit;
+    const int bx = blk / nbyc, by = blk % nbyc;
+    const int grp = c * nbxc * nbyc + blk;                  // ticket / norm-piece slot (capacity layout)
+    if (bx >= b.nbx || by >= b.nby) {
+        if (ks == 0 && tid == 0) v.norm_part[grp] = 0.0;    // a block that is not live at this bond contributes nothing
+        return;
+    }
+    const int nsl = (b.Y + YS_COLS - 1) / YS_COLS;
+    // the series of this pass and this workgroup's share of them
+    int p0 = 0, p1 = (int)v.N;
+    if (!mse) {
+        p0 = v.cls_off[c];
+        p1 = v.cls_off[c + 1];
+    }
+    int len = (p1 - p0 + ksplit - 1) / ksplit;
+    len = (len + 3) & ~3;
+    const int s0 = min(p1, p0 + ks * len), s1 = min(p1, s0 + len);
+    const int a0 = bx * b.aw, b0 = by * b.bw;
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * d;
+    const double* phr = v.phi + (int64_t)rid * v.N * d;
+    const double* yp0 = v.ypart + (int64_t)(mse ? c : 0) * v.N;
+    const double* yp1 = v.ypart + ((int64_t)(mse ? v.C : 1) + (mse ? c : 0)) * v.N;
+    // loader role: series lsm = tid / 8 of the stage, entries j and j + 8 of every factor
+    const int lsm = tid >> 3, j = tid & 7;
+    double r_le[2], r_re[2], r_pl[2], r_pr[2], r_y = 1.0, r_dl = 0.0;
+    bool r_ok = false;
+    auto load_stage = [&](int base) {
+        const int smp = base + lsm;
+        r_ok = smp < s1;
+        const int64_t sm = r_ok ? smp : s0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int jj = j + 8 * h;
+            r_le[h] = (r_ok && jj < b.aw && a0 + jj < b.Dl) ? (LEp ? LEp[sm * v.cap + a0 + jj] : 1.0) : 0.0;
+            r_re[h] = (r_ok && jj < b.bw && b0 + jj < b.Dr) ? (REn ? REn[sm * v.cap + b0 + jj] : 1.0) : 0.0;
+            r_pl[h] = (r_ok && jj < d) ? phl[sm * d + jj] : 0.0;
+            r_pr[h] = (r_ok && jj < d) ? phr[sm * d + jj] : 0.0;
+        }
+        if (r_ok) {
+            r_y = yp0[sm];
+            if (nsl > 1) r_y += yp1[sm];
+            r_dl = (mse && v.label[sm] == c) ? 1.0 : 0.0;
+        }
+    };
+    // consumer role: tile (tx, ty) of the block, series 4 u + kq of the wave's half of the stage
+    const int tile = wave & 3, kh = wave >> 2;
+    const int tx = tile >> 1, ty = tile & 1;
+    const int xr = 16 * tx + i16, yc = 16 * ty + i16;           // block-local row / column this lane feeds
+    const int al = xr / d, slx = xr - al * d;                   // X_i[row] = LE_i[a0 + al] * phi_l[i][slx]
+    const int spl = yc / b.bw, bl = yc - spl * b.bw;            // Y_i[col] = phi_r[i][spl] * RE_i[b0 + bl]
+    const bool xv = al < b.aw && a0 + al < b.Dl, yvld = spl < d && b0 + bl < b.Dr;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    double loss = 0.0;
+    const bool do_loss = bx == 0 && by == 0;
+#ifdef MPST_B2_DEBUG
+    unsigned long long* dbg = (v.dbg && tid == 0) ? v.dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define GSTAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+    GSTAMP(0);
+    if (s0 < s1) load_stage(s0);
+    for (int base = s0; base < s1; base += GS_KC) {
+        __syncthreads();                                   // the previous stage is consumed
+        {
+            double w = 0.0;
+            if (r_ok) {
+                w = mse ? (r_y - r_dl) : 1.0 / r_y;                                              // :489,:608 / :258,:367
+                if (do_loss && j == 0) loss += mse ? 0.5 * (r_y - r_dl) * (r_y - r_dl) : -log(r_y * r_y);   // :554 / :318
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int jj = j + 8 * h;
+                As[lsm * GS_LS + jj] = r_le[h];
+                Bs[lsm * GS_LS + jj] = r_re[h];
+                Pl[lsm * GS_LS + jj] = r_pl[h];
+                Pr[lsm * GS_LS + jj] = w * r_pr[h];
+            }
+        }
+        __syncthreads();
+        if (base + GS_KC < s1) load_stage(base + GS_KC);   // the next stage's loads fly during the matrix work
+#pragma unroll
+        for (int u = 0; u < GS_KC / 8; ++u) {
+            const int sm = 4 * (kh * (GS_KC / 8) + u) + kq;
+            if (base + 4 * (kh * (GS_KC / 8) + u) < s1) {          // wave-uniform: whole k-steps beyond the share are skipped
+                const double a = xv ? As[sm * GS_LS + al] * Pl[sm * GS_LS + slx] : 0.0;
+                const double bb = yvld ? Bs[sm * GS_LS + bl] * Pr[sm * GS_LS + spl] : 0.0;
+                acc = mfma_f64(a, bb, acc);
+            }
+        }
+    }
+    GSTAMP(1);
+    // the two halves of every tile meet in LDS: (half 0) + (half 1)
+    if (kh == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) comb[tile][r * 64 + lane] = acc[r];
+    }
+    if (do_loss) {                                          // only the lanes j == 0 carry a term
+        loss = wave_sum(loss);
+        if (lane == 0) redl[wave] = loss;
+    }
+    __syncthreads();
+    double* part = v.partial + ((int64_t)grp * ksplit + ks) * 1024;
+    if (kh == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * tx + kq + 4 * r, colb = 16 * ty + i16;
+            st_agent(part + row * 32 + colb, acc[r] + comb[tile][r * 64 + lane]);
+        }
+    }
+    if (do_loss && tid == 0) {
+        double l = 0.0;
+        for (int w = 0; w < 8; ++w) l += redl[w];
+        st_agent(v.lossp + c * ksplit + ks, l);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have left before the ticket is taken
+    __syncthreads();
+    GSTAMP(2);
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(v.tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = (t == (unsigned)ksplit - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    GSTAMP(3);
+    if (!last_s) return;
+    // ---- last arriver of this block: add the shares in share order, scale, publish ---------------------------------------
+    const double scale = mse ? v.invN : -(v.train_sep ? v.inv_count[c] : v.invN);           // :608 / :367,:424
+    const double* pbase = v.partial + (int64_t)grp * ksplit * 1024;
+    double n2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = tid + GS_T * e, row = idx >> 5, colb = idx & 31;
+        double s = 0.0;
+        for (int k0 = 0; k0 < ksplit; k0 += 8) {           // 8 loads in flight, added in share order
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (k0 + u < ksplit) ? ld_agent(pbase + (int64_t)(k0 + u) * 1024 + idx) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        const int aa = row / d, sx = row - aa * d, sy = colb / b.bw, bb2 = colb - sy * b.bw;
+        if (aa < b.aw && a0 + aa < b.Dl && sy < d && b0 + bb2 < b.Dr) {
+            const double gval = s * scale;
+            v.gradbuf[2 + (int64_t)c * b.L + (int64_t)((a0 + aa) * d + sx) * b.Y + sy * b.Dr + b0 + bb2] = gval;
+            n2 = fma(gval, gval, n2);
+        }
+    }
+    n2 = wave_sum(n2);
+    __syncthreads();
+    if (lane == 0) redl[wave] = n2;
+    __syncthreads();
+    GSTAMP(4);
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 8; ++w) t += redl[w];
+        v.norm_part[grp] = t;
+        __hip_atomic_store(v.tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the last block of the launch to finish adds the loss pieces (fixed order)
+        const unsigned total = (unsigned)(v.C * b.nbx * b.nby);
+        const unsigned t2 = __hip_atomic_fetch_add(v.tick + v.C * nbxc * nbyc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t2 == total - 1) {
+            double l = 0.0;
+            for (int cc = 0; cc < v.C; ++cc) {
+                const double w = mse ? v.invN : (v.train_sep ? v.inv_count[cc] : v.invN);     // :612 / :423,:371
+                double lc = 0.0;
+                for (int k = 0; k < ksplit; ++k) lc += ld_agent(v.lossp + cc * ksplit + k);
+                l += lc * w;
+            }
+            v.gradbuf[0] = l;
+            v.gradbuf[1] = 0.0;
+            __hip_atomic_store(v.tick + v.C * nbxc * nbyc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        GSTAMP(5);
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static inline int cdivf(int a, int b) { return (a + b - 1) / b; }
 
@@ -713,6 +1045,32 @@ void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s) {
 }
 void launch_fused_reduce(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_fused_reduce, dim3(v.n_norm_part), dim3(256), 0, s, v, lid);
+}
+// ---- sliced bond GEMMs: host-side geometry (depends on capacity, d, C and the data set only) -------------------------------
+int b2_blocks_cap(const View& v) {
+    const int aw = std::max(1, 32 / v.d);
+    return cdivf(v.cap, aw) * cdivf(v.cap, aw);
+}
+int b2_ksplit(const View& v, int64_t max_pass) {
+    static const int tgt = [] { const char* e = getenv("MPST_B2_WG"); return e ? std::max(1, atoi(e)) : 256; }();
+    const int groups = v.C * b2_blocks_cap(v);
+    int ks = std::max(1, tgt / groups);
+    ks = (int)std::min<int64_t>(ks, std::max<int64_t>(1, (max_pass + GS_KC - 1) / GS_KC));
+    return std::min(ks, 64);
+}
+int64_t b2_partial_elems(const View& v, int64_t max_pass) { return (int64_t)v.C * b2_blocks_cap(v) * b2_ksplit(v, max_pass) * 1024; }
+void launch_yhat_s(const View& v, int lid, hipStream_t s) {
+    const int nslc = cdivf(v.d * v.cap, YS_COLS);
+    const int ngroups = (v.ntiles + 1) / 2;
+    const int ghc = std::max(1, std::min(cdivf(ngroups, 8), 32));
+    const dim3 grid(8 * nslc * ghc, v.loss == MPST_LOSS_MSE ? v.C : 1);
+    if (v.d <= 4) hipLaunchKernelGGL(k_yhat_s<4>, grid, dim3(YS_T), 0, s, v, lid, nslc, ghc);
+    else hipLaunchKernelGGL(k_yhat_s<8>, grid, dim3(YS_T), 0, s, v, lid, nslc, ghc);
+}
+void launch_grad_s(const View& v, int lid, hipStream_t s) {
+    const int aw = std::max(1, 32 / v.d);
+    const int nbc = cdivf(v.cap, aw);
+    hipLaunchKernelGGL(k_grad_s, dim3(v.b2_ksplit * nbc * nbc, v.C), dim3(GS_T), 0, s, v, lid, v.b2_ksplit, nbc, nbc);
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);

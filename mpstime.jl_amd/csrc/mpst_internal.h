@@ -323,6 +323,7 @@ struct DataSet {
     Span* chunks = nullptr;      // class-pure chunks of <= CHUNK_S series
     int32_t nchunks = 0;
     int32_t* cls_chunk_off = nullptr;  // [C+1] first chunk of each class
+    int32_t* cls_off = nullptr;        // [C+1] first series of each class
     double* inv_count = nullptr;       // [C] 1 / (global series count of the class)
     Part* parts[2] = {nullptr, nullptr};          // [0] KLD, [1] MSE
     int32_t nparts[2] = {0, 0};
@@ -360,6 +361,13 @@ struct View {
     int32_t nparts, n_norm_part;
     double* norm_part;  // [n_norm_part] pieces of ||grad||^2
     double* btn;        // bt_new, written by k_gram_upd
+    // sliced bond GEMMs (k_yhat_s / k_grad_s, mpst_fused.hip)
+    const int32_t* cls_off;   // [C+1] first series of every class
+    double* ypart;      // [2 slices][passes][N] contributions of the column slices of B_c to yhat
+    double* lossp;      // [C][ksplit] loss pieces
+    unsigned int* tick; // [C * blocks_cap + 1] arrival tickets of the gradient blocks, + the launch-wide one
+    int32_t b2_ksplit;  // shares the series of a pass are split into
+    unsigned long long* dbg;   // bring-up stamps (-DMPST_B2_DEBUG), else null
     double* trace;      // track_cost: this bond's row of the loss trace ([update_iters + 1]) or null
     int32_t trace_it;   // which entry the launch at hand fills
     int32_t yhat_scaled; // k_yhat: multiply yhat by sc->inv_norm (loss at the normalised bt_new)
@@ -378,6 +386,12 @@ struct View {
 void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s);
 void launch_fused_reduce(const View& v, int lid, hipStream_t s);
 void launch_grad_norm(const View& v, int lid, hipStream_t s);
+// sliced bond GEMMs (k_yhat_s + k_grad_s): the pair that replaces k_bond_fused + k_fused_reduce
+void launch_yhat_s(const View& v, int lid, hipStream_t s);
+void launch_grad_s(const View& v, int lid, hipStream_t s);
+int b2_blocks_cap(const View& v);                          // gradient blocks per class at the capacity bond dimension
+int b2_ksplit(const View& v, int64_t max_pass);            // shares per block; max_pass = most series any pass walks
+int64_t b2_partial_elems(const View& v, int64_t max_pass);
 void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
 void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);

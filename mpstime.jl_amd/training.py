@@ -129,20 +129,20 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
         log(0.0)                                                                 # :657-689
         for its in range(opts.nsweeps):                                          # :726
             if verbosity > -1:
-                print(f"Using optimiser CustomGD with the \"{eopt['bbopt']}\" algorithm")
+                print(f"Using optimiser CustomGD with the \"{engine_options(opts, its)['bbopt']}\" algorithm")
                 print(f"Starting backward sweeep: [{its + 1}/{opts.nsweeps}]")
             if its > 0 and (isinstance(opts.loss_grad, tuple) or isinstance(opts.bbopt, tuple)):
                 eng.set_options(rebuild_caches=False, track_cost=opts.track_cost, **engine_options(opts, its))   # :727-728: this sweep's loss / optimiser
             st = eng.sweep()                                                     # :727-808
             if opts.track_cost and verbosity >= 1:
                 # what custGD / TSGO (loss_functions.jl:50-52,80-82) and apply_update (:181-184) print, bond by bond
-                tr = eng.loss_trace()
+                trace = eng.loss_trace()
                 nb = len(W) - 1
                 for q in range(2 * nb):
                     lid = nb - 1 - q if q < nb else q - nb
                     for it in range(opts.update_iters):
-                        print(f"Loss before step {it + 1}: {tr[q, it]}")
-                    print(f"Loss at site {lid + 1}*{lid + 2}: {tr[q, opts.update_iters]}")
+                        print(f"Loss before step {it + 1}: {trace[q, it]}")
+                    print(f"Loss at site {lid + 1}*{lid + 2}: {trace[q, opts.update_iters]}")
             if verbosity > -1:
                 print(f"Finished sweep {its + 1}. Time for sweep: {round(st['seconds'], 2)}s")
             acc = log(st["seconds"])

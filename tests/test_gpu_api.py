@@ -117,7 +117,18 @@ def test_fitmps_with_per_sweep_loss_and_track_cost(capsys):
     assert info_c["train_KL_div"][1] == info_a["train_KL_div"][1]          # first sweep identical
     assert info_c["train_KL_div"][2] != info_a["train_KL_div"][2]          # second one used the other loss / optimiser
     capsys.readouterr()
-    mt.fitMPS(Xtr, ytr, opts=base.set(nsweeps=1, verbosity=1, track_cost=True))
+    res, _, _ = mt.fitMPS(Xtr, ytr, opts=base.set(nsweeps=1, verbosity=1, track_cost=True))
     out = capsys.readouterr().out
     assert out.count("Loss before step 1:") == 2 * 11 and out.count("Loss at site") == 2 * 11
     assert "Loss at site 11*12:" in out and "Loss at site 1*2:" in out
+    # the returned model still carries the encoded training set (not the loss trace), and survives save / load
+    assert isinstance(res.train_data, mt.EncodedTimeSeriesSet) and res.train_data.phi.shape[0] == 60
+    import tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "m.npz")
+        mt.save_trained_mps(path, res)
+        assert mt.load_trained_mps(path) == res
+    # per-sweep optimiser names are printed per sweep
+    mt.fitMPS(Xtr, ytr, opts=base.set(verbosity=0, bbopt=["TSGO", "GD"]))
+    out = capsys.readouterr().out
+    assert out.count('"TSGO" algorithm') == 1 and out.count('"GD" algorithm') == 1
