@@ -151,6 +151,17 @@ View make_view(Ctx* c, int which) {
     v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
     v.trace = nullptr; v.trace_it = 0; v.yhat_scaled = 0;
     v.cls_off = s.cls_off; v.ypart = c->b2_ypart; v.lossp = c->b2_lossp; v.tick = c->b2_tick; v.b2_ksplit = c->b2_ksplit; v.dbg = c->b2_dbg;
+    {
+        int32_t so = 0, to = 0;
+        for (int k = 0; k <= MAX_C; ++k) {
+            v.kcls_off[k] = so;
+            v.kcls_tile[k] = to;
+            if (k < (int)s.counts.size()) {
+                so += (int32_t)s.counts[k];
+                to += (int32_t)((s.counts[k] + TILE_S - 1) / TILE_S);
+            }
+        }
+    }
     return v;
 }
 
@@ -209,8 +220,8 @@ int ensure_workspace(Ctx* c) {
             c->b2_ksplit = b2_ksplit(gv, max_pass);
             c->b2_norm_parts = c->C * b2_blocks_cap(gv);
             c->partial_elems = std::max(c->partial_elems, b2_partial_elems(gv, max_pass));
-            if ((rc = dalloc(c, &c->b2_ypart, (int64_t)2 * c->C * tr.N))) return rc;
-            if ((rc = dalloc(c, &c->b2_lossp, (int64_t)c->C * 64))) return rc;
+            if ((rc = dalloc(c, &c->b2_ypart, (int64_t)8 * c->C * tr.N))) return rc;
+            if ((rc = dalloc(c, &c->b2_lossp, (int64_t)c->C * 64))) return rc;     // GS_MAXKS shares per class
             if ((rc = dalloc(c, &c->b2_tick, (int64_t)c->b2_norm_parts + 1))) return rc;
             HIPC(c, hipMemset(c->b2_tick, 0, (size_t)(c->b2_norm_parts + 1) * sizeof(unsigned int)));
 #ifdef MPST_B2_DEBUG
@@ -251,6 +262,7 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->norm2, 1))) return rc;
     hipError_t ea = init_kernel_attrs(c->device);
     if (ea == hipSuccess) ea = eig_init_attrs(c->device);
+    if (ea == hipSuccess) ea = b2_init_attrs(c->device);
     if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
     c->ws_ready = true;
     c->eval_ready = false;
@@ -356,10 +368,13 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         // the next bond's tensor is assembled by this bond's last launch when the sweep moves on in the same direction
         const int chain = (next_bt_lid >= 0 && next_bt_lid == (going_left ? lid - 1 : lid + 1)) ? 1 : 0;
         if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }   // flatten_bt :733/:777
+        View vl = v;                      // after k_grad_s on one rank the loss is still in pieces (bond_loss)
+        vl.n_lossp = c->b2 ? c->b2_ksplit : 0;
         for (int it = 0; it < iters; ++it) {                                     // TSGO/custGD :44,:75
             if (c->b2) {
                 { ProfScope p(c, K_YHAT); launch_yhat_s(v, lid, s); }           // yhat, by column slices of B_c
                 { ProfScope p(c, K_GRAD); launch_grad_s(v, lid, s); }           // gradient blocks, reduced by their last arriver
+                if (c->nranks > 1) launch_loss_sum(vl, s);                      // the loss travels in gradbuf[0]
             } else {
                 { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }    // yhat + gradient partials
                 { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
@@ -371,11 +386,17 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
                 launch_grad_norm(v, lid, s);
             }
             v.trace_it = it;
-            if (it + 1 < iters) { ProfScope p(c, K_UPDATE); launch_update(v, lid, it == 0, s); }
+            if (it + 1 < iters) {
+                ProfScope p(c, K_UPDATE);
+                View vu = v;
+                if (c->b2 && c->nranks == 1) vu.n_lossp = c->b2_ksplit;
+                launch_update(vu, lid, it == 0, s);
+            }
         }
         {
             ProfScope p(c, K_GRAM);                                               // last step + decomposeBT :756/:798
             View vg = v;
+            if (c->b2 && c->nranks == 1) vg.n_lossp = c->b2_ksplit;
             // pieces of ||grad||^2: one per gradient block from k_grad_s; after an all-reduce k_grad_norm has rewritten them
             if (c->b2 && c->nranks == 1) vg.n_norm_part = c->b2_norm_parts;
             launch_gram_upd(vg, lid, going_left, iters == 1, s);

@@ -386,10 +386,10 @@ __global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_lef
     const double step = step_from_parts(v, red, &nrm);
     if (tile == 0 && threadIdx.x == 0) {
         if (first_iter) {
-            v.sc->loss = v.gradbuf[0];
+            v.sc->loss = bond_loss(v);
             v.sc->grad_norm = nrm;
         }
-        if (v.trace) v.trace[v.trace_it] = v.gradbuf[0];      // "Loss before step i" of the last iteration
+        if (v.trace) v.trace[v.trace_it] = bond_loss(v);      // "Loss before step i" of the last iteration
     }
     if (!live) return;
     d4 acc = {0, 0, 0, 0};
@@ -709,17 +709,21 @@ __global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_le
 //
 // k_bond_fused keeps a whole B_c (128 KB) per workgroup and writes a whole partial gradient (128 KB) per workgroup: at
 // N = 4096 both transfers cost more than the matrix work between them, and the partials (16.8 MB written, then re-read by
-// k_fused_reduce) are 14x the algorithmic bytes of the bond.  Here no workgroup moves more than ~50 KB either way:
-//   k_yhat_s   yhat_i = X_i^T B_c Y_i split over 64-column slices of B_c: one workgroup = 32 series x 64 columns, the
-//              slices' contributions go to ypart[slice][.] and are added in slice order by whoever reads them.
-//   k_grad_s   output-stationary gradient: one workgroup = one (class, 32 x 32 block of G_c, share of the class' series);
-//              a block is (a range of the left bond) x (all left site states) by (all right site states) x (a range of
-//              the right bond), so a series contributes 2 (32/d + d) numbers to it instead of a whole environment row.
-//              The shares of a block meet through memory: write-through partials (8 KB each), a ticket per block, and the
-//              LAST arriver adds them in share order - a fixed order, so the result does not depend on who was last -
-//              scales, writes the gradient and the block's piece of ||grad||^2.  The last block to finish adds the loss
-//              pieces.  loss_functions.jl:248-262,353-369 (KLD), :489-531,600-612 (MSE).
+// k_fused_reduce) are 14x the algorithmic bytes of the bond.  The pair below moves tens of KB per workgroup:
+//   k_yhat_s   yhat_i = X_i^T B_c Y_i split over 16-column slices of B_c: one workgroup = 128 series (one 16-series tile
+//              per wave) x one slice, so the B_c operand is 16 KB per workgroup and is shared by its 8 waves; X_i is formed
+//              on the fly from its factors (environment row, site vector) staged in LDS.  The slices' contributions go to
+//              ypart[series][slice] and are added in slice order by the reader.
+//   k_grad_s   output-stationary gradient: one workgroup = one (class, 16 x 16 block of G_c, share of the class' series).
+//              A block is (a range of the left bond) x (all left site states) by (all right site states) x (a range of
+//              the right bond), so a series contributes 2 (16/d + d) numbers to it instead of two environment rows.  The
+//              8 waves split the series and meet in LDS.  With ONE share per block (the headline shape) the block is final:
+//              no partial gradients exist at all.  With more shares (large N) they meet through memory: write-through
+//              partials (2 KB each), a ticket per block, and the LAST arriver adds them in share order - a fixed order, so
+//              the result does not depend on who was last.  loss_functions.jl:248-262,353-369 (KLD), :489-531,600-612 (MSE).
 // =====================================================================================================================
+constexpr int YS_W = 16;         // columns of B_c per slice
+constexpr int YS_MAXSL = 8;      // slices at the capacity of this path (d*chi <= 128)
 struct B2 {
     int Dl, Dr, X, Y;
     int64_t L;
@@ -742,39 +746,49 @@ __device__ __forceinline__ B2 b2_dims(const View& v, int lid) {
 __device__ __forceinline__ void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-constexpr int YS_T = 512;        // 8 waves: wave = (tile 0..1 of the group, 16-column tile 0..3 of the slice)
-constexpr int YS_COLS = 64;      // columns of B_c per slice
+constexpr int YS_T = 512;        // 8 waves, one 16-series tile each
 
-// grid.x = 8 * nslc * ghc (see launch_yhat_s): workgroup id -> (group g = 8 gh + gl, slice sl); grid.y = passes (MSE: C)
-template <int DM>
-__global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ghc) {
-    __shared__ __attribute__((aligned(16))) double Xs[2][16 * FXS];
-    __shared__ double red[2][4][16];
+// class-pure tile t of the data set from the tables in the kernel arguments (no dependent global load)
+__device__ __forceinline__ Span tile_span_k(const View& v, int t) {
+    int c = 0;
+#pragma unroll 1
+    for (int k = 1; k < v.C; ++k) c += (t >= v.kcls_tile[k]) ? 1 : 0;
+    Span s;
+    s.cls = c;
+    s.start = v.kcls_off[c] + TILE_S * (t - v.kcls_tile[c]);
+    s.count = t < v.ntiles ? min(TILE_S, v.kcls_off[c + 1] - s.start) : 0;
+    s.pad = 0;
+    return s;
+}
+
+// grid.x = nslc * ngw (see launch_yhat_s): workgroup id -> (group walker = id % ngw, slice = id / ngw); grid.y = passes (MSE: C)
+// Every wave stages, consumes and stores its own tile: no workgroup barrier, one round trip to memory per group.
+// LM: 16-entry pieces of an environment row a lane group fetches (capacity <= 16 LM); D4: d == 4 (the headline shapes).
+template <int LM, bool D4>
+__global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const B2 b = b2_dims(v, lid);
     const int d = v.d, rid = lid + 1;
     const bool mse = v.loss == MPST_LOSS_MSE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int id = blockIdx.x, gl = id & 7, rest = id >> 3, sl = rest % nslc, gh = rest / nslc;
-    if (sl * YS_COLS >= b.Y) return;
+    const int gw = (int)blockIdx.x % ngw, sl = (int)blockIdx.x / ngw;       // consecutive ids (XCDs) walk different series groups
+    if (sl * YS_W >= b.Y) return;
     const int pass = mse ? (int)blockIdx.y : 0;
-    const int tsel = wave >> 2, ct = wave & 3;
-    const int col = sl * YS_COLS + ct * 16 + i16;
+    const int col = sl * YS_W + i16;
     const bool cv = col < b.Y;
     const int sp = cv ? col / b.Dr : 0, bb = cv ? col - sp * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
     const double* phl = v.phi + (int64_t)lid * v.N * d;
     const double* phr = v.phi + (int64_t)rid * v.N * d;
-    const int ngroups = (v.ntiles + 1) >> 1;
-    const int half = tid >> 8, st = tid & 255;             // threads 0..255 stage tile 2g, 256..511 tile 2g + 1
+    const int ngroups = (v.ntiles + 7) >> 3;
+    const int ls = v.cap + 1, ps = d + 1;                  // LDS row strides (odd: the 16 rows a wave reads hit 16 banks)
+    double* LEs = smem + wave * 16 * (ls + ps);            // [16][ls] this wave's environment rows, zero beyond Dl
+    double* PHs = LEs + 16 * ls;                           // [16][ps] site vectors
     const int XP = (b.X + 3) & ~3;
-    double* ypart = v.ypart + ((int64_t)sl * (mse ? v.C : 1) + pass) * v.N;
-
-    d4 bq[8];
-    int cur_cls = -1;
-    int g = gh * 8 + gl;
-    if (g >= ngroups) return;
+    const unsigned magic = (65536u + (unsigned)d - 1u) / (unsigned)d;        // x / d = (x * magic) >> 16 for x < 1024
+    double* ypart = v.ypart + (int64_t)pass * v.N * YS_MAXSL;
 #ifdef MPST_B2_DEBUG
     unsigned long long* dbg = (v.dbg && tid == 0) ? v.dbg + (4096 + (int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
     int dbi = 0;
@@ -783,73 +797,147 @@ __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int 
 #define YSTAMP() do { } while (0)
 #endif
     YSTAMP();
-    StageRegs<DM> sr;
-    Span tst = (2 * g + half < v.ntiles) ? v.tiles[2 * g + half] : Span{0, 0, 0, 0};
-    stage16_load(sr, tst.start, tst.count, LEp, b.Dl, phl, d, v.cap, st);
-    for (; g < ngroups; g += 8 * ghc) {
-        const Span tl = (2 * g + tsel < v.ntiles) ? v.tiles[2 * g + tsel] : Span{0, 0, 0, 0};
-        const int cls = mse ? pass : tl.cls;
-        if (cls != cur_cls) {                              // (wave-uniform) B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
-            const double* Bc = v.bt + (int64_t)cls * b.L;
+    d4 bq[8];
+    int cur_cls = -1;
+#ifdef MPST_B2_DEBUG
+    if (b.Y > 0) YSTAMP();              // bond dimensions have arrived
+#endif
+    // The slice of B_c the first group needs goes through LDS once per workgroup (its 8 waves would otherwise each pull the
+    // same 16 KB through the CU's L1); a wave whose tile belongs to another class (class boundaries, later groups of a
+    // persistent workgroup) reads its fragment from global memory instead.  The first group's own rows are requested in the
+    // same breath: one round trip to memory before the first MFMA, not two.
+    const int cls0 = mse ? pass : tile_span_k(v, 8 * gw).cls;
+    double* Bsh = smem + 128 * (ls + ps);                  // [128][17]
+    double t4[4];
+    {
+        const double* Bc = v.bt + (int64_t)cls0 * b.L;
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int x = 16 * mt + kq + 4 * r;
-                    bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
-                }
-            cur_cls = cls;
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + YS_T * k, x = idx >> 4, cc = sl * YS_W + (idx & 15);
+            t4[k] = (x < b.X && cc < b.Y) ? Bc[(int64_t)x * b.Y + cc] : 0.0;
         }
-        double yv[4];
+    }
+    // this wave's tile of a group: 4 rows x 16 consecutive bond entries per load instruction, and the 4 Y values per lane
+    double lev[4][LM], phv[4], yv[4];
+    Span tl{0, 0, 0, 0};
+    auto load_tile = [&](int g) {
+        tl = tile_span_k(v, 8 * g + wave);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = kq + 4 * r;
             const int64_t smp = tl.start + (i < tl.count ? i : 0);
             yv[r] = (cv && i < tl.count) ? phr[smp * d + sp] * (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
         }
-        YSTAMP();
-        __syncthreads();                                   // the previous group's tiles are consumed
-        stage16_store(sr, Xs[half], tst.start, tst.count, b.Dl, phl, d, true, st);
-        __syncthreads();
-        YSTAMP();
-        if (g + 8 * ghc < ngroups) {                       // the next group's rows fly during this group's matrix work
-            const int gn = g + 8 * ghc;
-            tst = (2 * gn + half < v.ntiles) ? v.tiles[2 * gn + half] : Span{0, 0, 0, 0};
-            stage16_load(sr, tst.start, tst.count, LEp, b.Dl, phl, d, v.cap, st);
-        }
-        const double* Xt = Xs[tsel];
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 32; u += 2) {
-            if (4 * u < XP) acc0 = mfma_f64(Xt[i16 * FXS + 4 * u + kq], bq[u >> 2][u & 3], acc0);
-            if (4 * u + 4 < XP) acc1 = mfma_f64(Xt[i16 * FXS + 4 * u + 4 + kq], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
-            if ((u & 7) == 6) asm volatile("" ::: "memory");
-        }
+        for (int q = 0; q < 4; ++q) {
+            const int row = 4 * q + kq;
+            const bool valid = row < tl.count;
+            const int64_t smp = tl.start + (valid ? row : 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double x = sum16((acc0[r] + acc1[r]) * yv[r]);
-            if (i16 == 0) red[tsel][ct][kq + 4 * r] = x;
+            for (int m = 0; m < LM; ++m) {
+                const int a = i16 + 16 * m;
+                lev[q][m] = (valid && a < b.Dl) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
+            }
+            phv[q] = (valid && i16 < d) ? phl[smp * d + i16] : 0.0;
         }
+    };
+    if (gw < ngroups) load_tile(gw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + YS_T * k;
+        Bsh[(idx >> 4) * 17 + (idx & 15)] = t4[k];
+    }
+    __syncthreads();
+    for (int g = gw; g < ngroups; g += ngw) {
+        const Span tc = tl;                                // the tile whose rows are in the registers
+#ifdef MPST_B2_DEBUG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         YSTAMP();
-        __syncthreads();
-        if (tid < 32) {
-            const int ts = tid >> 4, j = tid & 15;
-            if (2 * g + ts < v.ntiles) {
-                const Span tt = v.tiles[2 * g + ts];
-                if (j < tt.count) ypart[tt.start + j] = (red[ts][0][j] + red[ts][1][j]) + (red[ts][2][j] + red[ts][3][j]);
+        if (tc.count > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * q + kq;
+#pragma unroll
+                for (int m = 0; m < LM; ++m) {
+                    const int a = i16 + 16 * m;
+                    if (a < v.cap) LEs[row * ls + a] = lev[q][m];
+                }
+                if (i16 == 0) LEs[row * ls + v.cap] = 0.0;          // the entry a = Dl = capacity the padded K extent can touch
+                if (i16 < d) PHs[row * ps + i16] = phv[q];
             }
         }
+        double yc[4] = {yv[0], yv[1], yv[2], yv[3]};
+        if (g + ngw < ngroups) load_tile(g + ngw);         // the next group's rows fly during this group's matrix work
+        if (tc.count <= 0) continue;                       // (wave-uniform; nothing below synchronises across waves)
+        const int cls = mse ? pass : tc.cls;
+        if (cls != cur_cls) {                              // B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
+            if (cls == cls0) {
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bq[mt][r] = Bsh[(16 * mt + kq + 4 * r) * 17 + i16];
+            } else {
+                const double* Bc = v.bt + (int64_t)cls * b.L;
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int x = 16 * mt + kq + 4 * r;
+                        bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
+                    }
+            }
+            cur_cls = cls;
+        }
+        YSTAMP();
+        {
+            const double* ler = LEs + i16 * ls;
+            const double* phx = PHs + i16 * ps;
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            if (D4) {
+                // x = 4 u + kq = a d + s with a = u, s = kq: the site factor is one register, the row entries sit at
+                // immediate offsets
+                const double ph = phx[kq];
+#pragma unroll
+                for (int u = 0; u < 32; u += 2) {
+                    if (4 * u < XP) acc0 = mfma_f64(ler[u] * ph, bq[u >> 2][u & 3], acc0);
+                    if (4 * u + 4 < XP) acc1 = mfma_f64(ler[u + 1] * ph, bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+                    if ((u & 7) == 6) asm volatile("" ::: "memory");      // at most 8 operands ahead of the matrix pipe
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 32; u += 2) {
+                    if (4 * u < XP) {
+                        const unsigned x = 4u * u + kq, a = (x * magic) >> 16, s = x - a * d;
+                        acc0 = mfma_f64(ler[a] * phx[s], bq[u >> 2][u & 3], acc0);
+                    }
+                    if (4 * u + 4 < XP) {
+                        const unsigned x = 4u * u + 4u + kq, a = (x * magic) >> 16, s = x - a * d;
+                        acc1 = mfma_f64(ler[a] * phx[s], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+                    }
+                    if ((u & 3) == 2) asm volatile("" ::: "memory");      // at most 4 operand pairs ahead of the matrix pipe
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x = sum16((acc0[r] + acc1[r]) * yc[r]);
+                const int i = kq + 4 * r;
+                if (i16 == 0 && i < tc.count) ypart[(int64_t)(tc.start + i) * YS_MAXSL + sl] = x;
+            }
+        }
+        YSTAMP();
     }
 }
 
 constexpr int GS_T = 512;        // 8 waves: wave = (MFMA tile 0..3 of the 32 x 32 block, half of a stage's series)
-constexpr int GS_KC = 64;        // series per stage
-constexpr int GS_LS = 17;        // LDS row stride of the staged factors (<= 16 entries per series and factor)
+constexpr int GS_KC = 256;       // series per stage: one round trip to memory each
+constexpr int GS_MAXKS = 64;
 
-// grid.x = ksplit * nbxc * nbyc (capacity), grid.y = C.  Workgroup id -> (ks = id % ksplit, block = id / ksplit).
-__global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbxc, int nbyc) {
-    __shared__ double As[GS_KC * GS_LS], Pl[GS_KC * GS_LS], Bs[GS_KC * GS_LS], Pr[GS_KC * GS_LS];
-    __shared__ double comb[4][256];
+// grid.x = ksplit * nbc * nbc (capacity), grid.y = C.  Workgroup id -> (ks = id % ksplit, block = id / ksplit).
+// AW2: compile-time bound of ceil(aw / 8), D2 of ceil(d / 8) (register arrays of the loader role).
+template <int AW2, int D2>
+__global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbc) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double redl[8];
     __shared__ int last_s;
     const B2 b = b2_dims(v, lid);
@@ -859,19 +947,15 @@ __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, in
     const int i16 = lane & 15, kq = lane >> 4;
     const int c = blockIdx.y;
     const int ks = (int)blockIdx.x % ksplit, blk = (int)blockIdx.x / ksplit;
-    const int bx = blk / nbyc, by = blk % nbyc;
-    const int grp = c * nbxc * nbyc + blk;                  // ticket / norm-piece slot (capacity layout)
+    const int bx = blk / nbc, by = blk % nbc;
+    const int grp = c * nbc * nbc + blk;                    // ticket / norm-piece slot (capacity layout)
     if (bx >= b.nbx || by >= b.nby) {
         if (ks == 0 && tid == 0) v.norm_part[grp] = 0.0;    // a block that is not live at this bond contributes nothing
         return;
     }
-    const int nsl = (b.Y + YS_COLS - 1) / YS_COLS;
+    const int nsl = (b.Y + YS_W - 1) / YS_W;
     // the series of this pass and this workgroup's share of them
-    int p0 = 0, p1 = (int)v.N;
-    if (!mse) {
-        p0 = v.cls_off[c];
-        p1 = v.cls_off[c + 1];
-    }
+    const int p0 = mse ? 0 : v.kcls_off[c], p1 = mse ? (int)v.N : v.kcls_off[c + 1];
     int len = (p1 - p0 + ksplit - 1) / ksplit;
     len = (len + 3) & ~3;
     const int s0 = min(p1, p0 + ks * len), s1 = min(p1, s0 + len);
@@ -880,28 +964,44 @@ __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, in
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
     const double* phl = v.phi + (int64_t)lid * v.N * d;
     const double* phr = v.phi + (int64_t)rid * v.N * d;
-    const double* yp0 = v.ypart + (int64_t)(mse ? c : 0) * v.N;
-    const double* yp1 = v.ypart + ((int64_t)(mse ? v.C : 1) + (mse ? c : 0)) * v.N;
-    // loader role: series lsm = tid / 8 of the stage, entries j and j + 8 of every factor
+    const double2* ypart2 = (const double2*)(v.ypart + (int64_t)(mse ? c : 0) * v.N * YS_MAXSL);
+    // record of a series in LDS: [LE slice (aw) | phi_l (d) | RE slice (bw) | phi_r (d) | 0], stride fs (odd); then the weights
+    const int o_pl = b.aw, o_re = b.aw + d, o_pr = b.aw + d + b.bw, zc = 2 * b.aw + 2 * d;
+    const int fs = (zc + 1) | 1;
+    double* wv = smem + GS_KC * fs;                         // [GS_KC] w_i of the stage's series (0 beyond the share)
+    // loader role 1: 8 lanes per series (entries j, j + 8 of every factor), 4 passes of 64 series per stage
     const int lsm = tid >> 3, j = tid & 7;
-    double r_le[2], r_re[2], r_pl[2], r_pr[2], r_y = 1.0, r_dl = 0.0;
+    double r_le[4][AW2], r_re[4][AW2], r_pl[4][D2], r_pr[4][D2];
+    // loader role 2 (threads < GS_KC): the slices' contributions to yhat of series base + tid, 64 contiguous bytes
+    double2 r_y[4];
+    double r_dl = 0.0;
     bool r_ok = false;
     auto load_stage = [&](int base) {
-        const int smp = base + lsm;
-        r_ok = smp < s1;
-        const int64_t sm = r_ok ? smp : s0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int jj = j + 8 * h;
-            r_le[h] = (r_ok && jj < b.aw && a0 + jj < b.Dl) ? (LEp ? LEp[sm * v.cap + a0 + jj] : 1.0) : 0.0;
-            r_re[h] = (r_ok && jj < b.bw && b0 + jj < b.Dr) ? (REn ? REn[sm * v.cap + b0 + jj] : 1.0) : 0.0;
-            r_pl[h] = (r_ok && jj < d) ? phl[sm * d + jj] : 0.0;
-            r_pr[h] = (r_ok && jj < d) ? phr[sm * d + jj] : 0.0;
+        for (int p = 0; p < 4; ++p) {
+            const int smp = base + 64 * p + lsm;
+            const bool ok = smp < s1;
+            const int64_t sm = ok ? smp : s0;
+#pragma unroll
+            for (int h = 0; h < AW2; ++h) {
+                const int jj = j + 8 * h;
+                r_le[p][h] = (ok && jj < b.aw && a0 + jj < b.Dl) ? (LEp ? LEp[sm * v.cap + a0 + jj] : 1.0) : 0.0;
+                r_re[p][h] = (ok && jj < b.bw && b0 + jj < b.Dr) ? (REn ? REn[sm * v.cap + b0 + jj] : 1.0) : 0.0;
+            }
+#pragma unroll
+            for (int h = 0; h < D2; ++h) {
+                const int jj = j + 8 * h;
+                r_pl[p][h] = (ok && jj < d) ? phl[sm * d + jj] : 0.0;
+                r_pr[p][h] = (ok && jj < d) ? phr[sm * d + jj] : 0.0;
+            }
         }
-        if (r_ok) {
-            r_y = yp0[sm];
-            if (nsl > 1) r_y += yp1[sm];
-            r_dl = (mse && v.label[sm] == c) ? 1.0 : 0.0;
+        if (tid < GS_KC) {
+            const int smp = base + tid;
+            r_ok = smp < s1;
+            const int64_t sm = r_ok ? smp : s0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r_y[q] = ypart2[sm * (YS_MAXSL / 2) + q];
+            r_dl = (mse && r_ok && v.label[sm] == c) ? 1.0 : 0.0;
         }
     };
     // consumer role: tile (tx, ty) of the block, series 4 u + kq of the wave's half of the stage
@@ -911,128 +1011,166 @@ __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, in
     const int al = xr / d, slx = xr - al * d;                   // X_i[row] = LE_i[a0 + al] * phi_l[i][slx]
     const int spl = yc / b.bw, bl = yc - spl * b.bw;            // Y_i[col] = phi_r[i][spl] * RE_i[b0 + bl]
     const bool xv = al < b.aw && a0 + al < b.Dl, yvld = spl < d && b0 + bl < b.Dr;
+    // operands of lanes outside the live block come from the record's zero cell: no select in the loop
+    const int ia = xv ? al : zc, ipl = xv ? o_pl + slx : zc, ib = yvld ? o_re + bl : zc, ipr = yvld ? o_pr + spl : zc;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     double loss = 0.0;
     const bool do_loss = bx == 0 && by == 0;
 #ifdef MPST_B2_DEBUG
     unsigned long long* dbg = (v.dbg && tid == 0) ? v.dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
 #define GSTAMP(i) do { if (dbg) dbg[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GWAITSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GSTAMP(i); } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
+#define GWAITSTAMP(i) do { } while (0)
 #endif
     GSTAMP(0);
     if (s0 < s1) load_stage(s0);
+    GWAITSTAMP(6);
     for (int base = s0; base < s1; base += GS_KC) {
         __syncthreads();                                   // the previous stage is consumed
-        {
+        if (tid < GS_KC) {
             double w = 0.0;
             if (r_ok) {
-                w = mse ? (r_y - r_dl) : 1.0 / r_y;                                              // :489,:608 / :258,:367
-                if (do_loss && j == 0) loss += mse ? 0.5 * (r_y - r_dl) * (r_y - r_dl) : -log(r_y * r_y);   // :554 / :318
+                const double ys[8] = {r_y[0].x, r_y[0].y, r_y[1].x, r_y[1].y, r_y[2].x, r_y[2].y, r_y[3].x, r_y[3].y};
+                double yh = 0.0;
+#pragma unroll
+                for (int q = 0; q < YS_MAXSL; ++q)
+                    if (q < nsl) yh += ys[q];                   // slice order
+                w = mse ? (yh - r_dl) : 1.0 / yh;                                              // :489,:608 / :258,:367
+                if (do_loss) loss += mse ? 0.5 * (yh - r_dl) * (yh - r_dl) : -log(yh * yh);      // :554 / :318
+            }
+            wv[tid] = w;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            double* rec = smem + (64 * p + lsm) * fs;
+#pragma unroll
+            for (int h = 0; h < AW2; ++h) {
+                const int jj = j + 8 * h;
+                if (jj < b.aw) {
+                    rec[jj] = r_le[p][h];
+                    rec[o_re + jj] = r_re[p][h];
+                }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < D2; ++h) {
                 const int jj = j + 8 * h;
-                As[lsm * GS_LS + jj] = r_le[h];
-                Bs[lsm * GS_LS + jj] = r_re[h];
-                Pl[lsm * GS_LS + jj] = r_pl[h];
-                Pr[lsm * GS_LS + jj] = w * r_pr[h];
+                if (jj < d) {
+                    rec[o_pl + jj] = r_pl[p][h];
+                    rec[o_pr + jj] = r_pr[p][h];
+                }
             }
+            if (j == 0) rec[zc] = 0.0;
         }
         __syncthreads();
+        GSTAMP(7);
         if (base + GS_KC < s1) load_stage(base + GS_KC);   // the next stage's loads fly during the matrix work
-#pragma unroll
-        for (int u = 0; u < GS_KC / 8; ++u) {
-            const int sm = 4 * (kh * (GS_KC / 8) + u) + kq;
-            if (base + 4 * (kh * (GS_KC / 8) + u) < s1) {          // wave-uniform: whole k-steps beyond the share are skipped
-                const double a = xv ? As[sm * GS_LS + al] * Pl[sm * GS_LS + slx] : 0.0;
-                const double bb = yvld ? Bs[sm * GS_LS + bl] * Pr[sm * GS_LS + spl] : 0.0;
-                acc = mfma_f64(a, bb, acc);
-            }
+        const double* rbase = smem + (kh * (GS_KC / 2) + kq) * fs;
+        const double *pa = rbase + ia, *pp = rbase + ipl, *pb = rbase + ib, *pq = rbase + ipr;
+        const double* wb = wv + kh * (GS_KC / 2) + kq;
+        const int fs4 = 4 * fs;
+#pragma unroll 8
+        for (int u = 0; u < GS_KC / 8; ++u) {               // series beyond the share are zero records with zero weight
+            const double a = *pa * *pp;
+            const double bbv = *pb * *pq * wb[4 * u];
+            acc = mfma_f64(a, bbv, acc);
+            pa += fs4;
+            pp += fs4;
+            pb += fs4;
+            pq += fs4;
         }
     }
     GSTAMP(1);
     // the two halves of every tile meet in LDS: (half 0) + (half 1)
+    __syncthreads();
     if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) comb[tile][r * 64 + lane] = acc[r];
+        for (int r = 0; r < 4; ++r) smem[tile * 256 + r * 64 + lane] = acc[r];
     }
-    if (do_loss) {                                          // only the lanes j == 0 carry a term
+    if (do_loss) {                                          // threads < GS_KC carry the terms
         loss = wave_sum(loss);
         if (lane == 0) redl[wave] = loss;
     }
     __syncthreads();
-    double* part = v.partial + ((int64_t)grp * ksplit + ks) * 1024;
-    if (kh == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * tx + kq + 4 * r, colb = 16 * ty + i16;
-            st_agent(part + row * 32 + colb, acc[r] + comb[tile][r * 64 + lane]);
-        }
-    }
-    if (do_loss && tid == 0) {
-        double l = 0.0;
-        for (int w = 0; w < 8; ++w) l += redl[w];
-        st_agent(v.lossp + c * ksplit + ks, l);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have left before the ticket is taken
-    __syncthreads();
-    GSTAMP(2);
-    if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(v.tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = (t == (unsigned)ksplit - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    GSTAMP(3);
-    if (!last_s) return;
-    // ---- last arriver of this block: add the shares in share order, scale, publish ---------------------------------------
     const double scale = mse ? v.invN : -(v.train_sep ? v.inv_count[c] : v.invN);           // :608 / :367,:424
-    const double* pbase = v.partial + (int64_t)grp * ksplit * 1024;
-    double n2 = 0.0;
+    // waves 0..3 (kh == 0) own the block's entries: lane holds rows kq + 4 r of tile (tx, ty), column i16
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t gidx[4];
+    bool ev[4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int idx = tid + GS_T * e, row = idx >> 5, colb = idx & 31;
-        double s = 0.0;
-        for (int k0 = 0; k0 < ksplit; k0 += 8) {           // 8 loads in flight, added in share order
-            double t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (k0 + u < ksplit) ? ld_agent(pbase + (int64_t)(k0 + u) * 1024 + idx) : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += t[u];
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * tx + kq + 4 * r, colb = 16 * ty + i16;
         const int aa = row / d, sx = row - aa * d, sy = colb / b.bw, bb2 = colb - sy * b.bw;
-        if (aa < b.aw && a0 + aa < b.Dl && sy < d && b0 + bb2 < b.Dr) {
-            const double gval = s * scale;
-            v.gradbuf[2 + (int64_t)c * b.L + (int64_t)((a0 + aa) * d + sx) * b.Y + sy * b.Dr + b0 + bb2] = gval;
-            n2 = fma(gval, gval, n2);
+        ev[r] = kh == 0 && aa < b.aw && a0 + aa < b.Dl && sy < d && b0 + bb2 < b.Dr;
+        gidx[r] = 2 + (int64_t)c * b.L + (int64_t)((a0 + aa) * d + sx) * b.Y + sy * b.Dr + b0 + bb2;
+        if (kh == 0) tot[r] = acc[r] + smem[tile * 256 + r * 64 + lane];
+    }
+    if (do_loss && tid == 0) v.lossp[c * ksplit + ks] = (redl[0] + redl[1]) + (redl[2] + redl[3]);    // waves 4..7 carry none
+    double n2 = 0.0;
+    if (ksplit == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (ev[r]) {
+                const double gval = tot[r] * scale;
+                v.gradbuf[gidx[r]] = gval;
+                n2 = fma(gval, gval, n2);
+            }
+    } else {
+        double* part = v.partial + ((int64_t)grp * ksplit + ks) * 1024 + tile * 256;
+        if (kh == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st_agent(part + r * 64 + lane, tot[r]);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores have left before the ticket is taken
+        __syncthreads();
+        GSTAMP(2);
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(v.tick + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_s = (t == (unsigned)ksplit - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        GSTAMP(3);
+        if (!last_s) return;
+        // last arriver: the shares in share order
+        const double* pbase = v.partial + (int64_t)grp * ksplit * 1024 + tile * 256;
+        if (kh == 0) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < ksplit; k0 += 4) {
+                double t[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        t[u][r] = (k0 + u < ksplit) ? ld_agent(pbase + (int64_t)(k0 + u) * 1024 + r * 64 + lane) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r] += t[u][r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ev[r]) {
+                    const double gval = s[r] * scale;
+                    v.gradbuf[gidx[r]] = gval;
+                    n2 = fma(gval, gval, n2);
+                }
+        }
+        if (tid == 0) __hip_atomic_store(v.tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     n2 = wave_sum(n2);
     __syncthreads();
     if (lane == 0) redl[wave] = n2;
     __syncthreads();
+    if (tid == 0) v.norm_part[grp] = (redl[0] + redl[1]) + (redl[2] + redl[3]);      // waves 4..7 carry no entries
     GSTAMP(4);
-    if (tid == 0) {
-        double t = 0.0;
-        for (int w = 0; w < 8; ++w) t += redl[w];
-        v.norm_part[grp] = t;
-        __hip_atomic_store(v.tick + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the last block of the launch to finish adds the loss pieces (fixed order)
-        const unsigned total = (unsigned)(v.C * b.nbx * b.nby);
-        const unsigned t2 = __hip_atomic_fetch_add(v.tick + v.C * nbxc * nbyc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t2 == total - 1) {
-            double l = 0.0;
-            for (int cc = 0; cc < v.C; ++cc) {
-                const double w = mse ? v.invN : (v.train_sep ? v.inv_count[cc] : v.invN);     // :612 / :423,:371
-                double lc = 0.0;
-                for (int k = 0; k < ksplit; ++k) lc += ld_agent(v.lossp + cc * ksplit + k);
-                l += lc * w;
-            }
-            v.gradbuf[0] = l;
-            v.gradbuf[1] = 0.0;
-            __hip_atomic_store(v.tick + v.C * nbxc * nbyc, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        GSTAMP(5);
+}
+
+// the loss of the bond from the pieces of k_grad_s (same order wherever it is formed): gradbuf[0..1] for the all-reduce
+__global__ __launch_bounds__(64) void k_loss_sum(View v) {
+    if (threadIdx.x == 0) {
+        v.gradbuf[0] = bond_loss(v);
+        v.gradbuf[1] = 0.0;
     }
 }
 
@@ -1047,30 +1185,51 @@ void launch_fused_reduce(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_fused_reduce, dim3(v.n_norm_part), dim3(256), 0, s, v, lid);
 }
 // ---- sliced bond GEMMs: host-side geometry (depends on capacity, d, C and the data set only) -------------------------------
+static int b2_aw(const View& v) { return std::max(1, 32 / v.d); }
 int b2_blocks_cap(const View& v) {
-    const int aw = std::max(1, 32 / v.d);
-    return cdivf(v.cap, aw) * cdivf(v.cap, aw);
+    const int nbc = cdivf(v.cap, b2_aw(v));
+    return nbc * nbc;
 }
+// shares per gradient block: enough workgroups to fill the chip (~256 in all), at least one stage of series each
 int b2_ksplit(const View& v, int64_t max_pass) {
-    static const int tgt = [] { const char* e = getenv("MPST_B2_WG"); return e ? std::max(1, atoi(e)) : 256; }();
-    const int groups = v.C * b2_blocks_cap(v);
-    int ks = std::max(1, tgt / groups);
-    ks = (int)std::min<int64_t>(ks, std::max<int64_t>(1, (max_pass + GS_KC - 1) / GS_KC));
-    return std::min(ks, 64);
+    if (const char* e = getenv("MPST_B2_KSPLIT")) return std::max(1, std::min(atoi(e), GS_MAXKS));
+    const int groups = std::max(1, v.C * b2_blocks_cap(v));
+    int64_t ks = std::max(1, 256 / groups);
+    ks = std::min<int64_t>(ks, std::max<int64_t>(1, (max_pass + GS_KC - 1) / GS_KC));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(ks, GS_MAXKS));
 }
 int64_t b2_partial_elems(const View& v, int64_t max_pass) { return (int64_t)v.C * b2_blocks_cap(v) * b2_ksplit(v, max_pass) * 1024; }
-void launch_yhat_s(const View& v, int lid, hipStream_t s) {
-    const int nslc = cdivf(v.d * v.cap, YS_COLS);
-    const int ngroups = (v.ntiles + 1) / 2;
-    const int ghc = std::max(1, std::min(cdivf(ngroups, 8), 32));
-    const dim3 grid(8 * nslc * ghc, v.loss == MPST_LOSS_MSE ? v.C : 1);
-    if (v.d <= 4) hipLaunchKernelGGL(k_yhat_s<4>, grid, dim3(YS_T), 0, s, v, lid, nslc, ghc);
-    else hipLaunchKernelGGL(k_yhat_s<8>, grid, dim3(YS_T), 0, s, v, lid, nslc, ghc);
+static size_t yhat_s_lds(const View& v) { return (size_t)128 * (v.cap + 1 + v.d + 1 + 17) * sizeof(double); }
+static size_t grad_s_lds(const View& v) { return std::max((size_t)GS_KC * (((2 * b2_aw(v) + 2 * v.d + 1) | 1) + 1), (size_t)4 * 256) * sizeof(double); }
+hipError_t b2_init_attrs(int device) {
+    static unsigned long long done = 0;
+    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if (device >= 0 && device < 64) done |= 1ull << device;
+    return hipSuccess;
 }
+void launch_yhat_s(const View& v, int lid, hipStream_t s) {
+    const int nslc = cdivf(v.d * v.cap, YS_W);
+    const int ngroups = cdivf(v.ntiles, 8);
+    const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / nslc)));      // group walkers per slice
+    const dim3 grid(nslc * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1);
+    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s<2, true>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s<2, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    else hipLaunchKernelGGL((k_yhat_s<4, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+}
+void launch_loss_sum(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, s, v); }
 void launch_grad_s(const View& v, int lid, hipStream_t s) {
-    const int aw = std::max(1, 32 / v.d);
-    const int nbc = cdivf(v.cap, aw);
-    hipLaunchKernelGGL(k_grad_s, dim3(v.b2_ksplit * nbc * nbc, v.C), dim3(GS_T), 0, s, v, lid, v.b2_ksplit, nbc, nbc);
+    const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);
+    const dim3 grid(v.b2_ksplit * nbc * nbc, v.C);
+    if (aw > 8) hipLaunchKernelGGL((k_grad_s<2, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);         // d = 2, 3
+    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s<1, 2>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);   // d = 9..16
+    else hipLaunchKernelGGL((k_grad_s<1, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);

@@ -363,10 +363,13 @@ struct View {
     double* btn;        // bt_new, written by k_gram_upd
     // sliced bond GEMMs (k_yhat_s / k_grad_s, mpst_fused.hip)
     const int32_t* cls_off;   // [C+1] first series of every class
-    double* ypart;      // [2 slices][passes][N] contributions of the column slices of B_c to yhat
+    int32_t kcls_off[MAX_C + 1];    // the same table, and the first 16-series tile of every class, in the kernel arguments:
+    int32_t kcls_tile[MAX_C + 1];   // no dependent global load between a workgroup's id and its series
+    double* ypart;      // [passes][N][8 slices] contributions of the 16-column slices of B_c to yhat
     double* lossp;      // [C][ksplit] loss pieces
     unsigned int* tick; // [C * blocks_cap + 1] arrival tickets of the gradient blocks, + the launch-wide one
     int32_t b2_ksplit;  // shares the series of a pass are split into
+    int32_t n_lossp;    // > 0: the bond's loss is still in lossp's pieces ([C][n_lossp]); 0: it is gradbuf[0]
     unsigned long long* dbg;   // bring-up stamps (-DMPST_B2_DEBUG), else null
     double* trace;      // track_cost: this bond's row of the loss trace ([update_iters + 1]) or null
     int32_t trace_it;   // which entry the launch at hand fills
@@ -382,6 +385,20 @@ struct View {
     double eta, cutoff;
 };
 
+// loss of the current bond: gradbuf[0], or - after k_grad_s on a single rank - the sum of its pieces (fixed order)
+__device__ __forceinline__ double bond_loss(const View& v) {
+    if (v.n_lossp <= 0) return v.gradbuf[0];
+    const bool mse = v.loss == MPST_LOSS_MSE;
+    double l = 0.0;
+    for (int cc = 0; cc < v.C; ++cc) {
+        const double w = mse ? v.invN : (v.train_sep ? v.inv_count[cc] : v.invN);     // loss_functions.jl:612 / :423,:371
+        double lc = 0.0;
+        for (int k = 0; k < v.n_lossp; ++k) lc += v.lossp[cc * v.n_lossp + k];
+        l += lc * w;
+    }
+    return l;
+}
+
 // fused path for bond tensors up to MAX_DIM x MAX_DIM (mpst_fused.hip)
 void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s);
 void launch_fused_reduce(const View& v, int lid, hipStream_t s);
@@ -389,9 +406,11 @@ void launch_grad_norm(const View& v, int lid, hipStream_t s);
 // sliced bond GEMMs (k_yhat_s + k_grad_s): the pair that replaces k_bond_fused + k_fused_reduce
 void launch_yhat_s(const View& v, int lid, hipStream_t s);
 void launch_grad_s(const View& v, int lid, hipStream_t s);
+void launch_loss_sum(const View& v, hipStream_t s);      // gradbuf[0..1] from k_grad_s's loss pieces (before an all-reduce)
 int b2_blocks_cap(const View& v);                          // gradient blocks per class at the capacity bond dimension
 int b2_ksplit(const View& v, int64_t max_pass);            // shares per block; max_pass = most series any pass walks
 int64_t b2_partial_elems(const View& v, int64_t max_pass);
+hipError_t b2_init_attrs(int device);
 void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
 void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);

@@ -590,10 +590,10 @@ __global__ __launch_bounds__(256) void k_update(View v, int lid, int first_iter)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) v.bt[i] -= step * g[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (first_iter) {
-            v.sc->loss = v.gradbuf[0];
+            v.sc->loss = bond_loss(v);
             v.sc->grad_norm = nrm;
         }
-        if (v.trace) v.trace[v.trace_it] = v.gradbuf[0];      // "Loss before step i", loss_functions.jl:50-52 / :80-82
+        if (v.trace) v.trace[v.trace_it] = bond_loss(v);      // "Loss before step i", loss_functions.jl:50-52 / :80-82
     }
 }
 

@@ -20,18 +20,22 @@ out = (C.c_ulonglong * (8192 * 8))()
 eng.lib.mpst_debug_b2.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 assert eng.lib.mpst_debug_b2(eng.ctx, out) == 0
 a = np.array(out, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
-g = a[:4096]; y = a[4096:]
-gl = g[g[:, 0] > 0]; yl = y[y[:, 0] > 0]
+g = a[:4096]
+gl = g[g[:, 0] > 0]
 print("k_grad_s workgroups with stamps:", len(gl))
 t0 = gl[:, 0].min()
 def us(x): return np.round(0.01 * x, 2)
 print(" start spread (us): max", us(gl[:, 0].max() - t0))
-for i, nm in ((1, "loop end"), (2, "stores drained"), (3, "ticket known")):
-    print(f" {nm}: median {us(np.median(gl[:, i] - gl[:, 0]))} max {us((gl[:, i] - gl[:, 0]).max())}  (since own start);  last WG at {us(gl[:, i].max() - t0)} since first start")
-la = gl[gl[:, 4] > 0]
-print(" last arrivers:", len(la), " reduce done: median", us(np.median(la[:, 4] - la[:, 3])), "max", us((la[:, 4] - la[:, 3]).max()), " end (incl. launch ticket) at", us(la[:, 5].max() - t0), "since first start")
+for i, nm in ((6, "first stage loaded"), (7, "first stage in LDS"), (1, "loop end"), (2, "stores drained"), (3, "ticket known"), (4, "block published"), (5, "loss ticket done")):
+    m = gl[:, i] > 0
+    if m.any():
+        dlt = gl[m, i] - gl[m, 0]
+        print(f" {nm}: n={m.sum()} median {us(np.median(dlt))} max {us(dlt.max())} (since own start); last at {us(gl[m, i].max() - t0)} since first start")
+y = a[4096:]
+yl = y[y[:, 0] > 0]
 print("k_yhat_s workgroups with stamps:", len(yl))
 t0 = yl[:, 0].min()
 print(" start spread max", us(yl[:, 0].max() - t0))
-for i, nm in ((1, "operands requested"), (2, "tiles staged"), (3, "mfma+rowdot done")):
-    print(f" {nm}: median {us(np.median(yl[:, i] - yl[:, 0]))} max {us((yl[:, i] - yl[:, 0]).max())}; last at {us(yl[:, i].max() - t0)}")
+for i, nm in ((1, "dims known"), (2, "loads returned, B in LDS"), (3, "tile in LDS, B fragment read"), (4, "mfma + rowdot + store issued")):
+    dlt = yl[:, i] - yl[:, 0]
+    print(f" {nm}: median {us(np.median(dlt))} max {us(dlt.max())}; last at {us(yl[:, i].max() - t0)}")
