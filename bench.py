@@ -68,15 +68,34 @@ def kernel_model(N, d, chi, C, info):
     dm = d * chi
     nb = ((dm + 63) // 64) ** 2
     nsplit = min(max(1, info.get("nchunks", 1)), max(1, -(-512 // (nb * C))))
-    model["grad_reduce+update"] = ("hbm", 0.5 * 8.0 * (nsplit + 5.0) * C * X * Y)
-    if info.get("fused"):
+    # bytes per scope: k_grad_reduce reads nsplit partial blocks per (class, output block) and writes the gradient;
+    # k_grad_norm + k_update read the gradient twice and read + write the bond tensor: (nsplit + 1) and 4 passes over
+    # C X Y doubles - the average of the two scopes (the slot's launches_per_sweep counts both)
+    model["grad_reduce+update"] = ("hbm", 0.5 * 8.0 * ((nsplit + 1.0) + 4.0) * C * X * Y)
+    if info.get("fused") and info.get("sliced_bond_gemms"):
+        # k_yhat_s / k_grad_s: one GEMM each (2 N X Y), no partial gradients per workgroup; the shares of a gradient block
+        # (grad_shares of them) meet inside k_grad_s
+        model.pop("grad_reduce+update", None)
+    elif info.get("fused"):
         P = info["nparts"]
         model["grad"] = ("mfma", 4.0 * N * X * Y)           # k_bond_fused: yhat AND the gradient partials
         model["grad_reduce+update"] = ("hbm", 8.0 * (P + C) * X * Y)   # k_fused_reduce: read P partials, write the gradient
+    if info.get("fused"):
         model["env"] = ("hbm", 8.0 * N * (chi + d + chi))  # k_env_split (+ 2mn chi flops of the back-split, + next bond tensor)
     if info.get("large_bond"):
         model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n ** 3)   # rocSOLVER dsyevd: sytrd + stedc + ormtr back-transformation
     return model
+
+
+def csrc_sha256():
+    """Digest of the kernel sources of this tree: ties quoted profile figures to the code they were measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_cpu_model():
@@ -214,6 +233,9 @@ def main():
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
                          "and stream each (hyper-parameter search / CV folds); 0 = skip")
+    ap.add_argument("--no-sharded-extra", action="store_true",
+                    help="with --gpus N > 1: skip the configs[3] (N = 32768 sharded) side measurement")
+    ap.add_argument("--sharded-N", type=int, default=32768)
     ap.add_argument("--workload", choices=["sweep", "impute"], default="sweep",
                     help="sweep: the headline training sweep (BASELINE configs[2]).  impute: BASELINE configs[4], the imputation engine "
                          "on a complex (Fourier) model with fp32 chain arithmetic; defaults N=8192 per GPU, T=200, chi=64, d=8")
@@ -263,6 +285,21 @@ def main():
         return t.tolist()
 
     import mpstime_jl_amd as mt
+
+    def note(msg):
+        """Preflight / decision log: stderr of rank 0 (stdout carries the one JSON line)."""
+        if rank == 0:
+            sys.stderr.write(f"[bench] {msg}\n")
+            sys.stderr.flush()
+
+    if world > 1:
+        cl = mt.comm_library()       # bound at run time: the copy torch has loaded, never a second one (include/mpstime_hip.h)
+        note(f"{world} ranks, rank 0 on cuda:{dev_index}" + (" (all ranks share one GPU: MPST_BENCH_SHARE_GPU=1, host group on gloo)" if share else ""))
+        note(f"librccl bound by libmpstime_hip.so: {cl['library']}, version {cl['version']} (built against {cl['built_against']})")
+        try:
+            note(f"torch.cuda.nccl.version() = {torch.cuda.nccl.version()}")
+        except Exception as e:
+            note(f"torch.cuda.nccl.version() unavailable: {e}")
     if args.workload == "impute":
         line = impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce)
         if rank == 0:
@@ -339,11 +376,24 @@ def main():
             times[name] = dt if good > 0 else None
         allreduce["trial_sweep_s"] = times
         working = [n for n in paths if times.get(n) is not None]
-        assert working, f"no working collective: {allreduce}"
+        for n in paths:
+            note(f"collective '{n}': " + (f"trial sweep {1e3 * times[n]:.2f} ms" if times.get(n) is not None
+                                           else f"FAILED ({allreduce.get(n + '_error', 'a peer failed')})"))
+        if "oneshot_error" in allreduce and "oneshot" not in paths:
+            note(f"collective 'oneshot' not available: {allreduce['oneshot_error']}")
+        if not working:
+            note(f"no working collective: {allreduce}")
+            sys.exit(3)
         pick = args.allreduce if args.allreduce in working else min(working, key=lambda n: times[n])
+        why = ("requested with --allreduce" if args.allreduce in working else
+               "the only candidate" + (" (RCCL refuses two ranks on one device)" if share else "") if len(paths) == 1 else
+               "the only one that worked" if len(working) == 1 else "the faster trial sweep")
+        note(f"picked '{pick}': {why}")
         if "oneshot" in paths:
             sh.select(eng, pick == "oneshot")
         allreduce["path"] = pick
+        allreduce["picked_because"] = why
+        allreduce["librccl"] = mt.comm_library()
         eng.set_mps(W0)
     eng.build_caches()
 
@@ -408,29 +458,37 @@ def main():
             kernels[k] = {"avg_us": round(per, 3), "launches_per_sweep": c, "share": round(us / max(sum(v[0] for v in breakdown.values()), 1e-9), 4),
                           "bound": b, "achieved": round(a / (per * 1e-6) / (1e12 if b == "mfma" else 1e9), 4),
                           "unit": "TFLOP/s" if b == "mfma" else "GB/s"}
-        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process, so the
-        # per-launch figure of the committed rocprofv3 --pmc passes over this same command is quoted
-        # (profiles/aggregate_pmc.py; FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
+        # HBM traffic / MFMA utilisation: PMC counters cannot be collected from inside this process, so the per-launch
+        # figures of the committed rocprofv3 --pmc passes over this same command are QUOTED - under their own key, and only
+        # when that profile was taken with the kernel sources of this tree (csrc_sha256; profiles/aggregate_pmc.py;
+        # FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
         traffic, traffic_src = None, None
-        fused = info.get("fused")
-        knames = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin", "yhat": "mpst::k_yhat",
-                  "grad": "mpst::k_bond_fused" if fused else "mpst::k_grad", "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
+        fused, b2 = info.get("fused"), info.get("sliced_bond_gemms")
+        knames = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin",
+                  "yhat": "mpst::k_yhat_s" if b2 else "mpst::k_yhat",
+                  "grad": "mpst::k_grad_s" if b2 else ("mpst::k_bond_fused" if fused else "mpst::k_grad"),
+                  "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
                   "split": "mpst::k_split", "env": "mpst::k_env_split" if fused else "mpst::k_env",
                   "grad_reduce+update": "mpst::k_fused_reduce" if fused else "mpst::k_grad_reduce"}
-        pmc_file = os.path.join("profiles", "r02_pmc_counters.json")
-        pmc = {}
+        pmc_file = os.path.join("profiles", "r03_pmc_counters.json")
+        pmc, pmc_quoted = {}, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, pmc_file)))["kernels"]
+            pj = json.load(open(os.path.join(ROOT, pmc_file)))
+            if pj.get("csrc_sha256") == csrc_sha256():
+                pmc = pj["kernels"]
         except Exception:
             pass
         headline = world == 1 and (N, T, chi, d) == (4096, 100, 32, 4)
         kname = knames.get(dominant)
-        if headline and kname in pmc and "hbm_bytes_per_launch_corrected" in pmc[kname]:
-            traffic, traffic_src = pmc[kname]["hbm_bytes_per_launch_corrected"], pmc_file
-        for k, kn in knames.items():
-            if headline and k in kernels and kn in pmc and "mfma_util" in pmc[kn]:
-                kernels[k]["mfma_util"] = pmc[kn]["mfma_util"]            # committed rocprofv3 --pmc pass of this command
-                kernels[k]["hbm_bytes_per_launch"] = pmc[kn].get("hbm_bytes_per_launch_corrected")
+        if headline and pmc:
+            pmc_quoted = {"source": pmc_file, "csrc_sha256": csrc_sha256(), "kernels": {}}
+            for k, kn in knames.items():
+                hit = [v for name, v in pmc.items() if name == kn or name.startswith(kn + "<") or name.startswith("void " + kn)]
+                if k in kernels and hit:
+                    pmc_quoted["kernels"][k] = {"mfma_util": hit[0].get("mfma_util"),
+                                                "hbm_bytes_per_launch": hit[0].get("hbm_bytes_per_launch_corrected")}
+            if dominant in pmc_quoted["kernels"]:
+                traffic, traffic_src = pmc_quoted["kernels"][dominant]["hbm_bytes_per_launch"], pmc_file
         out = {
             "metric": ("full sweeps/sec (N=4096,T=100,chi=32,d=4)" if (N, T, chi, d) == (4096, 100, 32, 4)
                        else f"full sweeps/sec (N={N},T={T},chi={chi},d={d}) - NOT the headline configuration"),
@@ -459,8 +517,65 @@ def main():
                          "avg_launch_us": avg_us, "launches": cnt, "algorithmic_per_launch": alg,
                          "in_kernel_us_last_launch": eng.eig_phases()["tridiag"] if dominant == "eig_tri" else None},
             "kernels": kernels,
+            "pmc_quoted": pmc_quoted,
             "device_encode": encode_info,
         }
+
+    # ---- extra with several ranks: BASELINE configs[3] - N = 32768 series sharded over the ranks (weak-scaling shape: the
+    # per-rank batch that makes the sharded kernels matter) - with the all-reduce time per optimiser step and the Amdahl
+    # bound from THIS run's own per-kernel profile.  Never `value`.
+    if world > 1 and not args.no_sharded_extra:
+        sharded = None
+        try:
+            N2 = args.sharded_N
+            full2 = make_inputs(N2, T, d)
+            eng2 = mt.SweepEngine(dev_index)
+            eng2.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True))
+            sh2 = mt.Shard(rank, world, rccl=not share)
+            local2, gc2 = sh2.split(full2)
+            sh2.attach(eng2)
+            eng2.set_dataset(0, local2.phi, local2.label_index, C, gc2)
+            eng2.set_mps(W0)
+            if allreduce.get("path") == "oneshot" or share:
+                sh2.attach_oneshot(eng2)
+                sh2.select(eng2, True)
+            eng2.build_caches()
+            for _ in range(2):
+                eng2.sweep()
+            sync()
+            tq = time.perf_counter()
+            nsw2 = 3
+            for _ in range(nsw2):
+                eng2.sweep()
+            sync()
+            dt2 = host_reduce([time.perf_counter() - tq], dist.ReduceOp.MAX)[0]
+            eng2.set_profile(0x7FF)
+            eng2.sweep()
+            bd2 = eng2.get_profile()
+            eng2.set_profile(0)
+            eng2.close()
+            nb = 2 * (T - 1)
+            per = {k: v[0] / nb for k, v in bd2.items() if v[1]}          # us per bond
+            shard_keys = ("yhat", "grad", "env")                          # N-proportional: they shrink with the shard
+            t_sh = sum(per.get(k, 0.0) for k in shard_keys)
+            t_ar = per.get("allreduce", 0.0)
+            t_rep = sum(v for k, v in per.items() if k not in shard_keys and k != "allreduce")
+            sharded = {"N": N2, "config": "configs[3] of BASELINE.json", "value": nsw2 / dt2, "unit": "sweeps/s",
+                       "ms_per_step": 1e3 * dt2 / nsw2, "per_rank_series": int(local2.phi.shape[0]),
+                       "allreduce_us_per_optimiser_step": (bd2["allreduce"][0] / bd2["allreduce"][1]) if bd2.get("allreduce", (0, 0))[1] else None,
+                       "us_per_bond": {"replicated (gram, eigensolver, split)": t_rep, "sharded (yhat, grad, env) at N/ranks": t_sh,
+                                       "allreduce": t_ar},
+                       # one GPU would spend about ranks * t_sh on the sharded kernels (they are N-proportional at this size)
+                       "amdahl": {"speedup_vs_1gpu_estimate": (t_rep + world * t_sh) / max(t_rep + t_sh + t_ar, 1e-9),
+                                  "ceiling_infinite_ranks": (t_rep + world * t_sh) / max(t_rep + t_ar, 1e-9),
+                                  "note": "from this run's event profile; the per-bond eigensolver is replicated on every rank"}}
+            note(f"configs[3] side measurement: N={N2} over {world} ranks: {sharded['value']:.2f} sweeps/s, all-reduce "
+                 f"{sharded['allreduce_us_per_optimiser_step']} us per optimiser step, Amdahl estimate {sharded['amdahl']['speedup_vs_1gpu_estimate']:.2f}x")
+        except Exception as e:
+            sharded = {"error": str(e)}
+            note(f"configs[3] side measurement failed: {e}")
+        if out is not None:
+            out["sharded_n32768"] = sharded
 
     # ---- extra: K independent fits sharing the GPU.  One fit is bound by the latency chain of its per-bond eigensolver
     # (one workgroup of 256 CUs busy for 3/4 of a bond), so independent fits - the reference farms hyper-parameter

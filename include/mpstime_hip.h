@@ -110,6 +110,11 @@ void mpst_destroy(void* ctx);
  * `unique_id` is the 128-byte ncclUniqueId produced on rank 0 and distributed by the host. */
 int  mpst_comm_unique_id(uint8_t out_id[128]);
 int  mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank);
+/* librccl is bound at run time, not linked: MPST_RCCL_LIB if set, else the copy the host process has already loaded (a
+ * Python host that imported torch holds torch's own librccl.so.1), else /opt/rocm/lib's - never two copies in one process.
+ * Reports "<path> (<how it was found>)" (or the reason it could not be loaded), the library's ncclGetVersion code and the
+ * NCCL_VERSION_CODE of the header this library was compiled against; mpst_comm_init refuses another major version. */
+int  mpst_comm_library(char* path_out, int32_t path_cap, int32_t* version_out, int32_t* built_against_out);
 
 /* One-shot direct-write all-reduce over xGMI, next to the RCCL path (the 262 KB message is latency-bound).
  * Every rank allocates an inbox in fine-grained device memory and exports it (64-byte hipIpcMemHandle_t); the host
@@ -296,7 +301,8 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * out[6] sweeps replayed from a hipGraph, out[7] bonds on which the blocked large-bond eigensolver handed over to the
  * library solver, out[8] bonds whose persistent tridiagonalisation gave up waiting for its peers and was redone one
  * launch per step, out[9] bonds whose XCD-local tridiagonalisation found its workgroups on more than one XCD and was
- * redone with the cross-XCD exchange, out[10..11] reserved */
+ * redone with the cross-XCD exchange, out[10] the fused chain runs the sliced bond GEMMs (k_yhat_s + k_grad_s: no partial
+ * gradients per workgroup), out[11] shares per gradient block of k_grad_s */
 int  mpst_get_info(void* ctx, int32_t* out /*[12]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader

@@ -3,7 +3,7 @@ Encodings API.  The hot path lives in libmpstime_hip.so (csrc/); everything here
 host-side mirror of the reference's interface for that path."""
 from . import _lib
 from ._lib import MPSTError, SVDError
-from .engine import SweepEngine
+from .engine import SweepEngine, comm_library
 from .options import MPSOptions, safe_options
 from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_encoding, symbolic_encoding,
                         transform_data, transform_train_data, transform_test_data, legendre_encode,
@@ -16,7 +16,7 @@ from .imputation import (ImputationProblem, init_imputation_problem, MPS_impute,
                          invert_test_transform)
 from . import options
 
-__all__ = ["SweepEngine", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
+__all__ = ["SweepEngine", "comm_library", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
            "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
            "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError", "ImputationProblem",
            "init_imputation_problem", "save_trained_mps", "load_trained_mps", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform"]

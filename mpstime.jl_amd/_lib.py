@@ -67,6 +67,7 @@ SYMBOLS = {
     "mpst_destroy": (None, [_vp]),
     "mpst_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "mpst_comm_init": (C.c_int, [_vp, C.POINTER(C.c_uint8), C.c_int, C.c_int]),
+    "mpst_comm_library": (C.c_int, [C.c_char_p, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "mpst_comm_ipc_export": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
     "mpst_comm_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "mpst_comm_select": (C.c_int, [_vp, C.c_int]),

@@ -2,6 +2,7 @@
 // marshalling, the sweep driver (src/Training/RealRealHighDimension.jl:724-851 restated as a
 // stream of kernel launches with no host read-back inside a sweep) and the RCCL plumbing.
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -16,6 +17,75 @@ using namespace mpst;
 namespace {
 
 thread_local std::string g_err;  // errors raised without a context (mpst_create)
+
+// ---- RCCL, bound at run time ----------------------------------------------------------------------------------------------
+// The library is NOT linked against librccl: a host process that has imported torch already holds torch's own copy
+// (torch/lib/librccl.so, same SONAME librccl.so.1 as /opt/rocm/lib's), and two copies of a collective library in one process
+// - two sets of bootstrap threads, IPC registries and topology caches - is a hazard on first multi-GPU contact.  Order:
+// MPST_RCCL_LIB (explicit path), then whatever librccl.so.1 the process has ALREADY loaded (RTLD_NOLOAD: the host's copy
+// wins), then the system one.  mpst_comm_init compares the version of the bound library with the header this file was
+// compiled against (same major version, see there) and mpst_comm_library reports path and version.
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    int version = 0;
+    std::string path, how, err;
+};
+Rccl* rccl_get() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return &r;
+    tried = true;
+    const char* envp = getenv("MPST_RCCL_LIB");
+    if (envp && *envp) {
+        r.h = dlopen(envp, RTLD_NOW | RTLD_LOCAL);
+        r.how = "MPST_RCCL_LIB";
+    }
+    if (!r.h && !envp) {
+        for (const char* nm : {"librccl.so.1", "librccl.so"}) {
+            if ((r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) { r.how = "already loaded by the host process"; break; }
+        }
+    }
+    if (!r.h && !envp) {
+        for (const char* nm : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+            if ((r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) { r.how = "system library"; break; }
+        }
+    }
+    if (!r.h) {
+        const char* de = dlerror();
+        r.err = std::string("librccl could not be loaded: ") + (de ? de : "not found");
+        return &r;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.GetVersion) {
+        r.err = "librccl lacks a required entry point";
+        r.h = nullptr;
+        return &r;
+    }
+    Dl_info di;
+    if (dladdr((void*)r.AllReduce, &di) && di.dli_fname) r.path = di.dli_fname;
+    (void)r.GetVersion(&r.version);
+    return &r;
+}
+// the entry points of the bound library, or null with the reason in *why
+Rccl* rccl_ready(std::string* why) {
+    Rccl* r = rccl_get();
+    if (!r->h) {
+        if (why) *why = r->err;
+        return nullptr;
+    }
+    return r;
+}
 
 enum KClass { K_YHAT = 0, K_GRAD, K_UPDATE, K_GRAM, K_EIG_TRI, K_SPLIT, K_ENV, K_BT, K_ALLREDUCE, K_EIG_VEC, K_EIG_FIN, K_NCLASS };
 
@@ -339,8 +409,10 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
     }
     if (!c->comm) return fail(c, MPST_ERR_INVALID, "%d ranks but neither an RCCL communicator nor attached inboxes", c->nranks);
     const size_t cnt = lid >= 0 ? 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap : (size_t)n_fixed;
-    ncclResult_t r = ncclAllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream);
-    if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", ncclGetErrorString(r));
+    Rccl* nc = rccl_ready(nullptr);
+    if (!nc) return fail(c, MPST_ERR_DEVICE, "RCCL is not available");
+    ncclResult_t r = nc->AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, MPST_ERR_DEVICE, "ncclAllReduce: %s", nc->GetErrorString(r));
     return 0;
 }
 
@@ -546,7 +618,7 @@ void mpst_destroy(void* ctx) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->sweep_graph) (void)hipGraphExecDestroy(c->sweep_graph);
-    if (c->comm) ncclCommDestroy(c->comm);
+    if (c->comm && rccl_ready(nullptr)) rccl_ready(nullptr)->CommDestroy(c->comm);
     ipc_release(c);
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
     dfree(&c->sites); dfree(&c->chi); dfree(&c->label_site); dfree(&c->LE); dfree(&c->RE); dfree(&c->bt);
@@ -567,8 +639,11 @@ void mpst_destroy(void* ctx) {
 int mpst_comm_unique_id(uint8_t out_id[128]) {
     ncclUniqueId id;
     static_assert(sizeof(id) == 128, "ncclUniqueId size");
-    ncclResult_t r = ncclGetUniqueId(&id);
-    if (r != ncclSuccess) return fail(nullptr, MPST_ERR_DEVICE, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    std::string why;
+    Rccl* nc = rccl_ready(&why);
+    if (!nc) return fail(nullptr, MPST_ERR_DEVICE, "%s", why.c_str());
+    ncclResult_t r = nc->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MPST_ERR_DEVICE, "ncclGetUniqueId: %s", nc->GetErrorString(r));
     memcpy(out_id, &id, 128);
     return 0;
 }
@@ -577,14 +652,34 @@ int mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank
     Ctx* c = (Ctx*)ctx;
     if (!c || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MPST_ERR_INVALID, "bad communicator arguments");
     HIPC(c, hipSetDevice(c->device));
-    if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+    std::string why;
+    Rccl* nc = rccl_ready(&why);
+    if (!nc) return fail(c, MPST_ERR_DEVICE, "%s", why.c_str());
+    // Only six entry points are used (ncclGetUniqueId / CommInitRank / CommDestroy / AllReduce / GetErrorString / GetVersion)
+    // with ncclDouble, ncclSum and the 128-byte ncclUniqueId - unchanged across the 2.x series - so a host's copy of another
+    // MINOR version (torch 2.10 ships 2.26.6 next to ROCm 7.2's 2.27.7) is accepted; another major version is not.
+    if (nc->version / 10000 != NCCL_VERSION_CODE / 10000 || nc->version < 21800)
+        return fail(c, MPST_ERR_DEVICE, "librccl %s has version %d, this library was built against %d (set MPST_RCCL_LIB to a matching one)",
+                    nc->path.c_str(), nc->version, (int)NCCL_VERSION_CODE);
+    if (c->comm) { nc->CommDestroy(c->comm); c->comm = nullptr; }
     c->nranks = nranks; c->rank = rank;
     c->epoch++;
     ncclUniqueId id;
     memcpy(&id, unique_id, 128);
-    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, id, rank);
-    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, MPST_ERR_DEVICE, "ncclCommInitRank: %s", ncclGetErrorString(r)); }
+    ncclResult_t r = nc->CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) { c->comm = nullptr; return fail(c, MPST_ERR_DEVICE, "ncclCommInitRank: %s", nc->GetErrorString(r)); }
     return 0;
+}
+
+int mpst_comm_library(char* path_out, int32_t path_cap, int32_t* version_out, int32_t* built_against_out) {
+    Rccl* nc = rccl_get();
+    if (version_out) *version_out = nc->version;
+    if (built_against_out) *built_against_out = (int32_t)NCCL_VERSION_CODE;
+    if (path_out && path_cap > 0) {
+        const std::string t = nc->h ? nc->path + " (" + nc->how + ")" : nc->err;
+        snprintf(path_out, (size_t)path_cap, "%s", t.c_str());
+    }
+    return nc->h ? 0 : MPST_ERR_DEVICE;
 }
 
 int mpst_comm_ipc_export(void* ctx, int nranks, int rank, uint8_t handle_out[64]) {
@@ -1480,7 +1575,8 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[7] = (int32_t)std::min<int64_t>(c->big_fallbacks, 1 << 30);
     out[8] = blocked_eig_coop_aborts(c->blk);      // bonds the persistent tridiagonalisation handed back to the launch-per-step path
     out[9] = blocked_eig_xcd_misplaced(c->blk);    // bonds whose XCD-local attempt found its workgroups on several XCDs (redone across the XCDs)
-    out[10] = out[11] = 0;
+    out[10] = c->b2 ? 1 : 0;                        // fused chain with the sliced bond GEMMs (k_yhat_s + k_grad_s)
+    out[11] = c->b2 ? c->b2_ksplit : 0;             // shares per gradient block of k_grad_s
     return 0;
 }
 
@@ -1501,7 +1597,8 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     return 0;
 }
 
-// not part of the ABI: stamps of the sliced bond kernels (-DMPST_B2_DEBUG builds), 8192 x 8 slots
+#ifdef MPST_B2_DEBUG
+// bring-up builds only (scratch/build_dbg.sh): stamps of the sliced bond kernels, 8192 x 8 slots
 int mpst_debug_b2(void* ctx, unsigned long long* out) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->b2_dbg || !out) return MPST_ERR_INVALID;
@@ -1511,7 +1608,10 @@ int mpst_debug_b2(void* ctx, unsigned long long* out) {
     return 0;
 }
 
-// not part of the ABI (include/mpstime_hip.h): raw stamp slots for kernel bring-up (-DMPST_TRI_DEBUG)
+#endif
+
+#ifdef MPST_TRI_DEBUG
+// bring-up builds only (-DMPST_TRI_DEBUG): raw stamp slots of the eigensolver kernels
 int mpst_debug_stamps(void* ctx, unsigned long long* out64) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->sc || !out64) return MPST_ERR_INVALID;
@@ -1522,6 +1622,7 @@ int mpst_debug_stamps(void* ctx, unsigned long long* out64) {
     for (int i = 0; i < 64; ++i) out64[i] = sc.eig_stamps[i];
     return 0;
 }
+#endif
 
 int mpst_selftest_mfma(void* ctx, const double* A, const double* B, int32_t K, double* C_out) {
     Ctx* c = (Ctx*)ctx;

@@ -335,7 +335,7 @@ class SweepEngine:
         self._chk(self.lib.mpst_get_info(self.ctx, out))
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
-                "xcd_local_misplaced": out[9]}
+                "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11]}
 
     def eig_phases(self):
         us = np.zeros(6)
@@ -362,3 +362,13 @@ class SweepEngine:
         self._chk(self.lib.mpst_selftest_eig(self.ctx, G.ctypes.data_as(dp), n, alg, lam.ctypes.data_as(dp),
                                              E.ctypes.data_as(dp), C.byref(sw)))
         return lam, E, sw.value
+
+
+def comm_library():
+    """Which librccl the HIP library has bound (it is loaded at run time, never linked): path + how it was found, the
+    library's ncclGetVersion code and the NCCL_VERSION_CODE the HIP library was compiled against."""
+    lib = L.load()
+    buf = C.create_string_buffer(1024)
+    ver, built = C.c_int32(0), C.c_int32(0)
+    rc = lib.mpst_comm_library(buf, 1024, C.byref(ver), C.byref(built))
+    return {"ok": rc == 0, "library": buf.value.decode(), "version": ver.value, "built_against": built.value}

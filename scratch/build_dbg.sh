@@ -12,5 +12,5 @@ for f in mpst_kernels mpst_fused mpst_eig mpst_eig_blocked mpst_encode mpst_allr
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" $extra -c $f.hip -o $out/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $out/*.o -o $root/scratch/libmpstime_hip_$name.so -L/opt/rocm/lib -lrccl -lrocsolver -lrocblas -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $out/*.o -o $root/scratch/libmpstime_hip_$name.so -L/opt/rocm/lib -lrocsolver -lrocblas -ldl -Wl,-rpath,/opt/rocm/lib
 ls -la $root/scratch/libmpstime_hip_$name.so
