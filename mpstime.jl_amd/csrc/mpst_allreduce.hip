@@ -7,14 +7,15 @@
 //
 // Inboxes are double-buffered by the parity of a per-call epoch: a rank can only start pushing epoch e+2 after it has
 // seen every peer's flag of epoch e+1, which a peer raises after it has finished reading epoch e.  One flag per peer
-// and call is therefore enough.  Every spin is bounded; on time-out the device-side status word is set and the call
-// returns MPST_ERR_DEVICE instead of hanging the node.
+// and call is therefore enough.  Every spin is bounded (ArParams.spin_limit shader cycles: 10 s unless MPST_AR_TIMEOUT_S
+// says otherwise - first-use peer mapping, a redone eigensolve on one rank or host jitter must not trip it); on time-out
+// the device-side status word is set, the call returns MPST_ERR_DEVICE instead of hanging the node, and the host retires
+// the one-shot path: flags, epochs and slots are then in an undefined cross-rank state.
 #include "mpst_internal.h"
 
 namespace mpst {
 
 constexpr int AR_WG = 64;                    // workgroups of the all-reduce kernel (all co-resident: 64 << 256 CUs)
-constexpr long long AR_SPIN_LIMIT = 1LL << 31;   // ~1 s of shader cycles
 
 __global__ __launch_bounds__(256) void k_allreduce_oneshot(ArParams p) {
     __shared__ int last;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void k_allreduce_oneshot(ArParams p) {
         const long long t0 = __builtin_readcyclecounter();
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != p.epoch) {
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_readcyclecounter() - t0 > AR_SPIN_LIMIT) {
+            if (__builtin_readcyclecounter() - t0 > p.spin_limit) {
                 *p.status = MPST_ERR_DEVICE;
                 break;
             }

@@ -145,6 +145,7 @@ struct Ctx {
     int64_t ipc_slot = 0;
     size_t ipc_flag_off = 0, ipc_ctr_off = 0, ipc_bytes = 0;
     bool use_ipc = false;                // all peers attached: gradient and evaluation sums go through the one-shot path
+    bool ipc_dead = false;               // a one-shot all-reduce timed out: its cross-rank state is undefined until the inboxes are exported again
     unsigned long long ar_epoch = 0;
     // profiling
     unsigned prof_mask = 0;
@@ -402,11 +403,17 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
         p.counter = (unsigned int*)((char*)c->ipc_local + c->ipc_ctr_off);
         p.nranks = c->nranks; p.rank = c->rank; p.slot = c->ipc_slot;
         p.epoch = ++c->ar_epoch;
+        {
+            static const double secs = [] { const char* e = getenv("MPST_AR_TIMEOUT_S"); const double v = e ? atof(e) : 10.0; return v > 0.0 ? v : 10.0; }();
+            p.spin_limit = (long long)(secs * 2.4e9);
+        }
         p.chi = c->chi; p.lid = lid; p.C = c->C; p.d = c->d; p.n_fixed = n_fixed;
         if (lid < 0 && n_fixed > c->ipc_slot) return fail(c, MPST_ERR_INVALID, "all-reduce message exceeds the inbox slot");
         launch_allreduce_oneshot(p, c->stream);
         return 0;
     }
+    if (c->ipc_dead && !c->comm)
+        return fail(c, MPST_ERR_DEVICE, "the one-shot all-reduce timed out earlier: export and attach the inboxes again (mpst_comm_ipc_export / _attach)");
     if (!c->comm) return fail(c, MPST_ERR_INVALID, "%d ranks but neither an RCCL communicator nor attached inboxes", c->nranks);
     const size_t cnt = lid >= 0 ? 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap : (size_t)n_fixed;
     Rccl* nc = rccl_ready(nullptr);
@@ -433,6 +440,8 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         vy.trace_it = n_it;
         launch_yhat(vy, lid, s);
         launch_trace_loss(vy, s);
+        // a shard's tile losses carry the GLOBAL 1/N: the sum over the ranks is the loss the single-rank run records
+        if (c->nranks > 1) (void)enqueue_allreduce(c, vy.trace + n_it, 1, -1);
     };
     const int rid = lid + 1;
     if (c->fused) {
@@ -727,6 +736,7 @@ int mpst_comm_ipc_attach(void* ctx, const uint8_t* all_handles) {
         }
     }
     c->use_ipc = true;
+    c->ipc_dead = false;
     c->epoch++;
     return 0;
 }
@@ -1225,6 +1235,11 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     }
     if (sc.status) {
         c->caches_valid = false;        // the state after a failed bond is unspecified: set_mps + build_caches to go on
+        if (sc.status == MPST_ERR_DEVICE && c->use_ipc) {
+            c->use_ipc = false;         // flags / epochs / slots are in an undefined cross-rank state: never reuse them
+            c->ipc_dead = true;
+            return fail(c, MPST_ERR_DEVICE, "the one-shot all-reduce timed out waiting for a peer (MPST_AR_TIMEOUT_S); the path is retired until the inboxes are exported again");
+        }
         return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
     }
     return 0;

@@ -425,6 +425,7 @@ struct ArParams {
     int nranks, rank;
     int64_t slot;               // doubles per inbox slot
     unsigned long long epoch;   // 1, 2, 3, ... identical on every rank
+    long long spin_limit;       // shader cycles a rank waits for its peers' flags before it gives up
     const int32_t* chi;         // live message length 2 + C * d*chi[lid] * d*chi[lid+2] when lid >= 0
     int lid, C, d;
     int64_t n_fixed;            // message length when lid < 0

@@ -193,16 +193,22 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
 
 def _impute_sharded(imp, mask, method, rows, shard, return_seconds=False, rng=None, **kw):
     """Rows i with i % world == rank on every rank (the classes stay balanced), results gathered with the host-side
-    process group; the uniform numbers of the sampling methods are drawn for the whole set on every rank from the same
-    generator, so a sharded run reproduces the single-process one."""
+    process group.  The uniform numbers of the sampling method (ITS) come from one seed shared by all ranks (rank 0's draw
+    from `rng`, broadcast) and one stream per rank derived from it - reproducible for a given `rng` state and world size, not
+    the single-process stream."""
     import torch.distributed as dist
     mine = np.arange(shard.rank, len(rows), shard.world)
-    if rng is not None and method == "ITS":
-        raise NotImplementedError("sharded ITS: pass per-rank generators through a single-process call per shard")
+    shard_rng = None
+    if method == "ITS":
+        # one seed for the whole call - rank 0's draw (from `rng` if given), broadcast over the host-side group - and one
+        # stream per rank derived from it: a sharded run with the same `rng` state and world size repeats itself
+        seed = [int((rng or np.random.default_rng()).integers(0, 2 ** 62))]
+        dist.broadcast_object_list(seed, src=0, group=shard.group)
+        shard_rng = np.random.default_rng([seed[0], shard.rank])
     ts = pred = None
     secs = 0.0
     if len(mine):
-        out = impute_dataset(imp, mask[mine], method, rows=np.asarray(rows)[mine], return_seconds=True, **kw)
+        out = impute_dataset(imp, mask[mine], method, rows=np.asarray(rows)[mine], return_seconds=True, rng=shard_rng, **kw)
         ts, pred, secs = out
     parts = [None] * shard.world
     dist.all_gather_object(parts, (mine, ts, pred, secs), group=shard.group)
