@@ -1238,7 +1238,12 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
-    if (CX && v.d > 5)
+    // two workgroups per CU (128 VGPRs each, 70-183 of them spilled) against one (256 VGPRs, no spill): the spilling
+    // build wins where the density loop is latency-bound - real models and complex ones with d <= 5 - because a second
+    // workgroup hides more than the scratch traffic costs (same-box A/B: profiles/r03_impute_occupancy_ab.txt;
+    // MPST_IMP_OCC=1|2 forces either)
+    static const int force_occ = [] { const char* e = getenv("MPST_IMP_OCC"); return e ? atoi(e) : 0; }();
+    if (force_occ == 1 || (force_occ != 2 && CX && v.d > 5))
         hipLaunchKernelGGL((k_imp_left<R, CX, 1>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
     else
         hipLaunchKernelGGL((k_imp_left<R, CX, 2>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);

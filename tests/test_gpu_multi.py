@@ -108,7 +108,7 @@ full = mt.EncodedTimeSeriesSet(ds.phi, ds.label_index.astype(np.int64), ds.label
 sh = mt.Shard(rank, world, rccl=False, oneshot=True)
 local, gcounts = sh.split(full)
 eng = mt.SweepEngine(dev)
-eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2)
+eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2, track_cost=True)
 eng.set_dataset(0, local.phi, local.label_index, 3, gcounts)
 eng.set_mps(W0)
 sh.attach_oneshot(eng)
@@ -116,7 +116,7 @@ eng.build_caches()
 for _ in range(2):
     eng.sweep()
 ev = eng.eval(0)
-np.savez(os.path.join(os.environ["MPST_OUT"], f"rank{rank}.npz"), mse=ev[0], kld=ev[1], acc=ev[2], conf=ev[3],
+np.savez(os.path.join(os.environ["MPST_OUT"], f"rank{rank}.npz"), mse=ev[0], kld=ev[1], acc=ev[2], conf=ev[3], trace=eng.loss_trace(),
          **{f"W{j}": t for j, t in enumerate(eng.get_mps())})
 dist.barrier()
 eng.close()
@@ -143,7 +143,7 @@ def test_oneshot_allreduce_ranks_sharing_the_gpus(tmp_path, loss, world):
     ds, W0 = make_problem(150, 8, 4, 4, 3, seed=21, balanced=False)
     eng = mt.SweepEngine(0)
     try:
-        eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2)
+        eng.set_options(chi_max=10, eta=0.05, loss=loss, update_iters=2, track_cost=True)
         eng.set_dataset(0, ds.phi, ds.label_index, 3)
         eng.set_mps(W0)
         eng.build_caches()
@@ -151,9 +151,15 @@ def test_oneshot_allreduce_ranks_sharing_the_gpus(tmp_path, loss, world):
             eng.sweep()
         ev = eng.eval(0)
         W1 = eng.get_mps()
+        trace1 = eng.loss_trace()
     finally:
         eng.close()
     T = len(W0)
+    # track_cost on a sharded fit: every entry of the trace - the losses before each optimiser step AND the one at the
+    # updated bond tensor - is the global loss, the same on every rank and equal to the single-rank run's
+    for r in range(world):
+        assert np.array_equal(outs[0]["trace"], outs[r]["trace"])
+    assert np.abs(outs[0]["trace"] - trace1).max() <= 1e-8 * max(1.0, np.abs(trace1).max())
     for r in range(1, world):
         for j in range(T):
             assert np.array_equal(outs[0][f"W{j}"], outs[r][f"W{j}"])           # bit-identical replicas
