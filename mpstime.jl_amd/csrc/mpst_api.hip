@@ -281,7 +281,16 @@ int ensure_workspace(Ctx* c) {
     c->fused = dm <= MAX_DIM && !c->opt.rescale_before && getenv("MPST_NO_FUSED") == nullptr;
     const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
     (void)pk;
-    c->b2 = c->fused && c->d >= 2 && c->d <= 16 && getenv("MPST_NO_B2") == nullptr;
+    // Which pair forms the gradient on the fused chain.  The sliced kernels (k_yhat_s + k_grad_s) move tens of KB per workgroup
+    // and no partial gradients: 26 us against 31 us per bond at N = 4096, 11.6 MB against 40 MB of HBM traffic.  Their cost per
+    // series is higher though (every series is read by 8 slice- and 16 block-workgroups: 2.7 against 1.5 us per 1000 series),
+    // so from about 8000 series per rank the persistent k_bond_fused + k_fused_reduce pair wins (N = 32768: 75 against 105 us;
+    // profiles/r03_*).  MPST_B2=0 / 1 forces either.
+    {
+        const char* e = getenv("MPST_B2");
+        const bool want = e ? atoi(e) != 0 : (tr.N <= 8192 && getenv("MPST_NO_B2") == nullptr);
+        c->b2 = c->fused && c->d >= 2 && c->d <= 16 && want;
+    }
     if (c->fused) {
         c->partial_elems = (int64_t)std::max(tr.nparts[0], tr.nparts[1]) * Lmax;   // independent of N: one partial per persistent workgroup
         if (c->b2) {

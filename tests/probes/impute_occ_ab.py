@@ -12,7 +12,7 @@ sys.argv = ["x", "--quick"]
 import importlib.util
 spec = importlib.util.spec_from_file_location("ib", os.path.join(%r, "tests", "probes", "impute_bench.py"))
 src = open(spec.origin).read().split("res = []")[0]      # helpers only (random_chain, block_mask, problem)
-ns = {}
+ns = {"__file__": spec.origin, "__name__": "impute_bench_helpers"}
 exec(compile(src, spec.origin, "exec"), ns)
 eng = mt.SweepEngine(0)
 for (N, T, d, chi, cx, compute) in [(4096, 100, 4, 32, False, "f64"), (4096, 100, 4, 32, False, "f32"), (4096, 100, 4, 32, True, "f64"),
