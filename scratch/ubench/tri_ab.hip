@@ -1,7 +1,7 @@
 // Same-box A/B harness for the n <= 128 tridiagonalisation: runs the engine's k_eig_tri (included from the product
 // source) and the prototypes of tri_proto.hip on the same Gram matrix, times them with HIP events, dumps per-step cycle
 // stamps and writes (d, e) of each so that a Python check can compare the spectra.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMPST_TRI_STEPPROF scratch/ubench/tri_ab.hip -o scratch/ubench/tri_ab.bin -lrocsolver -lrocblas -lrccl
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMPST_TRI_STEPPROF scratch/ubench/tri_ab.hip -o scratch/ubench/tri_ab.bin -lrocsolver -lrocblas -ldl
 #include "../../mpstime.jl_amd/csrc/mpst_eig.hip"
 #ifdef HAVE_PROTO
 #include "tri_proto_gen.hip"
@@ -99,7 +99,12 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(hw.data(), w, sizeof(double) * WS_TOTAL, hipMemcpyDeviceToHost));
         double tr = 0, trG = 0;
         for (int i = 0; i < n; ++i) { tr += hw[WS_DE + 2 * i]; trG += G[(size_t)i * n + i]; }
-        printf("variant %d: %.2f us per launch (%d back-to-back), in-kernel %.2f us = %llu cycles, trace err %.2e\n", which,
+        printf("variant %d [%s]: %.2f us per launch (%d back-to-back), in-kernel %.2f us = %llu cycles, trace err %.2e\n", which,
+#ifdef HAVE_PROTO
+               tri_proto_name(which),
+#else
+               "product k_eig_tri",
+#endif
                1e3 * ms / reps, reps, 0.01 * (double)(hs[1] - hs[0]), hs[7] - hs[6], std::fabs(tr - trG));
         printf("  step cycles:");
         for (int i = 0; i + 1 < n - 1; ++i)

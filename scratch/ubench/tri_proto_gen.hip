@@ -3,10 +3,10 @@
 // row group repeats the cheap part of a step for itself at its own 16 columns (the pending rank-2 update's scalars, the
 // updated next row, its norm, the reflector), then updates its row and multiplies it with the NEW reflector in the same
 // pass; the only exchange of a step is y = A v (one entry per row) plus the raw next row.
-// GENERATED by scratch/ubench/make_tri_proto.py from mpst_eig.hip + the step1 body below; do not edit by hand.
+// The two-barrier step is a copy of the product kernel's (mpst_eig.hip); the harness tri_ab.hip runs both on the same matrix.
 #pragma once
 namespace mpst {
-constexpr int TRI_PROTO_VARIANTS = 5;
+constexpr int TRI_PROTO_VARIANTS = 7;
 
 template <int ESW>
 __global__ __launch_bounds__(TRI_T) void k_eig_tri_h(View v, int lid, int going_left, const double* rawG, int rawn,
@@ -437,13 +437,21 @@ static void launch_tri_h(const double* G, int n, double* ws, unsigned long long*
     }
     hipLaunchKernelGGL(k_eig_tri_h<ESW>, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, 0, ws, stamps);
 }
+static const char* tri_proto_name(int which) {
+    static const char* nm[] = {"product k_eig_tri (two barriers per step)", "one barrier per step from era 0 (all steps)", "one barrier from era 1 (step 15)",
+                               "one barrier from era 2 (step 31)", "one barrier from era 3 (step 47)", "one barrier from era 4 (step 63)",
+                               "one barrier from era 6 (step 95)", "one barrier from era 7 (step 111)"};
+    return nm[which];
+}
 static void launch_tri_proto(int which, const double* G, int n, double* ws, unsigned long long* stamps, hipStream_t s) {
     switch (which) {
         case 1: launch_tri_h<0>(G, n, ws, stamps, s); break;
         case 2: launch_tri_h<1>(G, n, ws, stamps, s); break;
         case 3: launch_tri_h<2>(G, n, ws, stamps, s); break;
         case 4: launch_tri_h<3>(G, n, ws, stamps, s); break;
-        default: launch_tri_h<4>(G, n, ws, stamps, s); break;
+        case 5: launch_tri_h<4>(G, n, ws, stamps, s); break;
+        case 6: launch_tri_h<6>(G, n, ws, stamps, s); break;
+        default: launch_tri_h<7>(G, n, ws, stamps, s); break;
     }
 }
 }  // namespace mpst
