@@ -1136,15 +1136,15 @@ __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, in
         const double* pbase = v.partial + (int64_t)grp * ksplit * 1024 + tile * 256;
         if (kh == 0) {
             double s[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < ksplit; k0 += 4) {
-                double t[4][4];
+            for (int k0 = 0; k0 < ksplit; k0 += 8) {           // 32 loads in flight: one round trip for up to 8 shares
+                double t[8][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         t[u][r] = (k0 + u < ksplit) ? ld_agent(pbase + (int64_t)(k0 + u) * 1024 + r * 64 + lane) : 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[r] += t[u][r];
             }

@@ -276,7 +276,25 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri_h(View v, int lid, int going_
                 n0 = fma(x0, x0, n0);
                 n1 = fma(x1, x1, n1);
             }
+#ifdef TRI_LATE_SCALE
+            // v_j = scale * xm + e_{j+1}: the products A xm and A e_{j+1} do not need the reflector's scalars, so the update,
+            // both mat-vecs and their reductions run beside the norm -> rsqrt -> reciprocal chain instead of after it
+            double a0 = 0.0, a1 = 0.0, c0 = 0.0;
+#pragma unroll
+            for (int k = K0; k < NP; ++k) {
+                a0 = fma(A[2 * k], xm[k].x, a0);
+                a1 = fma(A[2 * k + 1], xm[k].y, a1);
+                if (k < K0 + 2) {
+                    const int c = 2 * q + 2 * QN * k;
+                    c0 += (c == j + 1 ? A[2 * k] : 0.0) + (c + 1 == j + 1 ? A[2 * k + 1] : 0.0);
+                }
+            }
             const double s = sum_q(n0 + n1);
+            const double yraw = sum_q(a0 + a1);
+            const double ycol = sum_q(c0);
+#else
+            const double s = sum_q(n0 + n1);
+#endif
             // reflector j (as finish_reflector of k_eig_tri)
             const double xx = fma(al, al, s);
             const bool nz = s != 0.0 && xx > 1e-280;
@@ -290,6 +308,19 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri_h(View v, int lid, int going_
             const double beta = nz ? -bneg : al;
             const double taun = nz ? (bneg + al) * ib : 0.0;
             const double scale = nz ? is : 0.0;
+#ifdef TRI_LATE_SCALE
+#pragma unroll
+            for (int k = K0; k < NP; ++k) {
+                double v0 = xm[k].x * scale, v1 = xm[k].y * scale;
+                if (k < K0 + 2) {
+                    const int c = 2 * q + 2 * QN * k;
+                    v0 = c == j + 1 ? 1.0 : v0;
+                    v1 = c + 1 == j + 1 ? 1.0 : v1;
+                }
+                vv[k] = make_double2(v0, v1);
+            }
+            const double yn = fma(scale, yraw, ycol);
+#else
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int k = K0; k < NP; ++k) {
@@ -304,6 +335,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri_h(View v, int lid, int going_
                 a1 = fma(A[2 * k + 1], v1, a1);
             }
             const double yn = sum_q(a0 + a1);
+#endif
             double* ybn = t.ps + (j & 1) * 128;
             if (q == 0) ybn[r] = r > j ? yn : 0.0;
             if (r == j + 1) {                                    // the raw row the next step starts from
