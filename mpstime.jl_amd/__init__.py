@@ -10,7 +10,7 @@ from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_en
                         legendre_encode_no_norm, fourier_encode, get_fourier_freqs, angle_encode, sahand_encode,
                         uniform_encode)
 from .training import (TrainedMPS, fitMPS, fit_encoded, classify, generate_startingMPS, trendy_sine, save_trained_mps,
-                       load_trained_mps)
+                       load_trained_mps, mps_content_digest)
 from .distributed import Shard, split_encoded
 from .imputation import (ImputationProblem, init_imputation_problem, MPS_impute, impute_dataset, kNN_impute, mar,
                          invert_test_transform)
@@ -19,4 +19,4 @@ from . import options
 __all__ = ["SweepEngine", "comm_library", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
            "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
            "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError", "ImputationProblem",
-           "init_imputation_problem", "save_trained_mps", "load_trained_mps", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform"]
+           "init_imputation_problem", "save_trained_mps", "load_trained_mps", "mps_content_digest", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform"]

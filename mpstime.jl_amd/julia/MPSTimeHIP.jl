@@ -30,6 +30,14 @@ end
 const MPST_ERR_UNSUPPORTED = -2
 const MPST_ERR_SVD = -4
 
+"""Which librccl the library bound (it is loaded at run time, never linked): `(path_and_how, version, built_against)`."""
+function comm_library()
+    buf = Vector{UInt8}(undef, 1024)
+    ver = Ref{Int32}(0); built = Ref{Int32}(0)
+    ccall((:mpst_comm_library, LIB), Cint, (Ptr{UInt8}, Int32, Ref{Int32}, Ref{Int32}), buf, Int32(length(buf)), ver, built)
+    return (unsafe_string(pointer(buf)), Int(ver[]), Int(built[]))
+end
+
 function check(ctx, rc)
     rc == 0 && return
     msg = unsafe_string(ccall((:mpst_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx))

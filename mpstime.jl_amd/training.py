@@ -303,6 +303,20 @@ def save_trained_mps(path, trained: TrainedMPS):
                         **{f"mps_{j}": t for j, t in enumerate(trained.mps)})
 
 
+def mps_content_digest(mps) -> str:
+    """SHA-256 over the site tensors in order: for every site its shape (int64, little endian) followed by its float64
+    (or complex128) entries in C order of (left bond, site, right bond[, label]).  Independent of the container (.npz zip
+    metadata, JLD2): the Julia snippet in INTEGRATION.md computes the same digest from an ITensors MPS, which closes the
+    save / load round trip (test/save_load.jl:17-24) for a maintainer who has Julia."""
+    import hashlib
+    h = hashlib.sha256()
+    for t in mps:
+        a = np.ascontiguousarray(t, dtype=np.complex128 if np.iscomplexobj(t) else np.float64)
+        h.update(np.asarray(a.shape, dtype="<i8").tobytes())
+        h.update(a.astype(a.dtype.newbyteorder("<"), copy=False).tobytes())
+    return h.hexdigest()
+
+
 def load_trained_mps(path) -> TrainedMPS:
     import json
     z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)

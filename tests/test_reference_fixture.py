@@ -218,3 +218,20 @@ def test_fit_outcome_brackets_the_reference_fit(ref):
         assert info["train_acc"][-1] == 1.0
         assert kl[5] > kld_ref > kl[-1], (seed, kl)            # entry k = after k sweeps (entry 0: the initial MPS)
         assert abs(kl[-1] - kld_ref) < 1.0
+
+
+REF_MPS_DIGEST = "0559cc1372c9561503946707a2d636d4413f8d9712b72c076c622d1619e412b6"
+
+
+def test_reference_mps_content_digest_and_npz_round_trip(ref, tmp_path):
+    """The container-independent digest of the reference's own trained MPS (mps_content_digest: shapes + entries in the
+    index order (left bond, site, right bond[, label])).  mpstime.jl_amd/julia/roundtrip_check.jl computes the same digest in
+    Julia from test/Data/ecg200/mps_saves/test_dataset.jld2 and from a .npz this package wrote: a maintainer with Julia
+    closes the save / load round trip (test/save_load.jl:17-24) by comparing the three values."""
+    assert mt.mps_content_digest(ref["W"]) == REF_MPS_DIGEST
+    opts = mt.MPSOptions(d=ref["d"], chi_max=ref["chi_max"], encoding="Legendre_No_Norm", verbosity=-1)
+    td = mt.EncodedTimeSeriesSet(ref["phi"], ref["label_index"].astype(np.int64), ref["label_index"].astype(np.int32), ref["X"], ref["cd"])
+    path = tmp_path / "ref_model.npz"
+    mt.save_trained_mps(str(path), mt.TrainedMPS(ref["W"], opts, td))
+    back = mt.load_trained_mps(str(path))
+    assert mt.mps_content_digest(back.mps) == REF_MPS_DIGEST
