@@ -5,6 +5,7 @@
 #include "../../mpstime.jl_amd/csrc/mpst_eig.hip"
 #ifdef HAVE_PROTO
 #include "tri_proto_gen.hip"
+#include "tri_rows2.hip"
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -67,13 +68,15 @@ int main(int argc, char** argv) {
         if (which == 0)
             hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, (const double*)dG, n, 0, w, stp);
 #ifdef HAVE_PROTO
-        else
+        else if (which <= TRI_PROTO_VARIANTS)
             launch_tri_proto(which, dG, n, w, stp, s);
+        else
+            launch_tri_rows2(dG, n, w, stp, s);
 #endif
     };
     const int nvar =
 #ifdef HAVE_PROTO
-        1 + TRI_PROTO_VARIANTS;
+        2 + TRI_PROTO_VARIANTS;
 #else
         1;
 #endif
@@ -101,7 +104,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; ++i) { tr += hw[WS_DE + 2 * i]; trG += G[(size_t)i * n + i]; }
         printf("variant %d [%s]: %.2f us per launch (%d back-to-back), in-kernel %.2f us = %llu cycles, trace err %.2e\n", which,
 #ifdef HAVE_PROTO
-               tri_proto_name(which),
+               which <= TRI_PROTO_VARIANTS ? tri_proto_name(which) : "two rows per thread (two-barrier steps, 32-column eras)",
 #else
                "product k_eig_tri",
 #endif
