@@ -6,6 +6,7 @@
 #ifdef HAVE_PROTO
 #include "tri_proto_gen.hip"
 #include "tri_rows2.hip"
+#include "tri_par.hip"
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -70,13 +71,15 @@ int main(int argc, char** argv) {
 #ifdef HAVE_PROTO
         else if (which <= TRI_PROTO_VARIANTS)
             launch_tri_proto(which, dG, n, w, stp, s);
-        else
+        else if (which == TRI_PROTO_VARIANTS + 1)
             launch_tri_rows2(dG, n, w, stp, s);
+        else
+            launch_tri_par(dG, n, w, stp, s);
 #endif
     };
     const int nvar =
 #ifdef HAVE_PROTO
-        2 + TRI_PROTO_VARIANTS;
+        3 + TRI_PROTO_VARIANTS;
 #else
         1;
 #endif
@@ -104,7 +107,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < n; ++i) { tr += hw[WS_DE + 2 * i]; trG += G[(size_t)i * n + i]; }
         printf("variant %d [%s]: %.2f us per launch (%d back-to-back), in-kernel %.2f us = %llu cycles, trace err %.2e\n", which,
 #ifdef HAVE_PROTO
-               which <= TRI_PROTO_VARIANTS ? tri_proto_name(which) : "two rows per thread (two-barrier steps, 32-column eras)",
+               which <= TRI_PROTO_VARIANTS ? tri_proto_name(which) : which == TRI_PROTO_VARIANTS + 1 ? "two rows per thread (two-barrier steps, 32-column eras)" : "product step with compile-time buffer parity",
 #else
                "product k_eig_tri",
 #endif
