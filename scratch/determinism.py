@@ -45,7 +45,9 @@ bad += run("headline chi32 (graph)", full.phi, full.label_index, 2, 32, 4, 3, 12
 bad += run("headline chi32 update_iters=2 MSE", full.phi, full.label_index, 2, 32, 4, 2, 6, update_iters=2, loss="MSE")
 bad += run("headline chi32 (plain stream, profiling)", full.phi, full.label_index, 2, 32, 4, 2, 6, prof=0x7FF)
 full8 = bench.make_inputs(8192, 100, 4)
-bad += run("N=8192 chi32 (256 partitions)", full8.phi, full8.label_index, 2, 32, 4, 2, 8)
+bad += run("N=8192 chi32 (sliced pair, 512-series shares)", full8.phi, full8.label_index, 2, 32, 4, 2, 8)
+full16 = bench.make_inputs(16384, 60, 4)
+bad += run("N=16384 chi32 (persistent k_bond_fused pair)", full16.phi, full16.label_index, 2, 32, 4, 2, 4)
 full2 = bench.make_inputs(240, 60, 8)
 bad += run("d8 chi37 (blocked eigensolver)", full2.phi, full2.label_index, 2, 37, 8, 1, 8)
 full3 = bench.make_inputs(512, 40, 8)
