@@ -206,6 +206,37 @@ def test_full_size_option_paths_against_c_oracle(engine_cls, kw):
         eng.close()
 
 
+def test_sliced_pair_with_multi_stage_shares_against_c_oracle(engine_cls):
+    """N = 8192 (the largest size at which the fused chain still picks k_yhat_s + k_grad_s): every gradient block has 8
+    shares of 512 series = two stages each, and one class holds 3 series fewer than the other so that shares end inside
+    a stage and inside a 16-series tile.  8 bonds where the sweep starts and 8 bulk bonds, engine and C oracle from a
+    common state."""
+    from oracle.c_oracle import COracle
+    import bench
+    N, T, chi, d = 8192, 40, 32, 4
+    full = bench.make_inputs(N, T, d)
+    keep = np.ones(N, dtype=bool)
+    keep[[5, 17, 40]] = False                                    # 3 series fewer in the first class
+    full = mt.EncodedTimeSeriesSet(full.phi[keep], full.labels[keep], full.label_index[keep], full.original_data[keep],
+                                   np.bincount(full.label_index[keep]))
+    W0 = mt.generate_startingMPS(4, T, d, 2, 77)
+    mk = lambda W: COracle(W, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=False)
+    eng = engine_cls(0)
+    sub = slice(0, N - 3, 64)
+    try:
+        eng.set_options(chi_max=chi, eta=0.01)
+        eng.set_dataset(0, full.phi, full.label_index, 2)
+        eng.set_mps(W0)
+        info = eng.info()
+        assert info["sliced_bond_gemms"] and info["grad_shares"] == 8
+        for first, count in ((0, 8), (50, 8)):
+            worst, flips = teacher_forced_segment(eng, mk, W0, full.phi, T, first, count, sub=sub)
+            assert worst["loss"] < 1e-10 and worst["grad"] < 1e-8 and worst["S"] < 1e-9 and worst["overlap"] < 1e-8, (first, worst)
+            assert flips <= 1
+    finally:
+        eng.close()
+
+
 def test_config4_n32768_on_one_gpu(engine_cls):
     """BASELINE.json configs[3] (N=32768, T=100, chi=32, d=4) on ONE GPU (it fits: 2 x 839 MB of environments): the first
     and the last 20 bonds of the first sweep against the C oracle from a common state, then the size-independent

@@ -48,6 +48,9 @@ CASES = [
     (3, 5, 3, 2, 6, 2, "KLD", "TSGO", False, 1, True),
     (60, 4, 7, 6, 18, 2, "KLD", "TSGO", False, 1, True),
     (96, 4, 4, 8, 32, 3, "MSE", "TSGO", False, 1, False),
+    # d > 8 (two site-vector pieces per loader lane in k_grad_s, one bond entry per gradient block row) and d = 16
+    (45, 4, 12, 5, 10, 2, "KLD", "TSGO", False, 1, False),
+    (30, 3, 16, 4, 8, 3, "MSE", "GD", False, 2, True),
 ]
 
 
