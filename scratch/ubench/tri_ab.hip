@@ -7,6 +7,7 @@
 #include "tri_proto_gen.hip"
 #include "tri_rows2.hip"
 #include "tri_par.hip"
+#include "tri_eg.hip"
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -56,8 +57,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dG, sizeof(double) * n * n));
     CK(hipMalloc(&ws, sizeof(double) * WS_TOTAL));
     CK(hipMalloc(&ws2, sizeof(double) * WS_TOTAL));
-    CK(hipMalloc(&st, 8 * 512));
-    CK(hipMemset(st, 0, 8 * 512));
+    CK(hipMalloc(&st, 8 * 8192));
+    CK(hipMemset(st, 0, 8 * 8192));
     CK(hipMemcpy(dG, G.data(), sizeof(double) * n * n, hipMemcpyHostToDevice));
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -73,13 +74,15 @@ int main(int argc, char** argv) {
             launch_tri_proto(which, dG, n, w, stp, s);
         else if (which == TRI_PROTO_VARIANTS + 1)
             launch_tri_rows2(dG, n, w, stp, s);
-        else
+        else if (which == TRI_PROTO_VARIANTS + 2)
             launch_tri_par(dG, n, w, stp, s);
+        else
+            launch_tri_eg(dG, n, w, stp, s);
 #endif
     };
     const int nvar =
 #ifdef HAVE_PROTO
-        3 + TRI_PROTO_VARIANTS;
+        4 + TRI_PROTO_VARIANTS;
 #else
         1;
 #endif
@@ -99,15 +102,15 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         run(which, st, w);
         CK(hipStreamSynchronize(s));
-        std::vector<unsigned long long> hs(512);
-        CK(hipMemcpy(hs.data(), st, 8 * 512, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> hs(8192);
+        CK(hipMemcpy(hs.data(), st, 8 * 8192, hipMemcpyDeviceToHost));
         std::vector<double> hw(WS_TOTAL);
         CK(hipMemcpy(hw.data(), w, sizeof(double) * WS_TOTAL, hipMemcpyDeviceToHost));
         double tr = 0, trG = 0;
         for (int i = 0; i < n; ++i) { tr += hw[WS_DE + 2 * i]; trG += G[(size_t)i * n + i]; }
         printf("variant %d [%s]: %.2f us per launch (%d back-to-back), in-kernel %.2f us = %llu cycles, trace err %.2e\n", which,
 #ifdef HAVE_PROTO
-               which <= TRI_PROTO_VARIANTS ? tri_proto_name(which) : which == TRI_PROTO_VARIANTS + 1 ? "two rows per thread (two-barrier steps, 32-column eras)" : "product step with compile-time buffer parity",
+               which <= TRI_PROTO_VARIANTS ? tri_proto_name(which) : which == TRI_PROTO_VARIANTS + 1 ? "two rows per thread (two-barrier steps, 32-column eras)" : which == TRI_PROTO_VARIANTS + 2 ? "product step with compile-time buffer parity" : "product + single-wave endgame (last 32 steps)",
 #else
                "product k_eig_tri",
 #endif
@@ -116,6 +119,14 @@ int main(int argc, char** argv) {
         for (int i = 0; i + 1 < n - 1; ++i)
             if (hs[64 + i] && hs[65 + i]) printf(" %llu", hs[65 + i] - hs[64 + i]);
         printf("\n");
+#ifdef TRI_EG_DEBUG
+        if (which == nvar - 1) {
+            FILE* fd = fopen("gpurun_out/tri_eg_dbg.txt", "w");
+            const double* dd = (const double*)(hs.data() + 512);
+            for (int i = 0; i < 4 * 1024 + 33; ++i) fprintf(fd, "%.17g\n", dd[i]);
+            fclose(fd);
+        }
+#endif
         if (f) {
             fprintf(f, "variant %d\n", which);
             for (int i = 0; i < n; ++i) fprintf(f, "%.17g %.17g\n", hw[WS_DE + 2 * i], hw[WS_ES + i]);
