@@ -63,6 +63,7 @@ struct BtBufs {
     double* lam;     // [CAP_LIMIT]
     double* res;     // [CAP_LIMIT]
     double* D;       // [CAP_LIMIT][CAP_LIMIT] Z^T Z - I
+    double* Tfac;    // [ncap/16][16][16] compact-WY factors of the reflector blocks (k_bt_larft)
     int32_t* flag;   // [1] 0 ok, 1 = verification failed (host falls back to the library)
     int32_t* ctl;    // [4] see k_bt_decide
     int ncap;
@@ -624,6 +625,75 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
 #endif
 }
 
+// ---- compact-WY factors of the reflector blocks ------------------------------------------------------------------------
+// Block bk = reflectors j0 .. j0+15 (j0 = 16 bk): H_{j0} H_{j0+1} ... H_{j0+15} = I - V T V^T with V = [v_j0 ... v_j0+15] and T
+// upper triangular (LAPACK dlarft, forward / columnwise): T_ii = tau_i, T_{0:i,i} = -tau_i T_{0:i,0:i} (V_{0:i}^T v_i).
+// One workgroup per block: S = V^T V on the fp64 MFMA (the contraction over the rows split over the 4 waves), then one wave
+// runs the 16-step recurrence, lane r holding row r of T.  Reflectors beyond n-3 (the tail of the last block) count as
+// identities (tau = 0).
+constexpr int BT_NB = 16;
+__global__ __launch_bounds__(BT_T) void k_bt_larft(View v, int lid, int going_left, int rawn, BtBufs b) {
+    __shared__ double part[4][256];
+    __shared__ double S[16][17];
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    if (bt_aborted(b)) return;
+    const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int j0 = BT_NB * (int)blockIdx.x, nref = n - 2;          // reflectors 0 .. n-3
+    if (j0 >= nref) return;
+    // rows n .. ncap-1 of this block's reflectors may hold entries of an earlier solve at a larger n (bond dimensions differ
+    // near the ends of the chain): cleared here, so that the back-transformation can fetch whole rows without a per-lane test
+    for (int e = tid; e < BT_NB * (ld - n); e += BT_T) {
+        const int m = e / (ld - n), r = n + e - m * (ld - n);
+        if (j0 + m < nref) b.Vall[(int64_t)(j0 + m) * ld + r] = 0.0;
+    }
+    const int jm = j0 + i16;                                        // this lane's reflector (as A row and as B column)
+    const bool jv = jm < nref;
+    const double* vrow = b.Vall + (int64_t)jm * ld;
+    // rows j0+1 .. n-1 carry the block (row j+1 is the leading one of reflector j); 4 rows per k-step
+    const int rbeg = j0 + 1, nrows = n - rbeg;
+    const int ks = (((nrows + 3) >> 2) + 3) >> 2;                   // k-steps per wave
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int u0 = wave * ks; u0 < (wave + 1) * ks; u0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = rbeg + 4 * (u0 + u) + kq;
+            x[u] = (jv && u0 + u < (wave + 1) * ks && row < n) ? vrow[row] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (u0 + u < (wave + 1) * ks) acc = mfma_f64(x[u], x[u], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            S[kq + 4 * r][i16] = (part[0][r * 64 + lane] + part[1][r * 64 + lane]) + (part[2][r * 64 + lane] + part[3][r * 64 + lane]);
+    }
+    __syncthreads();
+    if (wave == 0 && lane < 16) {
+        const int r = lane;
+        double T[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) T[m] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double tau = (j0 + i < nref) ? b.tau[j0 + i] : 0.0;
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m < i) s = fma(T[m], S[m][i], s);               // T[r][m] is zero for m < r
+            T[i] = r < i ? -tau * s : (r == i ? tau : 0.0);
+        }
+        double* out = b.Tfac + ((int64_t)blockIdx.x * 16 + r) * 16;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) out[m] = T[m];
+    }
+}
+
 __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
@@ -824,93 +894,110 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     __syncthreads();
     for (int j = tid; j < n; j += BT_T) z[j] *= sc;
     __syncthreads();
-    // back-transformation: z <- H_0 H_1 ... H_{n-3} z, one reflector after the other.  Every thread keeps its rows of z
-    // (r = tid + 256 q) in registers; the reflector rows are requested PD reflectors ahead (a load from L2 / the Infinity
-    // Cache takes ~1 us, a reflector's arithmetic ~0.2 us: one-ahead prefetching left the loop latency-bound at 0.5 us per
-    // reflector); the partial sums of the waves meet in a parity-indexed LDS slot, one barrier per reflector.
+    // back-transformation: z <- H_0 H_1 ... H_{n-3} z in blocks of 16 reflectors, last block first:
+    //     z <- z - V (T (V^T z)),   T from k_bt_larft.
+    // Every thread keeps its rows of z (r = tid + 256 q) in registers and fetches its rows of the block's 16 reflectors (for
+    // n <= 512 one block ahead); the 16 partial products of a thread meet through an LDS transpose (16 values x 256 threads ->
+    // 16 sums), T is applied by 16 lanes, and the update is 16 FMAs per row.  Three barriers per 16 reflectors instead of
+    // eight rounds of one barrier and three wave sums each (0.18 -> 0.05 ms at n = 512).
     {
-        constexpr int QV = BT_NMAX / BT_T, PD = 6;
-        __shared__ double part[2][4];
-        double* taus = Dp;                          // the pivots are not needed any more
-        for (int j = tid; j < n; j += BT_T) taus[j] = b.tau[j];
-        double zr[QV], vb[PD][QV];
+        constexpr int QV = BT_NMAX / BT_T;
+        // [16][257] partial products: over T, e^2 and the pivots at the head of the dynamic LDS (2064 + 1024 + 1024 doubles,
+        // all consumed by now); z behind them stays
+        static_assert(2 * (BT_NMAX + 8) + 2 * BT_NMAX >= 16 * (BT_T + 1), "the partial products fit over de, es, Dp");
+        double (*Ps)[BT_T + 1] = (double (*)[BT_T + 1])smem;
+        __shared__ double Ws[16], W2[16], Ts[16][17];
+        __syncthreads();
+        const int nref = n - 2, nblk = (nref + BT_NB - 1) / BT_NB;
+        const int nq = (n + BT_T - 1) / BT_T;                     // live row slots per thread
+        const bool ahead = nq <= 2;
+        double zr[QV];
 #pragma unroll
         for (int q = 0; q < QV; ++q) {
             const int r = tid + BT_T * q;
             zr[q] = r < n ? z[r] : 0.0;
         }
-        auto fetch = [&](double (&dst)[QV], int j) {
+        // rows tid, tid + 256 of block bk: entries at rows <= j are zero in Vall (never written); the tail of the last block
+        // is a wave-uniform test, rows >= n a per-thread constant
+        const bool rv0 = tid < n, rv1 = tid + BT_T < n;          // (the row stride may equal n: a row >= n would alias the next reflector)
+        auto fetch_block = [&](int bk, double (&dst)[16][2]) {
+            const double* base = b.Vall + (int64_t)(BT_NB * (bk > 0 ? bk : 0)) * ld + tid;
 #pragma unroll
-            for (int q = 0; q < QV; ++q) {
-                const int r = tid + BT_T * q;
-                dst[q] = (j >= 0 && r < n) ? b.Vall[(int64_t)j * ld + r] : 0.0;
+            for (int m = 0; m < 16; ++m) {
+                const bool live = bk >= 0 && BT_NB * bk + m < nref;
+                dst[m][0] = (live && rv0) ? base[0] : 0.0;
+                dst[m][1] = (live && rv1) ? base[BT_T] : 0.0;
+                base += ld;
             }
         };
+        // one block: partial products -> LDS transpose -> 16 sums -> T -> update; V rows in vb (nq <= 2) or fetched here
+        auto apply_block = [&](int bk, double (&vb2)[16][2], double tcur) {
+            double vw[16][QV - 2];                                     // row slots 2, 3 (n > 512): fetched per block, no prefetch
+            if (!ahead) {
+                fetch_block(bk, vb2);
+                const double* base = b.Vall + (int64_t)(BT_NB * bk) * ld + tid + 2 * BT_T;
 #pragma unroll
-        for (int u = 0; u < PD; ++u) fetch(vb[u], n - 3 - u);
-        __syncthreads();
-        // Two reflectors per round: H_{j-1} H_j z = z - f_j v_j - f_{j-1} v_{j-1} with f_j = tau_j v_j^T z and
-        // f_{j-1} = tau_{j-1} (v_{j-1}^T z - f_j v_{j-1}^T v_j): the three dot products share one reduction round and one
-        // barrier (the loop is bound by those, not by its arithmetic).
-        static_assert(PD % 2 == 0, "reflectors are applied in pairs");
-        __shared__ double part3[2][4][3];
-        int par = 0;
-        for (int j0 = n - 3; j0 >= 0; j0 -= PD) {
+                for (int m = 0; m < 16; ++m) {
+                    const bool live = BT_NB * bk + m < nref;
 #pragma unroll
-            for (int u = 0; u < PD; u += 2) {
-                const int j = j0 - u;
-                if (j >= 1) {                       // uniform: the pair (j, j-1)
-                    double sa = 0.0, sb = 0.0, sc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < QV; ++q) {
-                        const int r = tid + BT_T * q;
-                        if (r > j && r < n) {                                     // rows <= j of reflector j are zero
-                            sa = fma(vb[u][q], zr[q], sa);
-                            sc = fma(vb[u + 1][q], vb[u][q], sc);
-                        }
-                        if (r > j - 1 && r < n) sb = fma(vb[u + 1][q], zr[q], sb);
-                    }
-                    sa = wave_sum_fast(sa);
-                    sb = wave_sum_fast(sb);
-                    sc = wave_sum_fast(sc);
-                    if (lane == 0) {
-                        part3[par][wave][0] = sa;
-                        part3[par][wave][1] = sb;
-                        part3[par][wave][2] = sc;
-                    }
-                    __syncthreads();
-                    const double ta = (part3[par][0][0] + part3[par][1][0]) + (part3[par][2][0] + part3[par][3][0]);
-                    const double tb = (part3[par][0][1] + part3[par][1][1]) + (part3[par][2][1] + part3[par][3][1]);
-                    const double tc = (part3[par][0][2] + part3[par][1][2]) + (part3[par][2][2] + part3[par][3][2]);
-                    par ^= 1;
-                    const double fj = taus[j] * ta;
-                    const double fm = taus[j - 1] * fma(-fj, tc, tb);
-#pragma unroll
-                    for (int q = 0; q < QV; ++q) {
-                        const int r = tid + BT_T * q;
-                        if (r > j && r < n) zr[q] = fma(-fj, vb[u][q], zr[q]);
-                        if (r > j - 1 && r < n) zr[q] = fma(-fm, vb[u + 1][q], zr[q]);
-                    }
-                    fetch(vb[u], j - PD);
-                    fetch(vb[u + 1], j - 1 - PD);
-                } else if (j == 0) {                // uniform: a last single reflector
-                    double s = 0.0;
-#pragma unroll
-                    for (int q = 0; q < QV; ++q) {
-                        const int r = tid + BT_T * q;
-                        if (r > j && r < n) s = fma(vb[u][q], zr[q], s);
-                    }
-                    s = wave_sum_fast(s);
-                    if (lane == 0) part[par][wave] = s;
-                    __syncthreads();
-                    const double f = taus[j] * ((part[par][0] + part[par][1]) + (part[par][2] + part[par][3]));
-                    par ^= 1;
-#pragma unroll
-                    for (int q = 0; q < QV; ++q) {
-                        const int r = tid + BT_T * q;
-                        if (r > j && r < n) zr[q] = fma(-f, vb[u][q], zr[q]);
-                    }
+                    for (int q = 0; q < QV - 2; ++q) vw[m][q] = (live && tid + BT_T * (q + 2) < n) ? base[BT_T * q] : 0.0;
+                    base += ld;
                 }
+            }
+            Ts[tid >> 4][tid & 15] = tcur;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                double sm = fma(vb2[m][1], zr[1], vb2[m][0] * zr[0]);
+                if (!ahead) {
+#pragma unroll
+                    for (int q = 0; q < QV - 2; ++q) sm = fma(vw[m][q], zr[q + 2], sm);
+                }
+                Ps[m][tid] = sm;
+            }
+            __syncthreads();
+            {
+                const int m = tid >> 4, c = tid & 15;
+                double sm = 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sm += Ps[m][u * 16 + c];       // lanes c read consecutive words: no bank conflict
+                sm = sum16(sm);
+                if (c == 0) Ws[m] = sm;
+            }
+            __syncthreads();
+            if (tid < 16) {
+                double t2 = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) t2 = fma(Ts[tid][m], Ws[m], t2);       // T is upper triangular: zeros below
+                W2[tid] = t2;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const double wm = W2[m];
+                zr[0] = fma(-wm, vb2[m][0], zr[0]);
+                zr[1] = fma(-wm, vb2[m][1], zr[1]);
+                if (!ahead) {
+#pragma unroll
+                    for (int q = 0; q < QV - 2; ++q) zr[q + 2] = fma(-wm, vw[m][q], zr[q + 2]);
+                }
+            }
+        };
+        double va[16][2], vbb[16][2];
+        if (ahead && nblk > 0) fetch_block(nblk - 1, va);
+        double ta = nblk > 0 ? b.Tfac[(int64_t)(nblk - 1) * 256 + tid] : 0.0, tb = 0.0;      // T one block ahead as well
+        // two blocks per pass, the buffers alternating: the next block's rows and T fly during a block's work
+        for (int bk = nblk - 1; bk >= 0; bk -= 2) {
+            if (bk > 0) {
+                if (ahead) fetch_block(bk - 1, vbb);
+                tb = b.Tfac[(int64_t)(bk - 1) * 256 + tid];
+            }
+            apply_block(bk, va, ta);
+            if (bk > 0) {
+                if (bk > 1) {
+                    if (ahead) fetch_block(bk - 2, va);
+                    ta = b.Tfac[(int64_t)(bk - 2) * 256 + tid];
+                }
+                apply_block(bk - 1, vbb, tb);
             }
         }
 #pragma unroll
@@ -1181,7 +1268,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     const size_t n1 = ncap, n2 = (size_t)ncap * ncap;
     bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
-              al(&e->b.res, CAP_LIMIT) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
+              al(&e->b.res, CAP_LIMIT) && al(&e->b.Tfac, (size_t)((ncap + 15) / 16) * 256) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 4 * n1) && al(&e->cp.rowbuf, 4 * n1) &&
               hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
     if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
@@ -1205,7 +1292,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
 }
 void blocked_eig_destroy(BlockedEig* e) {
     if (!e) return;
-    double* ps[] = {e->b.A, e->b.D, e->b.Y, e->b.Vall, e->b.dd, e->b.ee, e->b.tau, e->b.Z, e->b.lam, e->b.res};
+    double* ps[] = {e->b.A, e->b.D, e->b.Y, e->b.Vall, e->b.dd, e->b.ee, e->b.tau, e->b.Z, e->b.lam, e->b.res, e->b.Tfac};
     for (double* p : ps)
         if (p) (void)hipFree(p);
     if (e->b.flag) (void)hipFree(e->b.flag);
@@ -1222,6 +1309,7 @@ static void enqueue_after_tridiag(const View& v, int lid, int going_left, const 
                                   int32_t* rawinfo, const BtBufs& b, hipStream_t s) {
     const int ncap = rawn > 0 ? rawn : b.ncap;
     const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
+    hipLaunchKernelGGL(k_bt_larft, dim3((ncap + BT_NB - 1) / BT_NB), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
     hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
     const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;
     for (int second = 0; second < 2; ++second) {
