@@ -545,6 +545,27 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
     const int Kc = going_left ? b.Y : b.X;             // contraction length of the first product
     const int Dc = going_left ? b.Dl : b.Dr;           // rows of T: the bond shared with the neighbouring site
     const int nj = (Dc + 15) >> 4;
+    // The neighbouring site's tensor - the other operand of the SECOND product - does not depend on T: it is requested now,
+    // so that the launch pays one round trip to memory for its operands instead of two in a row.  A wave owns the row
+    // (column) tiles wave and wave + 4 of bt' (d*chi <= 128: at most 8 tiles).
+    const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];           // the neighbouring site's outer bond
+    double wpre[2][CHAIN_J][4];
+    {
+        const double* Wn = v.sites + (int64_t)(going_left ? lid - 1 : lid + 2) * v.site_stride;
+        const int Xn = Dnb * d;                        // rows of bt' going left (x') / columns going right (y'')
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int tl = 16 * (wave + 4 * it) + i16;
+#pragma unroll
+            for (int j = 0; j < CHAIN_J; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 16 * j + 4 * r + kq;
+                    const bool ok = j < nj && tl < Xn && a < Dc;
+                    wpre[it][j][r] = ok ? (going_left ? Wn[(int64_t)tl * b.Dl + a] : Wn[(int64_t)a * Xn + tl]) : 0.0;
+                }
+        }
+    }
     const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;         // k-steps per wave
     const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
 #pragma unroll
@@ -580,27 +601,20 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
             T[j][r] = ((cpart[o] + cpart[CHAIN_J * 256 + o]) + (cpart[2 * CHAIN_J * 256 + o] + cpart[3 * CHAIN_J * 256 + o])) * inv;
         }
     if (going_left) {
-        const int Dlp = v.chi[lid - 1], Xp = Dlp * d, Yp = d * nk;
+        const int Xp = Dnb * d, Yp = d * nk;
         const int64_t Lp = (int64_t)Xp * Yp;
-        const double* Wl = v.sites + (int64_t)(lid - 1) * v.site_stride;       // [x'][a], a < Dl
         double* out = v.bt + (int64_t)c * Lp;
         const int ntx = (Xp + 15) >> 4;
-        for (int mt = wave; mt < ntx; mt += 4) {
-            const int x = 16 * mt + i16;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int mt = wave + 4 * it;
+            if (mt >= ntx) break;
             d4 acc = {0, 0, 0, 0};
-            double wl[CHAIN_J][4];
-#pragma unroll
-            for (int j = 0; j < CHAIN_J; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int a = 16 * j + 4 * r + kq;
-                    wl[j][r] = (j < nj && x < Xp && a < b.Dl) ? Wl[(int64_t)x * b.Dl + a] : 0.0;
-                }
 #pragma unroll
             for (int j = 0; j < CHAIN_J; ++j)
                 if (j < nj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma_f64(wl[j][r], T[j][r], acc);
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(wpre[it][j][r], T[j][r], acc);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -609,27 +623,21 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
             }
         }
     } else {
-        const int Drr = v.chi[lid + 3], Ypp = d * Drr, Xp = nk * d;
+        const int Ypp = d * Dnb, Xp = nk * d;
         const int64_t Lp = (int64_t)Xp * Ypp;
-        const double* Wr = v.sites + (int64_t)(lid + 2) * v.site_stride;       // [b][y''], b < Dr
         double* out = v.bt + (int64_t)c * Lp;
         const int nty = (Ypp + 15) >> 4;
-        for (int nt = wave; nt < nty; nt += 4) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int nt = wave + 4 * it;
+            if (nt >= nty) break;
             const int y = 16 * nt + i16;
             d4 acc = {0, 0, 0, 0};
-            double wr[CHAIN_J][4];
-#pragma unroll
-            for (int j = 0; j < CHAIN_J; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bb = 16 * j + 4 * r + kq;
-                    wr[j][r] = (j < nj && y < Ypp && bb < b.Dr) ? Wr[(int64_t)bb * Ypp + y] : 0.0;
-                }
 #pragma unroll
             for (int j = 0; j < CHAIN_J; ++j)
                 if (j < nj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], wr[j][r], acc);    // A[m = k][kk = b] = T^T tile, register r
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], wpre[it][j][r], acc);    // A[m = k][kk = b] = T^T tile, register r
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
