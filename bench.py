@@ -526,6 +526,10 @@ def main():
     # bound from THIS run's own per-kernel profile.  Never `value`.
     if world > 1 and not args.no_sharded_extra:
         sharded = None
+        eng2 = None
+        if out is not None:
+            # the headline figures are on stderr before the side measurement starts: whatever happens in it, they are logged
+            note("headline (before the configs[3] side measurement): " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}))
         try:
             N2 = args.sharded_N
             full2 = make_inputs(N2, T, d)
@@ -540,6 +544,21 @@ def main():
                 sh2.attach_oneshot(eng2)
                 sh2.select(eng2, True)
             eng2.build_caches()
+            setup_ok = 1.0
+        except Exception as e:
+            setup_ok = 0.0
+            sharded = {"error": f"setup: {e}"}
+        # every rank learns whether every rank got this far: nobody waits in a collective for a rank that has given up
+        if host_reduce([setup_ok], dist.ReduceOp.MIN)[0] <= 0:
+            if sharded is None:
+                sharded = {"error": "setup failed on another rank"}
+            note(f"configs[3] side measurement skipped: {sharded['error']}")
+            raise_skip = True
+        else:
+            raise_skip = False
+        try:
+            if raise_skip:
+                raise RuntimeError(sharded["error"])
             for _ in range(2):
                 eng2.sweep()
             sync()
@@ -572,8 +591,13 @@ def main():
             note(f"configs[3] side measurement: N={N2} over {world} ranks: {sharded['value']:.2f} sweeps/s, all-reduce "
                  f"{sharded['allreduce_us_per_optimiser_step']} us per optimiser step, Amdahl estimate {sharded['amdahl']['speedup_vs_1gpu_estimate']:.2f}x")
         except Exception as e:
-            sharded = {"error": str(e)}
-            note(f"configs[3] side measurement failed: {e}")
+            if not raise_skip:
+                sharded = {"error": str(e)}
+                note(f"configs[3] side measurement failed: {e}")
+            try:
+                eng2.close()
+            except Exception:
+                pass
         if out is not None:
             out["sharded_n32768"] = sharded
 
