@@ -73,3 +73,15 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".jl")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f"{f} refers to the oracle"
+
+
+def test_collective_library_is_bound_at_run_time_not_linked():
+    """RCCL is opened with dlopen when first needed (the copy already in the process wins), so the shared library
+    carries no DT_NEEDED entry for it; the probe reports which file was bound and both version numbers."""
+    so = os.path.join(ROOT, "mpstime.jl_amd", "csrc", "libmpstime_hip.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "librccl" not in needed
+    info = mt.comm_library()
+    assert info["ok"], info
+    assert "librccl" in info["library"]
+    assert info["version"] // 10000 == info["built_against"] // 10000      # same major: the ABI the loader accepts
