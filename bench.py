@@ -82,6 +82,10 @@ def kernel_model(N, d, chi, C, info):
         model["grad_reduce+update"] = ("hbm", 8.0 * (P + C) * X * Y)   # k_fused_reduce: read P partials, write the gradient
     if info.get("fused"):
         model["env"] = ("hbm", 8.0 * N * (chi + d + chi))  # k_env_split (+ 2mn chi flops of the back-split, + next bond tensor)
+    if info.get("eig_merged") and not info.get("large_bond"):
+        # k_eig_trivec: every eigenvector workgroup repeats the tridiagonalisation; the algorithmic count has it once
+        model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n * n * chi)
+        model.pop("eig_vec", None)
     if info.get("large_bond"):
         model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n ** 3)   # rocSOLVER dsyevd: sytrd + stedc + ormtr back-transformation
     return model
@@ -464,7 +468,7 @@ def main():
         # FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
         traffic, traffic_src = None, None
         fused, b2 = info.get("fused"), info.get("sliced_bond_gemms")
-        knames = {"eig_tri": "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin",
+        knames = {"eig_tri": "mpst::k_eig_trivec" if info.get("eig_merged") else "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin",
                   "yhat": "mpst::k_yhat_s" if b2 else "mpst::k_yhat",
                   "grad": "mpst::k_grad_s" if b2 else ("mpst::k_bond_fused" if fused else "mpst::k_grad"),
                   "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",

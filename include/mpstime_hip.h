@@ -302,8 +302,9 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * library solver, out[8] bonds whose persistent tridiagonalisation gave up waiting for its peers and was redone one
  * launch per step, out[9] bonds whose XCD-local tridiagonalisation found its workgroups on more than one XCD and was
  * redone with the cross-XCD exchange, out[10] the fused chain runs the sliced bond GEMMs (k_yhat_s + k_grad_s: no partial
- * gradients per workgroup), out[11] shares per gradient block of k_grad_s */
-int  mpst_get_info(void* ctx, int32_t* out /*[12]*/);
+ * gradients per workgroup), out[11] shares per gradient block of k_grad_s, out[12] the tridiagonalisation and the
+ * eigenvectors of a bond run in one launch (k_eig_trivec), out[13..15] reserved (0) */
+int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */

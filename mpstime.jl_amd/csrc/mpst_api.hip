@@ -492,7 +492,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             launch_gram_upd(vg, lid, going_left, iters == 1, s);
         }
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
-        { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
+        if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
         trace_final(c->btn);
         {
@@ -533,7 +533,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
     } else {
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
-        { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
+        if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
     }
     trace_final(c->bt);
@@ -1601,6 +1601,8 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[9] = blocked_eig_xcd_misplaced(c->blk);    // bonds whose XCD-local attempt found its workgroups on several XCDs (redone across the XCDs)
     out[10] = c->b2 ? 1 : 0;                        // fused chain with the sliced bond GEMMs (k_yhat_s + k_grad_s)
     out[11] = c->b2 ? c->b2_ksplit : 0;             // shares per gradient block of k_grad_s
+    out[12] = (!c->big && eig_merged()) ? 1 : 0;    // tridiagonalisation + eigenvectors in one launch (k_eig_trivec)
+    out[13] = out[14] = out[15] = 0;
     return 0;
 }
 

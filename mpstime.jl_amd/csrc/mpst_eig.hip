@@ -268,19 +268,18 @@ constexpr int NP = NE / 2;               // column pairs per thread
 constexpr int RPW = 64 / QN;             // rows per wave
 __device__ __forceinline__ double sum_q(double x) { return QN == 8 ? sum8(x) : sum4(x); }
 
-__global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
-                                                         int rawalg, double* __restrict__ ws,
-                                                         unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
+// position of reflector column j (0..15 inside its block of 16) in row c of a dense reflector block kept in LDS by the
+// merged kernel: pairs of columns are rotated by the row, so that the 64 rows a wave writes for ONE reflector land in 16
+// bank pairs instead of one (row stride = 16 doubles = all 64 lanes on the same bank otherwise)
+__device__ __forceinline__ int vsw(int c, int j) { return c * 16 + ((j + 2 * c) & 15); }
+
+// The tridiagonalisation proper.  DENSE = false: reflectors packed in t.Vs (k_eig_tri publishes them afterwards);
+// DENSE = true: written straight into the dense 16-column blocks Vd[8][128][16] (rotated, vsw) the back-transformation
+// of the same workgroup reads - the merged kernel k_eig_trivec.
+template <bool DENSE>
+__device__ __forceinline__ void tri_core(const double* __restrict__ G, const int n, const TriShared t, double* __restrict__ Vd,
+                                         unsigned long long* stamps) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!pb.tri) {
-        if (tid == 0) ws[WS_MISC + 3] = 0.0;
-        return;
-    }
-    const double* __restrict__ G = pb.G;
-    const int n = pb.n;
-    TriShared t = tri_carve(smem);
     if (stamps && tid == 0) {
         stamps[0] = __builtin_amdgcn_s_memrealtime();
         stamps[6] = __builtin_readcyclecounter();
@@ -300,6 +299,17 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
     if (tid < 256) {
         t.xs[tid] = 0.0;
         t.ps[tid] = 0.0;
+    }
+    if constexpr (DENSE) {
+        // what the standalone kernel's publication step guarantees: nothing but zeros beyond the problem
+        if (tid < 128) {
+            t.es[tid] = 0.0;
+            t.taus[tid] = 0.0;
+        }
+        for (int i = tid; i < (129 - n) * 128; i += TRI_T) {        // reflector columns n-1 .. 127 are never written
+            const int jr = n - 1 + (i >> 7), c = i & 127;
+            Vd[(jr >> 4) * 2048 + vsw(c, jr & 15)] = 0.0;
+        }
     }
     __syncthreads();
     // ---- Householder tridiagonalisation (dsytd2, full storage) -----------------------------
@@ -370,9 +380,15 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
     auto flush_reflector = [&]() {
         if (pend_i >= 0) {
             const int i = pend_i, c0 = lane, c1 = lane + 64;
-            const int off = voff(i, n) - i - 1;
-            if (c0 > i && c0 < n) t.Vs[off + c0] = pend_v0;
-            if (c1 > i && c1 < n) t.Vs[off + c1] = pend_v1;
+            if constexpr (DENSE) {
+                double* vb = Vd + (i >> 4) * 2048;                     // all 128 rows: zeros above the start and beyond n
+                vb[vsw(c0, i & 15)] = pend_v0;
+                vb[vsw(c1, i & 15)] = pend_v1;
+            } else {
+                const int off = voff(i, n) - i - 1;
+                if (c0 > i && c0 < n) t.Vs[off + c0] = pend_v0;
+                if (c1 > i && c1 < n) t.Vs[off + c1] = pend_v1;
+            }
             if (lane == 0) {
                 t.de[2 * i] = pend_d;
                 t.es[i] = pend_e;
@@ -518,6 +534,21 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
         }
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                         int rawalg, double* __restrict__ ws,
+                                                         unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
+    const int tid = threadIdx.x;
+    if (!pb.tri) {
+        if (tid == 0) ws[WS_MISC + 3] = 0.0;
+        return;
+    }
+    const int n = pb.n;
+    TriShared t = tri_carve(smem);
+    tri_core<false>(pb.G, n, t, nullptr, stamps);
     // ---- publish T, the reflectors and the bounds ------------------------------------------------
     if (tid < 256) ws[WS_DE + tid] = tid < 2 * n ? t.de[tid] : 0.0;
     if (tid < 128) {
@@ -541,15 +572,13 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
 // =====================================================================================
 // k_eig_vec: one workgroup per eigenvalue
 // =====================================================================================
-__global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int going_left, int rawn, int rawalg,
-                                                         double* __restrict__ ws, unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int cnt_s[8];
-    __shared__ double red_s[8];
-    __shared__ int arg_s[8];
-    const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, rawalg);
-    const int k = blockIdx.x;
-    if (!pb.tri || k >= pb.K0) return;
+// Everything k_eig_vec does for eigenvalue k.  MERGED = false: T and the reflectors come from the global workspace
+// (written by k_eig_tri); MERGED = true: they are already in this workgroup's LDS (tri_core<true>, rotated rows).
+template <bool MERGED>
+__device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, double* smem, int* cnt_s, double* red_s, int* arg_s,
+                                         double* __restrict__ ws, unsigned long long* stamps, const double lo_in,
+                                         const double hi_in, const double tnorm_in) {
+    auto vix = [](int c, int j) { return MERGED ? vsw(c, j) : c * 16 + j; };
     const int n = pb.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* Vd = smem;              // [8][128][16] reflectors (dense blocks of 16)
@@ -576,12 +605,17 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     // as direct global->LDS loads that stay in flight during the whole bisection (every barrier up to
     // the point where they are needed is an LDS-only barrier, and no ordinary global load result is
     // consumed in between - either would drain them).
-    double lo = ws[WS_MISC + 0], hi = ws[WS_MISC + 1];
-    const double tnorm = ws[WS_MISC + 2];
-    if ((tid >> 1) < n) de[tid] = ws[WS_DE + tid];
-    if (tid < 128) {
-        es[tid] = ws[WS_ES + tid];
-        taus[tid] = ws[WS_TAU + tid];
+    double lo = lo_in, hi = hi_in;
+    double tnorm = tnorm_in;
+    if constexpr (!MERGED) {
+        lo = ws[WS_MISC + 0];
+        hi = ws[WS_MISC + 1];
+        tnorm = ws[WS_MISC + 2];
+        if ((tid >> 1) < n) de[tid] = ws[WS_DE + tid];
+        if (tid < 128) {
+            es[tid] = ws[WS_ES + tid];
+            taus[tid] = ws[WS_TAU + tid];
+        }
     }
     // pad T to 1 + a multiple of 8 rows with decoupled rows (e^2 = 0) whose diagonal lies above every
     // abscissa: they add no sign change and let the Sturm loop run in whole groups of 8
@@ -590,9 +624,11 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         if ((tid >> 1) >= n) de[tid] = (tid & 1) ? 0.0 : dpad;
         if (tid < 16) de[256 + tid] = (tid & 1) ? 0.0 : dpad;
     }
+    if constexpr (!MERGED) {
 #pragma unroll
-    for (int m = 0; m < 32; ++m)
-        glds16(ws + WS_VS + 2 * (tid + m * VEC_THREADS), Vd + 2 * (wave * 64 + m * VEC_THREADS));
+        for (int m = 0; m < 32; ++m)
+            glds16(ws + WS_VS + 2 * (tid + m * VEC_THREADS), Vd + 2 * (wave * 64 + m * VEC_THREADS));
+    }
     lds_barrier();
     VDBG(0);
     // ---- multisection for the k-th largest eigenvalue ---------------------------------------------------
@@ -746,9 +782,9 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
             for (int bi = 0; bi < 4; ++bi) {
                 const int b = 2 * bi + (wave - 2);
                 d4 acc = {0.0, 0.0, 0.0, 0.0};
-                const double* vb = Vd + (size_t)b * 2048 + jl;
+                const double* vb = Vd + (size_t)b * 2048;
                 for (int c = 16 * b + q4; c < 128; c += 16) {
-                    const double a0 = vb[(c + 0) * 16], a1 = vb[(c + 4) * 16], a2 = vb[(c + 8) * 16], a3 = vb[(c + 12) * 16];
+                    const double a0 = vb[vix(c + 0, jl)], a1 = vb[vix(c + 4, jl)], a2 = vb[vix(c + 8, jl)], a3 = vb[vix(c + 12, jl)];
                     acc = mfma_f64(a0, a0, acc);
                     acc = mfma_f64(a1, a1, acc);
                     acc = mfma_f64(a2, a2, acc);
@@ -920,8 +956,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
             // (i) y = V_b^T z
             double part = 0.0;
             for (int c = 16 * b + q4; c < 128; c += 16) {
-                const double w0 = vb[(c + 0) * 16 + jl], w1 = vb[(c + 4) * 16 + jl], w2 = vb[(c + 8) * 16 + jl],
-                             w3 = vb[(c + 12) * 16 + jl];
+                const double w0 = vb[vix(c + 0, jl)], w1 = vb[vix(c + 4, jl)], w2 = vb[vix(c + 8, jl)], w3 = vb[vix(c + 12, jl)];
                 const double x0 = z[c], x1 = z[c + 4], x2 = z[c + 8], x3 = z[c + 12];
                 part = fma(w0, x0, part);
                 part = fma(w1, x1, part);
@@ -938,7 +973,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
             // (iii) z -= V_b u
             double2 u2[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) u2[m] = *(const double2*)&ub[2 * m];
+            for (int m = 0; m < 8; ++m) u2[m] = *(const double2*)&ub[MERGED ? 2 * ((m - c0) & 7) : 2 * m];   // rotated rows: pair slot m of row c holds reflector pair (m - c) & 7 (c1 = c0 + 64: the same)
             if (b < 4) {                                // rows 0..63 are above every reflector of blocks 4..7
                 const double2* r0 = (const double2*)&vb[c0 * 16];
 #pragma unroll
@@ -968,6 +1003,65 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
         }
     }
     if (st) stamps[5] = __builtin_amdgcn_s_memrealtime();
+}
+
+__global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int going_left, int rawn, int rawalg,
+                                                         double* __restrict__ ws, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int cnt_s[8];
+    __shared__ double red_s[8];
+    __shared__ int arg_s[8];
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, rawalg);
+    const int k = blockIdx.x;
+    if (!pb.tri || k >= pb.K0) return;
+    vec_core<false>(pb, k, smem, cnt_s, red_s, arg_s, ws, stamps, 0.0, 0.0, 0.0);
+}
+
+// =====================================================================================
+// k_eig_trivec: tridiagonalisation + one eigenpair in ONE launch, no exchange between workgroups
+// =====================================================================================
+// Every eigenvector workgroup repeats the whole tridiagonalisation for itself (same code, same data, same order of
+// operations: the same bits in all of them) and goes on with its own eigenvalue: T and the reflectors never leave LDS.
+// That removes a dependent launch (its cold start and first round trip to memory), the publication of 128 KB of
+// reflectors by one workgroup and their reload by 32, at the price of 31 CUs doing redundant work on a chip that has
+// nothing else to do at this point of the chain.  LDS layout = k_eig_vec's; the tridiagonalisation's scratch rows
+// live where the compact-WY factors (Tb) go later.  After the reduction the 12 waves the eigenvector part does not
+// need retire (a terminated wave no longer counts at s_barrier).
+__global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                            int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int cnt_s[8];
+    __shared__ double red_s[8];
+    __shared__ int arg_s[8];
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (!pb.tri) {
+        if (k == 0 && tid == 0) ws[WS_MISC + 3] = 0.0;
+        return;
+    }
+    if (k >= pb.K0) return;
+    double* Vd = smem;
+    double* de = Vd + 16384;
+    double* Tb = de + 272 + 128 * 6 + 8 + 128 + 8 + 24 + 24;      // k_eig_vec's carve: see vec_core
+    TriShared t{};
+    t.de = de;
+    t.es = de + 272;
+    t.taus = t.es + 128;
+    t.xs = Tb;
+    t.ps = Tb + 256;
+    t.Z = Tb + 512;             // [2][128] published rows
+    t.misc = Tb + 768;
+    unsigned long long* st = k == 0 ? stamps : nullptr;
+    tri_core<true>(pb.G, pb.n, t, Vd, st);
+    const double lo = t.misc[0], hi = t.misc[1], tnorm = t.misc[2];
+    if (k == 0 && tid == 0) {
+        ws[WS_MISC + 0] = lo;
+        ws[WS_MISC + 1] = hi;
+        ws[WS_MISC + 2] = tnorm;
+        ws[WS_MISC + 3] = 1.0;
+    }
+    if (tid >= VEC_THREADS) return;
+    vec_core<true>(pb, k, smem, cnt_s, red_s, arg_s, ws, st, lo, hi, tnorm);
 }
 
 // =====================================================================================
@@ -1252,19 +1346,33 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
 }
 
+// MPST_EIG_SPLIT=1: the three-kernel chain (k_eig_tri, k_eig_vec, k_eig_fin) instead of k_eig_trivec + k_eig_fin
+bool eig_merged() {
+    static const bool m = [] {
+        const char* e = getenv("MPST_EIG_SPLIT");
+        return !(e && e[0] && e[0] != '0');
+    }();
+    return m;
+}
+
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s) {
     unsigned long long* st = v.sc ? v.sc->eig_stamps : nullptr;
-    if (stage == 0)
+    const dim3 gvec(v.chi_max < TRI_KMAX ? (v.chi_max < 32 ? 32 : v.chi_max) : TRI_KMAX);
+    if (stage == 0 && eig_merged())
+        hipLaunchKernelGGL(k_eig_trivec, gvec, dim3(TRI_T), vec_lds_bytes(), s, v, lid, going_left, (const double*)nullptr, 0, 0,
+                           v.eig_ws, st);
+    else if (stage == 0)
         hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left,
                            (const double*)nullptr, 0, 0, v.eig_ws, st);
-    else if (stage == 1)
-        hipLaunchKernelGGL(k_eig_vec, dim3(v.chi_max < TRI_KMAX ? (v.chi_max < 32 ? 32 : v.chi_max) : TRI_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0,
-                           v.eig_ws, st);
-    else
+    else if (stage == 1) {
+        if (!eig_merged())
+            hipLaunchKernelGGL(k_eig_vec, gvec, dim3(VEC_THREADS), vec_lds_bytes(), s, v, lid, going_left, 0, 0, v.eig_ws, st);
+    } else
         hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
                            (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
 }
@@ -1272,10 +1380,15 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {
     View v{};
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
-    hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
-                       (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_eig_vec, dim3(RAW_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
-                       (unsigned long long*)nullptr);
+    if (eig_merged())
+        hipLaunchKernelGGL(k_eig_trivec, dim3(RAW_KMAX), dim3(TRI_T), vec_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
+                           (unsigned long long*)nullptr);
+    else {
+        hipLaunchKernelGGL(k_eig_tri, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws,
+                           (unsigned long long*)nullptr);
+        hipLaunchKernelGGL(k_eig_vec, dim3(RAW_KMAX), dim3(VEC_THREADS), vec_lds_bytes(), s, v, 0, 0, n, alg, ws,
+                           (unsigned long long*)nullptr);
+    }
     hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, 0, 0, G, n, alg, ws, lam, E, info,
                        (unsigned long long*)nullptr);
 }

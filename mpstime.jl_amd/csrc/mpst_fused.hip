@@ -464,6 +464,44 @@ __device__ __forceinline__ d4 gemm_tile_g(const double* __restrict__ A, int64_t 
     return acc;
 }
 
+// The same tile with the contraction cut into the four ranges chain_bt_block gives its four waves, the partial tiles
+// added as ((p0 + p1) + (p2 + p3)): the site tensor the back-split stores is then bit for bit the T that
+// chain_bt_block feeds into the next bond tensor, and a sweep replayed from the graph (chained tensors) equals the same
+// sweep stepped bond by bond (tensor re-assembled from the stored sites) in every bit.
+__device__ __forceinline__ d4 gemm_tile_g4(const double* __restrict__ A, int64_t sam, int64_t sak, int M,
+                                           const double* __restrict__ B, int64_t sbk, int64_t sbn, int N, int K, int m0, int n0) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m = m0 + i, n = n0 + i;
+    const bool mv = m < M, nv = n < N;
+    const double* ap = A + (int64_t)m * sam;
+    const double* bp = B + (int64_t)n * sbn;
+    const int ks4 = (((K + 3) >> 2) + 3) >> 2;         // k-steps per range, as in chain_bt_block
+    d4 p[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        p[w] = d4{0, 0, 0, 0};
+        const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
+        for (int q0 = kbeg; q0 < kend; q0 += 32) {
+            double a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = q0 + 4 * u + kq;
+                const bool kv = k < kend;
+                a[u] = (mv && kv) ? ap[(int64_t)k * sak] : 0.0;
+                b[u] = (nv && kv) ? bp[(int64_t)k * sbk] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (q0 + 4 * u < kend) p[w] = mfma_f64(a[u], b[u], p[w]);
+        }
+    }
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
+    return acc;
+}
+
 // decomposeBT back-split from the kept eigenvectors E (as k_split, reading bt_new from v.btn); `blk` of `nblk` workgroups
 __device__ __forceinline__ void split_block(const View& v, int lid, int going_left, int blk, int nblk) {
     const BondDimsF b = bond_dims_f(v, lid);
@@ -482,7 +520,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
             const int c = tile / (tx * tk), rem = tile - c * tx * tk;
             const int m0 = (rem / tk) * 16, n0 = (rem % tk) * 16;
             const double* Bc = v.btn + (int64_t)c * b.L;
-            const d4 acc = gemm_tile_g(Bc, b.Y, 1, b.X, v.E, ldE, 1, nk, b.Y, m0, n0);
+            const d4 acc = gemm_tile_g4(Bc, b.Y, 1, b.X, v.E, ldE, 1, nk, b.Y, m0, n0);
             double* out = Wl + (int64_t)c * b.X * nk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -502,7 +540,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
             const int c = tile / (tk * ty), rem = tile - c * tk * ty;
             const int m0 = (rem / ty) * 16, n0 = (rem % ty) * 16;
             const double* Bc = v.btn + (int64_t)c * b.L;
-            const d4 acc = gemm_tile_g(v.E, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0);
+            const d4 acc = gemm_tile_g4(v.E, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0);
             double* out = Wr + (int64_t)c * nk * b.Y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

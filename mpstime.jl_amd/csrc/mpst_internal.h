@@ -510,7 +510,8 @@ int impute_chi_limit(bool cx, bool f32);
 int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scratch elements of the large-chi environment kernel
 void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);
 // mpst_eig.hip
-void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri, 1 vec, 2 fin
+void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri (or tri + vec merged), 1 vec, 2 fin
+bool eig_merged();   // k_eig_trivec instead of k_eig_tri + k_eig_vec (default; MPST_EIG_SPLIT=1 restores the three-kernel chain)
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
 size_t eig_workspace_doubles();
 // library slow path for d*chi_max > MAX_DIM (rocSOLVER dsyevd at the capacity size, see mpst_eig.hip)

@@ -331,11 +331,12 @@ class SweepEngine:
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
 
     def info(self):
-        out = (C.c_int32 * 12)()
+        out = (C.c_int32 * 16)()
         self._chk(self.lib.mpst_get_info(self.ctx, out))
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
-                "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11]}
+                "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11],
+                "eig_merged": bool(out[12])}
 
     def eig_phases(self):
         us = np.zeros(6)

@@ -13,7 +13,8 @@ eng.set_mps(W)
 eng.build_caches()
 for _ in range(3):
     eng.sweep()
-eng.bond_step(7, True)
+for lid in range(14, 6, -1):      # the label sits on the last site after a sweep: walk left to a full-size bond
+    eng.bond_step(lid, True)
 out = (C.c_ulonglong * 64)()
 eng.lib.mpst_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 eng.lib.mpst_debug_stamps(eng.ctx, out)

@@ -23,12 +23,13 @@ def _engine(full, chi, W):
 
 def test_graph_sweep_equals_bond_steps_at_the_benchmarked_shape():
     """N = 4096, T = 100, chi = 32, d = 4 (BASELINE configs[2]).  From a common steady-state MPS: two mpst_sweep calls
-    against 2 x 198 mpst_bond_step calls.  The two paths differ in ONE piece of arithmetic: the chained path forms
-    T = bt_new E with the contraction split over four waves and feeds it on from the accumulators, the per-bond path stores
-    the split site tensor (one wave, sequential contraction) and multiplies again - the same numbers added in a different
-    order.  Every bond therefore starts from a state that differs in the last bits, and the sweep's own dynamics decide how
-    far that grows; measured: after one sweep the two states agree to 9e-13 in every gauge-invariant quantity, after two
-    to 5e-11 (bounds below: two orders of margin).  Bond dimensions and the confusion matrix are identical."""
+    against 2 x 198 mpst_bond_step calls - IDENTICAL BITS.  The two paths used to differ in one piece of arithmetic (the
+    chained path forms T = bt_new E with the contraction split over four waves and feeds it on from the accumulators, the
+    back-split stored the same product from one sequential accumulation); bonds therefore started from states differing in
+    the last bits, and the sweep's own dynamics - a truncated SVD is discontinuous where sigma_chi ~ sigma_chi+1 - decided
+    how far that grew: 3e-13 ... 6e-3 after ONE sweep depending on the starting MPS (scratch/path_dev.py).  The back-split
+    now adds its partial products in the chained path's order (gemm_tile_g4), the stored site tensor IS the chained T, and
+    the replayed graph equals the stepped sweep bit for bit - for every start tried."""
     N, T, d, chi = 4096, 100, 4, 32
     full = bench.make_inputs(N, T, d)
     W0 = mt.generate_startingMPS(4, T, d, 2, 1234)
@@ -53,12 +54,12 @@ def test_graph_sweep_equals_bond_steps_at_the_benchmarked_shape():
             res[path] = per
     finally:
         eng.close()
-    for s, tol in ((0, 1e-10), (1, 1e-8)):
+    for s in (0, 1):
         (Wa, (msa, kla, aca, cfa), chia), (Wb, (msb, klb, acb, cfb), chib) = res["sweep"][s], res["steps"][s]
         assert np.array_equal(chia, chib)
         ya, yb = R.contract_mps(Wa, full.phi[sub]), R.contract_mps(Wb, full.phi[sub])
         dev = np.abs(ya - yb).max() / np.abs(yb).max()
-        print(f"sweep {s + 1}: overlaps differ by {dev:.2e} (relative), KLD {kla:.12f} vs {klb:.12f}, bitwise equal: "
-              f"{all(np.array_equal(a, b) for a, b in zip(Wa, Wb))}")
-        assert dev < tol, (s, dev)
-        assert abs(kla - klb) < tol * max(1.0, abs(klb)) and aca == acb and np.array_equal(cfa, cfb)
+        same = all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(Wa, Wb))
+        print(f"sweep {s + 1}: overlaps differ by {dev:.2e} (relative), KLD {kla:.12f} vs {klb:.12f}, bitwise equal: {same}")
+        assert same, (s, dev)
+        assert kla == klb and msa == msb and aca == acb and np.array_equal(cfa, cfb)
