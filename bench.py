@@ -516,7 +516,7 @@ def main():
             "svd_group": {"algorithmic_flops_dense_svd": 4.0 * (chi * C * d) * (d * chi) ** 2 + 8.0 * (d * chi) ** 3,
                           "avg_us": round(sum(breakdown[k][0] / max(breakdown[k][1], 1) for k in ("gram", "eig_tri", "eig_vec", "eig_fin")
                                               if k in breakdown), 3)},
-            "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+            "roofline": {"kernel": dominant, "kernel_symbol": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_us": avg_us, "launches": cnt, "algorithmic_per_launch": alg,
                          "in_kernel_us_last_launch": eng.eig_phases()["tridiag"] if dominant == "eig_tri" else None},

@@ -289,14 +289,14 @@ int  mpst_selftest_eig(void* ctx, const double* G /*n*n symmetric*/, int32_t n, 
 /* Per-kernel timing with HIP events recorded on the engine's own stream around every launch
  * of the selected kernel classes during mpst_sweep / mpst_bond_step (bit k of kernel_mask):
  * 0 yhat, 1 grad (fused chain: yhat + gradient partials), 2 grad_reduce + update, 3 gram (fused chain: with the optimiser
- * step), 4 eig_tri (large-bond path: the whole library eigensolver), 5 split, 6 env (fused chain: + back-split + next
- * bond tensor), 7 bt_assemble, 8 all-reduce, 9 eig_vec, 10 eig_fin.
+ * step), 4 eig_tri (default chain: k_eig_trivec, tridiagonalisation + eigenvectors; large-bond path: the whole eigensolver), 5 split, 6 env (fused chain: + back-split + next
+ * bond tensor), 7 bt_assemble, 8 all-reduce, 9 eig_vec (only with MPST_EIG_SPLIT=1), 10 eig_fin.
  * mpst_set_profile also resets the accumulators; mpst_get_profile returns the summed device
  * microseconds and the launch count per class (arrays of 16). */
 int  mpst_set_profile(void* ctx, uint32_t kernel_mask);
 int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16]*/);
 /* which launch chain the context resolved to for its current sizes / options: out[0] fused chain (bond tensors up to
- * 128 x 128, 7 launches per bond), out[1] large-bond path (d*chi_max > 128), out[2] partial gradients per optimiser step
+ * 128 x 128, 6 launches per bond), out[1] large-bond path (d*chi_max > 128), out[2] partial gradients per optimiser step
  * of the fused chain, out[3] 64-series chunks of the unfused chain, out[4] capacity bond dimension, out[5] ranks,
  * out[6] sweeps replayed from a hipGraph, out[7] bonds on which the blocked large-bond eigensolver handed over to the
  * library solver, out[8] bonds whose persistent tridiagonalisation gave up waiting for its peers and was redone one
