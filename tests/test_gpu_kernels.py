@@ -84,3 +84,19 @@ def test_eigensolver_rank_deficient(eng):
         assert np.all(lam[8:] < 1e-12 * ref[0])
         assert np.abs(E[:, :8].T @ E[:, :8] - np.eye(8)).max() < 1e-12
         assert np.abs(G @ E[:, :8] - E[:, :8] * lam[:8]).max() < 1e-12 * ref[0]
+
+
+def test_split_eigensolver_chain_stays_correct():
+    """The default chain runs the tridiagonalisation inside every eigenvector workgroup (k_eig_trivec); the two separate
+    kernels it was merged from are still built and selected by MPST_EIG_SPLIT=1 (read once per process, hence the child):
+    the same LAPACK comparisons, the cluster fallback and the rank-deficient case must hold on that chain too."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("MPST_EIG_SPLIT"):
+        pytest.skip("already running the split chain")
+    env = dict(os.environ, MPST_EIG_SPLIT="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-x", "-k", "eigensolver and not split"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
