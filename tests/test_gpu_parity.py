@@ -51,6 +51,9 @@ CASES = [
     # d > 8 (two site-vector pieces per loader lane in k_grad_s, one bond entry per gradient block row) and d = 16
     (45, 4, 12, 5, 10, 2, "KLD", "TSGO", False, 1, False),
     (30, 3, 16, 4, 8, 3, "MSE", "GD", False, 2, True),
+    # more than 32 eigenpairs wanted from the 128 x 128 solver (d = 2, chi_max = 64: 64 eigenvector workgroups, 64-column
+    # eigenvector block in k_eig_fin)
+    (80, 14, 2, 48, 64, 2, "KLD", "TSGO", False, 1, True),
 ]
 
 
