@@ -14,9 +14,11 @@ from .training import (TrainedMPS, fitMPS, fit_encoded, classify, generate_start
 from .distributed import Shard, split_encoded
 from .imputation import (ImputationProblem, init_imputation_problem, MPS_impute, impute_dataset, kNN_impute, mar,
                          invert_test_transform)
+from .jld2 import JLD2File, read_jld2, load_trained_mps_jld2
 from . import options
 
 __all__ = ["SweepEngine", "comm_library", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
            "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
            "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError", "ImputationProblem",
-           "init_imputation_problem", "save_trained_mps", "load_trained_mps", "mps_content_digest", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform"]
+           "init_imputation_problem", "save_trained_mps", "load_trained_mps", "mps_content_digest", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform",
+           "JLD2File", "read_jld2", "load_trained_mps_jld2"]

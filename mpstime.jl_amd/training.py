@@ -318,7 +318,12 @@ def mps_content_digest(mps) -> str:
 
 
 def load_trained_mps(path) -> TrainedMPS:
+    """A model saved by save_trained_mps (.npz) - or, for a path ending in .jld2, a TrainedMPS the reference itself saved
+    with JLD2 (jld2.py)."""
     import json
+    if str(path).endswith(".jld2"):
+        from .jld2 import load_trained_mps_jld2
+        return load_trained_mps_jld2(path)
     z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
     o = json.loads(str(z["opts"]))
     for k in ("rescale", "data_bounds"):
