@@ -78,8 +78,6 @@ class JLD2File:
     def _read_links(self, addr):
         out = {}
         for t, _, d in self._messages(addr):
-            if t == 0x02 and False:
-                pass
             if t != 0x06:
                 continue
             fl, p, ltype = d[1], 2, 0
