@@ -151,6 +151,10 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
 #define MPST_BASIS_LEGENDRE         0   /* legendre(norm = true),  bases.jl:81-92 */
 #define MPST_BASIS_LEGENDRE_NO_NORM 1   /* legendre_no_norm,       bases.jl:108  (MPSOptions default) */
 #define MPST_BASIS_FOURIER          2   /* fourier_encode,         bases.jl:23-42 (mpst_encode_values; mean method of complex models) */
+/* the remaining closed-form bases, accepted as mean_basis of the imputation engine only (mpst_encode_* does not take them): */
+#define MPST_BASIS_STOUDENMIRE      3   /* angle_encode, d = 2,    bases.jl:7-21  (complex) */
+#define MPST_BASIS_SAHAND           4   /* sahand_encode, even d,  bases.jl:45-68 (complex) */
+#define MPST_BASIS_UNIFORM          5   /* uniform_encode,         bases.jl:2-4   (real) */
 typedef struct {
     int32_t basis;
     int32_t sigmoid_transform;      /* MPSOptions.sigmoid_transform */
@@ -222,8 +226,9 @@ int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[
  *                   rejection_threshold = :none; the reference draws them from a MersenneTwister),
  *                   MPST_IMPUTE_MEAN: expectation value (+ standard deviation when get_err), impute_mean :232-265 with
  *                   get_mean_from_rdm, sampling_utils.jl:66-96; the state the chain is re-conditioned on is the encoding
- *                   of the expectation value itself, evaluated on the device: Legendre bases only (mean_basis =
- *                   MPST_BASIS_LEGENDRE / MPST_BASIS_LEGENDRE_NO_NORM),
+ *                   of the expectation value itself, evaluated on the device with the closed form of the basis (mean_basis:
+ *                   MPST_BASIS_LEGENDRE / _LEGENDRE_NO_NORM / _UNIFORM for real models, _FOURIER / _STOUDENMIRE / _SAHAND
+ *                   for complex ones; the data-driven bases have no closed form and are not supported),
  *                   MPST_IMPUTE_ITS_REJECT: get_sample_from_rdm with a rejection threshold (:271-296): median and WMAD
  *                   first, then up to max_trials inverse-transform samples, the first one within
  *                   rejection_threshold * WMAD of the median is kept (the last one drawn if none is); err_out = WMAD
@@ -257,7 +262,7 @@ int  mpst_impute(void* ctx, int which, const uint8_t* missing, const double* gri
  *            and multiplied in fp32 (MFMA f32 16x16x4); the density on the grid, its cumulative sums and every selection
  *            stay fp64.  MPST_COMPUTE_F64: everything fp64.
  * site[j]: (s, l, r) column-major, the label site (s, l, r, c), like mpst_set_mps; phi: [N][T][d]; label_idx[N] in [0, C)
- * in any order.  chi_max <= 128, d <= 16.  mean_basis MPST_BASIS_FOURIER for complex models. */
+ * in any order.  chi_max <= 128, d <= 16.  mean_basis MPST_BASIS_FOURIER / _STOUDENMIRE / _SAHAND for complex models. */
 #define MPST_DTYPE_F64   0
 #define MPST_DTYPE_C64   1
 #define MPST_COMPUTE_F64 0

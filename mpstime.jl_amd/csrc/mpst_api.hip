@@ -1366,9 +1366,12 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
     if (ntrial < 1) return fail(c, MPST_ERR_INVALID, "max_trials must be at least 1");
     if (method == MPST_IMPUTE_ITS_REJECT && !(o->rejection_threshold >= 0.0)) return fail(c, MPST_ERR_INVALID, "rejection_threshold must be non-negative");
     if (method == MPST_IMPUTE_MEAN) {
-        const bool leg = o->mean_basis == MPST_BASIS_LEGENDRE || o->mean_basis == MPST_BASIS_LEGENDRE_NO_NORM;
-        if (!(m.is_complex ? o->mean_basis == MPST_BASIS_FOURIER : leg))
-            return fail(c, MPST_ERR_UNSUPPORTED, "the mean method re-encodes on the device: Legendre bases (real models) or Fourier (complex models) only");
+        const int mb = o->mean_basis;
+        const bool real_ok = mb == MPST_BASIS_LEGENDRE || mb == MPST_BASIS_LEGENDRE_NO_NORM || mb == MPST_BASIS_UNIFORM;
+        const bool cplx_ok = mb == MPST_BASIS_FOURIER || (mb == MPST_BASIS_STOUDENMIRE && m.d == 2) || (mb == MPST_BASIS_SAHAND && m.d % 2 == 0);
+        if (!(m.is_complex ? cplx_ok : real_ok))
+            return fail(c, MPST_ERR_UNSUPPORTED, "the mean method re-encodes on the device: Legendre / Uniform bases (real models), Fourier, "
+                                                 "Stoudenmire (d = 2) or Sahand (even d) (complex models) only");
     }
     const int lim = impute_chi_limit(m.is_complex != 0, m.compute_f32 != 0);
     if (m.cap > lim || m.d > 16)

@@ -619,7 +619,8 @@ struct ImpArgs {
     int64_t i0;                 // first instance of this chunk
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
-enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2 };
+enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2, IMP_BASIS_STOUDENMIRE = 3, IMP_BASIS_SAHAND = 4,
+       IMP_BASIS_UNIFORM = 5 };
 
 // OCC = workgroups per CU the kernel is compiled for.  Two (256 VGPRs) for real models and for complex ones with d <= 5: the
 // latency-bound loops gain more from the second resident workgroup than the ~300 B of spills cost (45 -> 32 ms at
@@ -1111,8 +1112,8 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
                 }
                 xsel = ex;
                 state_from_grid = false;
-                // state of E[x]: Legendre with the encoder's arithmetic (k_encode; bases.jl:77-92,108) or Fourier
-                // (bases.jl:23-42: cispi(f x) / sqrt(d), f = 0, 1, -1, 2, -2, ...)
+                // state of E[x]: Legendre with the encoder's arithmetic (k_encode; bases.jl:77-92,108), Fourier
+                // (bases.jl:23-42: cispi(f x) / sqrt(d), f = 0, 1, -1, 2, -2, ...) or one of the other closed forms
                 if (tid == 0) {
                     if (g.mean_basis == IMP_BASIS_FOURIER) {
                         for (int k = 0; k < d; ++k) {
@@ -1121,6 +1122,36 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
                             sincospi((double)f * ex, &sn, &cs);
                             ms.r[k] = (R)(cs / sqrt((double)d));
                             if constexpr (CX) ms.i[k] = (R)(sn / sqrt((double)d));
+                        }
+                    } else if (g.mean_basis == IMP_BASIS_STOUDENMIRE) {
+                        // angle_encode (bases.jl:7-21, periods = 1/4): cispi(3x/2) cos(pi x/2), cispi(-3x/2) sin(pi x/2)
+                        double s3, c3, sh, ch;
+                        sincospi(1.5 * ex, &s3, &c3);
+                        sincospi(0.5 * ex, &sh, &ch);
+                        ms.r[0] = (R)(c3 * ch);
+                        ms.r[1] = (R)(c3 * sh);
+                        if constexpr (CX) {
+                            ms.i[0] = (R)(s3 * ch);
+                            ms.i[1] = (R)(-s3 * sh);
+                        }
+                    } else if (g.mean_basis == IMP_BASIS_SAHAND) {
+                        // sahand_encode (bases.jl:45-68): d/2 intervals of width 2/d, two states each, zero outside their interval
+                        const double dxs = 2.0 / d;
+                        for (int k = 0; k < d; ++k) {
+                            const int interval = k / 2 + 1;
+                            const double startx = (interval - 1) * dxs;
+                            const bool inside = startx <= ex && ex <= interval * dxs;
+                            double s3, c3, sh, ch;
+                            sincospi(1.5 * ex / dxs, &s3, &c3);
+                            sincospi(0.5 * (ex - startx) / dxs, &sh, &ch);
+                            const bool odd = (k & 1) == 0;                  // i = k + 1 odd
+                            ms.r[k] = (R)(inside ? (odd ? c3 * ch : c3 * sh) : 0.0);
+                            if constexpr (CX) ms.i[k] = (R)(inside ? (odd ? s3 * ch : -s3 * sh) : 0.0);
+                        }
+                    } else if (g.mean_basis == IMP_BASIS_UNIFORM) {
+                        for (int k = 0; k < d; ++k) {
+                            ms.r[k] = (R)(1.0 / d);
+                            if constexpr (CX) ms.i[k] = R(0);
                         }
                     } else {
                         const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);

@@ -156,9 +156,11 @@ def impute_dataset(imp: ImputationProblem, missing_mask, method: str = "median",
             code, trials, thr = 4, int(max_trials), float(rejection_threshold)
         u = np.ascontiguousarray((rng or np.random.default_rng()).uniform(0.0, 1.0, (N, T, trials)))
     if method == "mean":
-        if enc.name not in ("Legendre_No_Norm", "Legendre_Norm", "Fourier"):
-            raise NotImplementedError("method 'mean' re-encodes the expectation value on the device: Legendre and Fourier bases only")
-        basis = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2}[enc.name]         # MPST_BASIS_*
+        codes = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2, "Stoudenmire": 3, "Sahand": 4, "Uniform": 5}    # MPST_BASIS_*
+        if enc.name not in codes:
+            raise NotImplementedError("method 'mean' re-encodes the expectation value on the device: closed-form bases only "
+                                      f"({', '.join(codes)}), not {enc.name}")
+        basis = codes[enc.name]
     own = engine is None
     eng = engine or SweepEngine(device)
     try:

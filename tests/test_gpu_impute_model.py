@@ -259,3 +259,41 @@ def test_config5_element_type_and_shape(engine_cls):
         first_tot += 1
     assert first_same == first_tot, (first_same, first_tot)
     assert same >= 0.85 * tot, (same, tot)
+
+
+@pytest.mark.parametrize("basis", ["Stoudenmire", "Sahand", "Uniform"])
+def test_mean_with_the_other_closed_form_bases(engine_cls, basis):
+    """impute_mean re-conditions on the encoding of E[x] (sampling_utils.jl:66-96), which the device evaluates from the
+    basis' closed form: angle_encode (bases.jl:7-21), sahand_encode (:45-68), uniform_encode (:2-4) next to Legendre and
+    Fourier.  Mean and standard deviation against the NumPy restatement with the host encoder as `encode`."""
+    import mpstime_jl_amd as mt
+    cx = basis != "Uniform"
+    d = {"Stoudenmire": 2, "Sahand": 4, "Uniform": 3}[basis]
+    code = {"Stoudenmire": 3, "Sahand": 4, "Uniform": 5}[basis]
+    fn = {"Stoudenmire": mt.angle_encode, "Sahand": mt.sahand_encode, "Uniform": mt.uniform_encode}[basis]
+    enc = lambda x: fn(np.asarray(x, dtype=np.float64), d)
+    N, T, chi, C, ngrid = 9, 8, 5, 2, 1001
+    rng = np.random.default_rng(17)
+    W = _complex_mps(T, d, chi, C, rng) if cx else R.random_mps(T, d, chi, C, rng)
+    xs = np.arange(ngrid) / (ngrid - 1.0)                     # these bases live on [0, 1]
+    X = rng.uniform(0.03, 0.97, (N, T))
+    y = rng.integers(0, C, N).astype(np.int32)
+    m = (rng.uniform(size=(N, T)) < 0.4).astype(np.uint8)
+    m[0] = 1
+    m[1] = 0
+    grid_phi, phi = enc(xs), enc(X)
+    eng = engine_cls(0)
+    try:
+        x_mean, e_mean, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, mean_basis=code)
+        if basis == "Stoudenmire":
+            with pytest.raises(mt.MPSTError, match="Stoudenmire"):
+                eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, mean_basis=0)       # a real basis for a complex model
+    finally:
+        eng.close()
+    classes = I.expand_label_index(W)
+    for i in range(N):
+        sites = np.flatnonzero(m[i])
+        if len(sites) == 0:
+            continue
+        xo, eo = I.impute(classes[y[i]], phi[i], sites, xs, grid_phi, "mean", "forwards", True, None, encode=lambda v: enc(v))
+        assert np.abs(x_mean[i, sites] - xo).max() < 1e-9 and np.abs(e_mean[i, sites] - eo).max() < 1e-9
