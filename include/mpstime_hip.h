@@ -151,7 +151,8 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
 #define MPST_BASIS_LEGENDRE         0   /* legendre(norm = true),  bases.jl:81-92 */
 #define MPST_BASIS_LEGENDRE_NO_NORM 1   /* legendre_no_norm,       bases.jl:108  (MPSOptions default) */
 #define MPST_BASIS_FOURIER          2   /* fourier_encode,         bases.jl:23-42 (mpst_encode_values; mean method of complex models) */
-/* the remaining closed-form bases, accepted as mean_basis of the imputation engine only (mpst_encode_* does not take them): */
+/* the remaining closed-form bases: mpst_encode_values and mean_basis of the imputation engine (a data set for the sweep holds
+ * real Legendre states only): */
 #define MPST_BASIS_STOUDENMIRE      3   /* angle_encode, d = 2,    bases.jl:7-21  (complex) */
 #define MPST_BASIS_SAHAND           4   /* sahand_encode, even d,  bases.jl:45-68 (complex) */
 #define MPST_BASIS_UNIFORM          5   /* uniform_encode,         bases.jl:2-4   (real) */

@@ -45,7 +45,7 @@ class mpst_encode_opts(C.Structure):
                 ("data_lb", C.c_double), ("data_ub", C.c_double), ("range_a", C.c_double), ("range_b", C.c_double)]
 
 
-BASIS = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2}      # canonical names (options.jl:243-279; :Legendre == :Legendre_No_Norm)
+BASIS = {"Legendre_Norm": 0, "Legendre_No_Norm": 1, "Fourier": 2, "Stoudenmire": 3, "Sahand": 4, "Uniform": 5}      # canonical names (options.jl:243-279; :Legendre == :Legendre_No_Norm)
 
 # every symbol include/mpstime_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _dp = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_double)

@@ -969,7 +969,8 @@ static int encode_core(Ctx* c, const double* X, int64_t N, int32_t T, int32_t d,
     EncDev e{};
     e.N = N; e.T = T; e.d = d;
     e.norm = eo->basis == MPST_BASIS_LEGENDRE;
-    e.fourier = eo->basis == MPST_BASIS_FOURIER;
+    e.fourier = eo->basis == MPST_BASIS_FOURIER || eo->basis == MPST_BASIS_STOUDENMIRE || eo->basis == MPST_BASIS_SAHAND;
+    e.basis = eo->basis;
     e.sigmoid = eo->sigmoid_transform; e.minmax = eo->minmax; e.is_test = test;
     e.med = eo->median; e.s = eo->iqr / 1.35;
     e.lb = eo->data_lb; e.ub = eo->data_ub; e.a = eo->range_a; e.b = eo->range_b;
@@ -1011,10 +1012,12 @@ int mpst_encode_values(void* ctx, const double* X, int64_t N, int32_t T, int32_t
     if (!c) return MPST_ERR_INVALID;
     if (!eo || !X || !phi_out) return fail(c, MPST_ERR_INVALID, "NULL argument");
     if (N <= 0 || T < 1 || d < 1 || d > 64) return fail(c, MPST_ERR_INVALID, "bad dimensions");
-    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM && eo->basis != MPST_BASIS_FOURIER)
-        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the Legendre and Fourier bases");
+    if (eo->basis < MPST_BASIS_LEGENDRE || eo->basis > MPST_BASIS_UNIFORM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the closed-form bases (Legendre, Fourier, Stoudenmire, Sahand, Uniform)");
+    if (eo->basis == MPST_BASIS_STOUDENMIRE && d != 2) return fail(c, MPST_ERR_INVALID, "Stoudenmire Angle encoding only supports d = 2!");
+    if (eo->basis == MPST_BASIS_SAHAND && d % 2) return fail(c, MPST_ERR_INVALID, "Sahand encoding only supports even dimension");
     HIPC(c, hipSetDevice(c->device));
-    const int zw = eo->basis == MPST_BASIS_FOURIER ? 2 : 1;
+    const int zw = (eo->basis == MPST_BASIS_FOURIER || eo->basis == MPST_BASIS_STOUDENMIRE || eo->basis == MPST_BASIS_SAHAND) ? 2 : 1;
     double* dphi = nullptr;
     struct T1 {
         double** a;

@@ -104,6 +104,40 @@ __global__ __launch_bounds__(256) void k_encode(EncDev e, const double* __restri
         if (scale != 1.0) x /= scale;
     }
     x = (e.b - e.a) * x + e.a;
+    if (e.basis == MPST_BASIS_STOUDENMIRE) {
+        // angle_encode (bases.jl:7-21, periods = 1/4): cispi(3x/2) cospi(x/2), cispi(-3x/2) sinpi(x/2)
+        double* outc = phi + idx * 4;
+        double s3, c3, sh, ch;
+        sincospi(1.5 * x, &s3, &c3);
+        sincospi(0.5 * x, &sh, &ch);
+        outc[0] = c3 * ch;
+        outc[1] = s3 * ch;
+        outc[2] = c3 * sh;
+        outc[3] = -s3 * sh;
+        return;
+    }
+    if (e.basis == MPST_BASIS_SAHAND) {
+        // sahand_encode (bases.jl:45-68): d/2 intervals of width 2/d, two states each, zero outside their interval
+        double* outc = phi + idx * e.d * 2;
+        const double dxs = 2.0 / e.d;
+        for (int k = 0; k < e.d; ++k) {
+            const int interval = k / 2 + 1;
+            const double startx = (interval - 1) * dxs;
+            const bool inside = startx <= x && x <= interval * dxs;
+            double s3, c3, sh, ch;
+            sincospi(1.5 * x / dxs, &s3, &c3);
+            sincospi(0.5 * (x - startx) / dxs, &sh, &ch);
+            const bool odd = (k & 1) == 0;
+            outc[2 * k] = inside ? (odd ? c3 * ch : c3 * sh) : 0.0;
+            outc[2 * k + 1] = inside ? (odd ? s3 * ch : -s3 * sh) : 0.0;
+        }
+        return;
+    }
+    if (e.basis == MPST_BASIS_UNIFORM) {
+        double* outu = phi + idx * e.d;
+        for (int k = 0; k < e.d; ++k) outu[k] = 1.0 / e.d;        // uniform_encode (bases.jl:2-4)
+        return;
+    }
     if (e.fourier) {
         // fourier_encode (bases.jl:23-42): cispi(f x) / sqrt(d) with f = 0, 1, -1, 2, -2, ...
         double* outc = phi + idx * e.d * 2;

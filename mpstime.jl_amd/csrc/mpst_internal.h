@@ -453,7 +453,8 @@ struct EncDev {
     int64_t N;
     int32_t T, d;
     int32_t norm, sigmoid, minmax, is_test;
-    int32_t fourier;        // 1: Fourier basis, phi holds (re, im) pairs
+    int32_t fourier;        // 1: complex basis (Fourier, Stoudenmire, Sahand), phi holds (re, im) pairs
+    int32_t basis;          // MPST_BASIS_*
     double med, s;          // robust sigmoid: 1 / (1 + exp(-(x - med) / s)), s = iqr / 1.35
     double lb, ub, a, b;    // data_bounds and the basis' input range
     double nrm;             // legendre: sqrt(Pl(1, d; normalized) * d)

@@ -137,16 +137,18 @@ class SweepEngine:
     def encode_values(self, X, basis="Legendre_No_Norm", d=4, sigmoid_transform=False, minmax=False, data_bounds=(0.0, 1.0),
                       enc_range=None, norms=None, rescale_out_of_bounds=False):
         """mpst_encode_values: the device preprocessing + encoding kernels on a raw (N, T) matrix, states back to the host -
-        (N, T, d) float64 for the Legendre bases, complex128 for "Fourier".  Defaults: X is already in the encoding's
+        (N, T, d) float64 for the Legendre / Uniform bases, complex128 for "Fourier", "Stoudenmire", "Sahand".  Defaults: X is already in the encoding's
         domain (no transforms, identity range map); with transforms the [0, 1] data is mapped onto ``enc_range``
-        (default (-1, 1)).  ``norms`` as for encode_dataset (a test set) or None."""
+        (default: the basis' own range, (-1, 1) for Legendre / Fourier, (0, 1) for Stoudenmire / Sahand / Uniform).  ``norms`` as for encode_dataset (a test set) or None."""
         from .encodings import model_encoding
+        basis_range = (-1.0, 1.0)
         try:
-            basis = model_encoding(basis).name
+            enc_ = model_encoding(basis)
+            basis, basis_range = enc_.name, (enc_.range or basis_range)
         except Exception:
             pass
         if basis not in L.BASIS:
-            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the Legendre and Fourier bases, not {basis!r}")
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the closed-form bases {sorted(L.BASIS)}, not {basis!r}")
         X = np.ascontiguousarray(X, dtype=np.float64)
         N, T = X.shape
         eo = L.mpst_encode_opts()
@@ -154,7 +156,7 @@ class SweepEngine:
         eo.is_test, eo.rescale_out_of_bounds = int(norms is not None), int(bool(rescale_out_of_bounds))
         eo.data_lb, eo.data_ub = map(float, data_bounds)
         if enc_range is None:
-            enc_range = (-1.0, 1.0) if (sigmoid_transform or minmax or norms is not None) else (0.0, 1.0)
+            enc_range = basis_range if (sigmoid_transform or minmax or norms is not None) else (0.0, 1.0)
         eo.range_a, eo.range_b = map(float, enc_range)
         if norms is None:
             eo.fit_sigmoid = int(bool(sigmoid_transform))
@@ -164,7 +166,7 @@ class SweepEngine:
             eo.sigmoid_transform = int(norms.sigmoid is not None)
             if norms.minmax is not None:
                 eo.lo, eo.hi = norms.minmax
-        cx = basis == "Fourier"
+        cx = basis in ("Fourier", "Stoudenmire", "Sahand")
         out = np.zeros((N, T, int(d)), dtype=np.complex128 if cx else np.float64)
         sec = C.c_double()
         self._chk(self.lib.mpst_encode_values(self.ctx, X.ctypes.data_as(C.POINTER(C.c_double)), N, T, int(d), C.byref(eo),

@@ -165,3 +165,32 @@ def test_encode_values_test_set_path_equals_the_data_set_path(engine_cls):
     finally:
         eng.close()
 
+
+
+@pytest.mark.parametrize("basis,d", [("Stoudenmire", 2), ("Sahand", 4), ("Sahand", 8), ("Uniform", 3)])
+def test_the_other_closed_form_bases_on_the_device(engine_cls, basis, d):
+    """angle_encode (bases.jl:7-21), sahand_encode (:45-68), uniform_encode (:2-4) through mpst_encode_values against the host
+    encoders - raw values in the bases' [0, 1] domain, and behind the training-set preprocessing."""
+    import mpstime_jl_amd as mt
+    fn = {"Stoudenmire": mt.angle_encode, "Sahand": mt.sahand_encode, "Uniform": mt.uniform_encode}[basis]
+    rng = np.random.default_rng(d + len(basis))
+    X = rng.uniform(0.0, 1.0, (29, 17))
+    X[0, :4] = [0.0, 1.0, 0.5, 0.25]                          # interval boundaries of the Sahand basis
+    Xr = rng.normal(size=(29, 17)) * 2.0
+    eng = engine_cls(0)
+    try:
+        phi, _ = eng.encode_values(X, basis, d)
+        phi_p, _ = eng.encode_values(Xr, basis, d, sigmoid_transform=True, minmax=True)
+        if basis == "Stoudenmire":
+            with pytest.raises(mt.MPSTError, match="d = 2"):
+                eng.encode_values(X, basis, 3)
+        if basis == "Sahand":
+            with pytest.raises(mt.MPSTError, match="even"):
+                eng.encode_values(X, basis, 3)
+    finally:
+        eng.close()
+    ref = fn(X, d)
+    assert phi.dtype == ref.dtype and np.abs(phi - ref).max() < 1e-14
+    opts = mt.MPSOptions(d=d, encoding=basis, verbosity=-1)
+    Xs, _ = mt.transform_train_data(Xr, opts, mt.model_encoding(basis).range)
+    assert np.abs(phi_p - fn(Xs, d)).max() < 1e-12
