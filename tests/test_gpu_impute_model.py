@@ -297,3 +297,33 @@ def test_mean_with_the_other_closed_form_bases(engine_cls, basis):
             continue
         xo, eo = I.impute(classes[y[i]], phi[i], sites, xs, grid_phi, "mean", "forwards", True, None, encode=lambda v: enc(v))
         assert np.abs(x_mean[i, sites] - xo).max() < 1e-9 and np.abs(e_mean[i, sites] - eo).max() < 1e-9
+
+
+def test_host_api_sahand_model_mean(engine_cls):
+    """impute_dataset(..., "mean") through the host mirror for a Sahand-encoded (complex) model: the basis code the host
+    passes down selects the device's closed form of sahand_encode for the re-conditioning state."""
+    import mpstime_jl_amd as mt
+    from mpstime_jl_amd.imputation import _scaled_instances
+    rng = np.random.default_rng(23)
+    T, d, chi, C, Ntr, Nte = 12, 4, 6, 2, 24, 8
+    W = _complex_mps(T, d, chi, C, rng)
+    opts = mt.MPSOptions(encoding="Sahand", d=d, chi_max=chi, verbosity=-1)
+    t = np.linspace(0, 1, T)
+    ytr = np.sort(rng.integers(0, C, Ntr))
+    Xtr = np.sin(2 * np.pi * (t[None, :] * (1 + ytr[:, None]) + rng.uniform(size=(Ntr, 1)))) + 0.1 * rng.normal(size=(Ntr, T))
+    yte = rng.integers(0, C, Nte)
+    Xte = np.sin(2 * np.pi * (t[None, :] * (1 + yte[:, None]) + rng.uniform(size=(Nte, 1)))) + 0.1 * rng.normal(size=(Nte, T))
+    td = mt.EncodedTimeSeriesSet(None, ytr, ytr.astype(np.int32), Xtr, np.bincount(ytr, minlength=C))
+    imp = mt.init_imputation_problem(mt.TrainedMPS(W, opts, td), Xte, yte, dx=2e-3, verbosity=0)
+    mask = rng.uniform(size=(Nte, T)) < 0.35
+    ts, sd = mt.impute_dataset(imp, mask, "mean", invert_transform=False)
+    enc, norms, raw, full, scaled, oob = _scaled_instances(imp, np.arange(Nte), mask)
+    phi = enc.encode(scaled, d)
+    classes = I.expand_label_index(W)
+    xs, gphi = imp.x_guess_range.xvals, imp.x_guess_range.xvals_enc
+    for k in range(Nte):
+        sites = np.flatnonzero(mask[k])
+        if len(sites) == 0:
+            continue
+        xo, eo = I.impute(classes[yte[k]], phi[k], sites, xs, gphi, "mean", "forwards", True, None, encode=lambda v: enc.encode(np.asarray(v), d))
+        assert np.abs(ts[k, sites] - xo).max() < 1e-9 and np.abs(sd[k, sites] - eo).max() < 1e-9
