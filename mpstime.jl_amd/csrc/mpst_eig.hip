@@ -262,6 +262,7 @@ __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_
 // Layout constants of the register-resident matrix: TRI_T threads, thread (r, q) owns NE elements of
 // row r as column pairs c = 2q + 2*QN*k + {0,1}; a wave holds RPW consecutive rows.
 constexpr int TRI_T = 1024;
+constexpr int EIG_TAIL_N = 128;       // trailing block the blocked solver hands to the one-workgroup reduction (= BT_TAIL there)
 constexpr int QN = TRI_T / 128;          // threads per row
 constexpr int NE = 16384 / TRI_T;        // elements per thread
 constexpr int NP = NE / 2;               // column pairs per thread
@@ -534,6 +535,33 @@ __device__ __forceinline__ void tri_core(const double* __restrict__ G, const int
         }
     }
     __syncthreads();
+}
+
+// The last EIG_TAIL_N steps of a LARGER tridiagonalisation (bond tensors beyond 128 x 128, mpst_eig_blocked.hip): once the
+// trailing matrix of the multi-workgroup reduction is 128 x 128 it fits one CU's registers, where a Householder step costs
+// 0.9 us instead of the 2.6 us of a step that exchanges vectors between 32 workgroups.  Gt is that trailing block with
+// every earlier reflector applied; the reflectors, tau, d and e of its reduction are written at offset m = n - nt into the
+// arrays the blocked path's later kernels read (Vall row j = reflector j, entries j .. n-1).
+__global__ __launch_bounds__(TRI_T) void k_eig_tail(View v, int lid, int going_left, int rawn, const double* __restrict__ Gt, int ld,
+                                                          double* __restrict__ Vall, double* __restrict__ dd, double* __restrict__ ee,
+                                                          double* __restrict__ tau, const int32_t* abort_flag) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (abort_flag && *(const volatile int32_t*)abort_flag != 0) return;
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, 0);
+    const int n = pb.n, tid = threadIdx.x;
+    if (n <= EIG_TAIL_N) return;                   // the multi-workgroup reduction did all the steps itself
+    const int nt = EIG_TAIL_N, m = n - nt;
+    TriShared t = tri_carve(smem);
+    tri_core<false>(Gt, nt, t, nullptr, nullptr);
+    if (tid < nt) {
+        dd[m + tid] = t.de[2 * tid];
+        ee[m + tid] = tid < nt - 1 ? t.es[tid] : 0.0;
+        tau[m + tid] = tid < nt - 1 ? t.taus[tid] : 0.0;
+    }
+    for (int idx = tid; idx < (nt - 1) * nt; idx += TRI_T) {
+        const int i = idx / nt, c = idx - i * nt;
+        if (c >= i) Vall[(int64_t)(m + i) * ld + m + c] = c == i ? 0.0 : t.Vs[voff(i, nt) + c - i - 1];
+    }
 }
 
 __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_left, const double* rawG, int rawn,
@@ -1345,6 +1373,7 @@ hipError_t eig_init_attrs(int device) {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
@@ -1375,6 +1404,11 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
     } else
         hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
                            (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
+}
+
+void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,
+                     double* tau, const int32_t* abort_flag, hipStream_t s) {
+    hipLaunchKernelGGL(k_eig_tail, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left, rawn, Gt, ld, Vall, dd, ee, tau, abort_flag);
 }
 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {

@@ -27,6 +27,9 @@ namespace mpst {
 constexpr int BT_G = 128;          // workgroups of a Householder step
 constexpr int BT_T = 256;
 constexpr int BT_NMAX = DIM_LIMIT; // 1024
+constexpr int BT_TAIL = 128;       // once the trailing matrix is this small the one-workgroup reduction of mpst_eig.hip finishes it (k_eig_tail)
+// first step the tail kernel takes over, or a value no step reaches (no hand-over: small n, or MPST_BT_NO_TAIL)
+__device__ __forceinline__ int bt_tail_start(int n, int use_tail) { return (use_tail && n > BT_TAIL) ? n - BT_TAIL : (1 << 30); }
 
 struct BtProblem {
     const double* G;
@@ -66,6 +69,8 @@ struct BtBufs {
     double* Tfac;    // [ncap/16][16][16] compact-WY factors of the reflector blocks (k_bt_larft)
     int32_t* flag;   // [1] 0 ok, 1 = verification failed (host falls back to the library)
     int32_t* ctl;    // [4] see k_bt_decide
+    double* tailG;   // [BT_TAIL][BT_TAIL] the trailing block handed to k_eig_tail (all earlier reflectors applied)
+    int use_tail;    // 1: the last BT_TAIL steps run in k_eig_tail
     int ncap;
     const int32_t* abort;   // persistent tridiagonalisation's abort word (null on the launch-per-step path): when it is set,
                             // dd / ee / Vall are stale or partial and every kernel after it must leave without publishing
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
     __shared__ double red[8];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x;
-    if (j > n - 2) return;
+    if (j > n - 2 || j >= bt_tail_start(n, b.use_tail)) return;
     // (a)
     if (j > 0) {
         const double* vprev = b.Vall + (int64_t)(j - 1) * ld;
@@ -232,6 +237,37 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
             s = wave_sum(s);
             if (lane == 0) b.Y[(int64_t)(j & 1) * ld + r] = tau * s;
         }
+    }
+}
+
+// launch-per-step path, before k_eig_tail: the trailing block with the pending update of step m-1 applied - the same
+// alpha, w and element-wise update as step m would form (and as the persistent kernel forms at its hand-over), so both
+// paths hand identical bits to the tail kernel
+__global__ __launch_bounds__(BT_T) void k_bt_tail_prep(View v, int lid, int going_left, int rawn, BtBufs b) {
+    __shared__ double vl[BT_NMAX];
+    __shared__ double wl[BT_NMAX];
+    __shared__ double red[8];
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    const int n = pb.n, ld = b.ncap, tid = threadIdx.x;
+    const int j = bt_tail_start(n, b.use_tail);
+    if (j > n - 2) return;
+    {
+        const double* vprev = b.Vall + (int64_t)(j - 1) * ld;
+        const double* yprev = b.Y + (int64_t)((j - 1) & 1) * ld;
+        double sA = 0.0, sB = 0.0;
+        for (int r = j + tid; r < n; r += BT_T) vl[r] = vprev[r];
+        for (int r = j + tid; r < n; r += 2 * BT_T) sA = fma(yprev[r], vprev[r], sA);
+        for (int r = j + tid + BT_T; r < n; r += 2 * BT_T) sB = fma(yprev[r], vprev[r], sB);
+        const double s = bt_block_sum512(sA, sB, red);
+        const double alpha = -0.5 * b.tau[j - 1] * s;
+        for (int r = j + tid; r < n; r += BT_T) wl[r] = fma(alpha, vl[r], yprev[r]);
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, nt = n - j;
+    for (int r = j + (int)blockIdx.x * 4 + wave; r < n; r += (int)gridDim.x * 4) {
+        const double* arow = b.A + (int64_t)r * ld;
+        const double vr = vl[r], wr = wl[r];
+        for (int c = j + lane; c < n; c += 64) b.tailG[(int64_t)(r - j) * nt + (c - j)] = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
     }
 }
 
@@ -498,6 +534,20 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
             s = wave_sum_fast(s);
             if (lane == 0) red_b[wave] = s;
             __syncthreads();
+            if (j == bt_tail_start(n, b.use_tail)) {
+                // hand-over to k_eig_tail: v_{j-1}, w_{j-1} are complete in LDS; every workgroup applies that pending update to
+                // its rows of the trailing block and writes them out - the reduction of the last BT_TAIL columns runs on
+                // one CU from here (0.9 us per step instead of this kernel's 2.6)
+                const int nt = n - j;
+                for (int k = wave; k < nown; k += NW) {
+                    const int r = g + k * G;
+                    if (r < j) continue;
+                    const double* arow = rows + k * ld;
+                    const double vr = vl[r], wr = wl[r];
+                    for (int c = j + lane; c < n; c += 64) b.tailG[(int64_t)(r - j) * nt + (c - j)] = fma(-wr, vl[c], fma(-vr, wl[c], arow[c]));
+                }
+                return;
+            }
             s = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += red_b[w];
@@ -1264,11 +1314,12 @@ static size_t bt_vec_lds() { return (size_t)(6 * BT_NMAX + 16) * sizeof(double);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     BlockedEig* e = new BlockedEig();
     e->b.ncap = ncap;
+    e->b.use_tail = getenv("MPST_BT_NO_TAIL") == nullptr ? 1 : 0;
     auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess; };
     const size_t n1 = ncap, n2 = (size_t)ncap * ncap;
     bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
-              al(&e->b.res, CAP_LIMIT) && al(&e->b.Tfac, (size_t)((ncap + 15) / 16) * 256) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
+              al(&e->b.res, CAP_LIMIT) && al(&e->b.tailG, (size_t)BT_TAIL * BT_TAIL) && al(&e->b.Tfac, (size_t)((ncap + 15) / 16) * 256) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 4 * n1) && al(&e->cp.rowbuf, 4 * n1) &&
               hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
     if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
@@ -1292,7 +1343,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
 }
 void blocked_eig_destroy(BlockedEig* e) {
     if (!e) return;
-    double* ps[] = {e->b.A, e->b.D, e->b.Y, e->b.Vall, e->b.dd, e->b.ee, e->b.tau, e->b.Z, e->b.lam, e->b.res, e->b.Tfac};
+    double* ps[] = {e->b.A, e->b.D, e->b.Y, e->b.Vall, e->b.dd, e->b.ee, e->b.tau, e->b.Z, e->b.lam, e->b.res, e->b.Tfac, e->b.tailG};
     for (double* p : ps)
         if (p) (void)hipFree(p);
     if (e->b.flag) (void)hipFree(e->b.flag);
@@ -1358,6 +1409,11 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         }
         BtBufs bt = b;
         bt.abort = mode ? e->cp.abort_flag : nullptr;
+        if (b.use_tail) {
+            // the last BT_TAIL steps on one CU (the kernels above stopped at step n - BT_TAIL; nothing to do for n <= BT_TAIL)
+            if (!mode) hipLaunchKernelGGL(k_bt_tail_prep, dim3(32), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
+            launch_eig_tail(v, lid, going_left, rawn, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
+        }
         enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, bt, s);
         e->host_flag[1] = 0;
         if (hipMemcpyAsync(e->host_flag, b.flag, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;

@@ -512,6 +512,8 @@ int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scrat
 void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri (or tri + vec merged), 1 vec, 2 fin
+void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,
+                     double* tau, const int32_t* abort_flag, hipStream_t s);   // last 128 steps of a larger reduction on one CU
 bool eig_merged();   // k_eig_trivec instead of k_eig_tri + k_eig_vec (default; MPST_EIG_SPLIT=1 restores the three-kernel chain)
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
 size_t eig_workspace_doubles();
