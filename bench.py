@@ -468,7 +468,7 @@ def main():
         # FETCH_SIZE doubled per the MI355X guide's gfx950 correction)
         traffic, traffic_src = None, None
         fused, b2 = info.get("fused"), info.get("sliced_bond_gemms")
-        knames = {"eig_tri": "mpst::k_eig_trivec" if info.get("eig_merged") else "mpst::k_eig_tri", "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin",
+        knames = {"eig_tri": ("mpst::k_bt_coop" if info.get("large_bond") else "mpst::k_eig_trivec" if info.get("eig_merged") else "mpst::k_eig_tri"), "eig_vec": "mpst::k_eig_vec", "eig_fin": "mpst::k_eig_fin",
                   "yhat": "mpst::k_yhat_s" if b2 else "mpst::k_yhat",
                   "grad": "mpst::k_grad_s" if b2 else ("mpst::k_bond_fused" if fused else "mpst::k_grad"),
                   "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
