@@ -309,7 +309,9 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * launch per step, out[9] bonds whose XCD-local tridiagonalisation found its workgroups on more than one XCD and was
  * redone with the cross-XCD exchange, out[10] the fused chain runs the sliced bond GEMMs (k_yhat_s + k_grad_s: no partial
  * gradients per workgroup), out[11] shares per gradient block of k_grad_s, out[12] the tridiagonalisation and the
- * eigenvectors of a bond run in one launch (k_eig_trivec), out[13..15] reserved (0) */
+ * eigenvectors of a bond run in one launch (k_eig_trivec), out[13] large-bond sweeps that were redone bond by bond because
+ * a bond's on-device verification failed, out[14] large bonds: the eigensolver's verdict is read once per sweep instead of
+ * once per bond (no host synchronisation inside a sweep), out[15] reserved (0) */
 int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader

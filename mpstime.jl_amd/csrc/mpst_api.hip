@@ -131,6 +131,13 @@ struct Ctx {
     BigEig* big = nullptr;            // d*cap > MAX_DIM: library eigensolver at the capacity size (fallback of the blocked one)
     BlockedEig* blk = nullptr;        // d*cap > MAX_DIM: hand-written blocked eigensolver
     int64_t big_fallbacks = 0;        // bonds on which the blocked solver's verification asked for the library
+    // large bonds, sweeps: the verdict of the blocked eigensolver is read once per sweep instead of once per bond (no host
+    // synchronisation inside the sweep); a sweep in which any bond failed is redone from a snapshot, bond by bond
+    bool big_opt = false, big_opt_active = false;
+    double* snap_sites = nullptr;
+    int32_t* snap_chi = nullptr;      // [T + 2]: chi, label_site
+    DevScalars* snap_sc = nullptr;
+    int big_redos = 0, big_force_fail = -1, big_solves = 0;
     bool ws_ready = false;      // training workspace (caches, bond tensor, gradient, eigensolver) allocated for the current sizes
     bool eval_ready = false;    // evaluation scratch (chains, yeval, pred) allocated for max(N_train, N_test)
     bool caches_valid = false;  // LE / RE describe the current MPS: set by mpst_build_caches, cleared by whatever invalidates them
@@ -328,12 +335,17 @@ int ensure_workspace(Ctx* c) {
     if ((rc = dalloc(c, &c->norm_scratch, (int64_t)3 * c->cap * c->cap))) return rc;
     if (c->big) { big_eig_destroy(c->big); c->big = nullptr; }
     if (c->blk) { blocked_eig_destroy(c->blk); c->blk = nullptr; }
+    dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);       // sized for the previous MPS
+    c->big_opt = false;
     if (dm > MAX_DIM) {
         std::string e;
         if ((rc = big_eig_create(&c->big, dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         const char* sel = getenv("MPST_BIG_EIG");
         if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        // MPST_BIG_SYNC=1: read the eigensolver's verdict after every bond (one host synchronisation per bond) instead of once per sweep
+        c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
+        if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);       // test hook: the n-th solve of the context is marked failed
     }
     if ((rc = dalloc(c, &c->eig_ws, (int64_t)eig_workspace_doubles()))) return rc;
     HIPC(c, hipMemset(c->eig_ws, 0, eig_workspace_doubles() * sizeof(double)));
@@ -525,7 +537,11 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
     if (c->big) {
         ProfScope p(c, K_EIG_TRI);
         int need_lib = 1;
-        if (c->blk) {
+        if (c->blk && c->big_opt_active) {
+            if (launch_eig_blocked_nosync(v, lid, going_left, c->blk, s)) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
+            if (c->big_force_fail >= 0 && c->big_solves++ == c->big_force_fail) blocked_eig_force_sticky(c->blk, s);      // test hook
+            need_lib = 0;
+        } else if (c->blk) {
             need_lib = launch_eig_blocked(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, c->blk, s);
             if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
             if (need_lib) c->big_fallbacks++;
@@ -643,6 +659,7 @@ void mpst_destroy(void* ctx) {
     dfree(&c->yhat); dfree(&c->tile_loss); dfree(&c->partial); dfree(&c->gradbuf); dfree(&c->gram); dfree(&c->lam);
     if (c->big) big_eig_destroy(c->big);
     if (c->blk) blocked_eig_destroy(c->blk);
+    dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);
     dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
@@ -1197,6 +1214,8 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // on host-side state (bond dimensions are read on the device), and the pre-built dispatch packets
     // shorten the dependent kernel-to-kernel hand-over that dominates the small kernels.  Per-kernel
     // profiling and the RCCL leg keep the plain stream path.
+    // (large bonds stay on the plain stream: replaying their ~8000 launches from a graph was measured to gain nothing - 725.0
+    // against 724.5 ms per sweep at (8192, 200, 64, 8) - and a capture must not overlap other threads' legacy-stream copies)
     const bool use_graph = c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
     if (use_graph && (!c->sweep_graph || c->graph_epoch != c->epoch)) {
         if (c->sweep_graph) {
@@ -1222,13 +1241,53 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         }
         c->graph_epoch = c->epoch;
     }
+    // large bonds: no verdict is read inside the sweep (launch_eig_blocked_nosync); the state the sweep starts from is kept
+    // so that a sweep in which a bond failed can be redone bond by bond
+    // (one rank only: a persistent kernel that runs out of patience is a rank-local event, and a rank that redoes its sweep
+    // alone would issue all-reduces its peers do not)
+    const bool optimistic = c->big && c->blk && c->big_opt && c->nranks == 1;
+    const size_t site_bytes = (size_t)c->site_stride * c->T * sizeof(double), chi_bytes = (size_t)(c->T + 1) * sizeof(int32_t);
+    if (optimistic) {
+        if (!c->snap_sites) {
+            int32_t* p = nullptr;
+            if ((rc = dalloc(c, &c->snap_sites, c->site_stride * c->T))) return rc;
+            HIPC(c, hipMalloc((void**)&p, chi_bytes + sizeof(int32_t)));
+            c->snap_chi = p;
+            HIPC(c, hipMalloc((void**)&c->snap_sc, sizeof(DevScalars)));
+        }
+        HIPC(c, hipMemcpyAsync(c->snap_sites, c->sites, site_bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->snap_chi, c->chi, chi_bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->snap_chi + c->T + 1, c->label_site, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+        HIPC(c, hipMemcpyAsync(c->snap_sc, c->sc, sizeof(DevScalars), hipMemcpyDeviceToDevice, c->stream));
+        c->big_opt_active = true;
+    }
     HIPC(c, hipEventRecord(c->ev_start, c->stream));
     if (use_graph) {
         HIPC(c, hipGraphLaunch(c->sweep_graph, c->stream));
     } else if ((rc = enqueue_sweep())) {
+        c->big_opt_active = false;
         return rc;
     }
     HIPC(c, hipGetLastError());         // launch-time failures of the ~2000 enqueues above
+    if (optimistic) {
+        c->big_opt_active = false;
+        const int st = blocked_eig_take_sticky(c->blk, c->stream);        // the one synchronisation of the sweep
+        if (st < 0) return fail(c, MPST_ERR_DEVICE, "reading the sweep's eigensolver verdict failed");
+        if (st) {
+            // some bond's verification failed, or a persistent tridiagonalisation gave up: everything after it ran on
+            // unspecified data.  Back to the start of the sweep, caches rebuilt, bond by bond with the verdict read each time.
+            c->big_redos++;
+            HIPC(c, hipMemcpyAsync(c->sites, c->snap_sites, site_bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(c->chi, c->snap_chi, chi_bytes, hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(c->label_site, c->snap_chi + c->T + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+            HIPC(c, hipMemcpyAsync(c->sc, c->snap_sc, sizeof(DevScalars), hipMemcpyDeviceToDevice, c->stream));
+            const int64_t cs = (int64_t)v.N * v.cap;
+            for (int j = 0; j <= c->T - 2; ++j)
+                launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1, c->LE + (int64_t)j * cs, c->stream);
+            if ((rc = enqueue_sweep())) return rc;
+            HIPC(c, hipGetLastError());
+        }
+    }
     HIPC(c, hipEventRecord(c->ev_stop, c->stream));
     HIPC(c, hipEventSynchronize(c->ev_stop));
     float ms = 0.f;
@@ -1608,7 +1667,9 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[10] = c->b2 ? 1 : 0;                        // fused chain with the sliced bond GEMMs (k_yhat_s + k_grad_s)
     out[11] = c->b2 ? c->b2_ksplit : 0;             // shares per gradient block of k_grad_s
     out[12] = (!c->big && eig_merged()) ? 1 : 0;    // tridiagonalisation + eigenvectors in one launch (k_eig_trivec)
-    out[13] = out[14] = out[15] = 0;
+    out[13] = c->big_redos;                          // large-bond sweeps redone bond by bond after a failed verdict
+    out[14] = (c->big_opt && c->nranks == 1) ? 1 : 0;                   // large bonds: the eigensolver's verdict is read once per sweep
+    out[15] = 0;
     return 0;
 }
 

@@ -69,6 +69,7 @@ struct BtBufs {
     double* Tfac;    // [ncap/16][16][16] compact-WY factors of the reflector blocks (k_bt_larft)
     int32_t* flag;   // [1] 0 ok, 1 = verification failed (host falls back to the library)
     int32_t* ctl;    // [4] see k_bt_decide
+    int32_t* sticky; // [1] set when any solve since the last reset ended with flag != 0 (sweeps that do not read the verdict per bond), or null
     double* tailG;   // [BT_TAIL][BT_TAIL] the trailing block handed to k_eig_tail (all earlier reflectors applied)
     int use_tail;    // 1: the last BT_TAIL steps run in k_eig_tail
     int ncap;
@@ -1229,6 +1230,9 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
 // 16 x 16 tiles of E on the MFMA, A operand = Z^T, B operand = -D/2 + I.  second = 1: the input is the first round's E.
 __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_left, int rawn, BtBufs b, double* rawE, int second) {
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
+    // the last launch of a solve: remember a failed verdict (verification, or the persistent kernel gave up) for callers that
+    // look at it once per sweep instead of once per bond
+    if (second && b.sticky && blockIdx.x == 0 && threadIdx.x == 0 && *b.flag != 0) *b.sticky = 1;
     if (bt_aborted(b) || !b.ctl[1] || (second && !b.ctl[2])) return;
     const bool raw = rawn > 0;
     const int n = pb.n, ld = b.ncap, kout = b.ctl[0];
@@ -1286,6 +1290,7 @@ struct BlockedEig {
     unsigned int seq = 0;              // solve sequence number: part of the key of the XCD-local exchange's entries
     int xcd_misplaced = 0;             // solves whose XCD-local attempt found its workgroups on more than one XCD
     int cooldown = 0;                  // solves left that skip the persistent kernels after one of them gave up waiting
+    int32_t* sticky = nullptr;         // device [1]: a solve enqueued by launch_eig_blocked_nosync failed since the last reset
 };
 static int coop_threads() {
     static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
@@ -1319,7 +1324,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     const size_t n1 = ncap, n2 = (size_t)ncap * ncap;
     bool ok = al(&e->b.A, n2) && al(&e->b.D, (size_t)CAP_LIMIT * CAP_LIMIT) && al(&e->b.Y, 2 * n1) && al(&e->b.Vall, n2) &&
               al(&e->b.dd, n1) && al(&e->b.ee, n1) && al(&e->b.tau, n1) && al(&e->b.Z, (size_t)CAP_LIMIT * n1) && al(&e->b.lam, CAP_LIMIT) &&
-              al(&e->b.res, CAP_LIMIT) && al(&e->b.tailG, (size_t)BT_TAIL * BT_TAIL) && al(&e->b.Tfac, (size_t)((ncap + 15) / 16) * 256) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess &&
+              al(&e->b.res, CAP_LIMIT) && al(&e->b.tailG, (size_t)BT_TAIL * BT_TAIL) && al(&e->b.Tfac, (size_t)((ncap + 15) / 16) * 256) && hipMalloc((void**)&e->b.flag, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->b.ctl, 4 * sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&e->sticky, sizeof(int32_t)) == hipSuccess &&
               hipHostMalloc((void**)&e->host_flag, 2 * sizeof(int32_t)) == hipSuccess && al(&e->cp.ybuf, 4 * n1) && al(&e->cp.rowbuf, 4 * n1) &&
               hipMalloc((void**)&e->cp.counter, 16) == hipSuccess;
     if (ok) {               // one 16-byte control block, cleared by one memset per solve: counter | abort flag | roll call
@@ -1328,7 +1333,7 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
         e->cp.roll = (unsigned long long*)(e->cp.counter + 2);
         e->cp.xsel = ordinal.fetch_add(1) & 7;
     }
-    if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
+    if (ok) ok = hipMemset(e->b.Vall, 0, n2 * sizeof(double)) == hipSuccess && hipMemset(e->b.ctl, 0, 4 * sizeof(int32_t)) == hipSuccess && hipMemset(e->sticky, 0, sizeof(int32_t)) == hipSuccess && hipMemset(e->b.Y, 0, 2 * n1 * sizeof(double)) == hipSuccess;
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<256, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
@@ -1348,6 +1353,7 @@ void blocked_eig_destroy(BlockedEig* e) {
         if (p) (void)hipFree(p);
     if (e->b.flag) (void)hipFree(e->b.flag);
     if (e->b.ctl) (void)hipFree(e->b.ctl);
+    if (e->sticky) (void)hipFree(e->sticky);
     if (e->host_flag) (void)hipHostFree(e->host_flag);
     if (e->cp.ybuf) (void)hipFree(e->cp.ybuf);
     if (e->cp.rowbuf) (void)hipFree(e->cp.rowbuf);
@@ -1434,6 +1440,39 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     }
     return *e->host_flag ? 1 : 0;
 }
+// The same solve without reading the verdict: for sweeps that check ONCE at their end whether any bond failed (and then
+// redo the sweep bond by bond).  No host synchronisation, no device-to-host copies; a failed verification or a persistent
+// kernel that gave up leaves its mark in e->sticky, and the bonds after it run on whatever the failed one left - the
+// caller discards that sweep.  Returns 0 or a negative error.
+int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig* e, hipStream_t s) {
+    const BtBufs& b = e->b;
+    const int ncap = b.ncap;
+    static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
+    if (no_coop) return MPST_ERR_UNSUPPORTED;
+    if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
+    BtBufs bt = b;
+    bt.abort = e->cp.abort_flag;
+    bt.sticky = e->sticky;
+    if (xcd_usable(ncap))
+        hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
+    else if (coop_threads() == 512)
+        hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
+    else
+        hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
+    if (b.use_tail) launch_eig_tail(v, lid, going_left, 0, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
+    enqueue_after_tridiag(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, bt, s);
+    return 0;
+}
+// 1 if a solve enqueued by launch_eig_blocked_nosync failed since the last call (synchronises the stream), 0 if none, < 0 on error
+int blocked_eig_take_sticky(BlockedEig* e, hipStream_t s) {
+    int32_t h = 0;
+    if (hipMemcpyAsync(&h, e->sticky, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+    if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
+    if (h && hipMemsetAsync(e->sticky, 0, sizeof(int32_t), s) != hipSuccess) return MPST_ERR_DEVICE;
+    return h ? 1 : 0;
+}
+void blocked_eig_force_sticky(BlockedEig* e, hipStream_t s) { (void)hipMemsetAsync(e->sticky, 1, sizeof(int32_t), s); }   // test hook
+
 int blocked_eig_coop_aborts(const BlockedEig* e) { return e ? e->coop_aborts : 0; }
 int blocked_eig_xcd_misplaced(const BlockedEig* e) { return e ? e->xcd_misplaced : 0; }
 

@@ -477,6 +477,9 @@ void launch_selftest_mfma(const double* A, const double* B, int K, double* C, hi
 // hand-written blocked eigensolver for d*chi_max > MAX_DIM (mpst_eig_blocked.hip); returns 1 when its on-device
 // verification asks for the library fallback
 struct BlockedEig;
+int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig* e, hipStream_t s);   // no verdict read: see blocked_eig_take_sticky
+int blocked_eig_take_sticky(BlockedEig* e, hipStream_t s);
+void blocked_eig_force_sticky(BlockedEig* e, hipStream_t s);
 int blocked_eig_coop_aborts(const BlockedEig* e);
 int blocked_eig_xcd_misplaced(const BlockedEig* e);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);

@@ -338,7 +338,7 @@ class SweepEngine:
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
                 "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11],
-                "eig_merged": bool(out[12])}
+                "eig_merged": bool(out[12]), "large_bond_sweep_redos": out[13], "large_bond_verdict_per_sweep": bool(out[14])}
 
     def eig_phases(self):
         us = np.zeros(6)

@@ -239,3 +239,40 @@ def test_blocked_tridiagonalisation_is_deterministic(eng):
     # the persistent tridiagonalisation carried every bond (it hands a bond back only when its workgroups cannot all
     # become resident), and nothing needed the library solver
     assert info["large_bond"] and info["persistent_tridiag_aborts"] == 0 and info["library_eig_fallbacks"] == 0
+
+
+def test_sweep_reads_the_verdict_once_and_redoes_a_failed_sweep(engine_cls):
+    """Large bonds: mpst_sweep no longer synchronises with the host after every bond to read the eigensolver's verdict - it
+    reads a sticky word once per sweep and, if any bond failed, redoes the sweep from a snapshot bond by bond (with the
+    library fallback).  MPST_BIG_FORCE_FAIL marks one solve as failed: the redone sweep, and the sweep after it, must give
+    the bits of a context that reads the verdict after every bond (MPST_BIG_SYNC=1)."""
+    import os
+    N, T, d, chi0, chimax, C = 96, 5, 8, 14, 20, 2          # d*chi = 160 > 128
+    ds, W0 = make_problem(N, T, d, chi0, C, seed=3)
+    opts = R.SweepOptions(nsweeps=2, chi_max=chimax, eta=0.05, loss_grad="KLD", bbopt="TSGO")
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in ("MPST_BIG_FORCE_FAIL", "MPST_BIG_SYNC")}
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        e = engine_cls(0)
+        try:
+            load_engine(e, ds, W0, opts)
+            e.build_caches()
+            st = [e.sweep() for _ in range(2)]
+            return e.get_mps(), e.info(), e.loss_trace() if hasattr(e, "loss_trace") else None, st
+        finally:
+            e.close()
+            for k, val in old.items():
+                os.environ.pop(k, None)
+                if val is not None:
+                    os.environ[k] = val
+
+    W_sync, i_sync, _, _ = run({"MPST_BIG_SYNC": "1"})
+    W_opt, i_opt, _, _ = run({})
+    W_redo, i_redo, _, _ = run({"MPST_BIG_FORCE_FAIL": "3"})
+    assert not i_sync["large_bond_verdict_per_sweep"] and i_opt["large_bond_verdict_per_sweep"]
+    assert i_opt["large_bond_sweep_redos"] == 0 and i_redo["large_bond_sweep_redos"] == 1
+    assert all(np.array_equal(a, b) for a, b in zip(W_sync, W_opt))
+    assert all(np.array_equal(a, b) for a, b in zip(W_sync, W_redo))
