@@ -375,7 +375,19 @@ def main():
             except Exception as e:
                 good = 0.0
                 allreduce[name + "_error"] = str(e)
+            # every rank holds the whole MPS and applies the same all-reduced update: after the trial sweeps the replicas must
+            # be identical - a collective that delivers wrong or differently ordered sums shows here, not in the results
+            fp = 0.0
+            if good > 0:
+                try:
+                    fp = float(int(mt.mps_content_digest(eng.get_mps())[:12], 16))      # 48 bits: exact in a double
+                except Exception as e:
+                    good = 0.0
+                    allreduce[name + "_error"] = str(e)
             good = host_reduce([good], dist.ReduceOp.MIN)[0]
+            if good > 0 and host_reduce([fp], dist.ReduceOp.MIN)[0] != host_reduce([fp], dist.ReduceOp.MAX)[0]:
+                good = 0.0
+                allreduce[name + "_error"] = "the ranks' MPS replicas differ after the trial sweeps"
             dt = host_reduce([dt], dist.ReduceOp.MAX)[0]
             times[name] = dt if good > 0 else None
         allreduce["trial_sweep_s"] = times
