@@ -27,6 +27,17 @@
  *   - site tensor j   column-major array of size (d, chi[j], chi[j+1]) and, on the
  *     label site, (d, chi[j], chi[j+1], C): element (s,l,r,c) at
  *     s + d*(l + chi[j]*(r + chi[j+1]*c)).  chi[0] = chi[T] = 1.
+ *
+ * Element types (opts.dtype, RealRealHighDimension.jl:442).  A context has ONE element type - MPST_F64 (default), MPST_F32,
+ *   MPST_C128, MPST_C64 - fixed by its first data set (mpst_set_dataset's `dtype`, or mpst_set_dtype before a device-side
+ *   encoding): encoded series and site tensors cross the boundary in that type (complex: interleaved (re, im), i.e. Julia's
+ *   ComplexF64 / ComplexF32 arrays).  Complex encodings (Fourier, Sahand, Stoudenmire) need a complex type, as in the reference
+ *   (RealRealHighDimension.jl:461-466); their training follows the reference's legacy ITensor engine, the only one that
+ *   accepts them (src/legacy_itensor/loss_functions.jl:433-640, RealRealLegacyITensor.jl:2-142): phi~ = conj(ps_l) (x) LE (x)
+ *   conj(ps_r) (x) RE, yhat = BT * phi~ (no conjugate on BT), loss -log|yhat|^2, grad = -conj(phi~ / yhat).  Whatever the
+ *   element type, overlaps, losses, the reduced gradient, the optimiser step, the Gram matrix of the bond tensor and its
+ *   eigen-decomposition are fp64; scalar results (losses, spectra, overlaps) are returned as doubles ((re, im) pairs of
+ *   doubles for the overlaps of a complex context).
  */
 #ifndef MPSTIME_HIP_H
 #define MPSTIME_HIP_H
@@ -37,7 +48,9 @@
 extern "C" {
 #endif
 
-#define MPST_ABI_VERSION 1
+/* 2: mpst_get_info writes 16 entries (1: 12), mpst_set_dtype / mpst_get_info_n added, element types other than Float64
+ *    accepted by mpst_set_dataset / mpst_set_mps.  A host compares mpst_version() with the header it was built against. */
+#define MPST_ABI_VERSION 2
 
 typedef enum {
     MPST_OK = 0,
@@ -134,6 +147,9 @@ int  mpst_comm_select(void* ctx, int oneshot);
 int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* label_idx,
                       int64_t N, int32_t T, int32_t d, int32_t C, int32_t dtype,
                       const int64_t* n_global_per_class);
+/* opts.dtype ahead of a device-side encoding (mpst_encode_dataset encodes in fp64 and stores in this type; without it a
+ * real basis gives MPST_F64 and a complex basis MPST_C128).  Must precede the data sets and the MPS. */
+int  mpst_set_dtype(void* ctx, int32_t dtype);
 
 /* Device-side preprocessing + encoding: the raw N x T matrix (row-major, already sorted by
  * class like mpst_set_dataset's input) goes through transform_train_data / transform_test_data
@@ -151,8 +167,7 @@ int  mpst_set_dataset(void* ctx, int which, const void* phi, const int32_t* labe
 #define MPST_BASIS_LEGENDRE         0   /* legendre(norm = true),  bases.jl:81-92 */
 #define MPST_BASIS_LEGENDRE_NO_NORM 1   /* legendre_no_norm,       bases.jl:108  (MPSOptions default) */
 #define MPST_BASIS_FOURIER          2   /* fourier_encode,         bases.jl:23-42 (mpst_encode_values; mean method of complex models) */
-/* the remaining closed-form bases: mpst_encode_values and mean_basis of the imputation engine (a data set for the sweep holds
- * real Legendre states only): */
+/* the remaining closed-form bases: */
 #define MPST_BASIS_STOUDENMIRE      3   /* angle_encode, d = 2,    bases.jl:7-21  (complex) */
 #define MPST_BASIS_SAHAND           4   /* sahand_encode, even d,  bases.jl:45-68 (complex) */
 #define MPST_BASIS_UNIFORM          5   /* uniform_encode,         bases.jl:2-4   (real) */
@@ -177,7 +192,8 @@ int  mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* l
  * eo as for mpst_encode_dataset (fits returned in it); oob_fix [N][2] or NULL. */
 int  mpst_encode_values(void* ctx, const double* X, int64_t N, int32_t T, int32_t d, mpst_encode_opts* eo, void* phi_out,
                         double* oob_fix, double* seconds);
-/* Encoded values of data set `which` back to the host, [N][T][d] (EncodedTimeSeriesSet.timeseries). */
+/* Encoded values of data set `which` back to the host, [N][T][d] in the context's element type
+ * (EncodedTimeSeriesSet.timeseries). */
 int  mpst_get_encoded(void* ctx, int which, double* phi_out);
 
 int  mpst_set_options(void* ctx, const mpst_options* o);
@@ -210,7 +226,7 @@ int  mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug*
 int  mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64_t* conf);
 
 /* classify(mps, states), src/summary.jl:116-136: predicted class slot per series,
- * and optionally the raw overlaps yhat[N][C]. */
+ * and optionally the raw overlaps yhat[N][C] (complex context: [N][C][2], (re, im)). */
 int  mpst_classify(void* ctx, int which, int32_t* pred /*[N]*/, double* yhat /*[N][C] or NULL*/);
 
 /* Imputation of missing values, batched over the instances of data set `which`:
@@ -311,8 +327,11 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * gradients per workgroup), out[11] shares per gradient block of k_grad_s, out[12] the tridiagonalisation and the
  * eigenvectors of a bond run in one launch (k_eig_trivec), out[13] large-bond sweeps that were redone bond by bond because
  * a bond's on-device verification failed, out[14] large bonds: the eigensolver's verdict is read once per sweep instead of
- * once per bond (no host synchronisation inside a sweep), out[15] reserved (0) */
+ * once per bond (no host synchronisation inside a sweep), out[15] 0, or 1 + dtype when the element-typed kernels
+ * (csrc/mpst_typed.hip) run the sweep */
 int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
+/* the same, at most n entries: for callers compiled against another revision of this header */
+int  mpst_get_info_n(void* ctx, int32_t* out, int32_t n);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libmpstime_hip.so")
 MPST_OK, MPST_ERR_INVALID, MPST_ERR_UNSUPPORTED, MPST_ERR_DEVICE, MPST_ERR_SVD, MPST_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 LOSS = {"KLD": 0, "MSE": 1}
 OPT = {"TSGO": 0, "GD": 1}
-F64 = 0
+F64, F32, C128, C64 = 0, 1, 2, 3       # mpst_set_dataset's dtype (include/mpstime_hip.h)
+ABI_VERSION = 2
 MAX_SPECTRUM = 512
 KERNEL_CLASSES = ("yhat", "grad", "grad_reduce+update", "gram", "eig_tri", "split", "env", "bt_assemble", "allreduce",
                   "eig_vec", "eig_fin")
@@ -71,6 +72,7 @@ SYMBOLS = {
     "mpst_comm_ipc_export": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]),
     "mpst_comm_ipc_attach": (C.c_int, [_vp, C.POINTER(C.c_uint8)]),
     "mpst_comm_select": (C.c_int, [_vp, C.c_int]),
+    "mpst_set_dtype": (C.c_int, [_vp, _i32]),
     "mpst_set_dataset": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_i32), _i64, _i32, _i32, _i32, _i32, C.POINTER(_i64)]),
     "mpst_encode_dataset": (C.c_int, [_vp, C.c_int, _dp, C.POINTER(_i32), _i64, _i32, _i32, _i32, C.POINTER(mpst_encode_opts),
                                       C.POINTER(_i64), _dp, _dp]),
@@ -97,6 +99,7 @@ SYMBOLS = {
     "mpst_get_profile": (C.c_int, [_vp, _dp, C.POINTER(_i64)]),
     "mpst_get_eig_phases": (C.c_int, [_vp, _dp]),
     "mpst_get_info": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "mpst_get_info_n": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
 }
 
 _lib = None
@@ -117,6 +120,9 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
+    if lib.mpst_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI version {lib.mpst_version()}, this binding was written for {ABI_VERSION}: rebuild "
+                           "(make -C mpstime.jl_amd/csrc)")
     _lib = lib
     return lib
 

@@ -97,6 +97,15 @@ struct Ctx {
     bool have_opt = false;
     int T = 0, d = 0, C = 0;
     int cap = 0;              // capacity bond dimension of all device buffers
+    // element type of the data sets and of the MPS (mpst_set_dataset's dtype = opts.dtype, RealRealHighDimension.jl:442).
+    // typed: everything runs through the element-typed kernels of mpst_typed.hip (always for fp32 / complex; MPST_TYPED=1
+    // sends Float64 through them too - the cross-check of the two implementations); the buffers marked (E) below then hold
+    // elements of esz bytes behind their double* names.
+    int dtype = MPST_F64;
+    bool have_dtype = false, typed = false;
+    int zw = 1;               // 2: complex
+    size_t esz = 8;           // bytes per element
+    double* tnorm_scratch = nullptr;   // typed normalize: three complex cap x cap matrices
     DataSet ds[2];
     // MPS
     bool have_mps = false;
@@ -203,6 +212,9 @@ void dfree(T** p) {
     *p = nullptr;
 }
 
+// (E) buffers: `n` elements of c->esz bytes behind a double* name
+int dalloc_e(struct Ctx* c, double** p, int64_t n);
+
 void free_dataset(DataSet& s) {
     dfree(&s.phi); dfree(&s.label); dfree(&s.tiles); dfree(&s.chunks); dfree(&s.cls_chunk_off); dfree(&s.cls_off); dfree(&s.inv_count);
     for (int k = 0; k < 2; ++k) { dfree(&s.parts[k]); dfree(&s.part_off[k]); }
@@ -243,6 +255,47 @@ View make_view(Ctx* c, int which) {
     return v;
 }
 
+int dalloc_e(Ctx* c, double** p, int64_t n) {
+    uint8_t* q = (uint8_t*)*p;
+    *p = nullptr;
+    int rc = dalloc(c, &q, std::max<int64_t>(n, 1) * (int64_t)c->esz);
+    *p = (double*)q;
+    return rc;
+}
+inline double* eoff(Ctx* c, double* base, int64_t elems) { return (double*)((char*)base + (size_t)elems * c->esz); }
+
+TView make_tview(Ctx* c, int which) {
+    TView t{};
+    const DataSet& s = c->ds[which];
+    t.T = c->T; t.d = c->d; t.C = c->C; t.chi_max = c->opt.chi_max; t.cap = c->cap;
+    t.cx = c->zw == 2; t.f32 = (c->dtype == MPST_F32 || c->dtype == MPST_C64);
+    t.N = s.N;
+    t.invN = s.Nglobal > 0 ? 1.0 / (double)s.Nglobal : 0.0;
+    t.phi = s.phi; t.label = s.label; t.tiles = s.tiles; t.chunks = s.chunks; t.cls_chunk_off = s.cls_chunk_off; t.inv_count = s.inv_count;
+    t.ntiles = s.ntiles; t.nchunks = s.nchunks;
+    t.chi = c->chi; t.label_site = c->label_site; t.sites = c->sites; t.site_stride = c->site_stride;
+    t.LE = c->LE; t.RE = c->RE; t.bt = c->bt; t.yhat = c->yhat; t.tile_loss = c->tile_loss; t.partial = c->partial;
+    t.gradbuf = c->gradbuf; t.norm_part = c->norm_part; t.n_norm_part = c->n_norm_part;
+    t.gram = c->gram; t.E = c->E; t.ldE = c->zw * c->cap; t.sc = c->sc;
+    t.loss = c->opt.loss; t.optimiser = c->opt.optimiser; t.rescale_before = c->opt.rescale_before; t.rescale_after = c->opt.rescale_after;
+    t.train_sep = c->opt.train_classes_separately;
+    t.eta = c->opt.eta; t.cutoff = c->opt.cutoff;
+    t.trace = nullptr; t.trace_it = 0; t.yhat_scaled = 0;
+    return t;
+}
+// what the fp64 eigensolvers see of a typed context: the (embedded) Gram matrix, doubled counts for complex elements
+View make_eig_view(Ctx* c) {
+    View v{};
+    v.T = c->T; v.d = c->d; v.C = c->C;
+    v.chi_max = c->zw * c->opt.chi_max;
+    v.cap = c->zw * c->cap;
+    v.chi = c->chi; v.label_site = c->label_site;
+    v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.eig_ws = c->eig_ws; v.sc = c->sc;
+    v.rescale_after = c->opt.rescale_after; v.svd_alg = c->opt.svd_alg; v.cutoff = c->opt.cutoff;
+    v.zw = c->zw;
+    return v;
+}
+
 void ipc_release(struct Ctx* c);
 
 // (re)allocate the evaluation scratch: sized by the larger of the two data sets, independent of the training
@@ -253,15 +306,75 @@ int ensure_eval(Ctx* c) {
     const int64_t en = std::max<int64_t>(1, std::max(c->ds[0].N, c->ds[1].N));
     c->eval_N = en;
     for (int k = 0; k < 2; ++k) {
-        if ((rc = dalloc(c, &c->chainL[k], en * c->cap))) return rc;
-        if ((rc = dalloc(c, &c->chainR[k], en * c->cap))) return rc;
+        if ((rc = dalloc_e(c, &c->chainL[k], en * c->cap))) return rc;
+        if ((rc = dalloc_e(c, &c->chainR[k], en * c->cap))) return rc;
     }
-    if ((rc = dalloc(c, &c->yeval, en * c->C))) return rc;
+    if ((rc = dalloc(c, &c->yeval, en * c->C * (c->typed ? 2 : 1)))) return rc;      // typed: (re, im) pairs
     if ((rc = dalloc(c, &c->out3, 4))) return rc;
     if ((rc = dalloc(c, &c->conf, (int64_t)MAX_C * MAX_C))) return rc;
     if ((rc = dalloc(c, &c->pred, en))) return rc;
     c->eval_ready = true;
     return 0;
+}
+
+// the element-typed context's workspace (mpst_typed.hip): (E) buffers in the element type, everything that decides the
+// truncation in fp64
+int ensure_workspace_typed(Ctx* c) {
+    const DataSet& tr = c->ds[MPST_TRAIN];
+    const int dm = c->d * c->cap, zw = c->zw;
+    const int64_t Lmax = (int64_t)dm * dm;
+    int rc;
+    if (zw * dm > DIM_LIMIT || zw * c->cap > CAP_LIMIT)
+        return fail(c, MPST_ERR_UNSUPPORTED, "complex element type: 2*d*chi_max = %d (2*chi_max = %d) exceeds the eigensolver's limits %d, %d", zw * dm, zw * c->cap, DIM_LIMIT, CAP_LIMIT);
+    if (c->d > 32) return fail(c, MPST_ERR_UNSUPPORTED, "the element-typed sweep holds d <= 32");
+    TView tv = make_tview(c, MPST_TRAIN);
+    if (typed_max_lds(tv) > 144 * 1024) return fail(c, MPST_ERR_UNSUPPORTED, "chi_max = %d, d = %d exceed the LDS staging of the element-typed kernels for this element type", c->cap, c->d);
+    c->fused = false;
+    c->b2 = false;
+    if ((rc = dalloc_e(c, &c->LE, c->cache_elems))) return rc;
+    if ((rc = dalloc_e(c, &c->RE, c->cache_elems))) return rc;
+    if ((rc = dalloc_e(c, &c->bt, c->C * Lmax))) return rc;
+    if ((rc = dalloc(c, &c->yhat, (int64_t)2 * c->C * tr.N))) return rc;
+    if ((rc = dalloc(c, &c->tile_loss, std::max<int64_t>((int64_t)c->C * tr.ntiles, 1)))) return rc;
+    c->partial_elems = (int64_t)c->C * typed_grad_nsplit(tv, tr.nchunks) * Lmax;
+    if ((rc = dalloc_e(c, &c->partial, c->partial_elems))) return rc;
+    c->n_norm_part = typed_norm_parts(tv);
+    if ((rc = dalloc(c, &c->norm_part, c->n_norm_part))) return rc;
+    if ((rc = dalloc(c, &c->loss_trace, (int64_t)2 * (c->T - 1) * (c->opt.update_iters + 1)))) return rc;
+    HIPC(c, hipMemset(c->loss_trace, 0, (size_t)2 * (c->T - 1) * (c->opt.update_iters + 1) * sizeof(double)));
+    if ((rc = dalloc(c, &c->gradbuf, 2 + c->C * Lmax * zw))) return rc;
+    HIPC(c, hipMemset(c->gradbuf, 0, (size_t)(2 + c->C * Lmax * zw) * sizeof(double)));
+    const int ne = std::max(zw * dm, MAX_DIM);
+    if ((rc = dalloc(c, &c->gram, (int64_t)ne * ne))) return rc;
+    if ((rc = dalloc(c, &c->lam, ne + 2))) return rc;
+    if ((rc = dalloc(c, &c->E, (int64_t)ne * zw * c->cap))) return rc;
+    if ((rc = dalloc(c, &c->tnorm_scratch, (int64_t)6 * c->cap * c->cap))) return rc;
+    if (c->big) { big_eig_destroy(c->big); c->big = nullptr; }
+    if (c->blk) { blocked_eig_destroy(c->blk); c->blk = nullptr; }
+    dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);
+    c->big_opt = false;
+    if (zw * dm > MAX_DIM) {
+        std::string e;
+        if ((rc = big_eig_create(&c->big, zw * dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        const char* sel = getenv("MPST_BIG_EIG");
+        if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, zw * dm, &e)))
+            return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
+        if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);
+    }
+    if ((rc = dalloc(c, &c->eig_ws, (int64_t)eig_workspace_doubles()))) return rc;
+    HIPC(c, hipMemset(c->eig_ws, 0, eig_workspace_doubles() * sizeof(double)));
+    if ((rc = dalloc(c, &c->sc, 1))) return rc;
+    HIPC(c, hipMemset(c->sc, 0, sizeof(DevScalars)));
+    if ((rc = dalloc(c, &c->norm2, 1))) return rc;
+    hipError_t ea = init_kernel_attrs(c->device);
+    if (ea == hipSuccess) ea = eig_init_attrs(c->device);
+    if (ea == hipSuccess) ea = typed_init_attrs(c->device);
+    if (ea != hipSuccess) return fail(c, MPST_ERR_DEVICE, "hipFuncSetAttribute failed: %s", hipGetErrorString(ea));
+    c->ws_ready = true;
+    c->eval_ready = false;
+    c->epoch++;
+    return ensure_eval(c);
 }
 
 // (re)allocate everything whose size depends on (training set, options, capacity)
@@ -277,9 +390,10 @@ int ensure_workspace(Ctx* c) {
     if (c->C > MAX_C) return fail(c, MPST_ERR_UNSUPPORTED, "more than %d classes unsupported", MAX_C);
     const int64_t Lmax = (int64_t)dm * dm;
     int rc;
-    if (c->ipc_local && 2 + c->C * Lmax > c->ipc_slot) ipc_release(c);   // inbox slots too small for the new capacity: export again
+    if (c->ipc_local && 2 + c->C * Lmax * c->zw > c->ipc_slot) ipc_release(c);   // inbox slots too small for the new capacity: export again
     c->caches_valid = false;
     c->cache_elems = (int64_t)c->T * tr.N * c->cap;
+    if (c->typed) return ensure_workspace_typed(c);
     if ((rc = dalloc(c, &c->LE, c->cache_elems))) return rc;
     if ((rc = dalloc(c, &c->RE, c->cache_elems))) return rc;
     if ((rc = dalloc(c, &c->bt, c->C * Lmax))) return rc;
@@ -428,7 +542,7 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
             static const double secs = [] { const char* e = getenv("MPST_AR_TIMEOUT_S"); const double v = e ? atof(e) : 10.0; return v > 0.0 ? v : 10.0; }();
             p.spin_limit = (long long)(secs * 2.4e9);
         }
-        p.chi = c->chi; p.lid = lid; p.C = c->C; p.d = c->d; p.n_fixed = n_fixed;
+        p.chi = c->chi; p.lid = lid; p.C = c->C * c->zw; p.d = c->d; p.n_fixed = n_fixed;      // complex gradients: (re, im) pairs
         if (lid < 0 && n_fixed > c->ipc_slot) return fail(c, MPST_ERR_INVALID, "all-reduce message exceeds the inbox slot");
         launch_allreduce_oneshot(p, c->stream);
         return 0;
@@ -436,7 +550,7 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
     if (c->ipc_dead && !c->comm)
         return fail(c, MPST_ERR_DEVICE, "the one-shot all-reduce timed out earlier: export and attach the inboxes again (mpst_comm_ipc_export / _attach)");
     if (!c->comm) return fail(c, MPST_ERR_INVALID, "%d ranks but neither an RCCL communicator nor attached inboxes", c->nranks);
-    const size_t cnt = lid >= 0 ? 2 + (size_t)c->C * c->d * c->cap * c->d * c->cap : (size_t)n_fixed;
+    const size_t cnt = lid >= 0 ? 2 + (size_t)c->zw * c->C * c->d * c->cap * c->d * c->cap : (size_t)n_fixed;
     Rccl* nc = rccl_ready(nullptr);
     if (!nc) return fail(c, MPST_ERR_DEVICE, "RCCL is not available");
     ncclResult_t r = nc->AllReduce(buf, buf, cnt, ncclDouble, ncclSum, c->comm, c->stream);
@@ -444,17 +558,102 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
     return 0;
 }
 
+// ---- eigensolver of a bond whose Gram matrix exceeds the LDS-resident solver (both element paths) -----------------------
+int enqueue_big_eig(Ctx* c, const View& v, int lid, int going_left) {
+    hipStream_t s = c->stream;
+    int need_lib = 1;
+    if (c->blk && c->big_opt_active) {
+        if (launch_eig_blocked_nosync(v, lid, going_left, c->blk, s)) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
+        if (c->big_force_fail >= 0 && c->big_solves++ == c->big_force_fail) blocked_eig_force_sticky(c->blk, s);      // test hook
+        need_lib = 0;
+    } else if (c->blk) {
+        need_lib = launch_eig_blocked(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, c->blk, s);
+        if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
+        if (need_lib) c->big_fallbacks++;
+    }
+    if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
+    return 0;
+}
+
+// ---- the per-bond chain of the element-typed sweep (mpst_typed.hip) -----------------------------------------------------
+int enqueue_bond_typed(Ctx* c, int lid, int going_left, int trace_row) {
+    hipStream_t s = c->stream;
+    TView t = make_tview(c, MPST_TRAIN);
+    const int n_it = c->opt.update_iters, rid = lid + 1;
+    if (c->opt.track_cost && trace_row >= 0) t.trace = c->loss_trace + (int64_t)trace_row * (n_it + 1);
+    { ProfScope p(c, K_BT); launch_tbt_assemble(t, lid, s); }                    // flatten_bt
+    if (t.rescale_before) launch_tbt_prescale(t, lid, s);
+    for (int it = 0; it < n_it; ++it) {
+        { ProfScope p(c, K_YHAT); launch_tyhat(t, lid, s); }
+        { ProfScope p(c, K_GRAD); launch_tgrad(t, lid, s); }
+        { ProfScope p(c, K_UPDATE); launch_tgrad_reduce(t, lid, s); }
+        if (c->nranks > 1) {
+            ProfScope p(c, K_ALLREDUCE);
+            int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
+            if (rc) return rc;
+            launch_tgrad_norm(t, lid, s);
+        }
+        t.trace_it = it;
+        { ProfScope p(c, K_UPDATE); launch_tupdate(t, lid, it == 0, s); }
+    }
+    { ProfScope p(c, K_GRAM); launch_tgram(t, lid, going_left, s); }             // decomposeBT: Gram matrix, fp64
+    const View ve = make_eig_view(c);
+    if (c->big) {
+        ProfScope p(c, K_EIG_TRI);
+        int rc = enqueue_big_eig(c, ve, lid, going_left);
+        if (rc) return rc;
+    } else {
+        { ProfScope p(c, K_EIG_TRI); launch_eig(ve, lid, going_left, 0, s); }
+        if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(ve, lid, going_left, 1, s); }
+        { ProfScope p(c, K_EIG_FIN); launch_eig(ve, lid, going_left, 2, s); }
+    }
+    if (t.trace) {          // track_cost: the loss at the updated (and, with rescale[2], normalised) bond tensor
+        TView ty = t;
+        ty.yhat_scaled = t.rescale_after;
+        launch_tyhat(ty, lid, s);
+        View vt = make_view(c, MPST_TRAIN);
+        vt.trace = t.trace;
+        vt.trace_it = n_it;
+        launch_trace_loss(vt, s);
+        if (c->nranks > 1) {
+            int rc = enqueue_allreduce(c, vt.trace + n_it, 1, -1);
+            if (rc) return rc;
+        }
+    }
+    { ProfScope p(c, K_SPLIT); launch_tsplit(t, lid, going_left, s); }
+    {
+        ProfScope p(c, K_ENV);                                                   // update_caches!: the new site tensor is the map
+        const int64_t cs = (int64_t)t.N * t.cap;
+        if (going_left)
+            launch_tenv(t, rid, 0, rid < c->T - 1 ? eoff(c, c->RE, (int64_t)(rid + 1) * cs) : nullptr, rid + 1, ENV_M_SITE_T, rid, eoff(c, c->RE, (int64_t)rid * cs), s);
+        else
+            launch_tenv(t, lid, 1, lid > 0 ? eoff(c, c->LE, (int64_t)(lid - 1) * cs) : nullptr, lid, ENV_M_SITE, lid + 1, eoff(c, c->LE, (int64_t)lid * cs), s);
+    }
+    return 0;
+}
+// construct_caches of the typed context: left environments of sites [0, upto), right environments of sites (from, T-1]
+void enqueue_caches_typed(Ctx* c, int left_upto, int right_from) {
+    TView t = make_tview(c, MPST_TRAIN);
+    const int64_t cs = (int64_t)t.N * t.cap;
+    ProfScope p(c, K_ENV);
+    for (int j = 0; j < left_upto && j <= c->T - 2; ++j)
+        launch_tenv(t, j, 1, j > 0 ? eoff(c, c->LE, (int64_t)(j - 1) * cs) : nullptr, j, ENV_M_SITE, j + 1, eoff(c, c->LE, (int64_t)j * cs), c->stream);
+    for (int j = c->T - 1; j > right_from && j >= 1; --j)
+        launch_tenv(t, j, 0, j < c->T - 1 ? eoff(c, c->RE, (int64_t)(j + 1) * cs) : nullptr, j + 1, ENV_M_SITE_T, j, eoff(c, c->RE, (int64_t)j * cs), c->stream);
+}
+
 // ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
 // have_bt: the bond tensor of this bond was already assembled by the previous bond's environment
 // kernel; next_bt_lid >= 0: assemble that bond's tensor inside this bond's environment kernel.
 int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt = false, int next_bt_lid = -1, int trace_row = -1) {
+    if (c->typed) return enqueue_bond_typed(c, lid, going_left, trace_row);
     hipStream_t s = c->stream;
     View v = v_in;
     const int n_it = c->opt.update_iters;
     if (c->opt.track_cost && trace_row >= 0) v.trace = c->loss_trace + (int64_t)trace_row * (n_it + 1);
     // track_cost: the loss at the updated (and, with rescale[2], normalised) bond tensor - one more forward pass over the batch
-    auto trace_final = [&](const double* bt_new) {
-        if (!v.trace) return;
+    auto trace_final = [&](const double* bt_new) -> int {
+        if (!v.trace) return 0;
         View vy = v;
         vy.bt = const_cast<double*>(bt_new);
         vy.yhat_scaled = v.rescale_after;
@@ -462,7 +661,8 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         launch_yhat(vy, lid, s);
         launch_trace_loss(vy, s);
         // a shard's tile losses carry the GLOBAL 1/N: the sum over the ranks is the loss the single-rank run records
-        if (c->nranks > 1) (void)enqueue_allreduce(c, vy.trace + n_it, 1, -1);
+        if (c->nranks > 1) return enqueue_allreduce(c, vy.trace + n_it, 1, -1);
+        return 0;
     };
     const int rid = lid + 1;
     if (c->fused) {
@@ -506,7 +706,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
         if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
-        trace_final(c->btn);
+        { int rc = trace_final(c->btn); if (rc) return rc; }
         {
             ProfScope p(c, K_ENV);                                                // back-split + update_caches! :759/:799
             const int64_t cs = (int64_t)v.N * v.cap;
@@ -536,23 +736,14 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
     { ProfScope p(c, K_GRAM); launch_gram(v, lid, going_left, s); }            // decomposeBT :756/:798
     if (c->big) {
         ProfScope p(c, K_EIG_TRI);
-        int need_lib = 1;
-        if (c->blk && c->big_opt_active) {
-            if (launch_eig_blocked_nosync(v, lid, going_left, c->blk, s)) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
-            if (c->big_force_fail >= 0 && c->big_solves++ == c->big_force_fail) blocked_eig_force_sticky(c->blk, s);      // test hook
-            need_lib = 0;
-        } else if (c->blk) {
-            need_lib = launch_eig_blocked(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, c->blk, s);
-            if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
-            if (need_lib) c->big_fallbacks++;
-        }
-        if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
+        int rc = enqueue_big_eig(c, v, lid, going_left);
+        if (rc) return rc;
     } else {
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
         if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
     }
-    trace_final(c->bt);
+    { int rc = trace_final(c->bt); if (rc) return rc; }
     { ProfScope p(c, K_SPLIT); launch_split(v, lid, going_left, s); }
     {
         ProfScope p(c, K_ENV);                                                  // update_caches! :759/:799
@@ -569,6 +760,11 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
 
 // construct_caches (RealRealHighDimension.jl:45-103)
 void enqueue_caches(Ctx* c, const View& v, int going_left) {
+    if (c->typed) {
+        if (going_left) enqueue_caches_typed(c, c->T - 1, c->T);
+        else enqueue_caches_typed(c, 0, 0);
+        return;
+    }
     const int64_t cs = (int64_t)v.N * v.cap;
     ProfScope p(c, K_ENV);
     if (going_left) {
@@ -603,6 +799,22 @@ int enqueue_eval(Ctx* c, int which) {
     std::vector<int32_t> chi; int32_t p;
     int rc = host_chi(c, chi, &p);
     if (rc) return rc;
+    if (c->typed) {
+        TView t = make_tview(c, which);
+        const void* Lt = nullptr; const void* Rt = nullptr;
+        int q = 0;
+        for (int j = 0; j < p; ++j) {
+            launch_tenv(t, j, 1, j > 0 ? c->chainL[q ^ 1] : nullptr, j, ENV_M_SITE, j + 1, c->chainL[q], c->stream);
+            Lt = c->chainL[q]; q ^= 1;
+        }
+        q = 0;
+        for (int j = c->T - 1; j > p; --j) {
+            launch_tenv(t, j, 0, j < c->T - 1 ? c->chainR[q ^ 1] : nullptr, j + 1, ENV_M_SITE_T, j, c->chainR[q], c->stream);
+            Rt = c->chainR[q]; q ^= 1;
+        }
+        launch_teval_final(t, Lt, Rt, c->yeval, c->stream);
+        return 0;
+    }
     const double* Lc = nullptr; const double* Rc = nullptr;
     int pp = 0;
     for (int j = 0; j < p; ++j) {
@@ -660,7 +872,7 @@ void mpst_destroy(void* ctx) {
     if (c->big) big_eig_destroy(c->big);
     if (c->blk) blocked_eig_destroy(c->blk);
     dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);
-    dfree(&c->norm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
+    dfree(&c->norm_scratch); dfree(&c->tnorm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
@@ -728,7 +940,7 @@ int mpst_comm_ipc_export(void* ctx, int nranks, int rank, uint8_t handle_out[64]
     ipc_release(c);
     c->nranks = nranks; c->rank = rank;
     const int64_t dm = (int64_t)c->d * c->cap;
-    c->ipc_slot = std::max<int64_t>(2 + c->C * dm * dm, 4 + (int64_t)c->C * c->C);
+    c->ipc_slot = std::max<int64_t>(2 + c->zw * c->C * dm * dm, 4 + (int64_t)c->C * c->C);
     c->ipc_slot = (c->ipc_slot + 15) & ~15ll;
     c->ipc_flag_off = (size_t)2 * nranks * c->ipc_slot * sizeof(double);
     c->ipc_ctr_off = c->ipc_flag_off + 16 * sizeof(unsigned long long);
@@ -835,7 +1047,7 @@ static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N
         s.Nglobal += s.gcounts[k];
     }
     int rc;
-    if ((rc = dalloc(c, &s.phi, N * T * d))) return rc;
+    if ((rc = dalloc_e(c, &s.phi, N * T * d))) return rc;
     if ((rc = dalloc(c, &s.label, N))) return rc;
     HIPC(c, hipMemcpy(s.label, label_idx, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
     // class-pure spans
@@ -917,22 +1129,51 @@ static int dataset_common(Ctx* c, int which, const int32_t* label_idx, int64_t N
     return 0;
 }
 
+// the element type of a context is fixed by its first data set (or mpst_set_dtype) and can only change once both are gone
+static int set_ctx_dtype(Ctx* c, int which, int dtype) {
+    if (dtype != MPST_F64 && dtype != MPST_F32 && dtype != MPST_C128 && dtype != MPST_C64) return fail(c, MPST_ERR_INVALID, "unknown dtype %d", dtype);
+    const bool other = c->ds[which ^ 1].N > 0 || c->have_mps;
+    if (c->have_dtype && dtype != c->dtype && other)
+        return fail(c, MPST_ERR_INVALID, "dtype %d disagrees with the context's element type %d (data sets and MPS share one element type, opts.dtype)", dtype, c->dtype);
+    if (!c->have_dtype || dtype != c->dtype) {
+        c->ws_ready = false;
+        c->eval_ready = false;
+    }
+    c->dtype = dtype;
+    c->have_dtype = true;
+    c->zw = (dtype == MPST_C128 || dtype == MPST_C64) ? 2 : 1;
+    c->esz = (size_t)((dtype == MPST_F32 || dtype == MPST_C64) ? 4 : 8) * c->zw;
+    c->typed = dtype != MPST_F64 || getenv("MPST_TYPED") != nullptr;
+    return 0;
+}
+
+int mpst_set_dtype(void* ctx, int32_t dtype) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c) return MPST_ERR_INVALID;
+    if (c->ds[0].N > 0 || c->ds[1].N > 0 || c->have_mps) {
+        if (c->have_dtype && dtype == c->dtype) return 0;
+        return fail(c, MPST_ERR_INVALID, "mpst_set_dtype must precede the data sets and the MPS");
+    }
+    return set_ctx_dtype(c, 0, dtype);
+}
+
 int mpst_set_dataset(void* ctx, int which, const void* phi_, const int32_t* label_idx, int64_t N, int32_t T, int32_t d,
                      int32_t C, int32_t dtype, const int64_t* n_global_per_class) {
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;
-    if (dtype != MPST_F64)
-        return fail(c, MPST_ERR_UNSUPPORTED, "only Float64 encodings are supported by the array sweep (complex encodings need use_legacy_ITensor, loss_functions.jl:203-217)");
-    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, phi_ != nullptr);
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 (train) or 1 (test)");
+    int rc = set_ctx_dtype(c, which, dtype);
+    if (rc) return rc;
+    rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, phi_ != nullptr);
     if (rc || N == 0) return rc;
     DataSet& s = c->ds[which];
     // site-major copy [T][N][d]
-    const double* phi = (const double*)phi_;
-    std::vector<double> tmp((size_t)N * T * d);
+    const size_t row = (size_t)d * c->esz;
+    const char* phi = (const char*)phi_;
+    std::vector<char> tmp((size_t)N * T * row);
     for (int64_t i = 0; i < N; ++i)
-        for (int t = 0; t < T; ++t)
-            memcpy(&tmp[((size_t)t * N + i) * d], &phi[((size_t)i * T + t) * d], (size_t)d * sizeof(double));
-    HIPC(c, hipMemcpy(s.phi, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        for (int t = 0; t < T; ++t) memcpy(&tmp[((size_t)t * N + i) * row], &phi[((size_t)i * T + t) * row], row);
+    HIPC(c, hipMemcpy(s.phi, tmp.data(), tmp.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1016,11 +1257,33 @@ int mpst_encode_dataset(void* ctx, int which, const double* X, const int32_t* la
     Ctx* c = (Ctx*)ctx;
     if (!c) return MPST_ERR_INVALID;
     if (!eo) return fail(c, MPST_ERR_INVALID, "NULL encode options");
-    if (eo->basis != MPST_BASIS_LEGENDRE && eo->basis != MPST_BASIS_LEGENDRE_NO_NORM)
-        return fail(c, MPST_ERR_UNSUPPORTED, "a data set holds real product states: Legendre bases only (complex bases cannot be trained by the array sweep, loss_functions.jl:203-217; mpst_encode_values encodes them for the imputation engine)");
-    int rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
+    if (eo->basis < MPST_BASIS_LEGENDRE || eo->basis > MPST_BASIS_UNIFORM)
+        return fail(c, MPST_ERR_UNSUPPORTED, "device-side encoding implements the closed-form bases (Legendre, Fourier, Stoudenmire, Sahand, Uniform)");
+    if (eo->basis == MPST_BASIS_STOUDENMIRE && d != 2) return fail(c, MPST_ERR_INVALID, "Stoudenmire Angle encoding only supports d = 2!");
+    if (eo->basis == MPST_BASIS_SAHAND && d % 2) return fail(c, MPST_ERR_INVALID, "Sahand encoding only supports even dimension");
+    if (which != MPST_TRAIN && which != MPST_TEST) return fail(c, MPST_ERR_INVALID, "which must be 0 (train) or 1 (test)");
+    // the element type: what mpst_set_dtype / the other data set fixed (opts.dtype), else the basis' own (Float64 / ComplexF64)
+    const bool bcx = eo->basis == MPST_BASIS_FOURIER || eo->basis == MPST_BASIS_STOUDENMIRE || eo->basis == MPST_BASIS_SAHAND;
+    const int natural = bcx ? MPST_C128 : MPST_F64;
+    const int want = c->have_dtype ? c->dtype : natural;
+    if (bcx && (want == MPST_F64 || want == MPST_F32))
+        return fail(c, MPST_ERR_INVALID, "Using a complex valued encoding but the MPS is real. If using a complex-valued custom encoding, set 'dtype <: Complex' in MPSOptions");   // RealRealHighDimension.jl:462-464
+    int rc = set_ctx_dtype(c, which, want);
+    if (rc) return rc;
+    rc = dataset_common(c, which, label_idx, N, T, d, C, n_global_per_class, X != nullptr);
     if (rc || N == 0) return rc;
-    return encode_core(c, X, N, T, d, eo, c->ds[which].phi, oob_fix, seconds);
+    if (want == natural) return encode_core(c, X, N, T, d, eo, c->ds[which].phi, oob_fix, seconds);
+    double* tmp = nullptr;
+    struct T1 {
+        double** a;
+        ~T1() { dfree(a); }
+    } t1{&tmp};
+    if ((rc = dalloc(c, &tmp, N * T * d * (bcx ? 2 : 1)))) return rc;
+    if ((rc = encode_core(c, X, N, T, d, eo, tmp, oob_fix, seconds))) return rc;
+    launch_tcast(tmp, bcx ? 1 : 0, c->ds[which].phi, c->zw == 2, want == MPST_F32 || want == MPST_C64, N * T * d, c->stream);
+    HIPC(c, hipGetLastError());
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 int mpst_encode_values(void* ctx, const double* X, int64_t N, int32_t T, int32_t d, mpst_encode_opts* eo, void* phi_out, double* oob_fix,
@@ -1061,12 +1324,13 @@ int mpst_get_encoded(void* ctx, int which, double* phi_out) {
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipStreamSynchronize(c->stream));
     const int64_t N = s.N;
-    const int T = c->T, d = c->d;
-    std::vector<double> tmp((size_t)N * T * d);
-    HIPC(c, hipMemcpy(tmp.data(), s.phi, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int T = c->T;
+    const size_t row = (size_t)c->d * c->esz;             // phi_out holds elements of the context's type
+    std::vector<char> tmp((size_t)N * T * row);
+    HIPC(c, hipMemcpy(tmp.data(), s.phi, tmp.size(), hipMemcpyDeviceToHost));
+    char* out = (char*)phi_out;
     for (int64_t i = 0; i < N; ++i)
-        for (int t = 0; t < T; ++t)
-            memcpy(&phi_out[((size_t)i * T + t) * d], &tmp[((size_t)t * N + i) * d], (size_t)d * sizeof(double));
+        for (int t = 0; t < T; ++t) memcpy(&out[((size_t)i * T + t) * row], &tmp[((size_t)t * N + i) * row], row);
     return 0;
 }
 
@@ -1090,25 +1354,26 @@ int mpst_set_mps(void* ctx, const void* const* site, const int32_t* chi, int32_t
         c->cap = cap;
         c->site_stride = (int64_t)C * cap * d * cap;
         int rc;
-        if ((rc = dalloc(c, &c->sites, c->site_stride * T))) return rc;
+        if ((rc = dalloc_e(c, &c->sites, c->site_stride * T))) return rc;
         if ((rc = dalloc(c, &c->chi, T + 1))) return rc;
         if ((rc = dalloc(c, &c->label_site, 1))) return rc;
         c->ws_ready = false;
     }
-    // boundary layout (s, l, r[, c]) column-major  ->  internal [c][l][s][r]
-    std::vector<double> buf((size_t)c->site_stride * T, 0.0);
+    // boundary layout (s, l, r[, c]) column-major  ->  internal [c][l][s][r]; elements of esz bytes (a pure permutation)
+    const size_t esz = c->esz;
+    std::vector<char> buf((size_t)c->site_stride * T * esz, 0);
     for (int j = 0; j < T; ++j) {
         const int Dl = chi[j], Dr = chi[j + 1], Cj = (j == label_site) ? C : 1;
-        const double* src = (const double*)site[j];
+        const char* src = (const char*)site[j];
         if (!src) return fail(c, MPST_ERR_INVALID, "site[%d] is NULL", j);
-        double* dst = &buf[(size_t)j * c->site_stride];
+        char* dst = &buf[(size_t)j * c->site_stride * esz];
         for (int cc = 0; cc < Cj; ++cc)
             for (int r = 0; r < Dr; ++r)
                 for (int l = 0; l < Dl; ++l)
                     for (int s = 0; s < d; ++s)
-                        dst[(((size_t)cc * Dl + l) * d + s) * Dr + r] = src[s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))];
+                        memcpy(dst + ((((size_t)cc * Dl + l) * d + s) * Dr + r) * esz, src + (s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))) * esz, esz);
     }
-    HIPC(c, hipMemcpy(c->sites, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->sites, buf.data(), buf.size(), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->chi, chi, (size_t)(T + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->label_site, &label_site, sizeof(int32_t), hipMemcpyHostToDevice));
     c->have_mps = true;
@@ -1137,19 +1402,20 @@ int mpst_get_mps(void* ctx, void* const* site_out) {
     std::vector<int32_t> chi; int32_t ls;
     int rc = host_chi(c, chi, &ls);
     if (rc) return rc;
-    std::vector<double> buf((size_t)c->site_stride * c->T);
-    HIPC(c, hipMemcpy(buf.data(), c->sites, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t esz = c->esz;
+    std::vector<char> buf((size_t)c->site_stride * c->T * esz);
+    HIPC(c, hipMemcpy(buf.data(), c->sites, buf.size(), hipMemcpyDeviceToHost));
     const int d = c->d;
     for (int j = 0; j < c->T; ++j) {
         const int Dl = chi[j], Dr = chi[j + 1], Cj = (j == ls) ? c->C : 1;
-        double* dst = (double*)site_out[j];
+        char* dst = (char*)site_out[j];
         if (!dst) return fail(c, MPST_ERR_INVALID, "site_out[%d] is NULL", j);
-        const double* src = &buf[(size_t)j * c->site_stride];
+        const char* src = &buf[(size_t)j * c->site_stride * esz];
         for (int cc = 0; cc < Cj; ++cc)
             for (int r = 0; r < Dr; ++r)
                 for (int l = 0; l < Dl; ++l)
                     for (int s = 0; s < d; ++s)
-                        dst[s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))] = src[(((size_t)cc * Dl + l) * d + s) * Dr + r];
+                        memcpy(dst + (s + (size_t)d * (l + (size_t)Dl * (r + (size_t)Dr * cc))) * esz, src + ((((size_t)cc * Dl + l) * d + s) * Dr + r) * esz, esz);
     }
     return 0;
 }
@@ -1163,7 +1429,9 @@ int mpst_build_caches(void* ctx) {
     // on the last site (the state fitMPS starts from) this is construct_caches(W; going_left=true).
     View v = make_view(c, MPST_TRAIN);
     const int64_t cs = (int64_t)v.N * v.cap;
-    {
+    if (c->typed) {
+        enqueue_caches_typed(c, ls, ls);
+    } else {
         ProfScope p(c, K_ENV);
         for (int j = 0; j < ls && j <= c->T - 2; ++j)
             launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1,
@@ -1246,14 +1514,14 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // (one rank only: a persistent kernel that runs out of patience is a rank-local event, and a rank that redoes its sweep
     // alone would issue all-reduces its peers do not)
     const bool optimistic = c->big && c->blk && c->big_opt && c->nranks == 1;
-    const size_t site_bytes = (size_t)c->site_stride * c->T * sizeof(double), chi_bytes = (size_t)(c->T + 1) * sizeof(int32_t);
+    const size_t site_bytes = (size_t)c->site_stride * c->T * c->esz, chi_bytes = (size_t)(c->T + 1) * sizeof(int32_t);
     if (optimistic) {
         if (!c->snap_sites) {
-            int32_t* p = nullptr;
-            if ((rc = dalloc(c, &c->snap_sites, c->site_stride * c->T))) return rc;
-            HIPC(c, hipMalloc((void**)&p, chi_bytes + sizeof(int32_t)));
-            c->snap_chi = p;
-            HIPC(c, hipMalloc((void**)&c->snap_sc, sizeof(DevScalars)));
+            // all three or none: a partial failure must not leave a half-allocated snapshot behind
+            if ((rc = dalloc_e(c, &c->snap_sites, c->site_stride * c->T)) || (rc = dalloc(c, &c->snap_chi, c->T + 2)) || (rc = dalloc(c, &c->snap_sc, 1))) {
+                dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);
+                return rc;
+            }
         }
         HIPC(c, hipMemcpyAsync(c->snap_sites, c->sites, site_bytes, hipMemcpyDeviceToDevice, c->stream));
         HIPC(c, hipMemcpyAsync(c->snap_chi, c->chi, chi_bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -1261,6 +1529,10 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         HIPC(c, hipMemcpyAsync(c->snap_sc, c->sc, sizeof(DevScalars), hipMemcpyDeviceToDevice, c->stream));
         c->big_opt_active = true;
     }
+    struct ActiveGuard {        // whatever path leaves this function, the per-bond eigensolver path reads its verdict again
+        bool& f;
+        ~ActiveGuard() { f = false; }
+    } active_guard{c->big_opt_active};
     HIPC(c, hipEventRecord(c->ev_start, c->stream));
     if (use_graph) {
         HIPC(c, hipGraphLaunch(c->sweep_graph, c->stream));
@@ -1281,9 +1553,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             HIPC(c, hipMemcpyAsync(c->chi, c->snap_chi, chi_bytes, hipMemcpyDeviceToDevice, c->stream));
             HIPC(c, hipMemcpyAsync(c->label_site, c->snap_chi + c->T + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
             HIPC(c, hipMemcpyAsync(c->sc, c->snap_sc, sizeof(DevScalars), hipMemcpyDeviceToDevice, c->stream));
-            const int64_t cs = (int64_t)v.N * v.cap;
-            for (int j = 0; j <= c->T - 2; ++j)
-                launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1, c->LE + (int64_t)j * cs, c->stream);
+            enqueue_caches(c, v, 1);
             if ((rc = enqueue_sweep())) return rc;
             HIPC(c, hipGetLastError());
         }
@@ -1370,7 +1640,8 @@ int mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64
     if (which != 0 && which != 1) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
     if ((rc = enqueue_eval(c, which))) return rc;
     View v = make_view(c, which);
-    launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    if (c->typed) launch_teval_reduce(make_tview(c, which), c->yeval, c->out3, c->conf, c->pred, c->stream);
+    else launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     double o[3];
@@ -1407,11 +1678,20 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
     if (which != 0 && which != 1) return fail(c, MPST_ERR_INVALID, "which must be 0 or 1");
     if ((rc = enqueue_eval(c, which))) return rc;
     View v = make_view(c, which);
-    launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
+    if (c->typed) launch_teval_reduce(make_tview(c, which), c->yeval, c->out3, c->conf, c->pred, c->stream);
+    else launch_eval_reduce(v, c->yeval, c->out3, c->conf, c->pred, c->stream);
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     if (pred) HIPC(c, hipMemcpy(pred, c->pred, (size_t)v.N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (yhat) HIPC(c, hipMemcpy(yhat, c->yeval, (size_t)v.N * c->C * sizeof(double), hipMemcpyDeviceToHost));
+    if (yhat) {
+        if (c->typed && c->zw == 1) {           // the typed kernels keep (re, im) pairs: a real context returns the real parts
+            std::vector<double> tmp((size_t)v.N * c->C * 2);
+            HIPC(c, hipMemcpy(tmp.data(), c->yeval, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < (size_t)v.N * c->C; ++i) yhat[i] = tmp[2 * i];
+        } else {
+            HIPC(c, hipMemcpy(yhat, c->yeval, (size_t)v.N * c->C * c->zw * sizeof(double), hipMemcpyDeviceToHost));
+        }
+    }
     return 0;
 }
 
@@ -1535,7 +1815,8 @@ int mpst_impute(void* ctx, int which, const uint8_t* missing, const double* grid
     if (s.N <= 0) return fail(c, MPST_ERR_INVALID, "data set %d is empty", which);
     HIPC(c, hipSetDevice(c->device));
     const View v = make_view(c, which);
-    const ImpModel m{v.sites, v.site_stride, v.chi, v.label_site, v.phi, v.label, s.N, c->T, c->d, c->cap, 0, 0};
+    const ImpModel m{v.sites, v.site_stride, v.chi, v.label_site, v.phi, v.label, s.N, c->T, c->d, c->cap, c->zw == 2 ? 1 : 0,
+                     (c->dtype == MPST_F32 || c->dtype == MPST_C64) ? 1 : 0};
     return run_impute(c, m, missing, grid_x, grid_phi, ngrid, o, u, x_out, err_out, seconds);
 }
 
@@ -1622,8 +1903,14 @@ int mpst_normalize(void* ctx) {
     int rc = check_ready(c);
     if (rc) return rc;
     View v = make_view(c, MPST_TRAIN);
-    launch_norm2(v, c->norm2, c->norm_scratch, c->stream);
-    launch_scale_sites(v, c->norm2, c->stream);
+    if (c->typed) {
+        TView t = make_tview(c, MPST_TRAIN);
+        launch_tnorm2(t, c->norm2, c->tnorm_scratch, c->stream);
+        launch_tscale_sites(t, c->norm2, c->stream);
+    } else {
+        launch_norm2(v, c->norm2, c->norm_scratch, c->stream);
+        launch_scale_sites(v, c->norm2, c->stream);
+    }
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -1669,7 +1956,16 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[12] = (!c->big && eig_merged()) ? 1 : 0;    // tridiagonalisation + eigenvectors in one launch (k_eig_trivec)
     out[13] = c->big_redos;                          // large-bond sweeps redone bond by bond after a failed verdict
     out[14] = (c->big_opt && c->nranks == 1) ? 1 : 0;                   // large bonds: the eigensolver's verdict is read once per sweep
-    out[15] = 0;
+    out[15] = c->typed ? 1 + c->dtype : 0;        // element-typed kernels in use: 1 + dtype
+    return 0;
+}
+
+int mpst_get_info_n(void* ctx, int32_t* out, int32_t n) {
+    int32_t full[16];
+    if (!out || n < 0) return MPST_ERR_INVALID;
+    int rc = mpst_get_info(ctx, full);
+    if (rc) return rc;
+    for (int i = 0; i < n && i < 16; ++i) out[i] = full[i];
     return 0;
 }
 
@@ -1754,12 +2050,15 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
         // alg 0: the hand-written blocked solver, library only if its verification asks for it; alg 2: the library alone
         std::string e;
         int need_lib = 1;
+        View vraw{};
+        vraw.zw = (alg & 4) ? 2 : 0;          // bit 2: G is the real embedding of a Hermitian matrix (one vector per eigenvalue pair)
+        alg &= 3;
         if (alg != 2) {
             BlockedEig* bl = nullptr;
             if ((rc = blocked_eig_create(&bl, n, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
             HIPC(c, hipMemsetAsync(dl, 0, (size_t)n * sizeof(double), c->stream));
             HIPC(c, hipMemsetAsync(dE, 0, (size_t)n * n * sizeof(double), c->stream));
-            need_lib = launch_eig_blocked(View{}, 0, 0, dG, n, dl, dE, ds, bl, c->stream);
+            need_lib = launch_eig_blocked(vraw, 0, 0, dG, n, dl, dE, ds, bl, c->stream);
             blocked_eig_destroy(bl);
             if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed");
         }

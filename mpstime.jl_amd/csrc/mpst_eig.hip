@@ -232,7 +232,10 @@ struct EigProblem {
     const double* G;
     int n, rows, nspec, K0;
     bool tri;       // tridiagonal path applicable
+    bool pair;      // real embedding of a complex Hermitian matrix (View::zw): n, rows, nspec, K0 are the doubled counts
 };
+// eigenvectors the vector kernels compute: one per eigenvalue pair in pair mode
+__device__ __forceinline__ int eig_nvec(const EigProblem& p) { return p.pair ? p.K0 >> 1 : p.K0; }
 __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_left, const double* rawG, int rawn,
                                               int rawalg) {
     EigProblem p;
@@ -242,15 +245,19 @@ __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_
         p.rows = rawn;
         p.nspec = rawn;
         p.K0 = rawn < RAW_KMAX ? rawn : RAW_KMAX;
-        p.tri = rawalg != MPST_SVD_JACOBI && rawn >= 2;
+        p.pair = (rawalg & 4) != 0 && (rawn & 1) == 0;            // test hook: rawG is an embedding, one vector per pair
+        if (p.pair) p.K0 &= ~1;
+        p.tri = (rawalg & 3) != MPST_SVD_JACOBI && rawn >= 2;
     } else {
+        const int zw = view_zw(v);
         const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
         const int X = Dl * v.d, Y = v.d * Dr;
         p.G = v.gram;
-        p.n = going_left ? Y : X;
-        p.rows = v.C * (going_left ? X : Y);
+        p.n = zw * (going_left ? Y : X);
+        p.rows = zw * v.C * (going_left ? X : Y);
         p.nspec = p.rows < p.n ? p.rows : p.n;                    // LAPACK's min(m, n)
-        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;         // eigenpairs that can survive maxdim
+        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;         // eigenpairs that can survive maxdim (pair mode: v.chi_max is doubled too)
+        p.pair = zw == 2;
         p.tri = v.svd_alg != MPST_SVD_JACOBI && p.K0 <= TRI_KMAX && p.n >= 2;
     }
     return p;
@@ -660,7 +667,7 @@ __device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, doub
     lds_barrier();
     VDBG(0);
     // ---- multisection for the k-th largest eigenvalue ---------------------------------------------------
-    const int target = n - 1 - k;       // ascending index
+    const int target = n - 1 - (pb.pair ? 2 * k : k);       // ascending index (pair mode: the upper one of the k-th pair)
     if (n >= 24) {
         // Two-sided Sturm count: the inertia of T - x is that of its twisted factorisation - negative top-down pivots
         // of rows 0..kk-1, negative bottom-up pivots of rows n-1..kk+1, and the sign of the twisted pivot at row kk.
@@ -1021,13 +1028,25 @@ __device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, doub
             }
             z[c1] = z1;
         }
-        double* Zk = ws + WS_Z + k;                    // [c][KS] layout: k_eig_fin reads it linearly
+        const int kc = pb.pair ? 2 * k : k;
+        double* Zk = ws + WS_Z + kc;                   // [c][KS] layout: k_eig_fin reads it linearly
         const int ks = kstride(pb.K0);
         if (c0 < n) Zk[c0 * ks] = z0;
         if (c1 < n) Zk[c1 * ks] = z1;
+        const double resk = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
         if (lane == 0) {
-            ws[WS_LAM + k] = lamk;
-            ws[WS_RES + k] = fmax(fmax(red_s[0], red_s[1]), fmax(red_s[2], red_s[3]));
+            ws[WS_LAM + kc] = lamk;
+            ws[WS_RES + kc] = resk;
+        }
+        if (pb.pair) {
+            // the partner of u = (u_re, u_im) in the double eigenspace: J u = (-u_im, u_re), i.e. i times the complex vector
+            const int nc = n >> 1;
+            if (c0 < n) Zk[c0 * ks + 1] = c0 < nc ? -z[c0 + nc] : z[c0 - nc];
+            if (c1 < n) Zk[c1 * ks + 1] = c1 < nc ? -z[c1 + nc] : z[c1 - nc];
+            if (lane == 0) {
+                ws[WS_LAM + kc + 1] = lamk;
+                ws[WS_RES + kc + 1] = resk;
+            }
         }
     }
     if (st) stamps[5] = __builtin_amdgcn_s_memrealtime();
@@ -1041,7 +1060,7 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
     __shared__ int arg_s[8];
     const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, rawalg);
     const int k = blockIdx.x;
-    if (!pb.tri || k >= pb.K0) return;
+    if (!pb.tri || k >= eig_nvec(pb)) return;
     vec_core<false>(pb, k, smem, cnt_s, red_s, arg_s, ws, stamps, 0.0, 0.0, 0.0);
 }
 
@@ -1067,7 +1086,7 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
         if (k == 0 && tid == 0) ws[WS_MISC + 3] = 0.0;
         return;
     }
-    if (k >= pb.K0) return;
+    if (k >= eig_nvec(pb)) return;
     double* Vd = smem;
     double* de = Vd + 16384;
     double* Tb = de + 272 + 128 * 6 + 8 + 128 + 8 + 24 + 24;      // k_eig_vec's carve: see vec_core
@@ -1291,26 +1310,14 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     tr = 0.0;
     for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
     __syncthreads();
+    if (pb.pair) tr *= 0.5;             // trace of the complex matrix
     const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
     const double cutoff = raw ? -1.0 : v.cutoff;
-    // NDTensors truncate! (relative cutoff) on P = lambda*inv^2.  The weight beyond the
-    // first K values is trace - sum(first K).  Evaluated redundantly by every thread.
+    // NDTensors truncate! (relative cutoff) on P = lambda*inv^2.  The weight beyond the first K values is
+    // trace - sum(first K).  Evaluated redundantly by every thread.  Returns the number of (real) vectors to keep: in pair
+    // mode both members of every kept pair.
     auto truncate = [&](const double* lam, int K) -> int {
-        const double inv2 = inv * inv;
-        const double scale0 = tr * inv2;
-        const double scale = scale0 == 0.0 ? 1.0 : scale0;
-        double kept = 0.0;
-        for (int i = 0; i < K; ++i) kept += lam[i] * inv2;
-        int nk = K;
-        double truncerr = scale0 - kept;
-        if (truncerr < 0.0 || nspec <= K) truncerr = 0.0;
-        if (nspec > 1) {
-            while (nk > 1 && truncerr + lam[nk - 1] * inv2 <= cutoff * scale) {
-                truncerr += lam[nk - 1] * inv2;
-                --nk;
-            }
-        }
-        return nk;
+        return (pb.pair ? 2 : 1) * truncate_rule(lam, K, nspec, tr, inv * inv, cutoff, pb.pair);
     };
     int sweeps = 0, nk = K0;
     bool done = false;
@@ -1335,15 +1342,17 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
         if (tid < nl) rawlam[tid] = lam_s[tid];
         if (tid == 0) *rawinfo = done ? -1 : (pb.tri ? 0 : sweeps);
     } else {
-        if (tid < K0) v.lam[tid] = lam_s[tid];
+        const int st = pb.pair ? 2 : 1;       // the spectrum and the counts the caller sees are those of the complex matrix
+        if (tid < K0 / st) v.lam[tid] = lam_s[st * tid];
         if (tid == 0) {
             bool bad = !(tr == tr) || tr > 1e300;
             for (int i = 0; i < K0; ++i) {
                 const double P = lam_s[i] * inv * inv;
                 if (!(P == P) || P > 1e300) bad = true;
             }
+            nk /= st;
             v.sc->n_keep = nk;
-            v.sc->n_spec = K0;
+            v.sc->n_spec = K0 / st;
             v.sc->bt_norm2 = tr;
             v.sc->inv_norm = inv;
             v.sc->eig_sweeps = sweeps;
@@ -1478,22 +1487,12 @@ __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int go
     for (int i = 0; i < EIG_THREADS / 64; ++i) tr += red[i];
     if (tid < K0) lam_s[tid] = fmax(D[ncap - 1 - tid], 0.0);
     __syncthreads();
+    if (pb.pair) tr *= 0.5;             // trace of the complex matrix
     const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
     const double cutoff = raw ? -1.0 : v.cutoff;
     const double inv2 = inv * inv;
-    const double scale0 = tr * inv2;
-    const double scale = scale0 == 0.0 ? 1.0 : scale0;
-    double kept = 0.0;
-    for (int i = 0; i < K0; ++i) kept += lam_s[i] * inv2;
-    int nk = K0;
-    double truncerr = scale0 - kept;
-    if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
-    if (nspec > 1) {
-        while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= cutoff * scale) {
-            truncerr += lam_s[nk - 1] * inv2;
-            --nk;
-        }
-    }
+    const int st = pb.pair ? 2 : 1;
+    int nk = st * truncate_rule(lam_s, K0, nspec, tr, inv2, cutoff, pb.pair);      // real vectors to publish
     const int kout = raw ? K0 : nk;
     for (int i = tid; i < n * kout; i += EIG_THREADS) {
         const int k = i / n, c = i - k * n;
@@ -1503,15 +1502,16 @@ __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int go
         if (tid < K0) rawlam[tid] = lam_s[tid];
         if (tid == 0) *rawinfo = *info ? 1000 + *info : -2;
     } else {
-        if (tid < K0) v.lam[tid] = lam_s[tid];
+        if (tid < K0 / st) v.lam[tid] = lam_s[st * tid];
         if (tid == 0) {
             bool bad = !(tr == tr) || tr > 1e300 || *info != 0;
             for (int i = 0; i < K0; ++i) {
                 const double P = lam_s[i] * inv2;
                 if (!(P == P) || P > 1e300) bad = true;
             }
+            nk /= st;
             v.sc->n_keep = nk;
-            v.sc->n_spec = K0;
+            v.sc->n_spec = K0 / st;
             v.sc->bt_norm2 = tr;
             v.sc->inv_norm = inv;
             v.sc->eig_sweeps = 0;

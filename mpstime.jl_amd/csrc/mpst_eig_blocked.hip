@@ -34,7 +34,10 @@ __device__ __forceinline__ int bt_tail_start(int n, int use_tail) { return (use_
 struct BtProblem {
     const double* G;
     int n, rows, nspec, K0;
+    bool pair;      // real embedding of a complex Hermitian matrix (View::zw == 2): all counts are the doubled ones, the vector
+                    // kernel computes one eigenvector per eigenvalue pair and stores its partner J u next to it
 };
+__device__ __forceinline__ int bt_nvec(const BtProblem& p) { return p.pair ? p.K0 >> 1 : p.K0; }
 __device__ __forceinline__ BtProblem bt_resolve(const View& v, int lid, int going_left, const double* rawG, int rawn) {
     BtProblem p;
     if (rawn > 0) {
@@ -43,14 +46,18 @@ __device__ __forceinline__ BtProblem bt_resolve(const View& v, int lid, int goin
         p.rows = rawn;
         p.nspec = rawn;
         p.K0 = rawn < CAP_LIMIT ? rawn : CAP_LIMIT;
+        p.pair = v.zw == 2 && (rawn & 1) == 0;                    // test hook (mpst_selftest_eig, alg bit 2)
+        if (p.pair) p.K0 &= ~1;
     } else {
+        const int zw = view_zw(v);
         const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
         const int X = Dl * v.d, Y = v.d * Dr;
         p.G = v.gram;
-        p.n = going_left ? Y : X;
-        p.rows = v.C * (going_left ? X : Y);
+        p.n = zw * (going_left ? Y : X);
+        p.rows = zw * v.C * (going_left ? X : Y);
         p.nspec = p.rows < p.n ? p.rows : p.n;
-        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;
+        p.K0 = p.nspec < v.chi_max ? p.nspec : v.chi_max;         // pair mode: v.chi_max is the doubled count too
+        p.pair = zw == 2;
     }
     return p;
 }
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x;
-    if (k >= pb.K0 || bt_aborted(b)) return;
+    if (k >= bt_nvec(pb) || bt_aborted(b)) return;
     double* de = smem;                  // [n + 8][2] (d_j, e_{j-1}^2), padded for sturm_count's groups of 8 rows
     double* es = de + 2 * (BT_NMAX + 8);      // [n]
     double* Dp = es + BT_NMAX;          // [n] forward pivots
@@ -797,8 +804,8 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         }
     }
     __syncthreads();
-    // multisection for the k-th largest eigenvalue
-    const int target = n - 1 - k;
+    // multisection for the k-th largest eigenvalue (pair mode: the upper one of the k-th pair)
+    const int target = n - 1 - (pb.pair ? 2 * k : k);
     if (n >= 24) {
         // two-sided Sturm count as in k_eig_vec: a pair of lanes runs the recurrence top-down over rows 0..kk-1 and
         // bottom-up over rows n-1..kk+1, the sign of the twisted pivot at row kk completes the inertia; 128 abscissae x 8
@@ -1058,10 +1065,20 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
         }
         __syncthreads();
     }
-    for (int j = tid; j < n; j += BT_T) b.Z[(int64_t)k * ld + j] = z[j];
+    const int kc = pb.pair ? 2 * k : k;
+    for (int j = tid; j < n; j += BT_T) b.Z[(int64_t)kc * ld + j] = z[j];
     if (tid == 0) {
-        b.lam[k] = lamk;
-        b.res[k] = tnorm > 0.0 ? ri / tnorm : ri;
+        b.lam[kc] = lamk;
+        b.res[kc] = tnorm > 0.0 ? ri / tnorm : ri;
+    }
+    if (pb.pair) {
+        // the partner in the double eigenspace: J u = (-u_im, u_re) - i times the complex eigenvector
+        const int nc = n >> 1;
+        for (int j = tid; j < n; j += BT_T) b.Z[(int64_t)(kc + 1) * ld + j] = j < nc ? -z[j + nc] : z[j - nc];
+        if (tid == 0) {
+            b.lam[kc + 1] = lamk;
+            b.res[kc + 1] = tnorm > 0.0 ? ri / tnorm : ri;
+        }
     }
 }
 
@@ -1162,22 +1179,12 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     const bool trace_ok = fabs(trT - tr) <= 1e-9 * fabs(tr) + 1e-300;
     if (tid < K0) lam_s[tid] = fmax(b.lam[tid], 0.0);
     __syncthreads();
+    if (pb.pair) tr *= 0.5;             // trace of the complex matrix
     const double inv = (!raw && v.rescale_after) ? 1.0 / sqrt(tr) : 1.0;
     const double cutoff = raw ? -1.0 : v.cutoff;
     const double inv2 = inv * inv;
-    const double scale0 = tr * inv2;
-    const double scale = scale0 == 0.0 ? 1.0 : scale0;
-    double kept = 0.0;
-    for (int i = 0; i < K0; ++i) kept += lam_s[i] * inv2;
-    int nk = K0;
-    double truncerr = scale0 - kept;
-    if (truncerr < 0.0 || nspec <= K0) truncerr = 0.0;
-    if (nspec > 1) {
-        while (nk > 1 && truncerr + lam_s[nk - 1] * inv2 <= cutoff * scale) {
-            truncerr += lam_s[nk - 1] * inv2;
-            --nk;
-        }
-    }
+    const int st = pb.pair ? 2 : 1;
+    int nk = st * truncate_rule(lam_s, K0, nspec, tr, inv2, cutoff, pb.pair);      // real vectors to verify and publish
     const int kout = raw ? K0 : nk;
     double rmax = tid < kout ? b.res[tid] : 0.0;
     rmax = wave_max(rmax);
@@ -1208,15 +1215,16 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
         if (tid < K0) rawlam[tid] = lam_s[tid];
         if (tid == 0) *rawinfo = ok ? -3 : -4;
     } else if (ok) {
-        if (tid < K0) v.lam[tid] = lam_s[tid];
+        if (tid < K0 / st) v.lam[tid] = lam_s[st * tid];
         if (tid == 0) {
             bool bad = !(tr == tr) || tr > 1e300;
             for (int i = 0; i < K0; ++i) {
                 const double P = lam_s[i] * inv2;
                 if (!(P == P) || P > 1e300) bad = true;
             }
+            nk /= st;
             v.sc->n_keep = nk;
-            v.sc->n_spec = K0;
+            v.sc->n_spec = K0 / st;
             v.sc->bt_norm2 = tr;
             v.sc->inv_norm = inv;
             v.sc->eig_sweeps = 0;

@@ -36,22 +36,6 @@ namespace mpst {
 constexpr int IMP_T = 256;
 constexpr int IMP_MAXD = 16;
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-template <typename R> struct Mx;
-template <> struct Mx<double> {
-    using acc_t = d4;
-    using vec2 = double2;
-    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return mfma_f64(a, b, c); }
-    static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
-};
-template <> struct Mx<float> {          // C/D map of the f32 16x16x4 form: row = 4 * (lane >> 4) + reg
-    using acc_t = f4;
-    using vec2 = float2;
-    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
-};
-
 // element e of an array of R (real) or of interleaved (re, im) pairs of R (complex)
 template <typename R, bool CX> __device__ __forceinline__ void zload(const R* __restrict__ p, int64_t e, R& re, R& im) {
     if constexpr (CX) {

@@ -1,5 +1,5 @@
 // Internal declarations shared by the translation units of libmpstime_hip.so.
-// gfx950 only; fp64 real path.
+// gfx950 only.  The fp64 real sweep (View) and the element-typed sweep (TView: fp32 / complex, mpst_typed.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,6 +18,24 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
 }
 
 __device__ __forceinline__ int hi32(double x) { return __double2hiint(x); }
+
+// The two MFMA forms the engine computes in, behind one interface: v_mfma_f64_16x16x4_f64 and v_mfma_f32_16x16x4_f32.  A / B
+// operands are laid out alike (lane l: A[l&15][l>>4], B[l>>4][l&15]); the C/D maps differ: f64 row = (l>>4) + 4*reg,
+// f32 row = 4*(l>>4) + reg.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <typename R> struct Mx;
+template <> struct Mx<double> {
+    using acc_t = d4;
+    using vec2 = double2;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return mfma_f64(a, b, c); }
+    static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
+};
+template <> struct Mx<float> {
+    using acc_t = f4;
+    using vec2 = float2;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
 
 // # eigenvalues of T smaller than x: sign changes of the Sturm sequence, division-free, rescaled by
 // a power of two every 8 steps.  (d_j, e_{j-1}^2) pairs are fetched 8 at a time so the LDS latency
@@ -383,7 +401,37 @@ struct View {
     // options
     int32_t loss, optimiser, rescale_before, rescale_after, train_sep, svd_alg;
     double eta, cutoff;
+    // 2: `gram` is the real 2n x 2n embedding [[Gr, -Gi], [Gi, Gr]] of a complex Hermitian Gram matrix (element-typed sweep,
+    // mpst_typed.hip): every eigenvalue is double, the eigensolvers compute ONE vector per pair and store its partner
+    // J u = (-u_im, u_re) next to it (columns 2k, 2k+1), the truncation rule runs on the de-duplicated spectrum and
+    // chi_max / cap of this view are the doubled (real) counts.  0 / 1: plain real symmetric problem.
+    int32_t zw;
 };
+__device__ __forceinline__ int view_zw(const View& v) { return v.zw == 2 ? 2 : 1; }
+
+// NDTensors truncate! (relative cutoff) as the eigensolvers' final kernels apply it: lam[0..K0) are the largest
+// eigenvalues of the Gram matrix (descending), tr its trace, nspec = min(rows, cols) of the decomposed matrix, inv2 the
+// rescale factor.  pair (complex problem in its real embedding): lam holds every eigenvalue twice and K0 / nspec are the
+// doubled counts (tr is the trace of the COMPLEX matrix, half the embedding's); the rule runs on the de-duplicated spectrum
+// and the complex count is returned.
+__device__ __forceinline__ int truncate_rule(const double* lam, int K0, int nspec, double tr, double inv2, double cutoff, bool pair) {
+    const int st = pair ? 2 : 1;
+    const int K = K0 / st, ns = nspec / st;
+    const double scale0 = tr * inv2;
+    const double scale = scale0 == 0.0 ? 1.0 : scale0;
+    double kept = 0.0;
+    for (int i = 0; i < K; ++i) kept += lam[st * i] * inv2;
+    int nk = K;
+    double truncerr = scale0 - kept;
+    if (truncerr < 0.0 || ns <= K) truncerr = 0.0;
+    if (ns > 1) {
+        while (nk > 1 && truncerr + lam[st * (nk - 1)] * inv2 <= cutoff * scale) {
+            truncerr += lam[st * (nk - 1)] * inv2;
+            --nk;
+        }
+    }
+    return nk;
+}
 
 // loss of the current bond: gradbuf[0], or - after k_grad_s on a single rank - the sum of its pieces (fixed order)
 __device__ __forceinline__ double bond_loss(const View& v) {
@@ -398,6 +446,62 @@ __device__ __forceinline__ double bond_loss(const View& v) {
     }
     return l;
 }
+
+// ---- element-typed sweep (mpst_typed.hip): fp32 / complex MPSs and encodings ------------------------------------------------
+// Buffers marked (E) hold elements of the context's type: float / double, or interleaved (re, im) pairs of them.
+struct TView {
+    int32_t T, d, C, chi_max, cap;
+    int32_t cx, f32;                // element type
+    int64_t N;
+    double invN;
+    const void* phi;                // (E) [T][N][d] product states (NOT conjugated: the kernels conjugate)
+    const int32_t* label;
+    const Span* tiles;
+    const Span* chunks;
+    const int32_t* cls_chunk_off;
+    const double* inv_count;
+    int32_t ntiles, nchunks;
+    int32_t* chi;
+    int32_t* label_site;
+    void* sites;                    // (E) T slots of site_stride elements, [c][l][s][r] compact
+    int64_t site_stride;
+    void* LE;                       // (E) [T][N][cap]
+    void* RE;
+    void* bt;                       // (E) [C][X][Y] compact
+    double* yhat;                   // [C][N][2] (re, im), fp64
+    double* tile_loss;              // [C][ntiles]
+    void* partial;                  // (E) gradient partials [C][nsplit][X][Y]
+    double* gradbuf;                // fp64 [2 + C*L*(1|2)]: loss, pad, grad - the all-reduce message
+    double* norm_part;              // pieces of ||grad||^2
+    int32_t n_norm_part;
+    double* gram;                   // fp64 Gram matrix (complex: the 2n x 2n real embedding)
+    double* E;                      // fp64 eigenvectors from the eigensolver, row stride ldE (complex: rows [0,n) Re, [n,2n) Im; vector k in column 2k)
+    int32_t ldE;
+    DevScalars* sc;
+    int32_t loss, optimiser, rescale_before, rescale_after, train_sep;
+    double eta, cutoff;
+    double* trace;
+    int32_t trace_it, yhat_scaled;
+};
+void launch_tbt_assemble(const TView& v, int lid, hipStream_t s);
+void launch_tbt_prescale(const TView& v, int lid, hipStream_t s);
+void launch_tenv(const TView& v, int site, int left_side, const void* prev, int prev_bond, int mode, int out_bond, void* out, hipStream_t s);
+void launch_tyhat(const TView& v, int lid, hipStream_t s);
+void launch_tgrad(const TView& v, int lid, hipStream_t s);
+void launch_tgrad_reduce(const TView& v, int lid, hipStream_t s);
+void launch_tgrad_norm(const TView& v, int lid, hipStream_t s);
+void launch_tupdate(const TView& v, int lid, int first_iter, hipStream_t s);
+void launch_tgram(const TView& v, int lid, int going_left, hipStream_t s);
+void launch_tsplit(const TView& v, int lid, int going_left, hipStream_t s);
+void launch_teval_final(const TView& v, const void* Lc, const void* Rc, double* yout, hipStream_t s);
+void launch_teval_reduce(const TView& v, const double* yin, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
+void launch_tnorm2(const TView& v, double* out_norm2, double* gscratch /* 6*cap*cap doubles */, hipStream_t s);
+void launch_tscale_sites(const TView& v, const double* norm2, hipStream_t s);
+void launch_tcast(const double* src, int src_cx, void* dst, int dst_cx, int dst_f32, int64_t n, hipStream_t s);
+int typed_grad_nsplit(const TView& v, int nchunks);
+int typed_norm_parts(const TView& v);
+size_t typed_max_lds(const TView& v);
+hipError_t typed_init_attrs(int device);
 
 // fused path for bond tensors up to MAX_DIM x MAX_DIM (mpst_fused.hip)
 void launch_bond_fused(const View& v, int lid, int assemble, hipStream_t s);

@@ -28,6 +28,15 @@ def _site_from_abi(buf, Dl, d, Dr, Cj):
     return np.ascontiguousarray(np.transpose(a, (1, 0, 2) + ((3,) if Cj else ())))
 
 
+DTYPES = {np.dtype(np.float64): L.F64, np.dtype(np.float32): L.F32, np.dtype(np.complex128): L.C128, np.dtype(np.complex64): L.C64}
+
+
+def _dtype_of(x):
+    """Element type of an array-like as the engine sees it (opts.dtype): float64 unless it already is one of the four."""
+    dt = np.asarray(x).dtype
+    return dt if dt in DTYPES else np.dtype(np.float64)
+
+
 class SweepEngine:
     def __init__(self, device: int = 0):
         self.lib = L.load()
@@ -37,6 +46,7 @@ class SweepEngine:
             raise L.MPSTError(rc, (self.lib.mpst_last_error(None) or b"").decode())
         self.T = self.d = self.C = 0
         self.N = [0, 0]
+        self.dtype = np.dtype(np.float64)      # element type of the data sets and the MPS (mpst_set_dataset's dtype)
 
     # -- plumbing ---------------------------------------------------------------------
     def _chk(self, rc):
@@ -70,8 +80,18 @@ class SweepEngine:
         self._iters = int(update_iters)
         self._chk(self.lib.mpst_set_options(self.ctx, C.byref(o)))
 
-    def set_dataset(self, which, phi, label_index, C_classes, global_counts=None):
-        phi = np.ascontiguousarray(phi, dtype=np.float64)
+    def set_dtype(self, dtype):
+        """opts.dtype for data sets that are encoded on the device (mpst_set_dtype); set_dataset takes it from its array."""
+        dt = np.dtype(dtype)
+        self._chk(self.lib.mpst_set_dtype(self.ctx, DTYPES[dt]))
+        self.dtype = dt
+        self._dtype_fixed = True
+
+    def set_dataset(self, which, phi, label_index, C_classes, global_counts=None, dtype=None):
+        """``dtype``: element type the engine trains in (float64 / float32 / complex128 / complex64 = opts.dtype); default
+        the array's own type."""
+        dt = np.dtype(dtype) if dtype is not None else _dtype_of(phi)
+        phi = np.ascontiguousarray(phi, dtype=dt)
         lab = np.ascontiguousarray(label_index, dtype=np.int32)
         N, T, d = phi.shape if phi.ndim == 3 and phi.size else (0, self.T, self.d)
         gc = None
@@ -79,9 +99,10 @@ class SweepEngine:
             gc = np.ascontiguousarray(global_counts, dtype=np.int64)
         self._chk(self.lib.mpst_set_dataset(
             self.ctx, which, phi.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.POINTER(C.c_int32)), N, T, d,
-            int(C_classes), L.F64, gc.ctypes.data_as(C.POINTER(C.c_int64)) if gc is not None else None))
+            int(C_classes), DTYPES[dt], gc.ctypes.data_as(C.POINTER(C.c_int64)) if gc is not None else None))
         self.T, self.d, self.C = T, d, int(C_classes)
         self.N[which] = N
+        self.dtype = dt
 
     def encode_dataset(self, which, X_sorted, label_index, C_classes, basis="Legendre_No_Norm", d=None, sigmoid_transform=True,
                        minmax=True, data_bounds=(0.0, 1.0), enc_range=(-1.0, 1.0), norms=None, rescale_out_of_bounds=True,
@@ -95,8 +116,8 @@ class SweepEngine:
             basis = model_encoding(basis).name           # canonical name; :Legendre is :Legendre_No_Norm (options.jl:245-246)
         except Exception:
             pass
-        if basis not in ("Legendre_Norm", "Legendre_No_Norm"):
-            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the real Legendre bases only, not {basis!r}")
+        if basis not in L.BASIS:
+            raise L.MPSTError(L.MPST_ERR_UNSUPPORTED, f"device-side encoding implements the closed-form bases {sorted(L.BASIS)}, not {basis!r}")
         X = np.ascontiguousarray(X_sorted, dtype=np.float64)
         lab = np.ascontiguousarray(label_index, dtype=np.int32)
         N, T = X.shape
@@ -128,6 +149,7 @@ class SweepEngine:
             fix.ctypes.data_as(dp) if fix is not None else None, C.byref(sec)))
         self.T, self.d, self.C = T, d, int(C_classes)
         self.N[which] = N
+        self.dtype = self._ctx_dtype(basis)
         if norms is None:
             out = Norms(sigmoid=(eo.median, eo.iqr) if sigmoid_transform else None, minmax=(eo.lo, eo.hi) if minmax else None)
             return out, sec.value
@@ -173,8 +195,15 @@ class SweepEngine:
                                               out.ctypes.data_as(C.c_void_p), None, C.byref(sec)))
         return out, sec.value
 
+    def _ctx_dtype(self, basis):
+        """element type after a device-side encoding: what set_dtype fixed, else the basis' own (float64 / complex128)"""
+        cx = basis in ("Fourier", "Stoudenmire", "Sahand")
+        if getattr(self, "_dtype_fixed", False):
+            return self.dtype
+        return np.dtype(np.complex128 if cx else np.float64)
+
     def get_encoded(self, which=0):
-        phi = np.zeros((self.N[which], self.T, self.d))
+        phi = np.zeros((self.N[which], self.T, self.d), dtype=self.dtype)
         self._chk(self.lib.mpst_get_encoded(self.ctx, which, phi.ctypes.data_as(C.POINTER(C.c_double))))
         return phi
 
@@ -185,7 +214,7 @@ class SweepEngine:
             assert len(label_site) == 1, "exactly one site must carry the label index"
             label_site = label_site[0]
         chi = np.array([W[0].shape[0]] + [t.shape[2] for t in W], dtype=np.int32)
-        bufs = [_site_to_abi(t) for t in W]
+        bufs = [_site_to_abi(t, self.dtype) for t in W]       # in the context's element type
         ptrs = (C.c_void_p * T)(*[b.ctypes.data for b in bufs])
         self._chk(self.lib.mpst_set_mps(self.ctx, ptrs, chi.ctypes.data_as(C.POINTER(C.c_int32)), T, int(label_site)))
 
@@ -200,7 +229,7 @@ class SweepEngine:
         bufs = []
         for j in range(self.T):
             n = self.d * chi[j] * chi[j + 1] * (self.C if j == ls else 1)
-            bufs.append(np.zeros(int(n), dtype=np.float64))
+            bufs.append(np.zeros(int(n), dtype=self.dtype))
         ptrs = (C.c_void_p * self.T)(*[b.ctypes.data for b in bufs])
         self._chk(self.lib.mpst_get_mps(self.ctx, ptrs))
         return [_site_from_abi(bufs[j], int(chi[j]), self.d, int(chi[j + 1]), self.C if j == ls else 0)
@@ -238,7 +267,7 @@ class SweepEngine:
     def classify(self, which=1, return_overlaps=False):
         N = self.N[which]
         pred = np.zeros(N, dtype=np.int32)
-        yh = np.zeros((N, self.C), dtype=np.float64)
+        yh = np.zeros((N, self.C), dtype=np.complex128 if self.dtype.kind == "c" else np.float64)     # overlaps are fp64 (pairs)
         self._chk(self.lib.mpst_classify(self.ctx, which, pred.ctypes.data_as(C.POINTER(C.c_int32)),
                                          yh.ctypes.data_as(C.POINTER(C.c_double))))
         return (pred, yh) if return_overlaps else pred
@@ -251,7 +280,7 @@ class SweepEngine:
         m = np.ascontiguousarray(missing, dtype=np.uint8)
         N, T = m.shape
         gx = np.ascontiguousarray(grid_x, dtype=np.float64)
-        gp = np.ascontiguousarray(grid_phi, dtype=np.float64)
+        gp = np.ascontiguousarray(grid_phi, dtype=np.complex128 if self.dtype.kind == "c" else np.float64)   # grid states: fp64 (pairs)
         assert gp.shape == (len(gx), self.d) and N == self.N[which] and T == self.T
         uu = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
         if uu is not None:
@@ -262,7 +291,7 @@ class SweepEngine:
         dp = C.POINTER(C.c_double)
         o = L.ImputeOpts(int(method), int(order), int(bool(get_wmad)), int(max_trials), int(mean_basis), 0, float(rejection_threshold))
         self._chk(self.lib.mpst_impute(self.ctx, which, m.ctypes.data_as(C.POINTER(C.c_uint8)), gx.ctypes.data_as(dp),
-                                       gp.ctypes.data_as(dp), len(gx), C.byref(o),
+                                       C.cast(gp.ctypes.data, dp), len(gx), C.byref(o),
                                        uu.ctypes.data_as(dp) if uu is not None else None, x.ctypes.data_as(dp),
                                        err.ctypes.data_as(dp), C.byref(sec)))
         return x, err, sec.value
@@ -338,7 +367,8 @@ class SweepEngine:
         return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
                 "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11],
-                "eig_merged": bool(out[12]), "large_bond_sweep_redos": out[13], "large_bond_verdict_per_sweep": bool(out[14])}
+                "eig_merged": bool(out[12]), "large_bond_sweep_redos": out[13], "large_bond_verdict_per_sweep": bool(out[14]),
+                "typed_kernels": bool(out[15]), "dtype": (out[15] - 1) if out[15] else L.F64}
 
     def eig_phases(self):
         us = np.zeros(6)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in mt._lib.SYMBOLS, f"{n} has no ctypes binding"
     assert sorted(mt._lib.SYMBOLS) == names
-    assert lib.mpst_version() == 1
+    assert lib.mpst_version() == mt._lib.ABI_VERSION == 2        # MPST_ABI_VERSION of the header
 
 
 def test_struct_layouts_match_the_header():

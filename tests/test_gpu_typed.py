@@ -1,0 +1,202 @@
+"""Element-typed sweep (csrc/mpst_typed.hip) against the CPU restatement of the reference's complex / reduced-precision
+semantics (oracle/ref_complex.py: legacy ITensor engine, src/legacy_itensor/loss_functions.jl:433-640).
+
+Every bond update of a sweep is compared with the oracle from a COMMON state (teacher forcing: free-running trajectories
+diverge chaotically, oracle/sensitivity_study.py), in gauge-invariant quantities: loss, ||grad||, the kept singular values,
+the kept bond dimension and the updated two-site tensor W[lid] W[rid] (the SVD's phase freedom cancels in the product).
+
+Tolerances (relative, stated per element type; observed values are printed with -s):
+    quantity            float64 / complex128      float32 / complex64
+    loss                1e-11                     2e-5     (sum of N fp32-accurate overlaps, -log|y|^2 in fp64)
+    ||grad||            1e-10                     1e-4
+    singular values     1e-9 sigma_1              2e-5 sigma_1   (Gram matrix and eigensolver are fp64 in every type)
+    two-site tensor     1e-8 max|.|               1e-4 max|.|
+For the fp32 types the oracle runs in DOUBLE precision on the fp32-rounded inputs: what is measured is the arithmetic of the
+engine, not the rounding of the inputs.
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_complex as RC
+from oracle import ref_numpy as R
+from tests.helpers import bond_of
+
+pytestmark = pytest.mark.gpu
+
+TOL = {
+    "f64": dict(loss=1e-11, grad=1e-10, S=1e-9, bond=1e-8),
+    "f32": dict(loss=2e-5, grad=1e-4, S=2e-5, bond=1e-4),
+}
+DT = {"float64": np.float64, "float32": np.float32, "complex128": np.complex128, "complex64": np.complex64}
+
+
+def caches_around(W, phi, ls):
+    """LE[0..ls-1], RE[ls+1..T-1] for a label on site ls (construct_caches on both sides of it)."""
+    T = len(W)
+    N = phi.shape[0]
+    LE, RE = [None] * T, [None] * T
+    prev = np.ones((N, 1), dtype=W[0].dtype)
+    for j in range(ls):
+        prev = np.einsum("is,ask,ia->ik", np.conj(phi[:, j, :]), W[j], prev)
+        LE[j] = prev
+    prev = np.ones((N, 1), dtype=W[0].dtype)
+    for j in range(T - 1, ls, -1):
+        prev = np.einsum("is,ksb,ib->ik", np.conj(phi[:, j, :]), W[j], prev)
+        RE[j] = prev
+    return LE, RE
+
+
+def two_site(Wl, Wr):
+    bt, shape4 = R.flatten_bt(Wl, Wr)
+    return R.unflatten_bt(bt, shape4)
+
+
+def run_teacher_forced(eng, ds64, W64, dtype, opts, nbonds=None):
+    """ds64 / W64: the problem in double precision (already rounded to the element type's precision)."""
+    T = len(W64)
+    eng.set_options(chi_max=opts.chi_max, eta=opts.eta, cutoff=opts.cutoff, update_iters=opts.update_iters, loss=opts.loss_grad,
+                    bbopt=opts.bbopt, rescale=opts.rescale, train_classes_separately=opts.train_classes_separately)
+    C = len(ds64.class_distribution)
+    eng.set_dataset(0, ds64.phi.astype(dtype), ds64.label_index, C)
+    W = [t.copy() for t in W64]
+    worst = dict(loss=0.0, grad=0.0, S=0.0, bond=0.0)
+    flips = 0
+    nb = 2 * (T - 1) if nbonds is None else nbonds
+    for q in range(nb):
+        lid, going_left = bond_of(q, T)
+        ls = lid + 1 if going_left else lid
+        eng.set_mps([t.astype(dtype) for t in W], label_site=ls)
+        eng.build_caches()
+        LE, RE = caches_around(W, ds64.phi, ls)
+        tr = {}
+        RC.bond_step(W, LE, RE, lid, ds64, opts, going_left, tr)
+        got = eng.bond_step(lid, going_left)
+        worst["loss"] = max(worst["loss"], abs(got["loss"] - tr["loss"]) / max(1.0, abs(tr["loss"])))
+        worst["grad"] = max(worst["grad"], abs(got["grad_norm"] - tr["grad_norm"]) / tr["grad_norm"])
+        nk = min(got["chi"], tr["chi"])
+        worst["S"] = max(worst["S"], np.abs(got["S"][:nk] - tr["S"][:nk]).max() / tr["S"][0])
+        if got["chi"] != tr["chi"]:
+            flips += 1
+            continue
+        Wg = eng.get_mps()
+        a, b = two_site(Wg[lid], Wg[lid + 1]), two_site(W[lid], W[lid + 1])
+        worst["bond"] = max(worst["bond"], np.abs(a - b).max() / np.abs(b).max())
+    return worst, flips
+
+
+def problem(N, T, d, chi, C, seed, dtype, balanced=True):
+    ds, W = RC.make_problem(N, T, d, chi, C, seed=seed, dtype=dtype, balanced=balanced)
+    big = np.complex128 if np.issubdtype(np.dtype(dtype), np.complexfloating) else np.float64
+    return RC.cast_problem(ds, W, big)       # rounded to `dtype`, held in double precision
+
+
+CASES = [
+    # N, T, d, chi_init, chi_max, C, loss, bbopt, iters, train_sep, balanced
+    (96, 6, 2, 3, 6, 2, "KLD", "TSGO", 1, False, True),
+    (130, 5, 3, 4, 8, 3, "KLD", "TSGO", 2, False, False),
+    (64, 6, 4, 4, 12, 1, "KLD", "TSGO", 1, False, True),
+    (80, 5, 2, 2, 5, 2, "MSE", "GD", 1, False, False),
+    (100, 4, 3, 3, 7, 2, "KLD", "GD", 1, True, False),
+    (70, 2, 3, 1, 3, 2, "KLD", "TSGO", 1, False, True),          # two-site MPS
+]
+
+
+@pytest.mark.parametrize("dtype", ["complex128", "float64", "complex64", "float32"])
+@pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}T{c[1]}d{c[2]}chi{c[4]}C{c[5]}{c[6]}{c[7]}" for c in CASES])
+def test_bond_by_bond_against_the_complex_oracle(dtype, case, monkeypatch):
+    import mpstime_jl_amd as mt
+    N, T, d, chi0, chimax, C, loss, bbopt, iters, sep, bal = case
+    if dtype == "float64":
+        monkeypatch.setenv("MPST_TYPED", "1")            # the Float64 specialisation of the typed kernels
+    ds, W = problem(N, T, d, chi0, C, 11, DT[dtype], bal)
+    opts = RC.SweepOptions(chi_max=chimax, eta=0.05 if bbopt == "TSGO" else 0.01, update_iters=iters, loss_grad=loss, bbopt=bbopt,
+                           train_classes_separately=sep)
+    eng = mt.SweepEngine(0)
+    try:
+        worst, flips = run_teacher_forced(eng, ds, W, DT[dtype], opts)
+        info = eng.info()
+    finally:
+        eng.close()
+    assert info["typed_kernels"]
+    tol = TOL["f32" if dtype in ("float32", "complex64") else "f64"]
+    print(dtype, case, worst, flips)
+    assert flips <= 1
+    for k in tol:
+        assert worst[k] < tol[k], (k, worst)
+
+
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_free_running_sweeps_and_evaluation(dtype):
+    """Two free-running sweeps (hipGraph path of mpst_sweep) of a complex model, then evaluation, classification and
+    normalisation against the oracle on the ENGINE's MPS."""
+    import mpstime_jl_amd as mt
+    ds, W = problem(128, 8, 3, 3, 2, 5, DT[dtype])
+    opts = RC.SweepOptions(chi_max=9, eta=0.05)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=opts.chi_max, eta=opts.eta)
+        eng.set_dataset(0, ds.phi.astype(DT[dtype]), ds.label_index, 2)
+        eng.set_dataset(1, ds.phi[::3].astype(DT[dtype]), ds.label_index[::3], 2)
+        eng.set_mps([t.astype(DT[dtype]) for t in W])
+        eng.build_caches()
+        Wo = [t.copy() for t in W]
+        LE = RE = None
+        for _ in range(2):
+            eng.sweep()
+            LE, RE = RC.sweep(Wo, ds, opts, LE, RE)
+        Wg = [t.astype(np.complex128) for t in eng.get_mps()]
+        mse, kld, acc, conf = eng.eval(0)
+        mo, ko, ao, co = RC.mse_loss_acc(Wg, ds, conf=True)
+        tol = 1e-10 if dtype == "complex128" else 2e-5
+        assert abs(mse - mo) < tol * max(1, abs(mo)) and abs(kld - ko) < tol * max(1, abs(ko)) and acc == ao and (conf == co).all()
+        pred, yh = eng.classify(1, return_overlaps=True)
+        yo = RC.contract_mps(Wg, ds.phi[::3])
+        assert np.abs(yh - yo).max() < tol * np.abs(yo).max()
+        assert (pred == RC.classify(Wg, ds.phi[::3])).all()
+        # the free-running trajectory itself: same loss to a loose tolerance after two sweeps (chaotic beyond that)
+        mo2, ko2, ao2 = RC.mse_loss_acc(Wo, ds)
+        assert abs(kld - ko2) < (1e-6 if dtype == "complex128" else 5e-3) * max(1, abs(ko2)), (kld, ko2)
+        eng.normalize()
+        Wn = [t.astype(np.complex128) for t in eng.get_mps()]
+        assert abs(RC.mps_norm(Wn) - 1.0) < (1e-12 if dtype == "complex128" else 1e-5)
+    finally:
+        eng.close()
+
+
+def test_real_encoding_needs_no_complex_type_but_complex_encoding_does():
+    import mpstime_jl_amd as mt
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=4)
+        eng.set_dtype(np.float64)
+        X = np.random.default_rng(0).uniform(0, 1, (8, 5))
+        with pytest.raises(mt.MPSTError, match="complex valued encoding but the MPS is real"):
+            eng.encode_dataset(0, X, np.zeros(8, dtype=np.int32), 1, basis="Fourier", d=4, sigmoid_transform=False, minmax=False,
+                               enc_range=(-1, 1))
+    finally:
+        eng.close()
+
+
+def test_device_fourier_encoding_becomes_a_complex_training_set():
+    import mpstime_jl_amd as mt
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 1, (40, 6))
+    y = (np.arange(40) >= 20).astype(np.int32)
+    for dt in (np.complex128, np.complex64):
+        eng = mt.SweepEngine(0)
+        try:
+            eng.set_options(chi_max=6, eta=0.05)
+            if dt == np.complex64:
+                eng.set_dtype(dt)
+            eng.encode_dataset(0, X, y, 2, basis="Fourier", d=4, sigmoid_transform=False, minmax=False, enc_range=(-1, 1))
+            phi = eng.get_encoded(0)
+            ref = R.fourier_encode(2 * X - 1, 4)
+            assert phi.dtype == dt and np.abs(phi - ref).max() < (1e-14 if dt == np.complex128 else 1e-6)
+            W = R.random_mps(6, 4, 3, 2, np.random.default_rng(4), dtype=np.complex128)
+            eng.set_mps(W)
+            eng.build_caches()
+            eng.sweep()
+            mse, kld, acc, _ = eng.eval(0)
+            assert np.isfinite(kld)
+        finally:
+            eng.close()
