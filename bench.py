@@ -213,6 +213,161 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
     return line
 
 
+NP_DT = {"f64": "float64", "f32": "float32", "c128": "complex128", "c64": "complex64"}
+
+
+def typed_inputs(N, T, d, C, cx, seed=1):
+    """Synthetic series of the headline generator, preprocessed as fitMPS does and encoded with the Fourier basis (complex element
+    types, BASELINE configs[4]) or Legendre (real).  C = 1: one class, else two."""
+    import mpstime_jl_amd as mt
+    rng = np.random.default_rng(seed)
+    half = N // 2 if C > 1 else N
+    X1, _ = mt.trendy_sine(T, half, period=(12.0, 15.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+    if C > 1:
+        X2, _ = mt.trendy_sine(T, N - half, period=(16.0, 19.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+        X = np.concatenate([X1, X2])
+        y = np.concatenate([np.ones(half, dtype=np.int64), 2 * np.ones(N - half, dtype=np.int64)])
+        keys = {1: 0, 2: 1}
+    else:
+        X, y, keys = X1, np.zeros(N, dtype=np.int64), {0: 0}
+    opts = mt.MPSOptions(d=d, encoding="Fourier" if cx else "Legendre", verbosity=-1)
+    enc = mt.model_encoding(opts.encoding)
+    Xs, _ = mt.transform_train_data(X, opts, enc.range)
+    return mt.encode_dataset(X, Xs, y, enc, d, keys)
+
+
+def typed_kernel_model(N, d, chi, C, cx, esz):
+    """Algorithmic flops / bytes per launch of the element-typed chain (csrc/mpst_typed.hip) at steady state; SURVEY 8(d)'s
+    formulas with the GEMM terms x 4 for complex elements.  (bound, amount, peak)."""
+    z = 4.0 if cx else 1.0
+    X = Y = d * chi
+    m, n = chi * C * d, d * chi
+    ne = (2 if cx else 1) * n                     # order of the real symmetric problem the fp64 eigensolver gets
+    f32peak = PEAK_FP32_MFMA_TFLOPS if esz in (4, 8) and esz // (2 if cx else 1) == 4 else PEAK_FP64_MFMA_TFLOPS
+    return {
+        "yhat": ("mfma", z * 2.0 * N * X * Y, f32peak),
+        "grad": ("mfma", z * 2.0 * N * X * Y, f32peak),
+        "env": ("mfma", z * 2.0 * N * X * chi, f32peak),
+        "gram": ("mfma", z * 2.0 * m * n * n, PEAK_FP64_MFMA_TFLOPS),
+        "split": ("mfma", z * 2.0 * m * n * chi, PEAK_FP64_MFMA_TFLOPS),
+        "bt_assemble": ("mfma", z * 2.0 * C * X * chi * Y, PEAK_FP64_MFMA_TFLOPS),
+        "eig_tri": ("mfma", 4.0 / 3.0 * ne ** 3 + 4.0 * ne * ne * (2 if cx else 1) * chi, PEAK_FP64_MFMA_TFLOPS),
+        "eig_fin": ("mfma", 8.0 * ne * chi * chi, PEAK_FP64_MFMA_TFLOPS),
+        "grad_reduce+update": ("hbm", 0.5 * esz * 6.0 * C * X * Y, PEAK_HBM_GBS),
+    }
+
+
+def typed_workload(args, mt, torch, rank, dev_index):
+    """Side line (never the headline `value` of BASELINE's metric): the training sweep in another element type - fp32, complex64,
+    complex128 - through csrc/mpst_typed.hip; defaults to BASELINE configs[4]'s training shape.  Besides throughput and the
+    per-kernel roofline it carries a tolerance study: from the state the timed sweeps end in, the same bond updates are run by
+    the engine in this type and in its double-precision counterpart, and the gauge-invariant per-bond quantities compared."""
+    dt = np.dtype(NP_DT[args.dtype])
+    cx = dt.kind == "c"
+    f32 = dt.itemsize // (2 if cx else 1) == 4
+    defaults = ap_defaults()
+    if all(getattr(args, k) == defaults[k] for k in defaults):
+        args.N, args.T, args.chi, args.d = 8192, 200, 64, 8            # BASELINE configs[4]'s training shape
+    N, T, d, chi = args.N, args.T, args.d, args.chi
+    C = args.classes if args.classes else (1 if cx else 2)
+    full = typed_inputs(N, T, d, C, cx)
+    W0 = mt.generate_startingMPS(4, T, d, C, 1234, dt)
+    eng = mt.SweepEngine(dev_index)
+    eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True))
+    eng.set_dataset(0, full.phi, full.label_index, C, dtype=dt)
+    eng.set_mps(W0)
+    eng.build_caches()
+    for _ in range(args.warmup):
+        eng.sweep()
+    info = eng.info()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_s = 0.0
+    for _ in range(args.steps):
+        dev_s += eng.sweep()["seconds"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mse, kld, acc, _ = eng.eval(0)
+    chi_now, _ = eng.get_chi()
+    Wend = eng.get_mps()
+    eng.set_profile(0x7FF)
+    eng.sweep()
+    breakdown = eng.get_profile()
+    eng.set_profile(0)
+    model = typed_kernel_model(N, d, chi, C, cx, dt.itemsize)
+    kernels = {}
+    for k, (us, cnt) in breakdown.items():
+        if not cnt:
+            continue
+        e = {"us_per_sweep": us, "launches_per_sweep": cnt, "avg_us": us / cnt}
+        if k in model:
+            bound, amt, peak = model[k]
+            ach = amt / (us / cnt * 1e-6) / (1e12 if bound == "mfma" else 1e9)
+            e.update({"bound": bound, "achieved": ach, "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": ach / peak})
+        kernels[k] = e
+    dominant = max(kernels, key=lambda k: kernels[k]["us_per_sweep"])
+    dk = kernels[dominant]
+    # ---- tolerance study: the same bond updates in this type and in double precision, from a common state -----------------
+    study = None
+    if f32:
+        wide = np.dtype(np.complex128 if cx else np.float64)
+        ref = mt.SweepEngine(dev_index)
+        try:
+            ref.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True))
+            ref.set_dataset(0, full.phi.astype(dt).astype(wide), full.label_index, C, dtype=wide)     # the fp32-rounded inputs, held in fp64
+            worst = {"loss": 0.0, "grad_norm": 0.0, "singular_values_rel_sigma1": 0.0, "chi_differs": 0}
+            Wc = [t.astype(wide) for t in Wend]
+            nb = min(args.study_bonds, T - 1)
+            for e in (eng, ref):
+                e.set_mps(Wc)
+                e.build_caches()
+            for q in range(nb):                       # the first nb bonds of a backward half-sweep, free running in both
+                lid = T - 2 - q
+                a, b = eng.bond_step(lid, True), ref.bond_step(lid, True)
+                worst["loss"] = max(worst["loss"], abs(a["loss"] - b["loss"]) / max(1.0, abs(b["loss"])))
+                worst["grad_norm"] = max(worst["grad_norm"], abs(a["grad_norm"] - b["grad_norm"]) / b["grad_norm"])
+                nk = min(a["chi"], b["chi"])
+                worst["singular_values_rel_sigma1"] = max(worst["singular_values_rel_sigma1"], float(np.abs(a["S"][:nk] - b["S"][:nk]).max() / b["S"][0]))
+                worst["chi_differs"] += int(a["chi"] != b["chi"])
+                if a["chi"] != b["chi"]:
+                    break
+                e_mps = eng.get_mps()
+                ref.set_mps([t.astype(wide) for t in e_mps])      # teacher forcing: both continue from the fp32 engine's state
+                ref.build_caches()
+            study = {"bonds": nb, "reference": f"the same engine in {wide.name} on the fp32-rounded inputs and state", "max_rel_deviation": worst,
+                     "note": "Gram matrix, eigensolver, losses, gradient reduction and the optimiser step are fp64 in every element type"}
+        finally:
+            ref.close()
+    eng.close()
+    if rank != 0:
+        return None
+    sweeps_per_s = args.steps / elapsed
+    survey = {"flops_per_sweep_real": 2 * (T - 1) * (4.0 * N * (d * chi) ** 2 + 2.0 * N * d * chi * chi) + 4.0 * N * T * d * chi * chi}
+    survey["flops_per_sweep_this_type"] = survey["flops_per_sweep_real"] * (4.0 if cx else 1.0)
+    peak = PEAK_FP32_MFMA_TFLOPS if f32 else PEAK_FP64_MFMA_TFLOPS
+    survey["mfma_roofline_sweeps_per_s"] = peak * 1e12 / survey["flops_per_sweep_this_type"]
+    survey["frac_of_mfma_roofline"] = sweeps_per_s / survey["mfma_roofline_sweeps_per_s"]
+    return {
+        "metric": "full sweeps/sec (side line: element type %s)" % dt.name, "value": sweeps_per_s, "unit": "sweeps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"training sweep N={N} T={T} chi={chi} d={d} C={C} {'Fourier' if cx else 'Legendre'} encoding, element type {dt.name} "
+                               "(BASELINE configs[4] training shape)" , "N": N, "T": T, "chi_max": chi, "d": d, "classes": C,
+                   "loss": "KLD", "optimiser": "TSGO", "eta": 0.01, "cutoff": 1e-10, "update_iters": 1, "rebuild_caches": False,
+                   "semantics": "legacy ITensor engine of the reference (src/legacy_itensor/loss_functions.jl:433-640)" if cx else "array engine"},
+        "roofline": {"kernel": dominant, "bound": dk.get("bound", "mfma"), "achieved": dk.get("achieved"), "peak": PEAK_FP64_MFMA_TFLOPS if dominant.startswith("eig") else peak,
+                     "unit": dk.get("unit", "TFLOP/s"), "frac": dk.get("frac"), "traffic": None,
+                     "avg_us": dk["avg_us"], "note": "dominant kernel class of one profiled sweep (HIP events on the engine's stream); the fp64 eigensolver of the "
+                     "Gram matrix (complex: its 2n x 2n real embedding, one eigenvector per eigenvalue pair) is a dependent chain of Householder steps, not a throughput kernel"},
+        "kernels": kernels,
+        "sweep_vs_survey_8d": survey,
+        "tolerance_study": study,
+        "device_seconds_per_sweep": dev_s / args.steps, "bonds_per_sweep": 2 * (T - 1), "us_per_bond": 1e6 * dev_s / args.steps / (2 * (T - 1)),
+        "chain": info, "max_chi": int(max(chi_now)), "train_kld_after": kld, "train_acc_after": acc,
+        "csrc_sha256": csrc_sha256(),
+    }
+
+
 def ap_defaults():
     return {"N": 4096, "T": 100, "chi": 32, "d": 4}
 
@@ -243,6 +398,12 @@ def main():
     ap.add_argument("--workload", choices=["sweep", "impute"], default="sweep",
                     help="sweep: the headline training sweep (BASELINE configs[2]).  impute: BASELINE configs[4], the imputation engine "
                          "on a complex (Fourier) model with fp32 chain arithmetic; defaults N=8192 per GPU, T=200, chi=64, d=8")
+    ap.add_argument("--dtype", choices=["f64", "f32", "c128", "c64"], default="f64",
+                    help="element type of the sweep.  f64: the headline (BASELINE's metric).  Anything else: a SIDE line through the element-typed "
+                         "kernels (csrc/mpst_typed.hip), by default at BASELINE configs[4]'s training shape N=8192 T=200 chi=64 d=8, Fourier encoding "
+                         "for the complex types, with a tolerance study against the double-precision type")
+    ap.add_argument("--classes", type=int, default=0, help="--dtype side line: number of classes (default 1 for complex types, 2 for f32)")
+    ap.add_argument("--study-bonds", type=int, default=6, help="--dtype side line: bonds of the tolerance study")
     ap.add_argument("--allreduce", choices=["auto", "rccl", "oneshot"], default="auto",
                     help="collective of the sharded sweep: RCCL, the one-shot direct-write kernel, or whichever one trial sweep shows faster")
     args = ap.parse_args()
@@ -304,6 +465,13 @@ def main():
             note(f"torch.cuda.nccl.version() = {torch.cuda.nccl.version()}")
         except Exception as e:
             note(f"torch.cuda.nccl.version() unavailable: {e}")
+    if args.dtype != "f64":
+        if world > 1:
+            note("--dtype side line runs on one GPU")
+            sys.exit(2)
+        line = typed_workload(args, mt, torch, rank, dev_index)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        return
     if args.workload == "impute":
         line = impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce)
         if rank == 0:

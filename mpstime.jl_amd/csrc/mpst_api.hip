@@ -106,6 +106,8 @@ struct Ctx {
     int zw = 1;               // 2: complex
     size_t esz = 8;           // bytes per element
     double* tnorm_scratch = nullptr;   // typed normalize: three complex cap x cap matrices
+    int32_t *xLE = nullptr, *xRE = nullptr, *yexp = nullptr;      // typed: binary exponents of the environment rows / overlaps
+    int32_t *xchainL[2] = {nullptr, nullptr}, *xchainR[2] = {nullptr, nullptr};
     DataSet ds[2];
     // MPS
     bool have_mps = false;
@@ -274,7 +276,8 @@ TView make_tview(Ctx* c, int which) {
     t.phi = s.phi; t.label = s.label; t.tiles = s.tiles; t.chunks = s.chunks; t.cls_chunk_off = s.cls_chunk_off; t.inv_count = s.inv_count;
     t.ntiles = s.ntiles; t.nchunks = s.nchunks;
     t.chi = c->chi; t.label_site = c->label_site; t.sites = c->sites; t.site_stride = c->site_stride;
-    t.LE = c->LE; t.RE = c->RE; t.bt = c->bt; t.yhat = c->yhat; t.tile_loss = c->tile_loss; t.partial = c->partial;
+    t.LE = c->LE; t.RE = c->RE; t.xLE = c->xLE; t.xRE = c->xRE; t.yexp = c->yexp;
+    t.bt = c->bt; t.yhat = c->yhat; t.tile_loss = c->tile_loss; t.partial = c->partial;
     t.gradbuf = c->gradbuf; t.norm_part = c->norm_part; t.n_norm_part = c->n_norm_part;
     t.gram = c->gram; t.E = c->E; t.ldE = c->zw * c->cap; t.sc = c->sc;
     t.loss = c->opt.loss; t.optimiser = c->opt.optimiser; t.rescale_before = c->opt.rescale_before; t.rescale_after = c->opt.rescale_after;
@@ -308,6 +311,7 @@ int ensure_eval(Ctx* c) {
     for (int k = 0; k < 2; ++k) {
         if ((rc = dalloc_e(c, &c->chainL[k], en * c->cap))) return rc;
         if ((rc = dalloc_e(c, &c->chainR[k], en * c->cap))) return rc;
+        if (c->typed && ((rc = dalloc(c, &c->xchainL[k], en)) || (rc = dalloc(c, &c->xchainR[k], en)))) return rc;
     }
     if ((rc = dalloc(c, &c->yeval, en * c->C * (c->typed ? 2 : 1)))) return rc;      // typed: (re, im) pairs
     if ((rc = dalloc(c, &c->out3, 4))) return rc;
@@ -333,6 +337,7 @@ int ensure_workspace_typed(Ctx* c) {
     c->b2 = false;
     if ((rc = dalloc_e(c, &c->LE, c->cache_elems))) return rc;
     if ((rc = dalloc_e(c, &c->RE, c->cache_elems))) return rc;
+    if ((rc = dalloc(c, &c->xLE, (int64_t)c->T * tr.N)) || (rc = dalloc(c, &c->xRE, (int64_t)c->T * tr.N)) || (rc = dalloc(c, &c->yexp, tr.N))) return rc;
     if ((rc = dalloc_e(c, &c->bt, c->C * Lmax))) return rc;
     if ((rc = dalloc(c, &c->yhat, (int64_t)2 * c->C * tr.N))) return rc;
     if ((rc = dalloc(c, &c->tile_loss, std::max<int64_t>((int64_t)c->C * tr.ntiles, 1)))) return rc;
@@ -625,9 +630,11 @@ int enqueue_bond_typed(Ctx* c, int lid, int going_left, int trace_row) {
         ProfScope p(c, K_ENV);                                                   // update_caches!: the new site tensor is the map
         const int64_t cs = (int64_t)t.N * t.cap;
         if (going_left)
-            launch_tenv(t, rid, 0, rid < c->T - 1 ? eoff(c, c->RE, (int64_t)(rid + 1) * cs) : nullptr, rid + 1, ENV_M_SITE_T, rid, eoff(c, c->RE, (int64_t)rid * cs), s);
+            launch_tenv(t, rid, 0, rid < c->T - 1 ? eoff(c, c->RE, (int64_t)(rid + 1) * cs) : nullptr, rid < c->T - 1 ? c->xRE + (int64_t)(rid + 1) * t.N : nullptr, rid + 1,
+                        ENV_M_SITE_T, rid, eoff(c, c->RE, (int64_t)rid * cs), c->xRE + (int64_t)rid * t.N, s);
         else
-            launch_tenv(t, lid, 1, lid > 0 ? eoff(c, c->LE, (int64_t)(lid - 1) * cs) : nullptr, lid, ENV_M_SITE, lid + 1, eoff(c, c->LE, (int64_t)lid * cs), s);
+            launch_tenv(t, lid, 1, lid > 0 ? eoff(c, c->LE, (int64_t)(lid - 1) * cs) : nullptr, lid > 0 ? c->xLE + (int64_t)(lid - 1) * t.N : nullptr, lid, ENV_M_SITE, lid + 1,
+                        eoff(c, c->LE, (int64_t)lid * cs), c->xLE + (int64_t)lid * t.N, s);
     }
     return 0;
 }
@@ -637,9 +644,11 @@ void enqueue_caches_typed(Ctx* c, int left_upto, int right_from) {
     const int64_t cs = (int64_t)t.N * t.cap;
     ProfScope p(c, K_ENV);
     for (int j = 0; j < left_upto && j <= c->T - 2; ++j)
-        launch_tenv(t, j, 1, j > 0 ? eoff(c, c->LE, (int64_t)(j - 1) * cs) : nullptr, j, ENV_M_SITE, j + 1, eoff(c, c->LE, (int64_t)j * cs), c->stream);
+        launch_tenv(t, j, 1, j > 0 ? eoff(c, c->LE, (int64_t)(j - 1) * cs) : nullptr, j > 0 ? c->xLE + (int64_t)(j - 1) * t.N : nullptr, j, ENV_M_SITE, j + 1,
+                    eoff(c, c->LE, (int64_t)j * cs), c->xLE + (int64_t)j * t.N, c->stream);
     for (int j = c->T - 1; j > right_from && j >= 1; --j)
-        launch_tenv(t, j, 0, j < c->T - 1 ? eoff(c, c->RE, (int64_t)(j + 1) * cs) : nullptr, j + 1, ENV_M_SITE_T, j, eoff(c, c->RE, (int64_t)j * cs), c->stream);
+        launch_tenv(t, j, 0, j < c->T - 1 ? eoff(c, c->RE, (int64_t)(j + 1) * cs) : nullptr, j < c->T - 1 ? c->xRE + (int64_t)(j + 1) * t.N : nullptr, j + 1, ENV_M_SITE_T, j,
+                    eoff(c, c->RE, (int64_t)j * cs), c->xRE + (int64_t)j * t.N, c->stream);
 }
 
 // ---- the per-bond launch chain (RealRealHighDimension.jl:733-762 / :777-801) ---------------
@@ -802,17 +811,18 @@ int enqueue_eval(Ctx* c, int which) {
     if (c->typed) {
         TView t = make_tview(c, which);
         const void* Lt = nullptr; const void* Rt = nullptr;
+        const int32_t *Lx = nullptr, *Rx = nullptr;
         int q = 0;
         for (int j = 0; j < p; ++j) {
-            launch_tenv(t, j, 1, j > 0 ? c->chainL[q ^ 1] : nullptr, j, ENV_M_SITE, j + 1, c->chainL[q], c->stream);
-            Lt = c->chainL[q]; q ^= 1;
+            launch_tenv(t, j, 1, j > 0 ? c->chainL[q ^ 1] : nullptr, j > 0 ? c->xchainL[q ^ 1] : nullptr, j, ENV_M_SITE, j + 1, c->chainL[q], c->xchainL[q], c->stream);
+            Lt = c->chainL[q]; Lx = c->xchainL[q]; q ^= 1;
         }
         q = 0;
         for (int j = c->T - 1; j > p; --j) {
-            launch_tenv(t, j, 0, j < c->T - 1 ? c->chainR[q ^ 1] : nullptr, j + 1, ENV_M_SITE_T, j, c->chainR[q], c->stream);
-            Rt = c->chainR[q]; q ^= 1;
+            launch_tenv(t, j, 0, j < c->T - 1 ? c->chainR[q ^ 1] : nullptr, j < c->T - 1 ? c->xchainR[q ^ 1] : nullptr, j + 1, ENV_M_SITE_T, j, c->chainR[q], c->xchainR[q], c->stream);
+            Rt = c->chainR[q]; Rx = c->xchainR[q]; q ^= 1;
         }
-        launch_teval_final(t, Lt, Rt, c->yeval, c->stream);
+        launch_teval_final(t, Lt, Lx, Rt, Rx, c->yeval, c->stream);
         return 0;
     }
     const double* Lc = nullptr; const double* Rc = nullptr;
@@ -872,7 +882,9 @@ void mpst_destroy(void* ctx) {
     if (c->big) big_eig_destroy(c->big);
     if (c->blk) blocked_eig_destroy(c->blk);
     dfree(&c->snap_sites); dfree(&c->snap_chi); dfree(&c->snap_sc);
-    dfree(&c->norm_scratch); dfree(&c->tnorm_scratch); dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
+    dfree(&c->norm_scratch); dfree(&c->tnorm_scratch); dfree(&c->xLE); dfree(&c->xRE); dfree(&c->yexp);
+    for (int k = 0; k < 2; ++k) { dfree(&c->xchainL[k]); dfree(&c->xchainR[k]); }
+    dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }

@@ -465,10 +465,13 @@ struct TView {
     int32_t* label_site;
     void* sites;                    // (E) T slots of site_stride elements, [c][l][s][r] compact
     int64_t site_stride;
-    void* LE;                       // (E) [T][N][cap]
+    void* LE;                       // (E) [T][N][cap], every row scaled by 2^-x (largest component in [0.5, 1)) ...
     void* RE;
+    int32_t* xLE;                   // ... [T][N] the exponents x (k_tenv)
+    int32_t* xRE;
     void* bt;                       // (E) [C][X][Y] compact
-    double* yhat;                   // [C][N][2] (re, im), fp64
+    double* yhat;                   // [C][N][2] (re, im), fp64: the overlap computed from the SCALED environments
+    int32_t* yexp;                  // [N] its exponent: yhat_true = yhat 2^yexp
     double* tile_loss;              // [C][ntiles]
     void* partial;                  // (E) gradient partials [C][nsplit][X][Y]
     double* gradbuf;                // fp64 [2 + C*L*(1|2)]: loss, pad, grad - the all-reduce message
@@ -485,7 +488,8 @@ struct TView {
 };
 void launch_tbt_assemble(const TView& v, int lid, hipStream_t s);
 void launch_tbt_prescale(const TView& v, int lid, hipStream_t s);
-void launch_tenv(const TView& v, int site, int left_side, const void* prev, int prev_bond, int mode, int out_bond, void* out, hipStream_t s);
+void launch_tenv(const TView& v, int site, int left_side, const void* prev, const int32_t* xprev, int prev_bond, int mode, int out_bond, void* out,
+                 int32_t* xout, hipStream_t s);
 void launch_tyhat(const TView& v, int lid, hipStream_t s);
 void launch_tgrad(const TView& v, int lid, hipStream_t s);
 void launch_tgrad_reduce(const TView& v, int lid, hipStream_t s);
@@ -493,7 +497,7 @@ void launch_tgrad_norm(const TView& v, int lid, hipStream_t s);
 void launch_tupdate(const TView& v, int lid, int first_iter, hipStream_t s);
 void launch_tgram(const TView& v, int lid, int going_left, hipStream_t s);
 void launch_tsplit(const TView& v, int lid, int going_left, hipStream_t s);
-void launch_teval_final(const TView& v, const void* Lc, const void* Rc, double* yout, hipStream_t s);
+void launch_teval_final(const TView& v, const void* Lc, const int32_t* Lx, const void* Rc, const int32_t* Rx, double* yout, hipStream_t s);
 void launch_teval_reduce(const TView& v, const double* yin, double* out3, int64_t* conf, int32_t* pred, hipStream_t s);
 void launch_tnorm2(const TView& v, double* out_norm2, double* gscratch /* 6*cap*cap doubles */, hipStream_t s);
 void launch_tscale_sites(const TView& v, const double* norm2, hipStream_t s);

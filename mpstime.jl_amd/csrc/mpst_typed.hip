@@ -160,10 +160,14 @@ __global__ __launch_bounds__(1024) void k_tbt_prescale(TView v, int lid) {
 // One wave per tile of 16 series (wave-local LDS, no workgroup barrier); the Khatri-Rao operand is formed from its factors on
 // the way into the MFMA; NT column tiles share every A fragment.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int TENV_NT = 4;
+constexpr int TENV_NT = 4, TENV_G = 2;        // column tiles per group, groups held in registers (cap <= 128: 8 tiles)
+// Every environment row leaves this kernel scaled by a power of two so that its largest component lies in [0.5, 1), the
+// exponent accumulating in a per-series int32 (xout = xprev + e): products of T site contractions shrink like d^(-T/2)
+// (1e-95 after 200 Fourier sites) and leave the range of fp32 after ~80 sites, of fp64 after ~600.  Powers of two are exact,
+// so nothing else changes; the KLD gradient phi~/yhat does not see the scale at all, the loss gets -2 (xL + xR) ln 2 back.
 template <typename R, bool CX>
-__global__ __launch_bounds__(256) void k_tenv(TView v, int site, int left_side, const void* __restrict__ prev, int prev_bond, int mode,
-                                               int out_bond, void* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_tenv(TView v, int site, int left_side, const void* __restrict__ prev, const int32_t* __restrict__ xprev,
+                                               int prev_bond, int mode, int out_bond, void* __restrict__ out, int32_t* __restrict__ xout) {
     using E = typename Et<R, CX>::type;
     using acc_t = typename Mx<R>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -207,10 +211,15 @@ __global__ __launch_bounds__(256) void k_tenv(TView v, int site, int left_side, 
     const int dhi = 4 / LO, dlo = 4 - dhi * LO;
     const int ZP = (Z + 3) & ~3;
     const int ntout = (Dout + 15) >> 4;
-    for (int g0 = 0; g0 < ntout; g0 += TENV_NT) {
-        acc_t aR[TENV_NT], aI[TENV_NT];
+    acc_t aR[TENV_G][TENV_NT], aI[TENV_G][TENV_NT];
 #pragma unroll
-        for (int t = 0; t < TENV_NT; ++t) aR[t] = aI[t] = acc_t{0, 0, 0, 0};
+    for (int g = 0; g < TENV_G; ++g)
+#pragma unroll
+        for (int t = 0; t < TENV_NT; ++t) aR[g][t] = aI[g][t] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < TENV_G; ++g) {
+        const int g0 = g * TENV_NT;
+        if (g0 >= ntout) break;
         int hi = kq / LO, lo = kq - hi * LO;
         constexpr int UB = 4;
         for (int kb = 0; kb < ZP; kb += 4 * UB) {
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(256) void k_tenv(TView v, int site, int left_side, 
                     Cp<R> a = {R(0), R(0)};
                     if (z < Z) a = cmulc(eld<R, CX>(Pv, i16 * PS + ia), eld<R, CX>(Ph, i16 * DS + is));
 #pragma unroll
-                    for (int t = 0; t < TENV_NT; ++t) mstep<R, CX>(a, bv[t][u], aR[t], aI[t]);
+                    for (int t = 0; t < TENV_NT; ++t) mstep<R, CX>(a, bv[t][u], aR[g][t], aI[g][t]);
                 }
                 lo += dlo;
                 hi += dhi;
@@ -242,14 +251,39 @@ __global__ __launch_bounds__(256) void k_tenv(TView v, int site, int left_side, 
                 }
             }
         }
+    }
+    // largest component of every row (16 lanes x all tiles), its binary exponent, the rescale, the store
+    int er[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double m = 0.0;
+#pragma unroll
+        for (int g = 0; g < TENV_G; ++g)
+#pragma unroll
+            for (int t = 0; t < TENV_NT; ++t) m = fmax(m, fmax(fabs((double)aR[g][t][r]), fabs((double)aI[g][t][r])));
+        m = max16(m);
+        er[r] = (m > 0.0 && m < 1e300) ? __builtin_amdgcn_frexp_exp(m) : 0;
+    }
+#pragma unroll
+    for (int g = 0; g < TENV_G; ++g) {
+        if (g * TENV_NT >= ntout) break;
 #pragma unroll
         for (int t = 0; t < TENV_NT; ++t) {
-            const int col = (g0 + t) * 16 + i16;
+            const int col = (g * TENV_NT + t) * 16 + i16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = Mx<R>::row(kq, r);
-                if (i < tl.count && col < Dout) est<R, CX>(out, (int64_t)(tl.start + i) * v.cap + col, Cp<R>{aR[t][r], aI[t][r]});
+                if (i < tl.count && col < Dout)
+                    est<R, CX>(out, (int64_t)(tl.start + i) * v.cap + col,
+                               Cp<R>{(R)__builtin_amdgcn_ldexp((double)aR[g][t][r], -er[r]), (R)__builtin_amdgcn_ldexp((double)aI[g][t][r], -er[r])});
             }
+        }
+    }
+    if (i16 == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = Mx<R>::row(kq, r);
+            if (i < tl.count) xout[tl.start + i] = (xprev ? xprev[tl.start + i] : 0) + er[r];
         }
     }
 }
@@ -410,14 +444,20 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
                 yi *= v.sc->inv_norm;
             }
             if (i < tl.count) {
-                double* yo = v.yhat + ((int64_t)c * v.N + tl.start + i) * 2;
+                // the environments are scaled by 2^-xL, 2^-xR (k_tenv): yhat = (yr, yi) 2^xs.  What is stored is the SCALED
+                // overlap and its exponent - all the KLD gradient needs (phi~/yhat does not see the scale)
+                const int64_t smp = tl.start + i;
+                const int xs = (lid > 0 ? v.xLE[(int64_t)(lid - 1) * v.N + smp] : 0) + (rid < v.T - 1 ? v.xRE[(int64_t)(rid + 1) * v.N + smp] : 0);
+                double* yo = v.yhat + ((int64_t)c * v.N + smp) * 2;
                 yo[0] = yr;
                 yo[1] = yi;
+                if (c == (mse ? 0 : tl.cls)) v.yexp[smp] = xs;
                 if (mse) {
                     const double mm = (tl.cls == c) ? 1.0 : 0.0;
-                    term = 0.5 * ((yr - mm) * (yr - mm) + yi * yi);
+                    const double tr_ = ldexp(yr, xs), ti_ = ldexp(yi, xs);
+                    term = 0.5 * ((tr_ - mm) * (tr_ - mm) + ti_ * ti_);
                 } else {
-                    term = -log(yr * yr + yi * yi);
+                    term = -log(yr * yr + yi * yi) - 2.0 * 0.6931471805599453 * (double)xs;
                 }
             }
         }
@@ -501,7 +541,9 @@ __global__ __launch_bounds__(256) void k_tgrad(TView v, int lid, int nsplit) {
                             const double* yp = v.yhat + ((int64_t)c * v.N + smp) * 2;
                             const double yr = yp[0], yi = yp[1];
                             if (mse) {
-                                u = Cp<R>{(R)(yr - ((ch.cls == c) ? 1.0 : 0.0)), (R)yi};
+                                // u 2^xs with the true overlap yhat = (yr, yi) 2^xs: the operands below carry 2^-xs
+                                const int xs = v.yexp[smp];
+                                u = Cp<R>{(R)ldexp(ldexp(yr, xs) - ((ch.cls == c) ? 1.0 : 0.0), xs), (R)ldexp(yi, 2 * xs)};
                             } else {
                                 const double q = 1.0 / (yr * yr + yi * yi);       // conj(1 / yhat) = yhat / |yhat|^2
                                 u = Cp<R>{(R)(yr * q), (R)(yi * q)};
@@ -776,7 +818,8 @@ __global__ __launch_bounds__(256) void k_tsplit(TView v, int lid, int going_left
 // evaluation (src/summary.jl:4-136): yhat_i[c] = sum L_i[a] conj(ps_i[s]) R_i[b] W_p[c][a][s][b], fp64 accumulation
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename R, bool CX>
-__global__ __launch_bounds__(256) void k_teval_final(TView v, const void* __restrict__ Lc, const void* __restrict__ Rc, double* __restrict__ yout) {
+__global__ __launch_bounds__(256) void k_teval_final(TView v, const void* __restrict__ Lc, const int32_t* __restrict__ Lx, const void* __restrict__ Rc,
+                                                     const int32_t* __restrict__ Rx, double* __restrict__ yout) {
     const int p = *v.label_site;
     const int Dl = v.chi[p], Dr = v.chi[p + 1], d = v.d;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -801,8 +844,9 @@ __global__ __launch_bounds__(256) void k_teval_final(TView v, const void* __rest
                 ai += ls.re * ti + ls.im * tr;
             }
         }
-        yout[(i * v.C + c) * 2 + 0] = ar;
-        yout[(i * v.C + c) * 2 + 1] = ai;
+        const int xs = (p > 0 ? Lx[i] : 0) + (p < v.T - 1 ? Rx[i] : 0);       // the chains are scaled by powers of two (k_tenv)
+        yout[(i * v.C + c) * 2 + 0] = ldexp(ar, xs);
+        yout[(i * v.C + c) * 2 + 1] = ldexp(ai, xs);
     }
 }
 
@@ -978,8 +1022,9 @@ void launch_tbt_assemble(const TView& v, int lid, hipStream_t s) {
     TLAUNCH(v, k_tbt_assemble, dim3(cdiv(tiles, 4), v.C), dim3(256), 0, s, v, lid);
 }
 void launch_tbt_prescale(const TView& v, int lid, hipStream_t s) { TLAUNCH(v, k_tbt_prescale, dim3(1), dim3(1024), 0, s, v, lid); }
-void launch_tenv(const TView& v, int site, int left_side, const void* prev, int prev_bond, int mode, int out_bond, void* out, hipStream_t s) {
-    TLAUNCH(v, k_tenv, dim3(cdiv(v.ntiles, 4)), dim3(256), tenv_lds(v), s, v, site, left_side, prev, prev_bond, mode, out_bond, out);
+void launch_tenv(const TView& v, int site, int left_side, const void* prev, const int32_t* xprev, int prev_bond, int mode, int out_bond, void* out,
+                 int32_t* xout, hipStream_t s) {
+    TLAUNCH(v, k_tenv, dim3(cdiv(v.ntiles, 4)), dim3(256), tenv_lds(v), s, v, site, left_side, prev, xprev, prev_bond, mode, out_bond, out, xout);
 }
 void launch_tyhat(const TView& v, int lid, hipStream_t s) {
     const int gy = v.loss == MPST_LOSS_MSE ? v.C : 1;
@@ -1011,8 +1056,8 @@ void launch_tsplit(const TView& v, int lid, int going_left, hipStream_t s) {
     const int tiles = v.C * cdiv(dm, 16) * cdiv(v.cap, 16);
     TLAUNCH(v, k_tsplit, dim3(cdiv(tiles, 4)), dim3(256), 0, s, v, lid, going_left);
 }
-void launch_teval_final(const TView& v, const void* Lc, const void* Rc, double* yout, hipStream_t s) {
-    TLAUNCH(v, k_teval_final, dim3((unsigned)((v.N + 255) / 256)), dim3(256), 0, s, v, Lc, Rc, yout);
+void launch_teval_final(const TView& v, const void* Lc, const int32_t* Lx, const void* Rc, const int32_t* Rx, double* yout, hipStream_t s) {
+    TLAUNCH(v, k_teval_final, dim3((unsigned)((v.N + 255) / 256)), dim3(256), 0, s, v, Lc, Lx, Rc, Rx, yout);
 }
 void launch_teval_reduce(const TView& v, const double* yin, double* out3, int64_t* conf, int32_t* pred, hipStream_t s) {
     hipLaunchKernelGGL(k_teval_reduce, dim3(1), dim3(1024), 0, s, v, yin, out3, conf, pred);

@@ -103,6 +103,20 @@ def safe_options(opts) -> MPSOptions:
     raise TypeError("opts must be an MPSOptions")
 
 
+_NUMPY_DTYPES = {"Float64": "float64", "Float32": "float32", "ComplexF64": "complex128", "ComplexF32": "complex64"}
+
+
+def numpy_dtype(name):
+    """opts.dtype (a Julia DataType name, options.jl:117) as the NumPy dtype the engine is given (mpst_set_dataset's dtype).
+    The reference's array engine takes Float64 only and sends everything else through its legacy ITensor engine; here the
+    element-typed kernels (csrc/mpst_typed.hip) train all four."""
+    import numpy as np
+    key = str(name).replace("Complex{Float64}", "ComplexF64").replace("Complex{Float32}", "ComplexF32")
+    if key not in _NUMPY_DTYPES:
+        raise ValueError(f"dtype {name!r} is not one of {sorted(_NUMPY_DTYPES)}")
+    return np.dtype(_NUMPY_DTYPES[key])
+
+
 def engine_options(opts: MPSOptions, sweep: int = 0) -> dict:
     """Resolve the symbols sweep number `sweep` consumes (model_loss_func :318-327, model_bbopt :298-311)
     and reject what the array engine - like the reference's own array path - does not implement."""
@@ -124,9 +138,7 @@ def engine_options(opts: MPSOptions, sweep: int = 0) -> dict:
         raise ValueError(f"Unknown Black Box Optimiser {opts.bbopt!r}, options are [CustomGD, Optim, OptimKit]")
     if opts.use_legacy_ITensor:
         raise RuntimeError("use_legacy_ITensor=true selects the reference's ITensor engine, which this package does not ship")
-    if opts.dtype not in ("Float64",):
-        raise RuntimeError("the array sweep is Float64-only (yhat is a Ref{Float64}, loss_functions.jl:203-217); "
-                           "complex encodings train only through use_legacy_ITensor in the reference")
+    numpy_dtype(opts.dtype)          # Float64, Float32, ComplexF64, ComplexF32: the element types the engine trains in
     alg = {"divide_and_conquer": 0, "qr_iteration": 0, "recursive": 1, "jacobi": 1}.get(opts.svd_alg)
     if alg is None:
         raise ValueError(f"Unknown svd_alg {opts.svd_alg!r}")

@@ -16,7 +16,7 @@ import numpy as np
 
 from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_encoding, transform_data)
 from .engine import SweepEngine
-from .options import MPSOptions, engine_options, safe_options
+from .options import MPSOptions, engine_options, numpy_dtype, safe_options
 
 
 @dataclass
@@ -39,17 +39,24 @@ def generate_startingMPS(chi_init, T, d, num_classes, init_rng=None, dtype=np.fl
     Julia; the distribution and canonical form are the same (NumPy default_rng(init_rng))."""
     rng = np.random.default_rng(init_rng)
     dims = [1] + [int(min(chi_init, d ** min(j, T - j, 40))) for j in range(1, T)] + [1]
+    dtype = np.dtype(dtype)
+    wide = np.complex128 if dtype.kind == "c" else np.float64       # canonicalise in double precision, store in opts.dtype
     W = []
     for j in range(T):
         shape = (dims[j], d, dims[j + 1]) + ((num_classes,) if j == T - 1 else ())
-        W.append(rng.standard_normal(shape).astype(dtype))
+        t = rng.standard_normal(shape)
+        if dtype.kind == "c":                    # random_mps(ComplexF64, ...): Gaussian real and imaginary parts (:17)
+            t = t + 1j * rng.standard_normal(shape)
+        W.append(t.astype(wide))
     for j in range(T - 1):                       # orthogonalize!(W, T) (:37)
         Dl, dd, Dr = W[j].shape
         Q, Rm = np.linalg.qr(W[j].reshape(Dl * dd, Dr))
         W[j] = Q.reshape(Dl, dd, Q.shape[1])
-        W[j + 1] = np.tensordot(Rm, W[j + 1], axes=(1, 0))
+        # the carried factor is renormalised at every site (the final normalize! fixes the scale anyway): its norm grows like
+        # (d chi)^(j/2) and its SQUARE overflowed fp64 for d = 8, T = 200 - an all-zero last site, yhat = 0, KLD = inf
+        W[j + 1] = np.tensordot(Rm / np.linalg.norm(Rm), W[j + 1], axes=(1, 0))
     W[-1] = W[-1] / np.linalg.norm(W[-1])        # normalize!(W) (:32)
-    return W
+    return [t.astype(dtype) for t in W]
 
 
 _INFO_KEYS = ("train_loss", "train_acc", "test_loss", "time_taken", "train_KL_div")
@@ -74,8 +81,10 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
         raise AssertionError("Training data must be sorted by class!")            # :624
     if len(te) and np.any(np.diff(te.label_index) < 0):
         raise AssertionError("Testing data must be sorted by class!")             # :625
-    if np.iscomplexobj(tr.phi):
-        raise RuntimeError("Using a complex valued encoding but the MPS is real (the array sweep is Float64-only)")
+    dt = numpy_dtype(opts.dtype)                                                  # :442: everything is built in opts.dtype
+    if np.iscomplexobj(tr.phi) and dt.kind != "c":
+        raise RuntimeError("Using a complex valued encoding but the MPS is real. If using a complex-valued custom "
+                           "encoding, set 'dtype <: Complex' in MPSOptions")     # :462-464
     has_test = len(te) > 0
     C = int(W[-1].shape[3]) if np.ndim(W[-1]) == 4 else None
     if C is None:
@@ -93,9 +102,9 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
         else:
             tr_local, te_local = tr, te
         if not preloaded:
-            eng.set_dataset(0, tr_local.phi, tr_local.label_index, C, gcounts)
+            eng.set_dataset(0, tr_local.phi, tr_local.label_index, C, gcounts, dtype=dt)
             if has_test:
-                eng.set_dataset(1, te_local.phi, te_local.label_index, C)
+                eng.set_dataset(1, te_local.phi, te_local.label_index, C, dtype=dt)
         eng.set_mps(W)
         if shard is not None and getattr(shard, "oneshot", False):
             shard.attach_oneshot(eng)                                           # inbox slots are sized from the gradient buffer
@@ -164,7 +173,7 @@ def fitMPS(X_train, y_train=None, X_test=None, y_test=None, opts: MPSOptions = M
     overloads without test data / labels (:413,:416).  X_* are (N, T) matrices, rows = series.
     Returns (TrainedMPS, training_information, encoded_test_states).
 
-    ``device_encode=True`` (real Legendre bases only) preprocesses and encodes on the GPU
+    ``device_encode=True`` (the closed-form bases: Legendre, Fourier, Stoudenmire, Sahand, Uniform) preprocesses and encodes on the GPU
     (mpst_encode_dataset): the raw matrices are uploaded, the product states are downloaded once for the
     returned EncodedTimeSeriesSets."""
     opts = safe_options(opts)
@@ -193,7 +202,7 @@ def fitMPS(X_train, y_train=None, X_test=None, y_test=None, opts: MPSOptions = M
     class_keys = {c: i for i, c in enumerate(classes.tolist())}                                          # :485-486
     num_classes = len(classes)
     if W is None:
-        W = generate_startingMPS(opts.chi_init, T, opts.d, num_classes, opts.init_rng)                   # :433-435
+        W = generate_startingMPS(opts.chi_init, T, opts.d, num_classes, opts.init_rng, numpy_dtype(opts.dtype))   # :433-435
     if device_encode:
         return _fit_device_encoded(W, X_train, y_train, X_test, y_test, opts, enc, class_keys, **kw)
     Xtr_s, Xte_s, norms, oob = transform_data(X_train, X_test, opts, enc.range)                          # :445
@@ -220,6 +229,7 @@ def _fit_device_encoded(W, X_train, y_train, X_test, y_test, opts, enc, class_ke
     eng = engine or SweepEngine(device)
     try:
         Xs, ys, li, counts = sorted_set(X_train, y_train)
+        eng.set_dtype(numpy_dtype(opts.dtype))
         common = dict(basis=enc.name, d=opts.d, sigmoid_transform=opts.sigmoid_transform, minmax=opts.minmax,
                       data_bounds=opts.data_bounds, enc_range=enc.range)
         norms, _ = eng.encode_dataset(0, Xs, li, C, **common)

@@ -200,3 +200,74 @@ def test_device_fourier_encoding_becomes_a_complex_training_set():
             assert np.isfinite(kld)
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("dtype,chi", [("complex128", 20), ("complex64", 20), ("float32", 40)])
+def test_large_bond_tensors_go_through_the_blocked_solver(dtype, chi):
+    """(2) d chi_max > 128: the Gram matrix (complex: its 160 x 160 embedding) is decomposed by the blocked solver of
+    mpst_eig_blocked.hip in pair mode; first half-sweep of an 8-site chain, teacher forced."""
+    import mpstime_jl_amd as mt
+    ds, W = problem(192, 8, 4, chi, 2, 21, DT[dtype])
+    opts = RC.SweepOptions(chi_max=chi, eta=0.05)
+    eng = mt.SweepEngine(0)
+    try:
+        worst, flips = run_teacher_forced(eng, ds, W, DT[dtype], opts, nbonds=9)
+        info = eng.info()
+    finally:
+        eng.close()
+    assert info["large_bond"] and info["typed_kernels"] and info["library_eig_fallbacks"] == 0
+    tol = TOL["f32" if dtype in ("float32", "complex64") else "f64"]
+    print(dtype, worst, flips)
+    assert flips <= 1
+    for k in tol:
+        assert worst[k] < tol[k], (k, worst)
+
+
+def test_fitMPS_trains_a_fourier_model():
+    """fitMPS(X, y; encoding = :Fourier) end to end in the Python mirror: complex128 (the reference's default dtype for a complex
+    encoding, options.jl:117) and complex64, against the oracle's sweeps on the same encoded data."""
+    import mpstime_jl_amd as mt
+    rng = np.random.default_rng(0)
+    X, y = R.trendy_sine_dataset(120, 12, rng)
+    Xte, yte = R.trendy_sine_dataset(40, 12, rng)
+    for dname, tol in (("ComplexF64", 1e-7), ("ComplexF32", 2e-3)):
+        opts = mt.MPSOptions(encoding="Fourier", d=4, chi_max=10, nsweeps=2, eta=0.05, verbosity=-1, dtype=dname, chi_init=3)
+        trained, info, test_states = mt.fitMPS(X, y, Xte, yte, opts)
+        assert len(info["train_KL_div"]) == 4 and np.isfinite(info["train_KL_div"]).all()
+        assert trained.mps[0].dtype == (np.complex128 if dname == "ComplexF64" else np.complex64)
+        # the oracle from the same starting MPS and encoded data
+        W0 = mt.generate_startingMPS(3, 12, 4, 2, opts.init_rng, np.complex128 if dname == "ComplexF64" else np.complex64)
+        ds = RC.EncodedSet(trained.train_data.phi.astype(W0[0].dtype), trained.train_data.label_index,
+                           np.bincount(trained.train_data.label_index).astype(np.int64))
+        Wo = [t.astype(np.complex128) for t in W0]
+        ds64 = RC.EncodedSet(ds.phi.astype(np.complex128), ds.label_index, ds.class_distribution)
+        so = RC.SweepOptions(chi_max=10, eta=0.05)
+        LE = RE = None
+        klds = [RC.mse_loss_acc(Wo, ds64)[1]]
+        for _ in range(2):
+            LE, RE = RC.sweep(Wo, ds64, so, LE, RE)
+            klds.append(RC.mse_loss_acc(Wo, ds64)[1])
+        got = np.array(info["train_KL_div"][:3])
+        assert np.abs(got - np.array(klds)).max() < tol * np.abs(klds).max(), (got, klds)
+        # predictions are those of the trained model on the encoded test states
+        pred = mt.classify(trained, test_states)
+        assert pred.shape == (40,) and set(np.unique(pred)) <= {1, 2}
+        assert np.mean(pred == np.sort(yte)) == info["test_acc"][-1]
+
+
+def test_config5_bond_shape_complex64():
+    """BASELINE configs[4]'s training shape (chi = 64, d = 8, one class, Fourier) on a short chain: 1024 x 1024 embedding through
+    the blocked solver, three bonds teacher forced against the double-precision oracle."""
+    import mpstime_jl_amd as mt
+    ds, W = problem(1024, 6, 8, 64, 1, 3, np.complex64)
+    opts = RC.SweepOptions(chi_max=64, eta=0.05)
+    eng = mt.SweepEngine(0)
+    try:
+        worst, flips = run_teacher_forced(eng, ds, W, np.complex64, opts, nbonds=3)
+        info = eng.info()
+    finally:
+        eng.close()
+    print(worst, flips, info)
+    assert info["large_bond"] and info["library_eig_fallbacks"] == 0
+    for k in TOL["f32"]:
+        assert worst[k] < TOL["f32"][k], (k, worst)
