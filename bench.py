@@ -433,6 +433,10 @@ def main():
     # MPST_BENCH_SHARE_GPU=1 (test mode for 1-GPU boxes): every rank on GPU local_rank mod #GPUs, host-side group on gloo,
     # no RCCL (it refuses two ranks on one device) - the sharded sweep then runs on the one-shot all-reduce alone
     share = os.environ.get("MPST_BENCH_SHARE_GPU") == "1"
+    if share:
+        # ranks that share a GPU also share its CUs: the all-reduce's spinning workgroups of all ranks together must leave room for
+        # a peer's next compute kernel (csrc/mpst_allreduce.hip: AR_WG).  Before the library is loaded: it reads the value once.
+        os.environ.setdefault("MPST_AR_WG", "4")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
     if world > 1:
         import torch.distributed as dist
@@ -609,6 +613,15 @@ def main():
         elapsed = host_reduce([elapsed], dist.ReduceOp.MAX)[0]
     mse, kld, acc, _ = eng.eval(0)
     chi_now, _ = eng.get_chi()
+    # every rank holds the whole MPS and applied the same all-reduced updates: after the TIMED sweeps the replicas must still be
+    # identical bit for bit (content digest per rank, compared over the host-side group)
+    replicas = None
+    if world > 1:
+        dg = mt.mps_content_digest(eng.get_mps())
+        fp = float(int(dg[:12], 16))                       # 48 bits: exact in a double
+        lo, hi = host_reduce([fp], dist.ReduceOp.MIN)[0], host_reduce([fp], dist.ReduceOp.MAX)[0]
+        replicas = {"identical_after_timed_sweeps": bool(lo == hi), "digest_rank0": dg[:16]}
+        note(f"MPS replicas after the timed sweeps: {'identical on all ranks' if lo == hi else 'DIFFER'} (rank 0 digest {dg[:16]})")
 
     # ---- separate, untimed passes for the roofline: HIP events on the engine's own stream around every launch of every
     # kernel class (one sweep), then around the dominant class only over the same K sweeps as the timed region ---------
@@ -688,7 +701,7 @@ def main():
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "train_KL_div_after": kld, "train_acc_after": acc,
             "allreduce": dict(allreduce, us_per_optimiser_step=(breakdown["allreduce"][0] / max(breakdown["allreduce"][1], 1)
-                                                                 if breakdown.get("allreduce", (0, 0))[1] else None)),
+                                                                 if breakdown.get("allreduce", (0, 0))[1] else None), replicas=replicas),
             "eig_fallbacks_total": fallbacks, "eig_phases_us_last_bond": eng.eig_phases(), "launch_chain": info,
             "timed_region": "K sweeps with profiling off" + (" (hipGraph replay)" if info.get("graph") else " (plain stream)") +
                             "; per-kernel figures from separate event-instrumented sweeps after it",

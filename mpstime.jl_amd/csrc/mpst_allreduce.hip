@@ -12,10 +12,18 @@
 // the device-side status word is set, the call returns MPST_ERR_DEVICE instead of hanging the node, and the host retires
 // the one-shot path: flags, epochs and slots are then in an undefined cross-rank state.
 #include "mpst_internal.h"
+#include <cstdlib>
 
 namespace mpst {
 
-constexpr int AR_WG = 64;                    // workgroups of the all-reduce kernel (all co-resident: 64 << 256 CUs)
+// Workgroups of the all-reduce kernel.  They must all be resident at once: every workgroup waits for the flags of ALL ranks,
+// its own included, and a rank's flag is raised by the last of its workgroups to have pushed.  64 << 256 CUs on a GPU a rank has
+// to itself.  When several ranks SHARE one GPU (bench / test mode on 1-GPU boxes) the spinning workgroups of all of them
+// together can cover every CU - 8 ranks x 64 = 512 workgroups - and a peer's next compute kernel that needs an empty CU
+// (k_eig_trivec: 1024 threads, 157 KB of LDS) is never placed: everybody then waits for that peer's flag until the time-out.
+// That is what lost `sharded_n32768` in round 3's 8-rank run (reproduced in profiles/r04_oneshot_shared_gpu.txt);
+// MPST_AR_WG caps the workgroups, bench.py sets it to 4 when MPST_BENCH_SHARE_GPU=1.
+constexpr int AR_WG = 64;
 
 __global__ __launch_bounds__(256) void k_allreduce_oneshot(ArParams p) {
     __shared__ int last;
@@ -52,6 +60,10 @@ __global__ __launch_bounds__(256) void k_allreduce_oneshot(ArParams p) {
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_readcyclecounter() - t0 > p.spin_limit) {
                 *p.status = MPST_ERR_DEVICE;
+                if (p.dbg) {            // who was missing, what its flag held, which call this was: the host puts it in the error text
+                    p.dbg[0] = (int32_t)threadIdx.x;
+                    p.dbg[1] = (int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & 0x7fffffffull);
+                }
                 break;
             }
         }
@@ -68,7 +80,12 @@ __global__ __launch_bounds__(256) void k_allreduce_oneshot(ArParams p) {
 }
 
 void launch_allreduce_oneshot(const ArParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(k_allreduce_oneshot, dim3(AR_WG), dim3(256), 0, s, p);
+    static const int wg = [] {
+        const char* e = getenv("MPST_AR_WG");
+        const int v = e ? atoi(e) : AR_WG;
+        return v < 1 ? 1 : (v > AR_WG ? AR_WG : v);
+    }();
+    hipLaunchKernelGGL(k_allreduce_oneshot, dim3(wg), dim3(256), 0, s, p);
 }
 
 }  // namespace mpst

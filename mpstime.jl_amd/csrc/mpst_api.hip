@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include "mpst_internal.h"
 
 using namespace mpst;
@@ -36,13 +37,10 @@ struct Rccl {
     int version = 0;
     std::string path, how, err;
 };
-Rccl* rccl_get() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
+void rccl_load(Rccl& r) {
     const char* envp = getenv("MPST_RCCL_LIB");
-    if (envp && *envp) {
+    if (envp && !*envp) envp = nullptr;                // an empty value means unset
+    if (envp) {
         r.h = dlopen(envp, RTLD_NOW | RTLD_LOCAL);
         r.how = "MPST_RCCL_LIB";
     }
@@ -53,13 +51,14 @@ Rccl* rccl_get() {
     }
     if (!r.h && !envp) {
         for (const char* nm : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) {
+            (void)dlerror();                           // the message reported below belongs to the last attempt, not to the probes above
             if ((r.h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) { r.how = "system library"; break; }
         }
     }
     if (!r.h) {
         const char* de = dlerror();
         r.err = std::string("librccl could not be loaded: ") + (de ? de : "not found");
-        return &r;
+        return;
     }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
@@ -70,11 +69,17 @@ Rccl* rccl_get() {
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString || !r.GetVersion) {
         r.err = "librccl lacks a required entry point";
         r.h = nullptr;
-        return &r;
+        return;
     }
     Dl_info di;
     if (dladdr((void*)r.AllReduce, &di) && di.dli_fname) r.path = di.dli_fname;
     (void)r.GetVersion(&r.version);
+}
+// one-time, thread-safe: contexts on different threads may call mpst_comm_init / mpst_comm_library concurrently
+Rccl* rccl_get() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
     return &r;
 }
 // the entry points of the bound library, or null with the reason in *why
@@ -149,6 +154,7 @@ struct Ctx {
     int32_t* snap_chi = nullptr;      // [T + 2]: chi, label_site
     DevScalars* snap_sc = nullptr;
     int big_redos = 0, big_force_fail = -1, big_solves = 0;
+    int big_cooldown = 0;             // sweeps left that read the verdict per bond after a sweep had to be redone
     bool ws_ready = false;      // training workspace (caches, bond tensor, gradient, eigensolver) allocated for the current sizes
     bool eval_ready = false;    // evaluation scratch (chains, yeval, pred) allocated for max(N_train, N_test)
     bool caches_valid = false;  // LE / RE describe the current MPS: set by mpst_build_caches, cleared by whatever invalidates them
@@ -156,6 +162,9 @@ struct Ctx {
     // multi-GPU
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    // MPST_FORCE_COLLECTIVE=1 at mpst_comm_init: the sharded launch chain (loss in the message, all-reduce, norm pieces from the
+    // summed gradient, plain stream) also with ONE rank - the RCCL leg then runs on every 1-GPU CI box (tests/test_gpu_multi.py)
+    bool force_coll = false;
     // one-shot direct-write all-reduce (mpst_allreduce.hip): this rank's inbox (fine-grained device memory, exported
     // over IPC) and the peers' inboxes as mapped here
     void* ipc_local = nullptr;           // [2][nranks][slot] doubles | 16 flags | 2 counters
@@ -298,6 +307,8 @@ View make_eig_view(Ctx* c) {
     v.zw = c->zw;
     return v;
 }
+
+inline bool multi(const Ctx* c) { return c->nranks > 1 || c->force_coll; }
 
 void ipc_release(struct Ctx* c);
 
@@ -531,7 +542,7 @@ void ipc_release(struct Ctx* c) {
     c->use_ipc = false;
 }
 int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
-    if (c->nranks <= 1) return 0;
+    if (!multi(c)) return 0;
     if (c->use_ipc) {
         ArParams p{};
         for (int r = 0; r < c->nranks; ++r) {
@@ -540,6 +551,7 @@ int enqueue_allreduce(Ctx* c, double* buf, int64_t n_fixed, int lid) {
         }
         p.buf = buf;
         p.status = &c->sc->status;
+        p.dbg = c->sc->pad;
         p.counter = (unsigned int*)((char*)c->ipc_local + c->ipc_ctr_off);
         p.nranks = c->nranks; p.rank = c->rank; p.slot = c->ipc_slot;
         p.epoch = ++c->ar_epoch;
@@ -592,7 +604,7 @@ int enqueue_bond_typed(Ctx* c, int lid, int going_left, int trace_row) {
         { ProfScope p(c, K_YHAT); launch_tyhat(t, lid, s); }
         { ProfScope p(c, K_GRAD); launch_tgrad(t, lid, s); }
         { ProfScope p(c, K_UPDATE); launch_tgrad_reduce(t, lid, s); }
-        if (c->nranks > 1) {
+        if (multi(c)) {
             ProfScope p(c, K_ALLREDUCE);
             int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
             if (rc) return rc;
@@ -620,7 +632,7 @@ int enqueue_bond_typed(Ctx* c, int lid, int going_left, int trace_row) {
         vt.trace = t.trace;
         vt.trace_it = n_it;
         launch_trace_loss(vt, s);
-        if (c->nranks > 1) {
+        if (multi(c)) {
             int rc = enqueue_allreduce(c, vt.trace + n_it, 1, -1);
             if (rc) return rc;
         }
@@ -670,7 +682,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         launch_yhat(vy, lid, s);
         launch_trace_loss(vy, s);
         // a shard's tile losses carry the GLOBAL 1/N: the sum over the ranks is the loss the single-rank run records
-        if (c->nranks > 1) return enqueue_allreduce(c, vy.trace + n_it, 1, -1);
+        if (multi(c)) return enqueue_allreduce(c, vy.trace + n_it, 1, -1);
         return 0;
     };
     const int rid = lid + 1;
@@ -685,12 +697,12 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             if (c->b2) {
                 { ProfScope p(c, K_YHAT); launch_yhat_s(v, lid, s); }           // yhat, by column slices of B_c
                 { ProfScope p(c, K_GRAD); launch_grad_s(v, lid, s); }           // gradient blocks, reduced by their last arriver
-                if (c->nranks > 1) launch_loss_sum(vl, s);                      // the loss travels in gradbuf[0]
+                if (multi(c)) launch_loss_sum(vl, s);                      // the loss travels in gradbuf[0]
             } else {
                 { ProfScope p(c, K_GRAD); launch_bond_fused(v, lid, 0, s); }    // yhat + gradient partials
                 { ProfScope p(c, K_UPDATE); launch_fused_reduce(v, lid, s); }
             }
-            if (c->nranks > 1) {
+            if (multi(c)) {
                 ProfScope p(c, K_ALLREDUCE);
                 int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
                 if (rc) return rc;
@@ -700,16 +712,16 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             if (it + 1 < iters) {
                 ProfScope p(c, K_UPDATE);
                 View vu = v;
-                if (c->b2 && c->nranks == 1) vu.n_lossp = c->b2_ksplit;
+                if (c->b2 && !multi(c)) vu.n_lossp = c->b2_ksplit;
                 launch_update(vu, lid, it == 0, s);
             }
         }
         {
             ProfScope p(c, K_GRAM);                                               // last step + decomposeBT :756/:798
             View vg = v;
-            if (c->b2 && c->nranks == 1) vg.n_lossp = c->b2_ksplit;
+            if (c->b2 && !multi(c)) vg.n_lossp = c->b2_ksplit;
             // pieces of ||grad||^2: one per gradient block from k_grad_s; after an all-reduce k_grad_norm has rewritten them
-            if (c->b2 && c->nranks == 1) vg.n_norm_part = c->b2_norm_parts;
+            if (c->b2 && !multi(c)) vg.n_norm_part = c->b2_norm_parts;
             launch_gram_upd(vg, lid, going_left, iters == 1, s);
         }
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
@@ -734,7 +746,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         { ProfScope p(c, K_YHAT); launch_yhat(v, lid, s); }
         { ProfScope p(c, K_GRAD); launch_grad(v, lid, s); }
         { ProfScope p(c, K_UPDATE); launch_grad_reduce(v, lid, s); }
-        if (c->nranks > 1) {
+        if (multi(c)) {
             ProfScope p(c, K_ALLREDUCE);
             int rc = enqueue_allreduce(c, c->gradbuf, 0, lid);
             if (rc) return rc;
@@ -922,6 +934,7 @@ int mpst_comm_init(void* ctx, const uint8_t unique_id[128], int nranks, int rank
                     nc->path.c_str(), nc->version, (int)NCCL_VERSION_CODE);
     if (c->comm) { nc->CommDestroy(c->comm); c->comm = nullptr; }
     c->nranks = nranks; c->rank = rank;
+    c->force_coll = getenv("MPST_FORCE_COLLECTIVE") != nullptr;
     c->epoch++;
     ncclUniqueId id;
     memcpy(&id, unique_id, 128);
@@ -1496,7 +1509,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // profiling and the RCCL leg keep the plain stream path.
     // (large bonds stay on the plain stream: replaying their ~8000 launches from a graph was measured to gain nothing - 725.0
     // against 724.5 ms per sweep at (8192, 200, 64, 8) - and a capture must not overlap other threads' legacy-stream copies)
-    const bool use_graph = c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
+    const bool use_graph = !multi(c) && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr;
     if (use_graph && (!c->sweep_graph || c->graph_epoch != c->epoch)) {
         if (c->sweep_graph) {
             (void)hipGraphExecDestroy(c->sweep_graph);
@@ -1525,7 +1538,8 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     // so that a sweep in which a bond failed can be redone bond by bond
     // (one rank only: a persistent kernel that runs out of patience is a rank-local event, and a rank that redoes its sweep
     // alone would issue all-reduces its peers do not)
-    const bool optimistic = c->big && c->blk && c->big_opt && c->nranks == 1;
+    const bool optimistic = c->big && c->blk && c->big_opt && !multi(c) && c->big_cooldown == 0;
+    if (c->big_cooldown > 0) c->big_cooldown--;
     const size_t site_bytes = (size_t)c->site_stride * c->T * c->esz, chi_bytes = (size_t)(c->T + 1) * sizeof(int32_t);
     if (optimistic) {
         if (!c->snap_sites) {
@@ -1561,6 +1575,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
             // some bond's verification failed, or a persistent tridiagonalisation gave up: everything after it ran on
             // unspecified data.  Back to the start of the sweep, caches rebuilt, bond by bond with the verdict read each time.
             c->big_redos++;
+            c->big_cooldown = 4;        // whatever made the persistent kernels fail (a shared GPU, CU masking) tends to last: the next sweeps take the per-bond path
             HIPC(c, hipMemcpyAsync(c->sites, c->snap_sites, site_bytes, hipMemcpyDeviceToDevice, c->stream));
             HIPC(c, hipMemcpyAsync(c->chi, c->snap_chi, chi_bytes, hipMemcpyDeviceToDevice, c->stream));
             HIPC(c, hipMemcpyAsync(c->label_site, c->snap_chi + c->T + 1, sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
@@ -1591,7 +1606,9 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         if (sc.status == MPST_ERR_DEVICE && c->use_ipc) {
             c->use_ipc = false;         // flags / epochs / slots are in an undefined cross-rank state: never reuse them
             c->ipc_dead = true;
-            return fail(c, MPST_ERR_DEVICE, "the one-shot all-reduce timed out waiting for a peer (MPST_AR_TIMEOUT_S); the path is retired until the inboxes are exported again");
+            return fail(c, MPST_ERR_DEVICE, "the one-shot all-reduce timed out waiting for a peer (MPST_AR_TIMEOUT_S): rank %d of %d saw rank %d's flag at epoch %d while waiting "
+                        "for one of the %llu calls issued so far; the path is retired until the inboxes are exported again", c->rank, c->nranks, sc.pad[0], sc.pad[1],
+                        (unsigned long long)c->ar_epoch);
         }
         return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
     }
@@ -1662,7 +1679,7 @@ int mpst_eval(void* ctx, int which, double* mse, double* kld, double* acc, int64
     double tot[4] = {o[0], o[1], o[2], (double)v.N};
     std::vector<int64_t> cf((size_t)c->C * c->C);
     HIPC(c, hipMemcpy(cf.data(), c->conf, cf.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-    if (c->nranks > 1) {
+    if (multi(c)) {
         // sums over shards: the 4 scalars and the C x C counts (exact in fp64) travel as one message
         std::vector<double> msg(4 + cf.size());
         for (int i = 0; i < 4; ++i) msg[i] = tot[i];
@@ -1959,7 +1976,7 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[3] = c->ds[MPST_TRAIN].nchunks;
     out[4] = c->cap;
     out[5] = c->nranks;
-    out[6] = (c->nranks == 1 && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
+    out[6] = (!multi(c) && !c->big && c->prof_mask == 0 && getenv("MPST_NO_GRAPH") == nullptr) ? 1 : 0;
     out[7] = (int32_t)std::min<int64_t>(c->big_fallbacks, 1 << 30);
     out[8] = blocked_eig_coop_aborts(c->blk);      // bonds the persistent tridiagonalisation handed back to the launch-per-step path
     out[9] = blocked_eig_xcd_misplaced(c->blk);    // bonds whose XCD-local attempt found its workgroups on several XCDs (redone across the XCDs)
@@ -1967,7 +1984,7 @@ int mpst_get_info(void* ctx, int32_t* out) {
     out[11] = c->b2 ? c->b2_ksplit : 0;             // shares per gradient block of k_grad_s
     out[12] = (!c->big && eig_merged()) ? 1 : 0;    // tridiagonalisation + eigenvectors in one launch (k_eig_trivec)
     out[13] = c->big_redos;                          // large-bond sweeps redone bond by bond after a failed verdict
-    out[14] = (c->big_opt && c->nranks == 1) ? 1 : 0;                   // large bonds: the eigensolver's verdict is read once per sweep
+    out[14] = (c->big_opt && !multi(c)) ? 1 : 0;                   // large bonds: the eigensolver's verdict is read once per sweep
     out[15] = c->typed ? 1 + c->dtype : 0;        // element-typed kernels in use: 1 + dtype
     return 0;
 }

@@ -427,6 +427,13 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
     double* wl = vl + ld;                // [ncap] w_{j-1}
     double* rows = wl + ld;              // [ceil(ncap / G)][ncap] this workgroup's rows g, g+G, ...
     const int nown = g < n ? (n - 1 - g) / G + 1 : 0;
+    // sweeps that read the verdict once at their end (launch_eig_blocked_nosync): a solve that failed earlier in the sweep has
+    // condemned it - the sweep is redone bond by bond anyway - so later bonds neither spin for their peers nor compute on the
+    // unspecified state: every workgroup sees the same sticky word (written by an earlier kernel of the stream) and leaves
+    if (b.sticky && *(const volatile int32_t*)b.sticky != 0) {
+        if (blockIdx.x == 0 && tid == 0) *cp.abort_flag = ABORT_PATIENCE;
+        return;
+    }
     if (g == 0 && tid == 0) *b.flag = 0;
     for (int k = 0; k < nown; ++k) {
         const int r = g + k * G;

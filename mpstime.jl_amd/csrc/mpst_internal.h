@@ -529,6 +529,7 @@ struct ArParams {
     unsigned long long* flags[AR_MAX_RANKS]; // base of every rank's flag block: [2 parities][8 ranks]
     double* buf;                // local message, replaced by the sum
     int32_t* status;            // device status word (DevScalars.status), set on time-out
+    int32_t* dbg;               // [2] on time-out: the rank whose flag was missing, the epoch its flag held (DevScalars.pad)
     unsigned int* counter;      // [2] local arrival counters
     int nranks, rank;
     int64_t slot;               // doubles per inbox slot

@@ -8,14 +8,30 @@
 #
 # Julia is not installed in the build container or on the GPU box (SURVEY.md fact 3), so this file
 # has been written to the C ABI in include/mpstime_hip.h but never executed; the Python mirror in
-# mpstime.jl_amd/ drives the identical ABI and is what the tests run.
+# mpstime.jl_amd/ drives the identical ABI and is what the tests run.  Every ITensors name used below exists in
+# ITensors 0.6.22 (the reference's pin): MPS, siteinds via MPSTime.get_siteinds, linkinds, dim, array, itensor, Index.
+# First run with Julia: `julia --project=<MPSTime.jl> mpstime.jl_amd/julia/roundtrip_check.jl <MPSTime.jl> --shim`
+# trains one small model through this shim and prints the content digest the Python mirror prints for the same inputs.
 module MPSTimeHIP
 
-using ITensors, ITensorMPS
+using ITensors          # the reference's only tensor dependency (src/MPSTime.jl:9, Project.toml:50 pins ITensors = 0.6.22, which still
+                        # carries MPS / siteinds / linkinds itself; ITensorMPS is NOT a dependency of MPSTime.jl)
 import MPSTime: EncodedTimeSeriesSet, PState, AbstractMPSOptions, MPSOptions, Options, TrainedMPS,
                 safe_options, find_label, get_siteinds, KLDLoss, MSELoss, BBOpt
 
 const LIB = get(ENV, "MPSTIME_HIP_LIB", "libmpstime_hip.so")
+const MPST_ABI_VERSION = 2      # include/mpstime_hip.h this file was written against
+
+function __init__()
+    v = ccall((:mpst_version, LIB), Cint, ())
+    v == MPST_ABI_VERSION || error("libmpstime_hip.so implements ABI version $v, MPSTimeHIP.jl was written for $MPST_ABI_VERSION")
+end
+
+# mpst_set_dataset's dtype: the element type everything crosses the boundary in (opts.dtype, RealRealHighDimension.jl:442)
+dtype_code(::Type{Float64}) = Int32(0)
+dtype_code(::Type{Float32}) = Int32(1)
+dtype_code(::Type{ComplexF64}) = Int32(2)
+dtype_code(::Type{ComplexF32}) = Int32(3)
 
 struct MpstOptions            # mpst_options, field for field
     chi_max::Int32; update_iters::Int32; loss::Int32; optimiser::Int32
@@ -46,10 +62,10 @@ function check(ctx, rc)
     error("mpstime_hip [$rc]: $msg")
 end
 
-"EncodedTimeSeriesSet -> (phi[d,T,N] Float64, label_idx 0-based Int32)"
-function pack_states(ets::EncodedTimeSeriesSet, d, T)
+"EncodedTimeSeriesSet -> (phi[d,T,N] in the element type E, label_idx 0-based Int32)"
+function pack_states(ets::EncodedTimeSeriesSet, d, T, ::Type{E}) where {E}
     N = length(ets.timeseries)
-    phi = Array{Float64}(undef, d, T, N)
+    phi = Array{E}(undef, d, T, N)
     lab = Vector{Int32}(undef, N)
     for (i, ps) in enumerate(ets.timeseries)
         for t in 1:T
@@ -61,19 +77,19 @@ function pack_states(ets::EncodedTimeSeriesSet, d, T)
 end
 
 "Site tensors in the boundary layout: column-major (s, l_left, l_right[, label])."
-function pack_mps(W::MPS)
+function pack_mps(W::MPS, ::Type{E}) where {E}
     T = length(W)
     pos, label_idx = find_label(W)
     sites = get_siteinds(W)
     links = linkinds(W)
-    bufs = Vector{Array{Float64}}(undef, T)
+    bufs = Vector{Array{E}}(undef, T)
     chi = ones(Int32, T + 1)
     for j in 1:T
         inds_j = Index[sites[j]]
         j > 1 && push!(inds_j, links[j-1]);  j > 1 && (chi[j] = dim(links[j-1]))
         j < T && push!(inds_j, links[j])
         j == pos && push!(inds_j, label_idx)
-        A = array(W[j], inds_j...)
+        A = E.(array(W[j], inds_j...))
         dl, dr = j > 1 ? dim(links[j-1]) : 1, j < T ? dim(links[j]) : 1
         bufs[j] = reshape(A, dim(sites[j]), dl, dr, (j == pos ? dim(label_idx) : 1))
     end
@@ -83,6 +99,8 @@ end
 function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeriesSet, opts::AbstractMPSOptions; device::Int=0)
     opts = safe_options(opts)
     T = length(W); d = opts.d
+    E = opts.dtype                      # Float64 | Float32 | ComplexF64 | ComplexF32
+    verbosity = opts.verbosity
     pos, label_idx = find_label(W)
     C = dim(label_idx)
     loss = opts.loss_grad isa KLDLoss ? 0 : opts.loss_grad isa MSELoss ? 1 : -1
@@ -92,18 +110,19 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
     c = ctx[]
     try
         o = MpstOptions(opts.chi_max, opts.update_iters, loss, optim, opts.rescale[1], opts.rescale[2],
-                        opts.train_classes_separately, opts.svd_alg == "recursive" ? 1 : 0, 0, 0, opts.eta, opts.cutoff)
+                        opts.train_classes_separately, opts.svd_alg == "recursive" ? 1 : 0, 0, opts.track_cost ? 1 : 0, opts.eta, opts.cutoff)
         check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, o))
         for (which, ets) in ((0, train), (1, test))
             isempty(ets.timeseries) && continue
-            phi, lab = pack_states(ets, d, T)
+            phi, lab = pack_states(ets, d, T, E)
             check(c, ccall((:mpst_set_dataset, LIB), Cint,
                   (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Int32}, Int64, Int32, Int32, Int32, Int32, Ptr{Int64}),
-                  c, which, phi, lab, length(lab), T, d, C, 0, C_NULL))
+                  c, which, phi, lab, length(lab), T, d, C, dtype_code(E), C_NULL))
         end
-        bufs, chi, ls, _, sites = pack_mps(W)
+        bufs, chi, ls, _, sites = pack_mps(W, E)
         check(c, ccall((:mpst_set_mps, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Int32, Int32),
               c, [pointer(b) for b in bufs], chi, T, ls))
+        verbosity > -1 && println("Using $(opts.update_iters) iterations per update.")                      # :629
         check(c, ccall((:mpst_build_caches, LIB), Cint, (Ptr{Cvoid},), c))
 
         has_test = !isempty(test.timeseries)
@@ -115,27 +134,46 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
             mse = Ref(0.0); kld = Ref(0.0); acc = Ref(0.0); conf = zeros(Int64, C, C)
             check(c, ccall((:mpst_eval, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Int64}), c, 0, mse, kld, acc, conf))
             push!(info["train_loss"], mse[]); push!(info["train_acc"], acc[]); push!(info["time_taken"], t); push!(info["train_KL_div"], kld[])
+            verbosity > -1 && println("Training KL Div. $(kld[]) | Training acc. $(acc[]).")                  # :679-684, :835-840
             if has_test
                 check(c, ccall((:mpst_eval, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Int64}), c, 1, mse, kld, acc, conf))
                 push!(info["test_loss"], mse[]); push!(info["test_acc"], acc[]); push!(info["test_KL_div"], kld[])
                 push!(info["test_conf"], permutedims(Float64.(conf)))     # C row-major [truth][pred] -> Julia [truth, pred]
+                verbosity > -1 && println("Test KL Div. $(kld[]) | Testing acc. $(acc[]).")
             end
             return acc[]
         end
         log!(0.0)
+        nb = T - 1
+        trace = zeros(Float64, opts.update_iters + 1, 2nb)
         for its in 1:opts.nsweeps
+            verbosity > -1 && println("Using optimiser $(opts.bbopt.name) with the \"$(opts.bbopt.fl)\" algorithm")   # :728
+            verbosity > -1 && println("Starting backward sweeep: [$its/$(opts.nsweeps)]")                              # :729
             st = Ref(MpstSweepStats(0, 0, 0, 0, 0))
             check(c, ccall((:mpst_sweep, LIB), Cint, (Ptr{Cvoid}, Ref{MpstSweepStats}), c, st))
+            if opts.track_cost && verbosity >= 1
+                # what custGD / TSGO (loss_functions.jl:50-52, :80-82) and apply_update (:181-184) print, bond by bond
+                check(c, ccall((:mpst_get_loss_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), c, trace))
+                for q in 1:2nb
+                    lid = q <= nb ? nb - q + 1 : q - nb
+                    for it in 1:opts.update_iters
+                        println("Loss before step $it: $(trace[it, q])")
+                    end
+                    println("Loss at site $lid*$(lid+1): $(trace[end, q])")
+                end
+            end
+            verbosity > -1 && println("Finished sweep $its. Time for sweep: $(round(st[].seconds, digits=2))s")        # :811
             acc = log!(st[].seconds)
             opts.exit_early && acc == 1.0 && break
         end
         check(c, ccall((:mpst_normalize, LIB), Cint, (Ptr{Cvoid},), c))
+        verbosity > -1 && println("\nMPS normalised!\n")                                                             # :853
         log!(NaN)
 
         # read the MPS back into ITensors (label back on site T after the forward half-sweep)
         chi_out = zeros(Int32, T + 1); ls_out = Ref{Int32}(0)
         check(c, ccall((:mpst_get_chi, LIB), Cint, (Ptr{Cvoid}, Ptr{Int32}, Ref{Int32}), c, chi_out, ls_out))
-        outs = [Array{Float64}(undef, d, chi_out[j], chi_out[j+1], (j - 1 == ls_out[] ? C : 1)) for j in 1:T]
+        outs = [Array{E}(undef, d, chi_out[j], chi_out[j+1], (j - 1 == ls_out[] ? C : 1)) for j in 1:T]
         check(c, ccall((:mpst_get_mps, LIB), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), c, [pointer(b) for b in outs]))
         links = [Index(Int(chi_out[j+1]), "Link,l=$j") for j in 1:T-1]
         Wn = MPS(T)

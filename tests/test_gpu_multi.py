@@ -222,3 +222,61 @@ def test_sharded_imputation_equals_single_process(tmp_path, world):
     for r in range(world):
         o = np.load(tmp_path / f"imp{r}.npz")
         assert np.array_equal(o["ts"], ts) and np.array_equal(o["err"], err)
+
+
+RCCL1_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MPST_ROOT"])
+import ctypes as C
+import numpy as np
+import torch                                    # loads torch's librccl: the copy libmpstime_hip.so binds at run time
+import mpstime_jl_amd as mt
+from tests.helpers import make_problem
+big = os.environ["MPST_CASE"] == "big"
+ds, W0 = make_problem(150, 8, 4, 4 if not big else 12, 3, seed=21, balanced=False)
+res = {}
+for forced in (0, 1):
+    eng = mt.SweepEngine(0)
+    eng.set_options(chi_max=10 if not big else 40, eta=0.05, update_iters=2, track_cost=True)
+    if forced:
+        os.environ["MPST_FORCE_COLLECTIVE"] = "1"
+        lib = mt._lib.load()
+        uid = (C.c_uint8 * 128)()
+        assert lib.mpst_comm_unique_id(uid) == 0, lib.mpst_last_error(None)
+        eng._chk(lib.mpst_comm_init(eng.ctx, uid, 1, 0))
+    eng.set_dataset(0, ds.phi, ds.label_index, 3)
+    eng.set_mps(W0)
+    eng.build_caches()
+    for _ in range(2):
+        eng.sweep()
+    res[forced] = dict(ev=eng.eval(0), W=eng.get_mps(), trace=eng.loss_trace(), info=eng.info(), prof=None)
+    if forced:
+        eng.set_profile(1 << 8)
+        eng.sweep()
+        res[forced]["prof"] = eng.get_profile()["allreduce"]
+    eng.close()
+assert res[1]["info"]["graph"] is False and res[0]["info"]["graph"] is (not big)
+assert res[1]["prof"][1] == 2 * 7 * 2, res[1]["prof"]            # one ncclAllReduce per optimiser step: 14 bonds x 2 iterations
+from oracle import ref_numpy as R
+y0, y1 = R.contract_mps(res[0]["W"], ds.phi), R.contract_mps(res[1]["W"], ds.phi)
+assert np.abs(y0 - y1).max() < 1e-9 * np.abs(y0).max(), np.abs(y0 - y1).max()
+assert np.abs(res[0]["trace"] - res[1]["trace"]).max() < 1e-9 * max(1.0, np.abs(res[0]["trace"]).max())
+assert abs(res[0]["ev"][1] - res[1]["ev"][1]) < 1e-9 * max(1.0, abs(res[0]["ev"][1])) and np.array_equal(res[0]["ev"][3], res[1]["ev"][3])
+print("RCCL leg ok:", mt.comm_library())
+"""
+
+
+@pytest.mark.parametrize("case", ["fused", "big"])
+def test_rccl_leg_runs_with_a_single_rank_communicator(tmp_path, case):
+    """The RCCL branch of the launch chain on a 1-GPU box: a communicator of ONE rank and MPST_FORCE_COLLECTIVE=1 send every
+    optimiser step through ncclAllReduce on the engine's stream (and the sweep through the plain-stream, loss-in-the-message,
+    norm-from-the-summed-gradient chain the sharded fit uses).  Same results as the single-rank chain to 1e-9; the number of
+    all-reduces is checked.  RCCL refuses two ranks on one device, so more than one rank needs more than one GPU
+    (test_two_rank_sweep_equals_single_gpu)."""
+    script = tmp_path / "worker.py"
+    script.write_text(RCCL1_WORKER)
+    env = dict(os.environ, MPST_ROOT=ROOT, MPST_CASE=case, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.pop("MPST_FORCE_COLLECTIVE", None)
+    r = subprocess.run([sys.executable, str(script)], env=env, timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "RCCL leg ok" in r.stdout
