@@ -389,6 +389,7 @@ def main():
     ap.add_argument("--rebuild-caches", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=24)
+    ap.add_argument("--cpu-full-sweep", action="store_true", help="also time ONE complete sweep of the CPU restatement (about half a minute at the headline shape)")
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
                          "and stream each (hyper-parameter search / CV folds); 0 = skip")
@@ -798,6 +799,24 @@ def main():
         if out is not None:
             out["sharded_n32768"] = sharded
 
+    # ---- extra: the same K sweeps WITH the reference's two cache rebuilds per sweep (RealRealHighDimension.jl:770,804), which the
+    # headline leaves out (bit-identical results; tests/test_gpu_parity.py::test_rebuild_caches_is_bit_identical)
+    if rank == 0 and world == 1 and not args.rebuild_caches:
+        try:
+            eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True), rebuild_caches=True)
+            eng.sweep()                             # capture + warm
+            torch.cuda.synchronize()
+            tr0 = time.perf_counter()
+            for _ in range(args.steps):
+                eng.sweep()
+            torch.cuda.synchronize()
+            trb = time.perf_counter() - tr0
+            out["rebuild_caches_on"] = {"value": args.steps / trb, "unit": "sweeps/s", "ms_per_step": 1e3 * trb / args.steps,
+                                        "note": "construct_caches twice per sweep as the reference does; same results bit for bit"}
+            eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True), rebuild_caches=False)
+        except Exception as e:
+            out["rebuild_caches_on"] = {"error": str(e)}
+
     # ---- extra: K independent fits sharing the GPU.  One fit is bound by the latency chain of its per-bond eigensolver
     # (one workgroup of 256 CUs busy for 3/4 of a bond), so independent fits - the reference farms hyper-parameter
     # candidates and CV folds out with @distributed - overlap almost perfectly.  Reported next to `value`, never as it.
@@ -848,6 +867,13 @@ def main():
             r = co.sweep(max_bonds=args.cpu_bonds, first_bond=skip)
             per_bond = r["seconds"] / max(r["bonds"], 1)
             sweep_s = per_bond * 2 * (T - 1) + 2 * t_cache
+            full_sweep_s = None
+            if args.cpu_full_sweep:                   # ONE whole sweep on the host (all 2(T-1) bonds + both cache rebuilds), timed, no extrapolation
+                co2 = COracle(Wnow, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=True, native=True)
+                t_f0 = time.perf_counter()
+                co2.build_caches()
+                co2.sweep()
+                full_sweep_s = time.perf_counter() - t_f0
             # (i) the SVD with every host core (as OpenBLAS would run it for Julia), (ii) the
             # NumPy / SciPy-gesdd oracle on the same inputs as a second data point
             import scipy.linalg
@@ -879,6 +905,8 @@ def main():
                           f"construct_caches ({t_cache:.2f} s) timed on this host, extrapolated to 2(T-1)={2 * (T - 1)} bonds "
                           f"+ 2 cache rebuilds; the Julia reference itself cannot run here",
                 "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model(), "seconds_sampled": r["seconds"] + t_cache,
+                "full_sweep_timed": None if full_sweep_s is None else {"seconds": full_sweep_s, "value": 1.0 / full_sweep_s, "unit": "sweeps/s",
+                                                                          "note": "one complete sweep (198 bonds + cache rebuilds) timed on this host, --cpu-full-sweep"},
                 "svd_gesdd_all_cores_ms": svd_ms,
                 "numpy_oracle": None if np_per_bond is None else {
                     "value": 1.0 / (np_per_bond * 2 * (T - 1)), "unit": "sweeps/s",

@@ -67,7 +67,7 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import csrc_sha256                 # digest of the kernel sources the passes were run on
     json.dump({"csrc_sha256": csrc_sha256(), "note": "rocprofv3 --kernel-trace --pmc, three separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
-                       "SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE) of the command in brackets (scratch/collect_profiles.sh)" + note + "; "
+                       "SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE) of the command in brackets (profiles/collect_profiles.sh)" + note + "; "
                        "per-launch averages; hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction of the MI355X guide); "
                        "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel duration x 2.4 GHz).", "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():

@@ -1,11 +1,11 @@
 #!/bin/bash
-# On the GPU box, from the repo root:  scratch/collect_profiles.sh <tag> <pmc: 0|1> <program + args ...>
-# Writes gpurun_out/r03/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of the command), the command's own
+# On the GPU box, from the repo root:  profiles/collect_profiles.sh <tag> <pmc: 0|1> <program + args ...>
+# Writes gpurun_out/${ROUND:-r04}/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of the command), the command's own
 # output, and - with pmc=1 - three separate counter passes aggregated by profiles/aggregate_pmc.py into pmc_counters.json.
 tag=$1; pmc=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 prog=$root/$1; shift      # the program is given relative to the repo root; the profiler runs from /tmp
-out=$root/gpurun_out/r03/$tag
+out=$root/gpurun_out/${ROUND:-r04}/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python3 $prog "$@" > $out/stdout_under_rocprof.txt 2> $out/kt.err
