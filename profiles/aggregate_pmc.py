@@ -27,7 +27,7 @@ def per_kernel(path, counters):
     dur = collections.defaultdict(lambda: [0.0, 0])
     seen = set()
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0]
         if r.get("Counter_Name") in counters:
             a = acc[name][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"])

@@ -23,7 +23,7 @@ if __name__ == "__main__":
     rows, _ = stats(sys.argv[1])
     lines = ["Name,Calls,TotalDurationNs,AverageNs,MinNs,MaxNs,Percentage"]
     for r in rows:
-        nm = r[0].split("(")[0]
+        nm = r[0].replace("(anonymous namespace)::", "").split("(")[0]
         lines.append(f"\"{nm}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]},{r[5]},{r[6]:.2f}")
     out = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
