@@ -213,6 +213,21 @@ int  mpst_build_caches(void* ctx);
 /* One full sweep = RealRealHighDimension.jl:727-808. */
 int  mpst_sweep(void* ctx, mpst_sweep_stats* out);
 
+/* One sweep of K independent fits of the same shape in ONE launch chain: contexts with the same T, d, C, chi_max, capacity,
+ * class counts and loss on one device (hyper-parameter candidates that share the shape - eta, cutoff, the data, the starting MPS
+ * may differ -, CV folds, restarts; the reference runs such fits as separate @distributed tasks, hyperparameters/tuning.jl).
+ * Every kernel launch carries all K fits, so a sweep costs the ~1200 launches of ONE fit: K separate contexts driven from K host
+ * threads reach 2.3x a single fit on one MI355X (the dispatch rate is the limit), one batched chain about 5-6x for K = 8.
+ * Results are those of K mpst_sweep calls, bit for bit.  Headline chain only (Float64, d*chi_max <= 128, <= 8192 series, one rank,
+ * update_iters = 1, no track_cost / rebuild_caches / profiling): MPST_ERR_UNSUPPORTED otherwise - drive such fits one by one.
+ * `out` ([K], may be NULL): seconds = device time of the whole batch.  Errors are reported on ctxs[0]. */
+int  mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out);
+/* Optional, before the first sweep of a context: it will be advanced in batches of about K fits.  The engine then splits every
+ * gradient block of THIS fit into fewer shares (K fits fill the chip together); the share count fixes the order of the partial
+ * sums, so mpst_sweep on the same context gives the same bits as mpst_sweep_batch, while a context without the hint differs from
+ * it in the last bits of the gradient. */
+int  mpst_set_batch_hint(void* ctx, int32_t K);
+
 /* opts.track_cost: the losses the reference prints during the last mpst_sweep, one row per bond in sweep order (backward
  * half-sweep first): update_iters entries "Loss before step i" (loss_functions.jl:50-52 / :80-82) followed by the loss
  * at the updated bond tensor, "Loss at site lid*rid" (:181-184).  out has 2(T-1) * (update_iters + 1) entries. */

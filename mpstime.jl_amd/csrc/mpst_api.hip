@@ -189,6 +189,13 @@ struct Ctx {
     // bumped by every call that changes what the captured kernels were given
     hipGraphExec_t sweep_graph = nullptr;
     uint64_t epoch = 1, graph_epoch = 0;
+    // mpst_sweep_batch with this context as the lead: the Views of the K fits on the device ([2][K]: plain, and the Gram launch's
+    // variant), the captured sweep and what it was captured for (context pointers and their epochs)
+    int batch_hint = 1;            // mpst_set_batch_hint: this context will be advanced in batches of about that many fits
+    View* batch_views = nullptr;
+    int batch_cap = 0;
+    hipGraphExec_t batch_graph = nullptr;
+    std::vector<std::pair<void*, uint64_t>> batch_key;
 };
 
 int fail(Ctx* c, int code, const char* fmt, ...) {
@@ -435,6 +442,9 @@ int ensure_workspace(Ctx* c) {
             gv.C = c->C; gv.d = c->d; gv.cap = c->cap;
             const int64_t max_pass = tr.N;                  // MSE walks every series in every pass; KLD at most that
             c->b2_ksplit = b2_ksplit(gv, max_pass);
+            // a context that runs in batches of K fits shares the chip with K - 1 others: fewer, longer shares per gradient block
+            // (less hand-over per fit; the share count fixes the order of the partial sums, so it belongs to the context, not to the call)
+            if (c->batch_hint > 1 && getenv("MPST_B2_KSPLIT") == nullptr) c->b2_ksplit = std::max(1, c->b2_ksplit / std::min(c->batch_hint, 8));
             c->b2_norm_parts = c->C * b2_blocks_cap(gv);
             c->partial_elems = std::max(c->partial_elems, b2_partial_elems(gv, max_pass));
             if ((rc = dalloc(c, &c->b2_ypart, (int64_t)8 * c->C * tr.N))) return rc;
@@ -886,6 +896,8 @@ void mpst_destroy(void* ctx) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->sweep_graph) (void)hipGraphExecDestroy(c->sweep_graph);
+    if (c->batch_graph) (void)hipGraphExecDestroy(c->batch_graph);
+    dfree(&c->batch_views);
     if (c->comm && rccl_ready(nullptr)) rccl_ready(nullptr)->CommDestroy(c->comm);
     ipc_release(c);
     free_dataset(c->ds[0]); free_dataset(c->ds[1]);
@@ -1611,6 +1623,142 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
                         (unsigned long long)c->ar_epoch);
         }
         return fail(c, MPST_ERR_SVD, "bond-tensor decomposition failed (non-finite spectrum or eigensolver did not converge)");
+    }
+    return 0;
+}
+
+// K independent fits of one shape advanced by ONE launch chain (hyper-parameter candidates, CV folds, restarts: what the
+// reference farms out with @distributed, tuning.jl).  Every launch of the headline chain carries all K fits (blockIdx.z), so the
+// kernel count per sweep is that of one fit; results are those of K separate mpst_sweep calls, bit for bit.
+int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
+    if (!ctxs || K < 1 || K > 64) return fail(nullptr, MPST_ERR_INVALID, "mpst_sweep_batch: 1..64 contexts");
+    Ctx* c0 = (Ctx*)ctxs[0];
+    if (!c0) return MPST_ERR_INVALID;
+    int rc;
+    for (int k = 0; k < K; ++k) {
+        Ctx* c = (Ctx*)ctxs[k];
+        if (!c) return fail(c0, MPST_ERR_INVALID, "context %d is NULL", k);
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail(c0, MPST_ERR_INVALID, "context %d appears twice", k);
+        if ((rc = check_ready(c))) {
+            if (c != c0) c0->err = c->err;
+            return rc;
+        }
+        if (!c->caches_valid) return fail(c0, MPST_ERR_INVALID, "context %d: call mpst_build_caches first", k);
+        if (c->host_label_site != c->T - 1) return fail(c0, MPST_ERR_INVALID, "context %d: a sweep starts with the label index on the last site", k);
+        const bool chain_ok = c->fused && c->b2 && !c->typed && !multi(c) && eig_merged() && c->opt.update_iters == 1 && !c->opt.track_cost &&
+                              !c->opt.rebuild_caches && c->prof_mask == 0;
+        if (!chain_ok)
+            return fail(c0, MPST_ERR_UNSUPPORTED, "context %d: mpst_sweep_batch runs the headline chain only (Float64, d*chi_max <= 128, <= 8192 series, one rank, "
+                                                 "update_iters = 1, no track_cost / rebuild_caches / profiling)", k);
+        const DataSet &a = c0->ds[MPST_TRAIN], &b = c->ds[MPST_TRAIN];
+        const bool same = c->device == c0->device && c->T == c0->T && c->d == c0->d && c->C == c0->C && c->cap == c0->cap && a.N == b.N && a.ntiles == b.ntiles &&
+                          a.counts == b.counts && c->opt.loss == c0->opt.loss && c->opt.train_classes_separately == c0->opt.train_classes_separately &&
+                          c->opt.chi_max == c0->opt.chi_max && c->b2_ksplit == c0->b2_ksplit && c->b2_norm_parts == c0->b2_norm_parts;
+        if (!same) return fail(c0, MPST_ERR_UNSUPPORTED, "context %d differs in shape from context 0 (T, d, C, capacity, chi_max, class counts, loss): batch fits of one shape", k);
+        HIPC(c0, hipStreamSynchronize(c->stream));
+    }
+    HIPC(c0, hipSetDevice(c0->device));
+    if (c0->batch_cap < K) {
+        dfree(&c0->batch_views);
+        if ((rc = dalloc(c0, &c0->batch_views, (int64_t)2 * K))) return rc;
+        c0->batch_cap = K;
+        c0->batch_key.clear();
+    }
+    std::vector<std::pair<void*, uint64_t>> key;
+    for (int k = 0; k < K; ++k) key.push_back({ctxs[k], ((Ctx*)ctxs[k])->epoch});
+    const View v0 = make_view(c0, MPST_TRAIN);
+    if (!c0->batch_graph || key != c0->batch_key) {
+        if (c0->batch_graph) {
+            (void)hipGraphExecDestroy(c0->batch_graph);
+            c0->batch_graph = nullptr;
+        }
+        std::vector<View> hv((size_t)2 * c0->batch_cap);
+        for (int k = 0; k < K; ++k) {
+            Ctx* c = (Ctx*)ctxs[k];
+            hv[k] = make_view(c, MPST_TRAIN);
+            View vg = hv[k];                    // the Gram launch reads the loss pieces and the gradient-norm pieces k_grad_s left
+            vg.n_lossp = c->b2_ksplit;
+            vg.n_norm_part = c->b2_norm_parts;
+            hv[(size_t)c0->batch_cap + k] = vg;
+        }
+        HIPC(c0, hipMemcpy(c0->batch_views, hv.data(), hv.size() * sizeof(View), hipMemcpyHostToDevice));
+        const View* dv = c0->batch_views;
+        const View* dvg = c0->batch_views + c0->batch_cap;
+        hipStream_t s = c0->stream;
+        HIPC(c0, hipStreamSynchronize(s));
+        HIPC(c0, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int bad = 0;
+        for (int k = 0; k < K && !bad; ++k)
+            if (hipMemsetAsync((char*)((Ctx*)ctxs[k])->sc + offsetof(DevScalars, status), 0, 12, s) != hipSuccess) bad = 1;
+        const int nb = c0->T - 1;
+        const int64_t cs = (int64_t)v0.N * v0.cap;
+        for (int q = 0; q < 2 * nb && !bad; ++q) {
+            const int lid = q < nb ? nb - 1 - q : q - nb, left = q < nb, rid = lid + 1;
+            const bool have = q > 0 && q != nb;                        // as mpst_sweep's fused chain: nothing was chained at the turning point
+            const int next = q + 1 < 2 * nb ? ((q + 1) < nb ? nb - 1 - (q + 1) : (q + 1) - nb) : -1;
+            const int chain = (next >= 0 && next == (left ? lid - 1 : lid + 1)) ? 1 : 0;
+            if (!have) launch_bt_assemble_b(v0, dv, K, lid, s);
+            launch_yhat_s_b(v0, dv, K, lid, s);
+            launch_grad_s_b(v0, dv, K, lid, s);
+            launch_gram_upd_b(v0, dvg, K, lid, left, 1, s);
+            launch_eig_b(v0, dv, K, lid, left, 0, s);
+            launch_eig_b(v0, dv, K, lid, left, 2, s);
+            if (left) launch_env_split_b(v0, dv, K, lid, 1, rid, 0, rid < c0->T - 1 ? (int64_t)(rid + 1) * cs : -1, rid + 1, rid, (int64_t)rid * cs, chain, s);
+            else launch_env_split_b(v0, dv, K, lid, 0, lid, 1, lid > 0 ? (int64_t)(lid - 1) * cs : -1, lid, lid + 1, (int64_t)lid * cs, chain, s);
+        }
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(s, &g);
+        if (bad || e != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            return fail(c0, MPST_ERR_DEVICE, "capture of the batched sweep failed: %s", hipGetErrorString(e));
+        }
+        HIPC(c0, hipGetLastError());
+        e = hipGraphInstantiate(&c0->batch_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            c0->batch_graph = nullptr;
+            return fail(c0, MPST_ERR_DEVICE, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+        }
+        c0->batch_key = key;
+    }
+    HIPC(c0, hipEventRecord(c0->ev_start, c0->stream));
+    HIPC(c0, hipGraphLaunch(c0->batch_graph, c0->stream));
+    HIPC(c0, hipEventRecord(c0->ev_stop, c0->stream));
+    HIPC(c0, hipEventSynchronize(c0->ev_stop));
+    HIPC(c0, hipGetLastError());
+    float ms = 0.f;
+    HIPC(c0, hipEventElapsedTime(&ms, c0->ev_start, c0->ev_stop));
+    int failed = -1;
+    for (int k = 0; k < K; ++k) {
+        Ctx* c = (Ctx*)ctxs[k];
+        DevScalars sc;
+        HIPC(c0, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+        std::vector<int32_t> chi(c->T + 1);
+        HIPC(c0, hipMemcpy(chi.data(), c->chi, chi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (out) {
+            out[k].seconds = 1e-3 * ms;            // of the whole batch: the fits advance together
+            out[k].svd_status = sc.status;
+            out[k].max_chi = *std::max_element(chi.begin(), chi.end());
+            out[k].eig_sweeps_total = sc.eig_sweeps_total;
+            out[k].eig_fallbacks = sc.eig_fallbacks;
+        }
+        if (sc.status) {
+            c->caches_valid = false;
+            if (failed < 0) failed = k;
+        }
+    }
+    if (failed >= 0) return fail(c0, MPST_ERR_SVD, "bond-tensor decomposition failed in fit %d of the batch (its svd_status is set; the other fits are intact)", failed);
+    return 0;
+}
+
+int mpst_set_batch_hint(void* ctx, int32_t K) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || K < 1) return fail(c, MPST_ERR_INVALID, "batch hint must be >= 1");
+    if (K != c->batch_hint) {
+        c->batch_hint = K;
+        c->ws_ready = false;
+        c->epoch++;
     }
     return 0;
 }

@@ -1074,8 +1074,8 @@ __global__ __launch_bounds__(VEC_THREADS) void k_eig_vec(View v, int lid, int go
 // nothing else to do at this point of the chain.  LDS layout = k_eig_vec's; the tridiagonalisation's scratch rows
 // live where the compact-WY factors (Tb) go later.  After the reduction the 12 waves the eigenvector part does not
 // need retire (a terminated wave no longer counts at s_barrier).
-__global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going_left, const double* rawG, int rawn,
-                                                            int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
+__device__ __forceinline__ void trivec_body(const View& v, int lid, int going_left, const double* rawG, int rawn,
+                                            int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int cnt_s[8];
     __shared__ double red_s[8];
@@ -1109,6 +1109,27 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
     }
     if (tid >= VEC_THREADS) return;
     vec_core<true>(pb, k, smem, cnt_s, red_s, arg_s, ws, st, lo, hi, tnorm);
+}
+__global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                            int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
+    trivec_body(v, lid, going_left, rawG, rawn, rawalg, ws, stamps);
+}
+// K independent fits per launch (blockIdx.z): see mpst_fused.hip.  The eigensolver reads a dozen scalar fields of the View: they
+// are copied into a local one (scalar registers after SROA) - through a reference into global memory the register-starved
+// reflector loop of trivec_body spilled 60 bytes per lane more and ran 55 us longer.
+__device__ __forceinline__ View eig_fields(const View& s) {
+    View v{};
+    v.T = s.T; v.d = s.d; v.C = s.C; v.chi_max = s.chi_max; v.cap = s.cap;
+    v.chi = s.chi; v.label_site = s.label_site;
+    v.gram = s.gram; v.lam = s.lam; v.E = s.E; v.eig_ws = s.eig_ws; v.sc = s.sc;
+    v.rescale_after = s.rescale_after; v.svd_alg = s.svd_alg; v.cutoff = s.cutoff; v.zw = s.zw;
+    return v;
+}
+// (rawG / rawn / rawalg stay run-time arguments - always null / 0 here: with them folded away the register allocation of the
+// reflector loop changes and spills 60 bytes per lane more)
+__global__ __launch_bounds__(TRI_T) void k_eig_trivec_b(const View* __restrict__ vs, int lid, int going_left, const double* rawG, int rawn, int rawalg) {
+    const View v = eig_fields(vs[blockIdx.z]);
+    trivec_body(v, lid, going_left, rawG, rawn, rawalg, v.eig_ws, v.sc->eig_stamps);
 }
 
 // =====================================================================================
@@ -1275,9 +1296,9 @@ __device__ bool fin_tri(double* smem, const double* zin, int n, int nk, double r
     return done;
 }
 
-__global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int going_left, const double* rawG, int rawn,
-                                                         int rawalg, double* __restrict__ ws, double* rawlam,
-                                                         double* rawE, int32_t* rawinfo, unsigned long long* stamps) {
+__device__ __forceinline__ void fin_body(const View& v, int lid, int going_left, const double* rawG, int rawn,
+                                         int rawalg, double* __restrict__ ws, double* rawlam,
+                                         double* rawE, int32_t* rawinfo, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double lam_s[MAX_DIM + 2];
     __shared__ double red[16];
@@ -1364,6 +1385,15 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int go
     }
     if (stamps && tid == 0) stamps[9] = __builtin_amdgcn_s_memrealtime();
 }
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_fin(View v, int lid, int going_left, const double* rawG, int rawn,
+                                                         int rawalg, double* __restrict__ ws, double* rawlam,
+                                                         double* rawE, int32_t* rawinfo, unsigned long long* stamps) {
+    fin_body(v, lid, going_left, rawG, rawn, rawalg, ws, rawlam, rawE, rawinfo, stamps);
+}
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_fin_b(const View* __restrict__ vs, int lid, int going_left) {
+    const View v = eig_fields(vs[blockIdx.z]);
+    fin_body(v, lid, going_left, nullptr, 0, 0, v.eig_ws, nullptr, nullptr, nullptr, v.sc->eig_stamps);
+}
 
 // raw-mode helper: clear the outputs of the test entry point
 __global__ void k_eig_clear(double* lam, double* E, int n) {
@@ -1385,6 +1415,8 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_fin_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
 }
@@ -1413,6 +1445,13 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
     } else
         hipLaunchKernelGGL(k_eig_fin, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, lid, going_left,
                            (const double*)nullptr, 0, 0, v.eig_ws, (double*)nullptr, (double*)nullptr, (int32_t*)nullptr, st);
+}
+
+// the merged chain for K fits of one shape (mpst_sweep_batch): stage 0 k_eig_trivec_b, stage 2 k_eig_fin_b
+void launch_eig_b(const View& v, const View* vs, int K, int lid, int going_left, int stage, hipStream_t s) {
+    const dim3 gvec(v.chi_max < TRI_KMAX ? (v.chi_max < 32 ? 32 : v.chi_max) : TRI_KMAX, 1, K);
+    if (stage == 0) hipLaunchKernelGGL(k_eig_trivec_b, gvec, dim3(TRI_T), vec_lds_bytes(), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
+    else hipLaunchKernelGGL(k_eig_fin_b, dim3(1, 1, K), dim3(EIG_THREADS), eig_lds_bytes(), s, vs, lid, going_left);
 }
 
 void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,

@@ -347,7 +347,7 @@ __device__ __forceinline__ double step_from_parts(const View& v, double* red, do
 // Gram matrix of bt_new = bt - step*grad viewed as the matrix decomposeBT hands to svd, one 16 x 16 tile per
 // workgroup, K split over the 4 waves.  The diagonal tiles see every entry of bt_new exactly once (their A-operand
 // panel) and write it to v.btn - a second buffer, the other tiles are still reading the old one.
-__global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_left, int first_iter) {
+__device__ __forceinline__ void gram_upd_body(const View& v, int lid, int going_left, int first_iter) {
     __shared__ double part[4][256];
     __shared__ double red[4];
     const BondDimsF b = bond_dims_f(v, lid);
@@ -688,9 +688,9 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
 
 // blocks [0, ntiles): new environment rows out_i = Z_i E (update_caches!); [ntiles, ntiles + nsplit): the back-split;
 // beyond: the next bond's tensor (chain_bt_block)
-__global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_left, int site, int left_side,
-                                                   const double* __restrict__ prev, int prev_bond, int out_bond,
-                                                   double* __restrict__ out, int nsplit, int ntb, int tp) {
+__device__ __forceinline__ void env_split_body(const View& v, int lid, int going_left, int site, int left_side,
+                                               const double* __restrict__ prev, int prev_bond, int out_bond,
+                                               double* __restrict__ out, int nsplit, int ntb, int tp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if ((int)blockIdx.x >= ntb + nsplit) {
         chain_bt_block(v, lid, going_left, (int)blockIdx.x - ntb - nsplit, smem);
@@ -811,7 +811,7 @@ __device__ __forceinline__ Span tile_span_k(const View& v, int t) {
 // Every wave stages, consumes and stores its own tile: no workgroup barrier, one round trip to memory per group.
 // LM: 16-entry pieces of an environment row a lane group fetches (capacity <= 16 LM); D4: d == 4 (the headline shapes).
 template <int LM, bool D4>
-__global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) {
+__device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, int ngw) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const B2 b = b2_dims(v, lid);
     const int d = v.d, rid = lid + 1;
@@ -982,7 +982,7 @@ constexpr int GS_MAXKS = 64;
 // grid.x = ksplit * nbc * nbc (capacity), grid.y = C.  Workgroup id -> (ks = id % ksplit, block = id / ksplit).
 // AW2: compile-time bound of ceil(aw / 8), D2 of ceil(d / 8) (register arrays of the loader role).
 template <int AW2, int D2>
-__global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbc) {
+__device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, int nbc) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double redl[8];
     __shared__ int last_s;
@@ -1212,6 +1212,37 @@ __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, in
     GSTAMP(4);
 }
 
+// ---- the kernels proper: one fit per launch (View in the kernel arguments), or K independent fits of the same shape per
+// launch (blockIdx.z picks the fit's View from a device array - mpst_sweep_batch): the command processor dispatches about
+// 70 k kernels a second however many queues feed it, which caps K concurrent single-fit chains at 2.3x one chain; one
+// chain of K-fold launches keeps the kernel count of ONE fit.
+__global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_left, int first_iter) { gram_upd_body(v, lid, going_left, first_iter); }
+__global__ __launch_bounds__(256) void k_gram_upd_b(const View* __restrict__ vs, int lid, int going_left, int first_iter) {
+    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    gram_upd_body(v, lid, going_left, first_iter);
+}
+__global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_left, int site, int left_side, const double* __restrict__ prev,
+                                                   int prev_bond, int out_bond, double* __restrict__ out, int nsplit, int ntb, int tp) {
+    env_split_body(v, lid, going_left, site, left_side, prev, prev_bond, out_bond, out, nsplit, ntb, tp);
+}
+// batched: the environment rows are addressed by element offsets into the fit's own LE / RE (prev_off < 0: boundary)
+__global__ __launch_bounds__(256) void k_env_split_b(const View* __restrict__ vs, int lid, int going_left, int site, int left_side, int64_t prev_off,
+                                                     int prev_bond, int out_bond, int64_t out_off, int nsplit, int ntb, int tp) {
+    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    double* base = left_side ? v.LE : v.RE;
+    env_split_body(v, lid, going_left, site, left_side, prev_off >= 0 ? base + prev_off : nullptr, prev_bond, out_bond, base + out_off, nsplit, ntb, tp);
+}
+template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) { yhat_s_body<LM, D4>(v, lid, nslc, ngw); }
+template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s_b(const View* __restrict__ vs, int lid, int nslc, int ngw) {
+    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    yhat_s_body<LM, D4>(v, lid, nslc, ngw);
+}
+template <int AW2, int D2> __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbc) { grad_s_body<AW2, D2>(v, lid, ksplit, nbc); }
+template <int AW2, int D2> __global__ __launch_bounds__(GS_T) void k_grad_s_b(const View* __restrict__ vs, int lid, int ksplit, int nbc) {
+    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    grad_s_body<AW2, D2>(v, lid, ksplit, nbc);
+}
+
 // the loss of the bond from the pieces of k_grad_s (same order wherever it is formed): gradbuf[0..1] for the all-reduce
 __global__ __launch_bounds__(64) void k_loss_sum(View v) {
     if (threadIdx.x == 0) {
@@ -1257,6 +1288,12 @@ hipError_t b2_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if (device >= 0 && device < 64) done |= 1ull << device;
     return hipSuccess;
 }
@@ -1270,6 +1307,40 @@ void launch_yhat_s(const View& v, int lid, hipStream_t s) {
     else hipLaunchKernelGGL((k_yhat_s<4, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
 }
 void launch_loss_sum(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, s, v); }
+// ---- batched launchers: v = the shape every fit of the batch shares, vs = the K Views on the device ----
+void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
+    const int nslc = cdivf(v.d * v.cap, YS_W);
+    const int ngroups = cdivf(v.ntiles, 8);
+    // group walkers per slice: about 512 workgroups over the whole batch - fewer, longer walks per fit amortise a workgroup's
+    // start-up and its slice of B_c over more series (the series a walker takes do not change any sum)
+    const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / (nslc * K))));
+    const dim3 grid(nslc * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1, K);
+    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s_b<2, true>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s_b<2, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else hipLaunchKernelGGL((k_yhat_s_b<4, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+}
+void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
+    const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);
+    const dim3 grid(v.b2_ksplit * nbc * nbc, v.C, K);
+    if (aw > 8) hipLaunchKernelGGL((k_grad_s_b<2, 1>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s_b<1, 2>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else hipLaunchKernelGGL((k_grad_s_b<1, 1>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+}
+void launch_gram_upd_b(const View& v, const View* vs, int K, int lid, int going_left, int first_iter, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    hipLaunchKernelGGL(k_gram_upd_b, dim3(cdivf(dm, 16) * cdivf(dm, 16), 1, K), dim3(256), 0, s, vs, lid, going_left, first_iter);
+}
+void launch_env_split_b(const View& v, const View* vs, int K, int lid, int going_left, int site, int left_side, int64_t prev_off, int prev_bond,
+                        int out_bond, int64_t out_off, int chain, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
+    const int nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
+    const int tp = (v.cap <= 32 && v.ntiles >= 512) ? 2 : 1;
+    const size_t lds = std::max((size_t)tp * 16 * FXS, chain ? (size_t)4 * CHAIN_J * 256 : (size_t)0) * sizeof(double);
+    const int ntb = std::max(1, std::min(v.ntiles, 512));
+    hipLaunchKernelGGL(k_env_split_b, dim3(ntb + nsplit + nchain, 1, K), dim3(256), lds, s, vs, lid, going_left, site, left_side, prev_off, prev_bond,
+                       out_bond, out_off, nsplit, ntb, tp);
+}
 void launch_grad_s(const View& v, int lid, hipStream_t s) {
     const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);
     const dim3 grid(v.b2_ksplit * nbc * nbc, v.C);

@@ -522,6 +522,14 @@ hipError_t b2_init_attrs(int device);
 void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
 void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);
+// the headline chain for K independent fits of one shape per launch (blockIdx.z selects the fit's View in the device array vs)
+void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);
+void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);
+void launch_gram_upd_b(const View& v, const View* vs, int K, int lid, int going_left, int first_iter, hipStream_t s);
+void launch_env_split_b(const View& v, const View* vs, int K, int lid, int going_left, int site, int left_side, int64_t prev_off, int prev_bond,
+                        int out_bond, int64_t out_off, int chain, hipStream_t s);
+void launch_eig_b(const View& v, const View* vs, int K, int lid, int going_left, int stage, hipStream_t s);
+void launch_bt_assemble_b(const View& v, const View* vs, int K, int lid, hipStream_t s);
 // one-shot direct-write all-reduce over peer-mapped inboxes (mpst_allreduce.hip)
 constexpr int AR_MAX_RANKS = 8;
 struct ArParams {

@@ -132,6 +132,10 @@ __device__ __forceinline__ void bt_assemble_block(const View& v, int lid, int bx
     }
 }
 __global__ __launch_bounds__(256) void k_bt_assemble(View v, int lid) { bt_assemble_block(v, lid, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_bt_assemble_b(const View* __restrict__ vs, int lid) {
+    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    bt_assemble_block(v, lid, blockIdx.x, blockIdx.y);
+}
 
 // normalize!(BT_init) when rescale[1] (loss_functions.jl:109-111): one workgroup, C*L <= 2*16384.
 __global__ __launch_bounds__(1024) void k_bt_prescale(View v, int lid) {
@@ -942,6 +946,11 @@ void launch_bt_assemble(const View& v, int lid, hipStream_t s) {
     const int dm = v.d * v.cap;
     const int tiles = cdiv(dm, 16) * cdiv(dm, 16);
     hipLaunchKernelGGL(k_bt_assemble, dim3(cdiv(tiles, 4), v.C), dim3(256), 0, s, v, lid);
+}
+void launch_bt_assemble_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int tiles = cdiv(dm, 16) * cdiv(dm, 16);
+    hipLaunchKernelGGL(k_bt_assemble_b, dim3(cdiv(tiles, 4), v.C, K), dim3(256), 0, s, vs, lid);
 }
 void launch_bt_prescale(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_bt_prescale, dim3(1), dim3(1024), 0, s, v, lid);

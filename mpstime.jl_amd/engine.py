@@ -80,6 +80,10 @@ class SweepEngine:
         self._iters = int(update_iters)
         self._chk(self.lib.mpst_set_options(self.ctx, C.byref(o)))
 
+    def set_batch_hint(self, K):
+        """This fit will be advanced in batches of about K (``sweep_batch``): fewer, longer gradient shares (mpst_set_batch_hint)."""
+        self._chk(self.lib.mpst_set_batch_hint(self.ctx, int(K)))
+
     def set_dtype(self, dtype):
         """opts.dtype for data sets that are encoded on the device (mpst_set_dtype); set_dataset takes it from its array."""
         dt = np.dtype(dtype)
@@ -395,6 +399,21 @@ class SweepEngine:
         self._chk(self.lib.mpst_selftest_eig(self.ctx, G.ctypes.data_as(dp), n, alg, lam.ctypes.data_as(dp),
                                              E.ctypes.data_as(dp), C.byref(sw)))
         return lam, E, sw.value
+
+
+def sweep_batch(engines):
+    """mpst_sweep_batch: one sweep of K independent fits of the same shape in ONE launch chain (every launch carries all K
+    fits).  ``engines``: SweepEngines prepared like for ``sweep()`` (options, data, MPS, build_caches).  Returns one stats dict per
+    engine; ``seconds`` is the device time of the whole batch.  Raises MPSTError(MPST_ERR_UNSUPPORTED) for fits outside the
+    headline chain or of different shapes - drive those with ``sweep()`` one by one."""
+    lib = L.load()
+    K = len(engines)
+    arr = (C.c_void_p * K)(*[e.ctx.value for e in engines])
+    st = (L.mpst_sweep_stats * K)()
+    rc = lib.mpst_sweep_batch(arr, K, st)
+    if rc:
+        engines[0]._chk(rc)
+    return [{"seconds": s.seconds, "max_chi": s.max_chi, "eig_sweeps_total": s.eig_sweeps_total, "eig_fallbacks": s.eig_fallbacks} for s in st]
 
 
 def comm_library():

@@ -63,3 +63,49 @@ def test_graph_sweep_equals_bond_steps_at_the_benchmarked_shape():
         print(f"sweep {s + 1}: overlaps differ by {dev:.2e} (relative), KLD {kla:.12f} vs {klb:.12f}, bitwise equal: {same}")
         assert same, (s, dev)
         assert kla == klb and msa == msb and aca == acb and np.array_equal(cfa, cfb)
+
+
+def test_batched_sweep_of_independent_fits_is_bit_identical():
+    """mpst_sweep_batch: K fits of one shape (different data, starting MPS, eta and cutoff) advanced by one launch chain give the
+    bits of K separate mpst_sweep calls, sweep after sweep; a fit of another shape is refused."""
+    import mpstime_jl_amd as mt
+    from tests.helpers import make_problem
+    K = 4
+    probs = [make_problem(256, 12, 4, 4, 2, seed=50 + k) for k in range(K)]
+    etas = [0.05, 0.02, 0.05, 0.1]
+
+    def fresh(k, chi=12):
+        e = mt.SweepEngine(0)
+        e.set_batch_hint(K)                 # the share count of the gradient blocks belongs to the context: solo and batched sweeps agree bit for bit
+        e.set_options(chi_max=chi, eta=etas[k], cutoff=1e-10 if k != 2 else 1e-8)
+        ds, W = probs[k]
+        e.set_dataset(0, ds.phi, ds.label_index, 2)
+        e.set_mps(W)
+        e.build_caches()
+        return e
+
+    solo = [fresh(k) for k in range(K)]
+    bat = [fresh(k) for k in range(K)]
+    try:
+        for sweep in range(3):
+            for e in solo:
+                e.sweep()
+            st = mt.sweep_batch(bat)
+            assert len(st) == K and all(s["eig_fallbacks"] == 0 for s in st)
+            for a, b in zip(solo, bat):
+                for ta, tb in zip(a.get_mps(), b.get_mps()):
+                    assert np.array_equal(ta, tb)
+                assert a.eval(0)[:3] == b.eval(0)[:3]
+        # a single sweep() on a batched context continues from the same state
+        solo[1].sweep()
+        bat[1].sweep()
+        assert all(np.array_equal(x, y) for x, y in zip(solo[1].get_mps(), bat[1].get_mps()))
+        other = fresh(0, chi=8)
+        try:
+            with pytest.raises(mt.MPSTError, match="differs in shape"):
+                mt.sweep_batch([bat[0], other])
+        finally:
+            other.close()
+    finally:
+        for e in solo + bat:
+            e.close()
