@@ -438,6 +438,9 @@ def main():
         # ranks that share a GPU also share its CUs: the all-reduce's spinning workgroups of all ranks together must leave room for
         # a peer's next compute kernel (csrc/mpst_allreduce.hip: AR_WG).  Before the library is loaded: it reads the value once.
         os.environ.setdefault("MPST_AR_WG", "4")
+        # ... and time-share it: with 8 processes on one GPU an optimiser step takes ~10 ms and a rank can fall seconds behind
+        # its peers (profiles/r04_oneshot_shared_gpu.txt); the 10 s default of the bounded spins is for a GPU per rank
+        os.environ.setdefault("MPST_AR_TIMEOUT_S", "180")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
     if world > 1:
         import torch.distributed as dist
@@ -464,7 +467,7 @@ def main():
 
     if world > 1:
         cl = mt.comm_library()       # bound at run time: the copy torch has loaded, never a second one (include/mpstime_hip.h)
-        note(f"{world} ranks, rank 0 on cuda:{dev_index}" + (" (all ranks share one GPU: MPST_BENCH_SHARE_GPU=1, host group on gloo)" if share else ""))
+        note(f"{world} ranks, rank 0 on cuda:{dev_index}" + (f" (all ranks share one GPU: MPST_BENCH_SHARE_GPU=1, host group on gloo, MPST_AR_WG={os.environ.get('MPST_AR_WG')})" if share else ""))
         note(f"librccl bound by libmpstime_hip.so: {cl['library']}, version {cl['version']} (built against {cl['built_against']})")
         try:
             note(f"torch.cuda.nccl.version() = {torch.cuda.nccl.version()}")
@@ -729,6 +732,11 @@ def main():
             # the headline figures are on stderr before the side measurement starts: whatever happens in it, they are logged
             note("headline (before the configs[3] side measurement): " + json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step")}))
         try:
+            # the headline engine is done (nothing below uses it with several ranks): its stream must not stay around as a second
+            # user queue per process - 8 ranks x 2 queues oversubscribe the hardware queue slots of a SHARED GPU and every
+            # optimiser step then waits for a 10 ms scheduling quantum (measured: 10.0 ms per all-reduce, round 4)
+            eng.close()
+            eng = None
             N2 = args.sharded_N
             full2 = make_inputs(N2, T, d)
             eng2 = mt.SweepEngine(dev_index)
@@ -930,7 +938,8 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -280,3 +280,73 @@ def test_rccl_leg_runs_with_a_single_rank_communicator(tmp_path, case):
     r = subprocess.run([sys.executable, str(script)], env=env, timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "RCCL leg ok" in r.stdout
+
+
+TYPED_ONESHOT_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["MPST_ROOT"])
+import numpy as np
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+import mpstime_jl_amd as mt
+from oracle import ref_complex as RC
+dt = np.dtype(os.environ["MPST_DTYPE"])
+dev = rank % max(torch.cuda.device_count(), 1)
+ds, W0 = RC.make_problem(150, 8, 4, 4, 3, seed=21, dtype=dt, balanced=False)
+full = mt.EncodedTimeSeriesSet(ds.phi, ds.label_index.astype(np.int64), ds.label_index, np.zeros((0, 0)), ds.class_distribution)
+sh = mt.Shard(rank, world, rccl=False, oneshot=True)
+local, gcounts = sh.split(full)
+eng = mt.SweepEngine(dev)
+eng.set_options(chi_max=10, eta=0.05)
+eng.set_dataset(0, local.phi, local.label_index, 3, gcounts)
+eng.set_mps(W0)
+sh.attach_oneshot(eng)
+eng.build_caches()
+for _ in range(2):
+    eng.sweep()
+ev = eng.eval(0)
+np.savez(os.path.join(os.environ["MPST_OUT"], f"rank{rank}.npz"), kld=ev[1], conf=ev[3], **{f"W{j}": t for j, t in enumerate(eng.get_mps())})
+dist.barrier()
+eng.close()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "float32"])
+def test_sharded_typed_sweep_over_the_oneshot_allreduce(tmp_path, dtype):
+    """The element-typed sweep sharded over two ranks (sharing the GPU on this pool): the all-reduce message is the fp64 gradient
+    buffer - interleaved (re, im) pairs for a complex model, twice the real length - through the one-shot kernel; replicas are
+    bit-identical and agree with the single-rank fit."""
+    import mpstime_jl_amd as mt
+    from oracle import ref_complex as RC
+    script = tmp_path / "worker.py"
+    script.write_text(TYPED_ONESHOT_WORKER)
+    env = dict(os.environ, MPST_ROOT=ROOT, MPST_OUT=str(tmp_path), MPST_DTYPE=dtype, MPST_AR_WG="8",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(_free_port()), str(script)], check=True, env=env, timeout=600)
+    outs = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    dt = np.dtype(dtype)
+    ds, W0 = RC.make_problem(150, 8, 4, 4, 3, seed=21, dtype=dt, balanced=False)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=10, eta=0.05)
+        eng.set_dataset(0, ds.phi, ds.label_index, 3)
+        eng.set_mps(W0)
+        eng.build_caches()
+        for _ in range(2):
+            eng.sweep()
+        ev = eng.eval(0)
+        W1 = eng.get_mps()
+    finally:
+        eng.close()
+    T = len(W0)
+    for j in range(T):
+        assert np.array_equal(outs[0][f"W{j}"], outs[1][f"W{j}"])
+    assert outs[0]["kld"] == outs[1]["kld"] and np.array_equal(outs[0]["conf"], outs[1]["conf"])
+    wide = np.complex128 if dt.kind == "c" else np.float64
+    yo = RC.contract_mps([t.astype(wide) for t in W1], ds.phi.astype(wide))
+    ys = RC.contract_mps([outs[0][f"W{j}"].astype(wide) for j in range(T)], ds.phi.astype(wide))
+    assert np.abs(yo - ys).max() < 2e-3 * np.abs(yo).max()          # fp32 storage, two chaotic sweeps: the shards sum in another order
+    assert abs(float(outs[0]["kld"]) - ev[1]) <= 2e-3 * max(1.0, abs(ev[1]))
