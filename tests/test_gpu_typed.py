@@ -271,3 +271,66 @@ def test_config5_bond_shape_complex64():
     assert info["large_bond"] and info["library_eig_fallbacks"] == 0
     for k in TOL["f32"]:
         assert worst[k] < TOL["f32"][k], (k, worst)
+
+
+def test_rescale_before_and_track_cost_in_the_typed_chain():
+    """rescale = (true, true) (normalize!(BT) before the update, legacy loss_functions.jl:194-196) and opts.track_cost (the losses
+    before every optimiser step and at the updated, rescaled bond tensor) through the element-typed kernels, complex128."""
+    import mpstime_jl_amd as mt
+    ds, W = problem(90, 6, 3, 3, 2, 17, np.complex128, balanced=False)
+    opts = RC.SweepOptions(chi_max=7, eta=0.05, update_iters=2, rescale=(True, True))
+    eng = mt.SweepEngine(0)
+    try:
+        worst, flips = run_teacher_forced(eng, ds, W, np.complex128, opts)
+        assert flips == 0 and all(worst[k] < TOL["f64"][k] for k in TOL["f64"]), worst
+        # one free-running sweep with the trace: every recorded loss is the oracle's at that point
+        eng.set_options(chi_max=7, eta=0.05, update_iters=2, rescale=(True, True), track_cost=True)
+        eng.set_mps(W)
+        eng.build_caches()
+        eng.sweep()
+        trace = eng.loss_trace()
+        Wo = [t.copy() for t in W]
+        LE, RE = RC.construct_caches(Wo, ds.phi, True)
+        T = len(W)
+        for q in range(T - 1):                                   # the backward half-sweep
+            lid = T - 2 - q
+            bt, shape4 = RC.flatten_bt(Wo[lid], Wo[lid + 1])
+            bt5 = RC.unflatten_bt(bt, shape4)
+            bt5 = bt5 / np.linalg.norm(bt5)
+            LEp = LE[lid - 1] if lid > 0 else None
+            REp = RE[lid + 2] if lid + 1 < T - 1 else None
+            l0, g0 = RC.loss_grad(bt5, LEp, REp, ds, lid, lid + 1)
+            b1 = bt5 - opts.eta * g0 / np.linalg.norm(g0)
+            l1, g1 = RC.loss_grad(b1, LEp, REp, ds, lid, lid + 1)
+            b2 = b1 - opts.eta * g1 / np.linalg.norm(g1)
+            b2 = b2 / np.linalg.norm(b2)
+            l2, _ = RC.loss_grad(b2, LEp, REp, ds, lid, lid + 1)
+            assert np.abs(trace[q] - np.array([l0, l1, l2])).max() < 1e-9 * max(1.0, abs(l0)), (q, trace[q], l0, l1, l2)
+            RC.bond_step(Wo, LE, RE, lid, ds, opts, True)
+    finally:
+        eng.close()
+
+
+def test_imputation_from_a_complex_context():
+    """mpst_impute on a context that holds a complex model and complex data (what a Fourier fit leaves behind) equals
+    mpst_impute_model_run on the same tensors - the context's element type reaches the imputation engine."""
+    import mpstime_jl_amd as mt
+    ds, W = problem(24, 8, 4, 5, 2, 9, np.complex128)
+    xs = -1.0 + (2.0 / 200) * np.arange(201)
+    gphi = R.fourier_encode(xs, 4)
+    rng = np.random.default_rng(0)
+    miss = (rng.uniform(size=(24, 8)) < 0.4).astype(np.uint8)
+    for dt in (np.complex128, np.complex64):
+        eng = mt.SweepEngine(0)
+        try:
+            eng.set_options(chi_max=5)
+            eng.set_dataset(0, ds.phi.astype(dt), ds.label_index, 2)
+            eng.set_mps([t.astype(dt) for t in W])
+            x1, e1, _ = eng.impute(0, miss, xs, gphi, method=0)
+            Wm = [t.astype(dt).astype(np.complex128) for t in W]
+            x2, e2, _ = eng.impute_model(Wm, ds.phi.astype(dt).astype(np.complex128), ds.label_index, miss, xs, gphi, method=0,
+                                         compute="f64" if dt == np.complex128 else "f32")
+            assert np.array_equal(x1, x2) and np.array_equal(e1, e2)
+            assert np.all(x1[miss == 0] == 0.0) and np.any(x1[miss == 1] != 0.0)
+        finally:
+            eng.close()
