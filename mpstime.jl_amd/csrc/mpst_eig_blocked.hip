@@ -80,6 +80,8 @@ struct BtBufs {
     double* tailG;   // [BT_TAIL][BT_TAIL] the trailing block handed to k_eig_tail (all earlier reflectors applied)
     int use_tail;    // 1: the last BT_TAIL steps run in k_eig_tail
     int ncap;
+    int cnative;     // 1: pair mode through the NATIVE Hermitian reduction (k_bt_coop_c): dd / ee describe the real tridiagonal matrix of
+                     // order n/2, Vall / tau hold complex reflectors (double2, row stride ncap/2), k_bt_back_c back-transforms
     const int32_t* abort;   // persistent tridiagonalisation's abort word (null on the launch-per-step path): when it is set,
                             // dd / ee / Vall are stale or partial and every kernel after it must leave without publishing
 };
@@ -690,6 +692,248 @@ __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left,
 #endif
 }
 
+// ---- pair mode, native: Hermitian tridiagonalisation with complex reflectors ----------------------------------------------
+// What the embedding costs: the 2n x 2n real problem takes 2n - 2 dependent Householder steps, each exchanging 2n-vectors.
+// The Hermitian matrix G = Gr + i Gi itself (read out of the embedding k_tgram wrote: Gr = M[0:n, 0:n], Gi = M[n:2n, 0:n]) is
+// reduced here by n - 1 steps of zhetd2 (LAPACK, UPLO = 'L') in the data flow of k_bt_coop - workgroup g keeps rows g, g+G, ...
+// in LDS for the whole factorisation, the rank-2 update of step j-1 is applied during step j, a step exchanges y and the next
+// row - with complex arithmetic in these places (conjugates as in the NumPy model the kernel was transcribed from):
+//   alpha_{j-1} = -tau/2 (y^H v),  w = y + alpha v;   column j = conj(row j) - v conj(w_j) - w conj(v_j)
+//   zlarfg: beta = -sign(Re a0) sqrt(|a0|^2 + |x|^2) REAL, tau = (beta - a0) / beta COMPLEX, v = x / (a0 - beta)
+//   A[r][c] -= v_r conj(w_c) + w_r conj(v_c),   y_r = tau sum_c A[r][c] v_c
+// T is real symmetric tridiagonal of order n with a SIMPLE spectrum: k_bt_vec works on it as on any real problem (no pairs),
+// k_bt_back_c applies Q = H_0 ... H_{n-2} (the last reflector is a pure phase, tau != 0) and writes the eigenvector of the
+// embedding (Re u, Im u) with its partner J u next to it, so k_bt_gram / k_bt_decide / k_bt_polish run unchanged.
+__device__ __forceinline__ double2 c_mul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 c_mulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a conj(b)
+__device__ __forceinline__ double2 ld_c(const double2* p) {
+    return make_double2(__hip_atomic_load(&p->x, __ATOMIC_RELAXED, SC_AGENT), __hip_atomic_load(&p->y, __ATOMIC_RELAXED, SC_AGENT));
+}
+__device__ __forceinline__ void st_c(double2* p, double2 v) {
+    __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, SC_AGENT);
+    __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, SC_AGENT);
+}
+constexpr int BTC_NT = 512, BTC_NMAX = BT_NMAX / 2;
+__global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+    constexpr int NT = BTC_NT, NW = NT / 64;
+    static_assert(BTC_NMAX <= NT, "one element of every length-n vector per thread");
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double red_a[NW][2], red_b[NW];
+    __shared__ double2 bc[2];
+    __shared__ int sh_ok;
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
+    const int nf = pb.n, n = pb.n >> 1, ld = b.ncap >> 1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int G = (int)gridDim.x, g = (int)blockIdx.x;
+    double2* xs = (double2*)smem;        // [ld] the reflector v_j (v_{j-1} when a step starts)
+    double2* vl = xs + ld;               // [ld] v_{j-1}
+    double2* wl = vl + ld;               // [ld] w_{j-1}
+    double2* rows = wl + ld;             // [ceil(ld / G)][ld] this workgroup's rows g, g+G, ...
+    const int nown = g < n ? (n - 1 - g) / G + 1 : 0;
+    if (b.sticky && *(const volatile int32_t*)b.sticky != 0) {       // the sweep is condemned already (see k_bt_coop)
+        if (blockIdx.x == 0 && tid == 0) *cp.abort_flag = ABORT_PATIENCE;
+        return;
+    }
+    if (g == 0 && tid == 0) *b.flag = 0;
+    for (int k = 0; k < nown; ++k) {
+        const int r = g + k * G;
+        for (int c = tid; c < n; c += NT) rows[k * ld + c] = make_double2(pb.G[(int64_t)r * nf + c], pb.G[(int64_t)(n + r) * nf + c]);
+    }
+    for (int c = tid; c < ld; c += NT) xs[c] = vl[c] = wl[c] = make_double2(0.0, 0.0);
+    __syncthreads();
+    double2* Vc = (double2*)b.Vall;
+    double2* tauc = (double2*)b.tau;
+    if (n == 1) {
+        if (g == 0 && tid == 0) {
+            b.dd[0] = pb.G[0];
+            b.ee[0] = 0.0;
+        }
+        return;
+    }
+    double2* ybuf = (double2*)cp.ybuf;
+    double2* rowbuf = (double2*)cp.rowbuf;
+    if (g == 0)
+        for (int c = tid; c < n; c += NT) st_c(rowbuf + c, rows[c]);
+    bt_coop_arrive<SC_AGENT>(cp);
+    double2 tau_prev = make_double2(0.0, 0.0);
+    for (int j = 0; j <= n - 2; ++j) {
+        if (!bt_coop_wait<SC_AGENT>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+        const double2* yprev = ybuf + (int64_t)((j + 1) & 1) * ld;
+        const double2* rowj = rowbuf + (int64_t)(j & 1) * ld;
+        const int idx = j + tid;
+        const bool ok = idx < n;
+        const double2 zero = make_double2(0.0, 0.0);
+        double2 yp = (ok && j > 0) ? ld_c(yprev + idx) : zero;
+        const double2 aj = ok ? ld_c(rowj + idx) : zero;
+        const double2 vp = (ok && j > 0) ? xs[idx] : zero;
+        const double2 yj = j > 0 ? ld_c(yprev + j) : zero;
+        // (a) alpha_{j-1} = -tau/2 (y^H v)
+        double2 alpha;
+        {
+            double sr = yp.x * vp.x + yp.y * vp.y, si = yp.x * vp.y - yp.y * vp.x;        // conj(y) v
+            sr = wave_sum_fast(sr);
+            si = wave_sum_fast(si);
+            if (lane == 0) {
+                red_a[wave][0] = sr;
+                red_a[wave][1] = si;
+            }
+            __syncthreads();
+            double ar = 0.0, ai = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                ar += red_a[w][0];
+                ai += red_a[w][1];
+            }
+            alpha = c_mul(make_double2(-0.5 * tau_prev.x, -0.5 * tau_prev.y), make_double2(ar, ai));
+        }
+        // (b) column j with the pending update: conj(row j) - v conj(w_j) - w conj(v_j); v_{j-1}[j] is the leading one
+        const double2 wj = j > 0 ? make_double2(yj.x + alpha.x, yj.y + alpha.y) : zero;
+        double2 col;
+        double2 tau = zero;
+        double beta, dj;
+        {
+            if (j > 0) {
+                const double2 av = c_mul(alpha, vp);
+                yp = make_double2(yp.x + av.x, yp.y + av.y);                                   // w_{j-1} from here on
+            } else {
+                yp = zero;
+            }
+            const double2 t1 = c_mulc(vp, wj);
+            col = make_double2(aj.x - t1.x - (j > 0 ? yp.x : 0.0), -aj.y - t1.y - (j > 0 ? yp.y : 0.0));
+            double s = (idx >= j + 2 && ok) ? col.x * col.x + col.y * col.y : 0.0;
+            if (ok) {
+                vl[idx] = vp;
+                wl[idx] = yp;
+            }
+            if (tid == 0) bc[0] = col;                 // d_j (its real part)
+            if (tid == 1) bc[1] = col;                 // the leading entry of the column below the diagonal
+            s = wave_sum_fast(s);
+            if (lane == 0) red_b[wave] = s;
+            __syncthreads();
+            s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red_b[w];
+            const double2 a0 = bc[1];
+            dj = bc[0].x;
+            // zlarfg
+            double2 scale = zero;
+            const double xx = a0.x * a0.x + a0.y * a0.y + s;
+            if ((s > 0.0 || a0.y != 0.0) && xx > 1e-280) {
+                const double nrm = sqrt(xx);
+                beta = -copysign(nrm, a0.x);
+                tau = make_double2((beta - a0.x) / beta, -a0.y / beta);
+                const double dr = a0.x - beta, di = a0.y, dn = 1.0 / (dr * dr + di * di);
+                scale = make_double2(dr * dn, -di * dn);                                        // 1 / (a0 - beta)
+            } else {
+                beta = a0.x;
+            }
+            if (ok) xs[idx] = idx <= j ? zero : (idx == j + 1 ? make_double2(1.0, 0.0) : c_mul(col, scale));
+            __syncthreads();
+        }
+        auto bookkeeping = [&]() {
+            const int per = (n + G - 1) / G, i2 = g * per + tid;
+            if (tid < per && i2 >= j && i2 < n) Vc[(int64_t)j * ld + i2] = xs[i2];
+            if (g == j % G && tid == 0) {
+                tauc[j] = tau;
+                b.dd[j] = dj;
+                b.ee[j] = beta;
+            }
+        };
+        tau_prev = tau;
+        if (j == n - 2) {
+            bookkeeping();
+            if ((n - 1) % G == g && tid == 0) {
+                const int k = (n - 1 - g) / G;
+                const double2 vv = vl[n - 1], ww = wl[n - 1];
+                b.dd[n - 1] = rows[k * ld + (n - 1)].x - 2.0 * (vv.x * ww.x + vv.y * ww.y);      // - 2 Re(v conj(w))
+                b.ee[n - 1] = 0.0;
+            }
+            break;
+        }
+        // (c) own rows r > j: pending update, product with the new reflector; the owner of row j+1 publishes it
+        double2* ynew = ybuf + (int64_t)(j & 1) * ld;
+        double2* rownext = rowbuf + (int64_t)((j + 1) & 1) * ld;
+        for (int k = wave; k < nown; k += NW) {
+            const int r = g + k * G;
+            if (r <= j) continue;
+            double2* arow = rows + k * ld;
+            const double2 vr = vl[r], wr = wl[r];
+            const bool pub = r == j + 1;
+            double sr = 0.0, si = 0.0;
+            for (int c = j + 1 + lane; c < n; c += 64) {
+                const double2 t1 = c_mulc(vr, wl[c]), t2 = c_mulc(wr, vl[c]);
+                const double2 a_ = make_double2(arow[c].x - t1.x - t2.x, arow[c].y - t1.y - t2.y);
+                arow[c] = a_;
+                const double2 pr = c_mul(a_, xs[c]);
+                sr += pr.x;
+                si += pr.y;
+                if (pub) st_c(rownext + c, a_);
+            }
+            sr = wave_sum_fast(sr);
+            si = wave_sum_fast(si);
+            if (lane == 0) st_c(ynew + r, c_mul(tau, make_double2(sr, si)));
+        }
+        bt_coop_arrive<SC_AGENT>(cp);
+        bookkeeping();
+    }
+}
+
+// u = H_0 H_1 ... H_{n-2} z for the eigenvectors z of T that k_bt_vec left in rows 2k of Z (first n entries, real): one WAVE per
+// vector (8 elements per lane at n = 512, reductions on DPP: no workgroup barrier), reflectors from L2 (the four waves of a
+// workgroup walk the same rows).  Writes (Re u, Im u) into row 2k and J u = (-Im u, Re u) into row 2k + 1.
+__global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_left, BtBufs b) {
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
+    if (bt_aborted(b)) return;
+    const int n = pb.n >> 1, ld = b.ncap, ldc = b.ncap >> 1, lane = threadIdx.x & 63;
+    const int k = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= bt_nvec(pb)) return;
+    constexpr int QE = BTC_NMAX / 64;
+    double* zrow = b.Z + (int64_t)(2 * k) * ld;
+    double2 z[QE];
+#pragma unroll
+    for (int q = 0; q < QE; ++q) {
+        const int i = lane + 64 * q;
+        z[q] = make_double2(i < n ? zrow[i] : 0.0, 0.0);
+    }
+    const double2* Vc = (const double2*)b.Vall;
+    const double2* tauc = (const double2*)b.tau;
+    for (int j = n - 2; j >= 0; --j) {
+        const double2* vj = Vc + (int64_t)j * ldc;
+        double2 vv[QE];
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int q = 0; q < QE; ++q) {
+            const int i = lane + 64 * q;
+            vv[q] = (i > j && i < n) ? vj[i] : make_double2(0.0, 0.0);
+            sr += vv[q].x * z[q].x + vv[q].y * z[q].y;                 // conj(v) z
+            si += vv[q].x * z[q].y - vv[q].y * z[q].x;
+        }
+        sr = wave_sum_fast(sr);
+        si = wave_sum_fast(si);
+        const double2 t = c_mul(tauc[j], make_double2(sr, si));
+#pragma unroll
+        for (int q = 0; q < QE; ++q) {
+            const double2 u = c_mul(t, vv[q]);
+            z[q].x -= u.x;
+            z[q].y -= u.y;
+        }
+    }
+    double* zp = zrow + ld;
+#pragma unroll
+    for (int q = 0; q < QE; ++q) {
+        const int i = lane + 64 * q;
+        if (i < n) {
+            zrow[i] = z[q].x;
+            zrow[n + i] = z[q].y;
+            zp[i] = -z[q].y;
+            zp[n + i] = z[q].x;
+        }
+    }
+    if (lane == 0) {
+        b.lam[2 * k + 1] = b.lam[2 * k];
+        b.res[2 * k + 1] = b.res[2 * k];
+    }
+}
+
 // ---- compact-WY factors of the reflector blocks ------------------------------------------------------------------------
 // Block bk = reflectors j0 .. j0+15 (j0 = 16 bk): H_{j0} H_{j0+1} ... H_{j0+15} = I - V T V^T with V = [v_j0 ... v_j0+15] and T
 // upper triangular (LAPACK dlarft, forward / columnwise): T_ii = tau_i, T_{0:i,i} = -tau_i T_{0:i,0:i} (V_{0:i}^T v_i).
@@ -701,7 +945,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_larft(View v, int lid, int going_le
     __shared__ double part[4][256];
     __shared__ double S[16][17];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
-    if (bt_aborted(b)) return;
+    if (bt_aborted(b) || b.cnative) return;
     const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const int j0 = BT_NB * (int)blockIdx.x, nref = n - 2;          // reflectors 0 .. n-3
@@ -765,7 +1009,10 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     __shared__ int cnt_s[4];
     __shared__ int arg_s[4];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
-    const int n = pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // native pair mode (k_bt_coop_c): T is the real tridiagonal matrix of the Hermitian problem itself - order n/2, simple spectrum;
+    // this kernel then stops at the eigenvector of T (k_bt_back_c applies the complex reflectors)
+    const bool nat = b.cnative != 0;
+    const int n = nat ? pb.n >> 1 : pb.n, ld = b.ncap, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = blockIdx.x;
     if (k >= bt_nvec(pb) || bt_aborted(b)) return;
     double* de = smem;                  // [n + 8][2] (d_j, e_{j-1}^2), padded for sturm_count's groups of 8 rows
@@ -812,7 +1059,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     }
     __syncthreads();
     // multisection for the k-th largest eigenvalue (pair mode: the upper one of the k-th pair)
-    const int target = n - 1 - (pb.pair ? 2 * k : k);
+    const int target = n - 1 - ((pb.pair && !nat) ? 2 * k : k);
     if (n >= 24) {
         // two-sided Sturm count as in k_eig_vec: a pair of lanes runs the recurrence top-down over rows 0..kk-1 and
         // bottom-up over rows n-1..kk+1, the sign of the twisted pivot at row kk completes the inertia; 128 abscissae x 8
@@ -959,6 +1206,14 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
     __syncthreads();
     for (int j = tid; j < n; j += BT_T) z[j] *= sc;
     __syncthreads();
+    if (nat) {
+        for (int j = tid; j < n; j += BT_T) b.Z[(int64_t)(2 * k) * ld + j] = z[j];
+        if (tid == 0) {
+            b.lam[2 * k] = lamk;
+            b.res[2 * k] = tnorm > 0.0 ? ri / tnorm : ri;
+        }
+        return;
+    }
     // back-transformation: z <- H_0 H_1 ... H_{n-3} z in blocks of 16 reflectors, last block first:
     //     z <- z - V (T (V^T z)),   T from k_bt_larft.
     // Every thread keeps its rows of z (r = tid + 256 q) in registers and fetches its rows of the block's 16 reflectors (for
@@ -1165,9 +1420,10 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
         return;
     }
     double part = 0.0, partT = 0.0;
+    const int nT = b.cnative ? n >> 1 : n;          // native pair mode: T is the tridiagonal matrix of the Hermitian problem (order n/2)
     for (int i = tid; i < n; i += 512) {
         part += pb.G[(size_t)i * n + i];
-        partT += b.dd[i];
+        if (i < nT) partT += b.dd[i];
     }
     double tr = wave_sum(part), trT = wave_sum(partT);
     if ((tid & 63) == 0) {
@@ -1183,7 +1439,8 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     }
     // the one check of T against G itself (residuals and orthonormality below are relative to T): an orthogonal
     // similarity keeps the trace, so a tridiagonal matrix that belongs to another bond does not pass
-    const bool trace_ok = fabs(trT - tr) <= 1e-9 * fabs(tr) + 1e-300;
+    const double trG = b.cnative ? 0.5 * tr : tr;       // trace of the complex matrix = half the embedding's
+    const bool trace_ok = fabs(trT - trG) <= 1e-9 * fabs(trG) + 1e-300;
     if (tid < K0) lam_s[tid] = fmax(b.lam[tid], 0.0);
     __syncthreads();
     if (pb.pair) tr *= 0.5;             // trace of the complex matrix
@@ -1330,6 +1587,16 @@ static bool xcd_usable(int ncap) {
 }
 
 static size_t bt_vec_lds() { return (size_t)(6 * BT_NMAX + 16) * sizeof(double); }
+// native Hermitian reduction (pair mode): 8 complex rows per workgroup; MPST_BT_NO_CNATIVE=1 keeps the embedded real reduction
+static int coopc_grid(int ncap) { return std::max(1, std::min(128, (ncap / 2 + 7) / 8)); }
+static size_t coopc_lds(int ncap) {
+    const int nc = ncap / 2, G = coopc_grid(ncap);
+    return (size_t)(3 + (nc + G - 1) / G) * nc * sizeof(double2);
+}
+static bool cnative_usable(const View& v, int ncap) {
+    static const bool off = getenv("MPST_BT_NO_CNATIVE") != nullptr;
+    return !off && v.zw == 2 && (ncap & 1) == 0 && ncap / 2 <= BTC_NMAX && coopc_lds(ncap) <= 150 * 1024;
+}
 
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     BlockedEig* e = new BlockedEig();
@@ -1352,7 +1619,8 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
     if (ok) ok = hipFuncSetAttribute((const void*)k_bt_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bt_vec_lds()) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<256, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop_c, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -1383,6 +1651,7 @@ static void enqueue_after_tridiag(const View& v, int lid, int going_left, const 
     const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
     hipLaunchKernelGGL(k_bt_larft, dim3((ncap + BT_NB - 1) / BT_NB), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
     hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
+    if (b.cnative) hipLaunchKernelGGL(k_bt_back_c, dim3((kmax / 2 + 3) / 4), dim3(256), 0, s, v, lid, going_left, b);
     const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;
     for (int second = 0; second < 2; ++second) {
         if (second) hipLaunchKernelGGL(k_bt_copyback, dim3(64), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, (const double*)rawE);
@@ -1403,6 +1672,7 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
     // mode 2: persistent kernel confined to one XCD; 1: persistent kernel across the XCDs; 0: one launch per step
     int mode = (rawn == 0 && !no_coop) ? (xcd_usable(ncap) ? 2 : 1) : 0;
+    if (rawn == 0 && !no_coop && cnative_usable(v, ncap)) mode = 3;          // pair mode: the Hermitian problem itself (k_bt_coop_c)
     // after a persistent kernel ran out of patience (its workgroups could not all become resident: the GPU is shared with
     // other work) the next solves go straight to the launch-per-step path instead of each paying the wait again
     if (mode && e->cooldown > 0) {
@@ -1412,7 +1682,9 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
-            if (mode == 2)
+            if (mode == 3)
+                hipLaunchKernelGGL(k_bt_coop_c, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp);
+            else if (mode == 2)
                 hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (coop_threads() == 512)
                 hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
@@ -1430,7 +1702,8 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         }
         BtBufs bt = b;
         bt.abort = mode ? e->cp.abort_flag : nullptr;
-        if (b.use_tail) {
+        bt.cnative = mode == 3 ? 1 : 0;
+        if (b.use_tail && mode != 3) {
             // the last BT_TAIL steps on one CU (the kernels above stopped at step n - BT_TAIL; nothing to do for n <= BT_TAIL)
             if (!mode) hipLaunchKernelGGL(k_bt_tail_prep, dim3(32), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
             launch_eig_tail(v, lid, going_left, rawn, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
@@ -1447,6 +1720,9 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (mode == 2 && e->host_flag[1] == ABORT_PLACEMENT) {
             e->xcd_misplaced++;
             mode = 1;
+        } else if (mode == 3) {
+            e->coop_aborts++;
+            mode = 1;           // the embedded real reduction, across the XCDs
         } else {
             e->coop_aborts++;
             e->cooldown = 32;
@@ -1468,13 +1744,17 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
     BtBufs bt = b;
     bt.abort = e->cp.abort_flag;
     bt.sticky = e->sticky;
-    if (xcd_usable(ncap))
+    const bool nat = cnative_usable(v, ncap);
+    bt.cnative = nat ? 1 : 0;
+    if (nat)
+        hipLaunchKernelGGL(k_bt_coop_c, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp);
+    else if (xcd_usable(ncap))
         hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
     else if (coop_threads() == 512)
         hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
     else
         hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
-    if (b.use_tail) launch_eig_tail(v, lid, going_left, 0, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
+    if (b.use_tail && !nat) launch_eig_tail(v, lid, going_left, 0, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
     enqueue_after_tridiag(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, bt, s);
     return 0;
 }
