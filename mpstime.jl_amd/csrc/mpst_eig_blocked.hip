@@ -322,7 +322,10 @@ __device__ __forceinline__ unsigned long long tag_key(unsigned int seq, int kind
 __device__ __forceinline__ void st_tag(double* base, int idx, double x, unsigned long long key) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x), t = key ^ bits;
     const u32x4 q = {(unsigned int)bits, (unsigned int)(bits >> 32), (unsigned int)t, (unsigned int)(t >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(base + 2 * idx), "v"(q) : "memory");
+    // s_nop: a VMEM store of more than 64 bits reads its data registers over two cycles and the next VALU write of those registers
+    // needs a wait state (CDNA3 ISA, data hazards).  The compiler's hazard recogniser does not look into inline asm: two of these
+    // back to back (the complex reduction stores re and im) reused the registers of q and tore the first entry's tag.
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(base + 2 * idx), "v"(q) : "memory");
 }
 __device__ __forceinline__ bool tag_ok(const u32x4 q, unsigned long long key, double& x) {
     const unsigned long long bits = (unsigned long long)q.x | ((unsigned long long)q.y << 32);
@@ -349,6 +352,28 @@ __device__ __forceinline__ bool ld5_tag(const double* p0, const double* p1, cons
     ok = tag_ok(q2, k2, v2) && ok;
     ok = tag_ok(q3, k3, v3) && ok;
     ok = tag_ok(q4, k4, v4) && ok;
+    return ok;
+}
+// six entries (three complex numbers) of the native Hermitian reduction, same protocol
+__device__ __forceinline__ bool ld6_tag(const double* p0, const double* p1, const double* p2, const double* p3, const double* p4, const double* p5,
+                                        unsigned long long ka, unsigned long long kb, unsigned long long kc, double2& v0, double2& v1, double2& v2) {
+    u32x4 q0, q1, q2, q3, q4, q5;
+    asm volatile("global_load_dwordx4 %0, %6, off nt\n\t"
+                 "global_load_dwordx4 %1, %7, off nt\n\t"
+                 "global_load_dwordx4 %2, %8, off nt\n\t"
+                 "global_load_dwordx4 %3, %9, off nt\n\t"
+                 "global_load_dwordx4 %4, %10, off nt\n\t"
+                 "global_load_dwordx4 %5, %11, off nt\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3), "=&v"(q4), "=&v"(q5)
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+                 : "memory");
+    bool ok = tag_ok(q0, ka, v0.x);
+    ok = tag_ok(q1, ka, v0.y) && ok;
+    ok = tag_ok(q2, kb, v1.x) && ok;
+    ok = tag_ok(q3, kb, v1.y) && ok;
+    ok = tag_ok(q4, kc, v2.x) && ok;
+    ok = tag_ok(q5, kc, v2.y) && ok;
     return ok;
 }
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF; }   // HW_REG_XCC_ID[3:0]
@@ -714,7 +739,12 @@ __device__ __forceinline__ void st_c(double2* p, double2 v) {
     __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, SC_AGENT);
 }
 constexpr int BTC_NT = 512, BTC_NMAX = BT_NMAX / 2;
-__global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp) {
+// TAGGED: the XCD-local exchange of k_bt_coop<512, SC_XCD> (self-validating 16-byte entries - two per complex number -, polls through
+// the XCD's L2, no counter; every `stride`-th workgroup of the launch takes part, a roll call checks that they share an XCD), else
+// agent-scope atomics and the counting barrier.
+template <bool TAGGED>
+__global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
+    if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NT = BTC_NT, NW = NT / 64;
     static_assert(BTC_NMAX <= NT, "one element of every length-n vector per thread");
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -723,7 +753,7 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     __shared__ int sh_ok;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
     const int nf = pb.n, n = pb.n >> 1, ld = b.ncap >> 1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int G = (int)gridDim.x, g = (int)blockIdx.x;
+    const int G = ((int)gridDim.x + stride - 1) / stride, g = (int)blockIdx.x / stride;
     double2* xs = (double2*)smem;        // [ld] the reflector v_j (v_{j-1} when a step starts)
     double2* vl = xs + ld;               // [ld] v_{j-1}
     double2* wl = vl + ld;               // [ld] w_{j-1}
@@ -751,21 +781,52 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     }
     double2* ybuf = (double2*)cp.ybuf;
     double2* rowbuf = (double2*)cp.rowbuf;
-    if (g == 0)
-        for (int c = tid; c < n; c += NT) st_c(rowbuf + c, rows[c]);
-    bt_coop_arrive<SC_AGENT>(cp);
+    // TAGGED: a parity buffer holds 2 ld entries of 16 bytes (re, im of element e at entries 2e, 2e + 1) = 4 ld doubles
+    auto put_c = [&](double* base, int e, double2 x, unsigned long long key) {
+        st_tag(base, 2 * e, x.x, key);
+        st_tag(base, 2 * e + 1, x.y, key);
+    };
+    if (TAGGED && !bt_coop_roll_call(cp, G, &sh_ok)) return;          // leaves sh_ok = 1
+    if (g == 0) {
+        for (int c = tid; c < n; c += NT) {
+            if constexpr (TAGGED) put_c(cp.rowbuf, c, rows[c], tag_key(seq, 2, 0));
+            else st_c(rowbuf + c, rows[c]);
+        }
+    }
+    if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
     double2 tau_prev = make_double2(0.0, 0.0);
     for (int j = 0; j <= n - 2; ++j) {
-        if (!bt_coop_wait<SC_AGENT>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
-        const double2* yprev = ybuf + (int64_t)((j + 1) & 1) * ld;
-        const double2* rowj = rowbuf + (int64_t)(j & 1) * ld;
         const int idx = j + tid;
         const bool ok = idx < n;
         const double2 zero = make_double2(0.0, 0.0);
-        double2 yp = (ok && j > 0) ? ld_c(yprev + idx) : zero;
-        const double2 aj = ok ? ld_c(rowj + idx) : zero;
+        double2 yp, aj, yj;
+        if constexpr (TAGGED) {
+            const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * 4 * ld;
+            const double* rowj = cp.rowbuf + (int64_t)(j & 1) * 4 * ld;
+            const unsigned long long kr = tag_key(seq, 2, j), ky = j > 0 ? tag_key(seq, 1, j - 1) : kr;
+            const double* ysrc = j > 0 ? yprev : rowj;            // step 0 has no y: poll the row entries twice
+            const int c0 = ok ? idx : j;                           // out-of-range lanes poll entry j and drop it
+            int spins = 0;
+            while (!ld6_tag(ysrc + 4 * c0, ysrc + 4 * c0 + 2, rowj + 4 * c0, rowj + 4 * c0 + 2, ysrc + 4 * j, ysrc + 4 * j + 2, ky, kr, ky, yp, aj, yj)) {
+                if ((++spins & 255) == 0 &&
+                    (spins > (1 << 19) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sh_ok = 0;                                     // seen by everybody after the next barrier
+                    break;
+                }
+            }
+            yp = (ok && j > 0) ? yp : zero;
+            aj = ok ? aj : zero;
+            yj = j > 0 ? yj : zero;
+        } else {
+            if (!bt_coop_wait<SC_AGENT>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+            const double2* yprev = ybuf + (int64_t)((j + 1) & 1) * ld;
+            const double2* rowj = rowbuf + (int64_t)(j & 1) * ld;
+            yp = (ok && j > 0) ? ld_c(yprev + idx) : zero;
+            aj = ok ? ld_c(rowj + idx) : zero;
+            yj = j > 0 ? ld_c(yprev + j) : zero;
+        }
         const double2 vp = (ok && j > 0) ? xs[idx] : zero;
-        const double2 yj = j > 0 ? ld_c(yprev + j) : zero;
         // (a) alpha_{j-1} = -tau/2 (y^H v)
         double2 alpha;
         {
@@ -777,6 +838,7 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
                 red_a[wave][1] = si;
             }
             __syncthreads();
+            if (TAGGED && sh_ok == 0) return;          // somebody's poll ran out of patience: all leave together
             double ar = 0.0, ai = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -852,6 +914,9 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
         // (c) own rows r > j: pending update, product with the new reflector; the owner of row j+1 publishes it
         double2* ynew = ybuf + (int64_t)(j & 1) * ld;
         double2* rownext = rowbuf + (int64_t)((j + 1) & 1) * ld;
+        double* ynew_t = cp.ybuf + (int64_t)(j & 1) * 4 * ld;
+        double* rownext_t = cp.rowbuf + (int64_t)((j + 1) & 1) * 4 * ld;
+        const unsigned long long key_y = tag_key(seq, 1, j), key_r = tag_key(seq, 2, j + 1);
         for (int k = wave; k < nown; k += NW) {
             const int r = g + k * G;
             if (r <= j) continue;
@@ -866,13 +931,19 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
                 const double2 pr = c_mul(a_, xs[c]);
                 sr += pr.x;
                 si += pr.y;
-                if (pub) st_c(rownext + c, a_);
+                if (pub) {
+                    if constexpr (TAGGED) put_c(rownext_t, c, a_, key_r);
+                    else st_c(rownext + c, a_);
+                }
             }
             sr = wave_sum_fast(sr);
             si = wave_sum_fast(si);
-            if (lane == 0) st_c(ynew + r, c_mul(tau, make_double2(sr, si)));
+            if (lane == 0) {
+                if constexpr (TAGGED) put_c(ynew_t, r, c_mul(tau, make_double2(sr, si)), key_y);
+                else st_c(ynew + r, c_mul(tau, make_double2(sr, si)));
+            }
         }
-        bt_coop_arrive<SC_AGENT>(cp);
+        if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
         bookkeeping();
     }
 }
@@ -896,26 +967,42 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
     }
     const double2* Vc = (const double2*)b.Vall;
     const double2* tauc = (const double2*)b.tau;
-    for (int j = n - 2; j >= 0; --j) {
-        const double2* vj = Vc + (int64_t)j * ldc;
-        double2 vv[QE];
-        double sr = 0.0, si = 0.0;
+    // the next reflector's entries (and its tau) are requested before the current one is applied: the loop is a chain of L2 round
+    // trips otherwise (0.43 ms for 511 reflectors at n = 512)
+    auto fetch = [&](int j, double2 (&dst)[QE], double2& tj) {
+        const double2* vj = Vc + (int64_t)(j >= 0 ? j : 0) * ldc;
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
             const int i = lane + 64 * q;
-            vv[q] = (i > j && i < n) ? vj[i] : make_double2(0.0, 0.0);
+            dst[q] = (j >= 0 && i > j && i < n) ? vj[i] : make_double2(0.0, 0.0);
+        }
+        tj = j >= 0 ? tauc[j] : make_double2(0.0, 0.0);
+    };
+    auto apply = [&](const double2 (&vv)[QE], double2 tj) {
+        double sr = 0.0, si = 0.0;
+#pragma unroll
+        for (int q = 0; q < QE; ++q) {
             sr += vv[q].x * z[q].x + vv[q].y * z[q].y;                 // conj(v) z
             si += vv[q].x * z[q].y - vv[q].y * z[q].x;
         }
         sr = wave_sum_fast(sr);
         si = wave_sum_fast(si);
-        const double2 t = c_mul(tauc[j], make_double2(sr, si));
+        const double2 t = c_mul(tj, make_double2(sr, si));
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
             const double2 u = c_mul(t, vv[q]);
             z[q].x -= u.x;
             z[q].y -= u.y;
         }
+    };
+    double2 va[QE], vb[QE], ta, tb;
+    fetch(n - 2, va, ta);
+    for (int j = n - 2; j >= 0; j -= 2) {
+        fetch(j - 1, vb, tb);
+        apply(va, ta);
+        if (j - 1 < 0) break;
+        fetch(j - 2, va, ta);
+        apply(vb, tb);
     }
     double* zp = zrow + ld;
 #pragma unroll
@@ -1593,6 +1680,17 @@ static size_t coopc_lds(int ncap) {
     const int nc = ncap / 2, G = coopc_grid(ncap);
     return (size_t)(3 + (nc + G - 1) / G) * nc * sizeof(double2);
 }
+// XCD-local variant: 32 workgroups on one XCD, ceil(n / 32) complex rows each.  Measured slower than the agent-scope exchange at
+// both sizes tried (n_c = 256: 1.72 vs 1.21 ms per bond, n_c = 512: 4.58 vs 3.41): two tagged entries per complex element and,
+// at n_c = 512, twice the rows per workgroup.  Opt-in (MPST_BT_C_XCD=1) for measurements only.
+static size_t coopc_xcd_lds(int ncap) {
+    const int nc = ncap / 2;
+    return (size_t)(3 + (nc + XCD_G - 1) / XCD_G) * nc * sizeof(double2);
+}
+static bool cnative_xcd_usable(int ncap) {
+    static const bool on = getenv("MPST_BT_C_XCD") != nullptr && getenv("MPST_BT_NO_XCD") == nullptr;
+    return on && coopc_xcd_lds(ncap) <= 156 * 1024;
+}
 static bool cnative_usable(const View& v, int ncap) {
     static const bool off = getenv("MPST_BT_NO_CNATIVE") != nullptr;
     return !off && v.zw == 2 && (ncap & 1) == 0 && ncap / 2 <= BTC_NMAX && coopc_lds(ncap) <= 150 * 1024;
@@ -1620,7 +1718,8 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
                  hipFuncSetAttribute((const void*)k_bt_coop<256, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop_c, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -1672,7 +1771,8 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
     // mode 2: persistent kernel confined to one XCD; 1: persistent kernel across the XCDs; 0: one launch per step
     int mode = (rawn == 0 && !no_coop) ? (xcd_usable(ncap) ? 2 : 1) : 0;
-    if (rawn == 0 && !no_coop && cnative_usable(v, ncap)) mode = 3;          // pair mode: the Hermitian problem itself (k_bt_coop_c)
+    // pair mode: the Hermitian problem itself (k_bt_coop_c) - 4: confined to one XCD, 3: across the XCDs
+    if (rawn == 0 && !no_coop && cnative_usable(v, ncap)) mode = cnative_xcd_usable(ncap) ? 4 : 3;
     // after a persistent kernel ran out of patience (its workgroups could not all become resident: the GPU is shared with
     // other work) the next solves go straight to the launch-per-step path instead of each paying the wait again
     if (mode && e->cooldown > 0) {
@@ -1682,8 +1782,10 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
-            if (mode == 3)
-                hipLaunchKernelGGL(k_bt_coop_c, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp);
+            if (mode == 4)
+                hipLaunchKernelGGL(k_bt_coop_c<true>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
+            else if (mode == 3)
+                hipLaunchKernelGGL(k_bt_coop_c<false>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
             else if (mode == 2)
                 hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (coop_threads() == 512)
@@ -1702,8 +1804,8 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         }
         BtBufs bt = b;
         bt.abort = mode ? e->cp.abort_flag : nullptr;
-        bt.cnative = mode == 3 ? 1 : 0;
-        if (b.use_tail && mode != 3) {
+        bt.cnative = mode >= 3 ? 1 : 0;
+        if (b.use_tail && mode < 3) {
             // the last BT_TAIL steps on one CU (the kernels above stopped at step n - BT_TAIL; nothing to do for n <= BT_TAIL)
             if (!mode) hipLaunchKernelGGL(k_bt_tail_prep, dim3(32), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
             launch_eig_tail(v, lid, going_left, rawn, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
@@ -1720,7 +1822,10 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (mode == 2 && e->host_flag[1] == ABORT_PLACEMENT) {
             e->xcd_misplaced++;
             mode = 1;
-        } else if (mode == 3) {
+        } else if (mode == 4 && e->host_flag[1] == ABORT_PLACEMENT) {
+            e->xcd_misplaced++;
+            mode = 3;           // the same reduction with the cross-XCD exchange
+        } else if (mode >= 3) {
             e->coop_aborts++;
             mode = 1;           // the embedded real reduction, across the XCDs
         } else {
@@ -1746,8 +1851,10 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
     bt.sticky = e->sticky;
     const bool nat = cnative_usable(v, ncap);
     bt.cnative = nat ? 1 : 0;
-    if (nat)
-        hipLaunchKernelGGL(k_bt_coop_c, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp);
+    if (nat && cnative_xcd_usable(ncap))
+        hipLaunchKernelGGL(k_bt_coop_c<true>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
+    else if (nat)
+        hipLaunchKernelGGL(k_bt_coop_c<false>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
     else if (xcd_usable(ncap))
         hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
     else if (coop_threads() == 512)
