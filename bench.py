@@ -251,7 +251,8 @@ def typed_kernel_model(N, d, chi, C, cx, esz):
         "gram": ("mfma", z * 2.0 * m * n * n, PEAK_FP64_MFMA_TFLOPS),
         "split": ("mfma", z * 2.0 * m * n * chi, PEAK_FP64_MFMA_TFLOPS),
         "bt_assemble": ("mfma", z * 2.0 * C * X * chi * Y, PEAK_FP64_MFMA_TFLOPS),
-        "eig_tri": ("mfma", 4.0 / 3.0 * ne ** 3 + 4.0 * ne * ne * (2 if cx else 1) * chi, PEAK_FP64_MFMA_TFLOPS),
+        # complex: native Hermitian reduction (zhetd2 count = 4 x the real one at order n) + back-transformation of chi complex vectors
+        "eig_tri": ("mfma", (16.0 / 3.0 * n ** 3 + 16.0 * n * n * chi) if cx else (4.0 / 3.0 * n ** 3 + 4.0 * n * n * chi), PEAK_FP64_MFMA_TFLOPS),
         "eig_fin": ("mfma", 8.0 * ne * chi * chi, PEAK_FP64_MFMA_TFLOPS),
         "grad_reduce+update": ("hbm", 0.5 * esz * 6.0 * C * X * Y, PEAK_HBM_GBS),
     }
@@ -358,7 +359,7 @@ def typed_workload(args, mt, torch, rank, dev_index):
         "roofline": {"kernel": dominant, "bound": dk.get("bound", "mfma"), "achieved": dk.get("achieved"), "peak": PEAK_FP64_MFMA_TFLOPS if dominant.startswith("eig") else peak,
                      "unit": dk.get("unit", "TFLOP/s"), "frac": dk.get("frac"), "traffic": None,
                      "avg_us": dk["avg_us"], "note": "dominant kernel class of one profiled sweep (HIP events on the engine's stream); the fp64 eigensolver of the "
-                     "Gram matrix (complex: its 2n x 2n real embedding, one eigenvector per eigenvalue pair) is a dependent chain of Householder steps, not a throughput kernel"},
+                     "Gram matrix (complex: Hermitian reduction to a real tridiagonal matrix with complex reflectors, eigenvectors returned in the 2n embedding the split reads) is a dependent chain of Householder steps, not a throughput kernel"},
         "kernels": kernels,
         "sweep_vs_survey_8d": survey,
         "tolerance_study": study,

@@ -95,6 +95,7 @@ SYMBOLS = {
     "mpst_impute_model_run": (C.c_int, [_vp, C.POINTER(ImputeModel), C.POINTER(C.c_uint8), _dp, _vp, _i32, C.POINTER(ImputeOpts), _dp, _dp,
                                         _dp, _dp]),
     "mpst_get_impute_phases": (C.c_int, [_vp, _dp]),
+    "mpst_get_impute_info": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
     "mpst_selftest_mfma": (C.c_int, [_vp, _dp, _dp, _i32, _dp]),
     "mpst_selftest_eig": (C.c_int, [_vp, _dp, _i32, _i32, _dp, _dp, C.POINTER(_i32)]),
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),

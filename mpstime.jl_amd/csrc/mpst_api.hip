@@ -182,6 +182,7 @@ struct Ctx {
     size_t ev_used = 0;
     double prof_us[16] = {0};
     double impute_phase_s[2] = {0, 0};   // last imputation call: environment pass, density sweep
+    int impute_trig = 0;                 // ... and whether its densities were evaluated in closed form (Fourier states on a uniform grid)
     int64_t prof_cnt[16] = {0};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // one full sweep captured as a hipGraph (bond dimensions live on the device and every grid is sized
@@ -1872,6 +1873,28 @@ int mpst_classify(void* ctx, int which, int32_t* pred, double* yhat) {
     return 0;
 }
 
+// Are the grid states the Fourier basis (src/Encodings/bases.jl:23-42: cispi(f_s x) / sqrt(d), f = 0, 1, -1, 2, -2, ...) on a uniform
+// grid?  Then the kernels evaluate the conditional densities and their cumulative sums in closed form instead of streaming the
+// table (k_imp_left<..., TRIG>).  Decided from the tables the caller handed over, to 1e-12; MPST_IMP_NO_TRIG=1 keeps the table path.
+static bool fourier_grid(const double* gx, const double* gp, int n, int d, double* x0, double* dxu) {
+    if (getenv("MPST_IMP_NO_TRIG")) return false;
+    const double a = gx[0], h = (gx[n - 1] - gx[0]) / (double)(n - 1);
+    if (!(h > 0.0) || !((d - 1) * h < 1.0)) return false;
+    const double tolx = 1e-12 * std::max(1.0, std::max(fabs(a), fabs(gx[n - 1])));
+    const double inv = 1.0 / sqrt((double)d);
+    for (int k = 0; k < n; ++k) {
+        if (fabs(gx[k] - (a + k * h)) > tolx) return false;
+        for (int s = 0; s < d; ++s) {
+            const int f = (s + 1) / 2 * ((s & 1) ? 1 : -1);
+            const double ang = M_PI * (double)f * gx[k];
+            if (fabs(gp[2 * ((size_t)k * d + s)] - cos(ang) * inv) > 1e-12 || fabs(gp[2 * ((size_t)k * d + s) + 1] - sin(ang) * inv) > 1e-12) return false;
+        }
+    }
+    *x0 = a;
+    *dxu = h;
+    return true;
+}
+
 // shared tail of the two imputation entry points: option checks, scratch, launches, results
 static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const double* grid_x, const void* grid_phi, int32_t ngrid,
                       const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
@@ -1933,8 +1956,11 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         HIPC(c, hipMemset(dx, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
+        double gx0 = 0.0, gdx = 0.0;
+        const int trig = (m.is_complex && fourier_grid(grid_x, (const double*)grid_phi, ngrid, d, &gx0, &gdx)) ? 1 : 0;
+        c->impute_trig = trig;
         const ImputeParams q{dmiss, dR, dW, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
-                             ntrial, o->mean_basis, o->rejection_threshold};
+                             ntrial, o->mean_basis, o->rejection_threshold, trig, gx0, gdx};
         // one event between the two kernels of every chunk: the split of the pass into its environment and density halves
         // (mpst_get_impute_phases) costs nothing against kernels of tens of milliseconds
         struct Evs {
@@ -1979,6 +2005,14 @@ int mpst_get_impute_phases(void* ctx, double* seconds_out) {
     if (!c || !seconds_out) return MPST_ERR_INVALID;
     seconds_out[0] = c->impute_phase_s[0];
     seconds_out[1] = c->impute_phase_s[1];
+    return 0;
+}
+
+int mpst_get_impute_info(void* ctx, int32_t* out, int32_t n) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !out || n < 0) return MPST_ERR_INVALID;
+    const int32_t full[1] = {c->impute_trig};
+    for (int i = 0; i < n && i < 1; ++i) out[i] = full[i];
     return 0;
 }
 

@@ -601,6 +601,7 @@ struct ImpArgs {
     int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
     double reject_thr;
     int64_t i0;                 // first instance of this chunk
+    double x0, dxu;             // TRIG kernels: the uniform grid x_k = x0 + k dxu
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2, IMP_BASIS_STOUDENMIRE = 3, IMP_BASIS_SAHAND = 4,
@@ -609,7 +610,16 @@ enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER
 // OCC = workgroups per CU the kernel is compiled for.  Two (256 VGPRs) for real models and for complex ones with d <= 5: the
 // latency-bound loops gain more from the second resident workgroup than the ~300 B of spills cost (45 -> 32 ms at
 // chi = 32); complex models with larger d keep the whole register file (their density loop spills too much at 256).
-template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC) void k_imp_left(ImpModel v, ImpArgs g) {
+//
+// TRIG (complex models whose grid states are the Fourier basis cispi(f_s x) / sqrt(d) on a uniform grid - detected on the host from
+// the tables themselves): p(x) = |rho phi(x)|^2 = sum_ss' conj(phi_s) (rho^H rho)_ss' phi_s' is a trigonometric polynomial with the
+// d harmonics m = f_s' - f_s >= 0, and the prefix sums of the reference's cumulative trapezoid over the grid are geometric series:
+//   p(x) = c_0 + sum_m Re(c_m e^{i pi m x}),   S_K = sum_{k<=K} p(x_k) = c_0 (K + 1) + sum_m Re(B_m (1 - w_m^{K+1})),
+//   w_m = e^{i pi m dx},  B_m = c_m e^{i pi m x_0} / (1 - w_m) = c_m i e^{i pi (m x_0 - m dx / 2)} / (2 sin(pi m dx / 2)).
+// Neither the 20 001 x d table of grid states nor p_k and S_k ever exist: the median, the quantiles and the WMAD evaluate S at the
+// O(log n) indices their searches visit, the mode and the mean evaluate p at every grid value from 2 d coefficients in LDS.
+template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_bounds__(IMP_T, OCC) void k_imp_left(ImpModel v, ImpArgs g) {
+    static_assert(CX || !TRIG, "the closed-form densities are those of the (complex) Fourier basis");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[4];
@@ -617,6 +627,7 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
     __shared__ double rhoi[CX ? IMP_MAXD * IMP_MAXD : 1]; // imaginary part
     __shared__ double wtot[4];                              // totals of the four quarters of the grid (prefix sums)
     __shared__ int isel[4];
+    __shared__ double tcr[TRIG ? IMP_MAXD : 1], tci[TRIG ? IMP_MAXD : 1], tbr[TRIG ? IMP_MAXD : 1], tbi[TRIG ? IMP_MAXD : 1];
     constexpr int ZW = CX ? 2 : 1;
     const int64_t i = g.i0 + blockIdx.x;
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
@@ -760,10 +771,91 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
                 }
                 __syncthreads();
             }
-            // p_k = |rho phi_k|^2: grid values interleaved over the threads (consecutive lanes read consecutive encoded
-            // states: coalesced); then every thread sums its CONTIGUOUS segment for the block-wide scan
             double pmax = -1.0;
             int kmax = 0;
+            double tsum = 0.0, tbound = 0.0;                  // TRIG: sum_m Re(B_m); c_0 + sum_m |c_m| >= max p
+            if constexpr (TRIG) {
+                if (tid < d) {
+                    const int m = tid;
+                    double cr = 0.0, ci = 0.0;
+                    for (int a = 0; a < d; ++a) {
+                        const int fa = (a + 1) / 2 * ((a & 1) ? 1 : -1), fb = fa + m;
+                        const int bx = fb == 0 ? 0 : (fb > 0 ? 2 * fb - 1 : -2 * fb);        // the state of frequency fb
+                        if (bx >= d) continue;
+                        for (int s_ = 0; s_ < d; ++s_) {                                      // (rho^H rho)[a][bx]
+                            const double ar = rho[s_ * IMP_MAXD + a], ai = rhoi[s_ * IMP_MAXD + a];
+                            const double br = rho[s_ * IMP_MAXD + bx], bi = rhoi[s_ * IMP_MAXD + bx];
+                            cr = fma(ar, br, fma(ai, bi, cr));
+                            ci = fma(ar, bi, fma(-ai, br, ci));
+                        }
+                    }
+                    const double sc = (m == 0 ? 1.0 : 2.0) / (double)d;
+                    cr *= sc;
+                    ci = m == 0 ? 0.0 : ci * sc;
+                    tcr[m] = cr;
+                    tci[m] = ci;
+                    double br_ = 0.0, bi_ = 0.0;
+                    if (m > 0) {
+                        double sa, ca, sn, cs;
+                        sincospi(0.5 * m * g.dxu, &sa, &ca);
+                        sincospi((double)m * g.x0 - 0.5 * m * g.dxu, &sn, &cs);
+                        const double er = -sn / (2.0 * sa), ei = cs / (2.0 * sa);               // i e^{i pi (m x0 - m dx / 2)} / (2 sin)
+                        br_ = cr * er - ci * ei;
+                        bi_ = cr * ei + ci * er;
+                    }
+                    tbr[m] = br_;
+                    tbi[m] = bi_;
+                }
+                __syncthreads();
+                tbound = tcr[0];
+                for (int m = 1; m < d; ++m) {
+                    tsum += tbr[m];
+                    tbound += sqrt(tcr[m] * tcr[m] + tci[m] * tci[m]);
+                }
+            }
+            // TRIG: p at a grid value / the inclusive prefix sum S_K, from the coefficients
+            auto Ptrig = [&](double x) {
+                double s1, c1;
+                sincospi(x, &s1, &c1);
+                double c = c1, sn = s1, acc = TRIG ? tcr[0] : 0.0;
+                if constexpr (TRIG)
+                    for (int m = 1; m < d; ++m) {
+                        acc = fma(tcr[m], c, acc);
+                        acc = fma(-tci[m], sn, acc);
+                        const double cn = fma(c, c1, -sn * s1);
+                        sn = fma(sn, c1, c * s1);
+                        c = cn;
+                    }
+                return acc;
+            };
+            auto Strig = [&](int K) {
+                double s1, c1;
+                sincospi((double)(K + 1) * g.dxu, &s1, &c1);
+                double c = c1, sn = s1, acc = TRIG ? fma(tcr[0], (double)(K + 1), tsum) : 0.0;
+                if constexpr (TRIG)
+                    for (int m = 1; m < d; ++m) {
+                        acc = fma(-tbr[m], c, acc);
+                        acc = fma(tbi[m], sn, acc);
+                        const double cn = fma(c, c1, -sn * s1);
+                        sn = fma(sn, c1, c * s1);
+                        c = cn;
+                    }
+                return acc;
+            };
+            // TRIG: the maximum over the grid, only where a method needs it (mode; the WMAD's one-weight-above-half rule)
+            auto scan_pmax = [&]() {
+                for (int k = tid; k < n; k += IMP_T) {
+                    const double pk = Ptrig(g.grid_x[k]);
+                    if (pk > pmax) {
+                        pmax = pk;
+                        kmax = k;
+                    }
+                }
+            };
+            const int nrow = (n + 63) >> 6, rpw = (nrow + 3) >> 2, quarter = rpw * 64;
+            if constexpr (!TRIG) {
+            // p_k = |rho phi_k|^2: grid values interleaved over the threads (consecutive lanes read consecutive encoded
+            // states: coalesced); then every thread sums its CONTIGUOUS segment for the block-wide scan
             if constexpr (CX) {
                 // rho stays in LDS (every lane reads the same entry: broadcast), two grid values per round trip
                 const double2* gp = reinterpret_cast<const double2*>(g.grid_phi);
@@ -917,7 +1009,6 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
             // four quarter totals sit in LDS and Sabs() adds the right ones.  No barrier inside the pass.  (The first
             // version gave every thread a contiguous segment: four passes of uncoalesced, latency-bound loads, 64 us per
             // imputed site whatever chi and d - 70 % of the kernel at chi = 32.)
-            const int nrow = (n + 63) >> 6, rpw = (nrow + 3) >> 2, quarter = rpw * 64;
             const int row0 = wave * rpw, row1 = min(nrow, row0 + rpw);
             {
                 constexpr int PF = 8;
@@ -949,13 +1040,19 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
             }
             __threadfence_block();
             __syncthreads();
+            }
             const double woff1 = wtot[0], woff2 = woff1 + wtot[1], woff3 = woff2 + wtot[2];
             auto Sabs = [&](int k) {
+                if constexpr (TRIG) return Strig(k);
                 const int qd = k / quarter;
                 return S[k] + (qd == 0 ? 0.0 : (qd == 1 ? woff1 : (qd == 2 ? woff2 : woff3)));
             };
-            const double Stot = woff3 + wtot[3];
-            const double p0 = p[0];
+            auto Pat = [&](int k) {
+                if constexpr (TRIG) return Ptrig(g.grid_x[k]);
+                return p[k];
+            };
+            const double Stot = TRIG ? Strig(n - 1) : woff3 + wtot[3];
+            const double p0 = Pat(0);
             auto cdf_at = [&](int k) { return k == 0 ? 0.0 : 0.5 * dx * ((Sabs(k - 1) + Sabs(k)) - p0); };   // cumulative trapezoid
             const double Z = cdf_at(n - 1);
             // first index of the block-wide maximum of p (mode; also the weighted median's "one weight above half" rule)
@@ -1016,9 +1113,13 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
             auto wmad = [&](int kc) {
                 const double xc = g.grid_x[kc];
                 const double mid = 0.5 * (Stot / Z);
-                double gm;
-                const int km = arg_pmax(gm);
-                if (gm / Z > mid) return fabs(g.grid_x[km] - xc);
+                // (TRIG: no grid value can outweigh half the total unless the bound c_0 + sum |c_m| does - never on a fine grid)
+                if (!TRIG || tbound / Z > mid) {
+                    if constexpr (TRIG) scan_pmax();
+                    double gm;
+                    const int km = arg_pmax(gm);
+                    if (gm / Z > mid) return fabs(g.grid_x[km] - xc);
+                }
                 auto light = [&](int jj) {          // the window of half-width jj does NOT yet outweigh half the total
                     const int hi = min(n - 1, kc + jj), lo = kc - jj - 1;
                     const double shi = Sabs(hi), slo = lo >= 0 ? Sabs(lo) : 0.0;
@@ -1041,6 +1142,7 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
             double xsel = 0.0, err = 0.0;
             bool state_from_grid = true;
             if (g.method == IMP_MODE) {
+                if constexpr (TRIG) scan_pmax();
                 double gm;
                 ksel = arg_pmax(gm);                                         // get_mode_from_rdm, sampling_utils.jl:98-143
             } else if (g.method == IMP_MEDIAN) {
@@ -1070,7 +1172,7 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const int k = kb + q * IMP_T;
-                        t[q] = k < n ? p[k] : 0.0;
+                        t[q] = k < n ? Pat(k) : 0.0;
                         xx[q] = k < n ? g.grid_x[k] : 0.0;
                     }
 #pragma unroll
@@ -1085,7 +1187,7 @@ template <typename R, bool CX, int OCC> __global__ __launch_bounds__(IMP_T, OCC)
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
                             const int k = kb + q * IMP_T;
-                            t[q] = k < n ? p[k] : 0.0;
+                            t[q] = k < n ? Pat(k) : 0.0;
                             xx[q] = k < n ? g.grid_x[k] : ex;
                         }
 #pragma unroll
@@ -1232,6 +1334,14 @@ hipError_t impute_init_attrs(int device) {
                                  (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;                                \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
                                  (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;
+#define IMP_ATTR_TRIG(R, F32)                                                                                                      \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                 (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;                              \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                 (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;
+    IMP_ATTR_TRIG(double, false)
+    IMP_ATTR_TRIG(float, true)
+#undef IMP_ATTR_TRIG
     IMP_ATTR(double, false, false)
     IMP_ATTR(double, true, false)
     IMP_ATTR(float, false, true)
@@ -1252,12 +1362,20 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
                            (R*)q.Rbuf, q.max_missing, i0, q.rev);
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
-              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0};
+              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0, q.x0, q.dxu};
     // two workgroups per CU (128 VGPRs each, 70-183 of them spilled) against one (256 VGPRs, no spill): the spilling
     // build wins where the density loop is latency-bound - real models and complex ones with d <= 5 - because a second
     // workgroup hides more than the scratch traffic costs (same-box A/B: profiles/r03_impute_occupancy_ab.txt;
     // MPST_IMP_OCC=1|2 forces either)
     static const int force_occ = [] { const char* e = getenv("MPST_IMP_OCC"); return e ? atoi(e) : 0; }();
+    if constexpr (CX) {
+        if (q.trig) {
+            // closed-form densities: no density loop, so no reason to keep the whole register file for one workgroup
+            if (force_occ == 1) hipLaunchKernelGGL((k_imp_left<R, CX, 1, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+            else hipLaunchKernelGGL((k_imp_left<R, CX, 2, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+            return;
+        }
+    }
     if (force_occ == 1 || (force_occ != 2 && CX && v.d > 5))
         hipLaunchKernelGGL((k_imp_left<R, CX, 1>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
     else

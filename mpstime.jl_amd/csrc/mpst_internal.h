@@ -626,6 +626,8 @@ struct ImputeParams {
     double *pbuf, *sbuf, *x_out, *err_out;
     int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
     double reject_thr;
+    int trig;                   // the grid states are the Fourier basis on the uniform grid x0 + k dxu: densities in closed form
+    double x0, dxu;
 };
 int impute_chi_limit(bool cx, bool f32);
 int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scratch elements of the large-chi environment kernel

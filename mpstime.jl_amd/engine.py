@@ -351,6 +351,12 @@ class SweepEngine:
         self._chk(self.lib.mpst_get_impute_phases(self.ctx, out.ctypes.data_as(C.POINTER(C.c_double))))
         return float(out[0]), float(out[1])
 
+    def impute_info(self):
+        """how the last imputation call ran: {"closed_form_densities": bool} (Fourier grid states on a uniform grid)"""
+        out = (C.c_int32 * 1)()
+        self._chk(self.lib.mpst_get_impute_info(self.ctx, out, 1))
+        return {"closed_form_densities": bool(out[0])}
+
     def normalize(self):
         self._chk(self.lib.mpst_normalize(self.ctx))
 

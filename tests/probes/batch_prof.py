@@ -2,7 +2,8 @@
 import sys
 import time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import mpstime_jl_amd as mt
 import bench

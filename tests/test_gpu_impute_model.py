@@ -69,6 +69,7 @@ def test_complex_fourier_model_fp64(engine_cls, cfg, order):
         x_mode, _, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 1, False, order=o)
         x_its, _, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u, order=o)
         x_mean, e_mean, _ = eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, order=o)
+        assert eng.impute_info()["closed_form_densities"]          # Fourier states on a uniform grid: recognised
     finally:
         eng.close()
     _check(W, xs, grid_phi, phi, y, m, x_med, e_med, "median", order)
@@ -81,6 +82,55 @@ def test_complex_fourier_model_fp64(engine_cls, cfg, order):
             continue
         xo, eo = I.impute(classes[y[i]], phi[i], sites, xs, grid_phi, "mean", order, True, None, encode=enc)
         assert np.abs(x_mean[i, sites] - xo).max() < 1e-9 and np.abs(e_mean[i, sites] - eo).max() < 1e-9
+
+
+@pytest.mark.parametrize("compute", ["f64", "f32"])
+def test_closed_form_densities_equal_the_table_path(engine_cls, compute, monkeypatch):
+    """Fourier grid states on a uniform grid: densities and cumulative sums from 2d coefficients (k_imp_left<..., TRIG>) against
+    the same kernel streaming the table of grid states (MPST_IMP_NO_TRIG=1), every method, on the reference's 20 001-value
+    grid; a grid that is not uniform, or states that are not the Fourier basis, keep the table path."""
+    N, T, d, chi, C = 12, 16, 8, 12, 2
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=77, ngrid=20001, cx=True)
+    u = rng.uniform(0.02, 0.98, (N, T, 3))
+    eng = engine_cls(0)
+    try:
+        runs = {}
+        for tag in ("trig", "table"):
+            if tag == "table":
+                monkeypatch.setenv("MPST_IMP_NO_TRIG", "1")
+            runs[tag] = [eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 1, False, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u[:, :, :1], compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 4, True, u, max_trials=3, rejection_threshold=1.0, compute=compute)[:2]]
+            assert eng.impute_info()["closed_form_densities"] == (tag == "trig")
+        monkeypatch.delenv("MPST_IMP_NO_TRIG")
+        xs2 = xs.copy()
+        xs2[5000] += 1e-6
+        eng.impute_model(W, phi, y, m, xs2, grid_phi, 0, True, compute=compute)
+        assert not eng.impute_info()["closed_form_densities"]
+        gp2 = grid_phi.copy()
+        gp2[:, 3] = np.conj(gp2[:, 3])
+        eng.impute_model(W, phi, y, m, xs, gp2, 0, True, compute=compute)
+        assert not eng.impute_info()["closed_form_densities"]
+    finally:
+        eng.close()
+    mask = m.astype(bool)
+    dx = xs[1] - xs[0]
+    for k, ((xa, ea), (xb, eb)) in enumerate(zip(runs["trig"], runs["table"])):
+        if k == 3:          # mean: sums over the grid in another order
+            assert np.abs(xa - xb)[mask].max() < 1e-11 and np.abs(ea - eb)[mask].max() < 1e-11
+            continue
+        # selections: the same grid value, up to a cumulative sum that lands within rounding of a threshold (then one step, and
+        # the conditioning carries the difference on: such instances are counted, not compared further)
+        bad = [i for i in range(N) if not np.array_equal(xa[i], xb[i])]
+        assert len(bad) <= 1, (k, bad)
+        for i in bad:
+            first = int(np.argmax(xa[i] != xb[i]))
+            assert abs(xa[i, first] - xb[i, first]) <= dx * 1.0000001
+        good = [i for i in range(N) if i not in bad]
+        if ea is not None and k in (0, 4):
+            assert np.abs(ea[good] - eb[good]).max() <= dx * 1.0000001
 
 
 def test_real_model_run_is_the_context_path(engine_cls):
