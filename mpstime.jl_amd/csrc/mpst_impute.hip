@@ -208,8 +208,8 @@ __device__ __forceinline__ void lds_tile(typename Mx<R>::acc_t& accr, typename M
         accr = Mx<R>::mma(ar, br, accr);
         if constexpr (CX) {
             const R ai = A.i[ia0 + 4 * u], bi = B.i[ib0 + bstep * u];
+            acci = Mx<R>::mma(ai, br, acci);                 // the two accumulator chains alternate
             accr = Mx<R>::mma(TB ? ai : -ai, bi, accr);
-            acci = Mx<R>::mma(ai, br, acci);
             acci = Mx<R>::mma(TB ? -ar : ar, bi, acci);
         }
     }
@@ -240,7 +240,8 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
     const int msz = cp * ld, bsz = 16 * ld;
     const int tpr = cp >> 4;                                   // tiles per row of a padded matrix: 1, 2, 3 or 4
     const int ngrp = tpr >= 3 ? 1 : (tpr == 2 ? 2 : 4);        // groups of waves that take row blocks in turn
-    const int grp = wave / (4 / ngrp), wc = wave % (4 / ngrp);  // this wave's group and column tile
+    const int ncol = 4 / ngrp;                                  // waves (column tiles) per group
+    const int grp = wave / ncol, wc = wave % ncol;              // this wave's group and column tile
     const Plane<R> Rc{smem, smem + (ZW - 1) * msz};                                      // current environment matrix
     const Plane<R> Ms{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};                // M_j or W_j[s] as an (out x in) matrix of this pass
     const Plane<R> T1{smem + 2 * ZW * msz, smem + 2 * ZW * msz + (ZW - 1) * ngrp * bsz};  // one 16-row block of Ms * R per group
@@ -346,8 +347,11 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
                         }
                     }
                     __syncthreads();
-                    // R'[16 rb .., 16 wc ..] += T1 block * Ms[16 wc .. 16 wc + 15][:]^H
-                    if (rb < tmo && wc < tmo) lds_tile<R, CX, true>(rnr[it], rni[it], Tg, 0, Ms, 16 * wc, ksi, ld);
+                    // R'[16 rb .., 16 wc2 ..] += T1 block * Ms[16 wc2 .. 16 wc2 + 15][:]^H - R' is Hermitian: only the tiles on and
+                    // above the diagonal are formed (10 of 16 at chi = 64), and the column tile a wave takes rotates with the
+                    // row block so that the idle turns are spread over the four SIMDs (the CU's other workgroup fills them)
+                    const int wc2 = (wc + rb) % ncol;
+                    if (rb < tmo && wc2 < tmo && wc2 >= rb) lds_tile<R, CX, true>(rnr[it], rni[it], Tg, 0, Ms, 16 * wc2, ksi, ld);
                     __syncthreads();
                 }
             }
@@ -356,14 +360,20 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
         // (every density below is scale-free); rows / columns beyond Do must be zero for the next site
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int rb = grp + it * ngrp;
+            const int rb = grp + it * ngrp, wc2 = (wc + rb) % ncol;
+            if (wc2 < rb) continue;                 // below the diagonal: written by the owner of the mirrored tile
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc + i16;
+                const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc2 + i16;
                 if (row < cp && col < cp) {
-                    const bool live = rb < tmo && wc < tmo && row < Do && col < Do;
-                    Rc.r[row * ld + col] = live ? rnr[it][r] : R(0);
-                    if constexpr (CX) Rc.i[row * ld + col] = live ? rni[it][r] : R(0);
+                    const bool live = rb < tmo && wc2 < tmo && row < Do && col < Do;
+                    const R xr = live ? rnr[it][r] : R(0), xi = (CX && live) ? rni[it][r] : R(0);
+                    Rc.r[row * ld + col] = xr;
+                    if constexpr (CX) Rc.i[row * ld + col] = xi;
+                    if (wc2 > rb) {
+                        Rc.r[col * ld + row] = xr;
+                        if constexpr (CX) Rc.i[col * ld + row] = -xi;
+                    }
                 }
             }
         }
