@@ -161,6 +161,7 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
         x, e, secs = eng.impute_model(W, phi, lab, m, xs, gphi, 0, True, compute="f32")
         dev_s += secs
     eng_phases = eng.impute_phases()
+    closed_form = eng.impute_info()["closed_form_densities"]
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -184,6 +185,15 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
     roof_den = {"kernel": "k_imp_left<float, complex>", "bound": "hbm", "achieved": bytes_den / t_den / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": bytes_den / t_den / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_ms": 1e3 * t_den,
                 "note": f"its density loop does {flops_den / t_den / 1e12:.2f} TFLOP/s of fp64 VALU work (vector peak 78.6) at one workgroup per CU; the p / prefix-sum streams are the HBM figure"}
+    if closed_form:
+        # Fourier states on a uniform grid: densities and cumulative sums come from 2d coefficients, no table, no p / S streams.  What
+        # is left per instance is a dependent chain of T matrix-vector products (L W_j: the site tensors come from the L2) plus, per
+        # missing site, one read of its chi x chi environment (the only HBM stream) and O(log ngrid) closed-form evaluations
+        bytes_den = sites * chi * chi * 8.0 + N * T * d * 8.0
+        roof_den = {"kernel": "k_imp_left<float, complex, closed-form densities>", "bound": "hbm", "achieved": bytes_den / t_den / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": bytes_den / t_den / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_ms": 1e3 * t_den,
+                    "note": "latency chain: one workgroup per instance walks its T sites (matrix-vector products against site tensors served by the L2, "
+                            "then the selections on 2d Fourier coefficients); bytes = the environments of the missing sites + the encoded series"}
     line = {"metric": "site-imputations/sec (imputation engine, BASELINE configs[4])", "value": value, "unit": "site-imputations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 model; f32 chain contractions (MFMA f32 16x16x4), f64 densities",
@@ -191,6 +201,7 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
             "config": {"workload": f"median imputation + WMAD of a 50 % block, N={N} instances per GPU, T={T}, chi={chi}, d={d} Fourier "
                                    f"(complex random canonical MPS), 20001-value grid", "parallelism": f"instances sharded over {world} GPU(s), no collective"},
             "roofline": roof_env if dom_env else roof_den, "roofline_other_kernel": roof_den if dom_env else roof_env,
+            "closed_form_densities": bool(closed_form),
             "wall_ms_per_step_incl_pcie_and_host_packing": 1e3 * wall / args.steps}
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import impute_numpy as I         # the checker, timed as the CPU baseline on a bounded sample

@@ -97,137 +97,68 @@ template <typename R, bool CX> __device__ __forceinline__ SiteView<R> site_view(
 }
 
 // ---- right environments ------------------------------------------------------------------------------------------------
-// C (M x N, row stride ld) (+)= A (M x K) * B, all in LDS, 16 x 16 tiles on the MFMA shared out over the 4 waves.
-// tb = false: B is K x N row-major; tb = true: B holds the N x K operand whose conjugate transpose is meant, C += A * B^H.
-// Complex operands are (real plane, imaginary plane) pairs.  Rows / columns beyond M / N / K must be zero in the operands
-// (the buffers are kept zero-padded to multiples of 16).
+// Matrices in LDS are (real plane, imaginary plane) pairs, zero-padded to multiples of 16 rows / columns.
 template <typename R> struct Plane {
     R *r, *i;
 };
-// one unit of lds_mm: a 16-row block of C times NTE (compile-time) column tiles.  Nothing in the k-loop is predicated: a
-// runtime "is this tile live" test around every MFMA made the compiler shuttle the accumulators between VGPRs and AccVGPRs
-// and wait out every MFMA's latency (5.8 us for a 64^3 product whose matrix-pipe time is 1.7 us).
-template <typename R, bool CX, int NTE, bool TB>
-__device__ __forceinline__ void lds_mm_unit(Plane<R> Cm, Plane<R> A, Plane<R> B, int m0, int nb, int ks, int ld, bool accumulate) {
-    using acc_t = typename Mx<R>::acc_t;
-    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
-    acc_t accr[NTE], acci[NTE];
+
+// The environment of the sites beyond a missing site, R' = sum_s Ms R Ms^H with Ms = W_j[s] (missing site) or
+// sum_q conj(phi_q) W_j[q] (known site).  LDS holds R, the site matrix and the whole product T1 = Ms R: one workgroup per CU,
+// a wave per 16 x 16 tile (16 waves at chi = 64), 3 barriers per site matrix, and W_j[s + 1] is on its way into registers while
+// W_j[s] is used.  (Round 3's kernel kept one 16-row block of T1 and two workgroups of 4 waves per CU: 8 x 4 x 2 phases of
+// 64 MFMAs per site with a barrier after each - 482 ms at configs[4] for 175 ms of matrix time; this one 313 ms.)  Both products read their operands ALONG rows: T1 = Ms R = Ms (R)^H because R is Hermitian, R' += T1 Ms^H;
+// the MFMA does not care which k goes with which (k-quarter, step) slot as long as A and B agree, so lane (row, kq) takes
+// k = kq * ks + u: consecutive steps are consecutive addresses, one ds_read_b128 feeds 4 (fp32) or 2 (fp64) steps.
+template <int NW> __device__ __forceinline__ double blk_sum_n(double x, double* red) {
+    x = wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+    __syncthreads();
+    double t = 0.0;
 #pragma unroll
-    for (int t = 0; t < NTE; ++t) {
-        accr[t] = acc_t{0, 0, 0, 0};
-        acci[t] = acc_t{0, 0, 0, 0};
-    }
-    if (accumulate) {
-#pragma unroll
-        for (int t = 0; t < NTE; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
-                accr[t][r] = Cm.r[at];
-                if constexpr (CX) acci[t][r] = Cm.i[at];
-            }
-    }
-    const int ia0 = (m0 + i16) * ld + kq;
-    int ib0[NTE];
-#pragma unroll
-    for (int t = 0; t < NTE; ++t) ib0[t] = TB ? ((nb + t) * 16 + i16) * ld + kq : kq * ld + (nb + t) * 16 + i16;
-    const int bstep = TB ? 4 : 4 * ld;
-    for (int u = 0; u < ks; ++u) {
-        const R ar = A.r[ia0 + 4 * u];
-        R ai = R(0);
-        if constexpr (CX) ai = A.i[ia0 + 4 * u];
-        R br[NTE], bi[NTE];
-#pragma unroll
-        for (int t = 0; t < NTE; ++t) {
-            br[t] = B.r[ib0[t] + bstep * u];
-            if constexpr (CX) bi[t] = B.i[ib0[t] + bstep * u];
-        }
-#pragma unroll
-        for (int t = 0; t < NTE; ++t) {
-            accr[t] = Mx<R>::mma(ar, br[t], accr[t]);
-            if constexpr (CX) {
-                // plain: (ar + i ai)(br + i bi);  TB: (ar + i ai)(br - i bi)
-                accr[t] = Mx<R>::mma(TB ? ai : -ai, bi[t], accr[t]);
-                acci[t] = Mx<R>::mma(ai, br[t], acci[t]);
-                acci[t] = Mx<R>::mma(TB ? -ar : ar, bi[t], acci[t]);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NTE; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int at = (m0 + Mx<R>::row(kq, r)) * ld + (nb + t) * 16 + i16;
-            Cm.r[at] = accr[t][r];
-            if constexpr (CX) Cm.i[at] = acci[t][r];
-        }
+    for (int w = 0; w < NW; ++w) t += red[w];
+    return t;
 }
+// C (+)= A[a_row0 .. +15][:] * B[n0 .. +15][:]^H over k = 0 .. 4 ks - 1; ks a multiple of 16 / sizeof(R), rows 16-byte aligned
 template <typename R, bool CX>
-__device__ __forceinline__ void lds_mm(Plane<R> Cm, Plane<R> A, Plane<R> B, int M, int N, int K, int ld, bool tb, bool accumulate) {
-    const int wave = threadIdx.x >> 6;
-    const int tm = (M + 15) >> 4, tn = (N + 15) >> 4, ks = (K + 3) >> 2;
-    // a wave owns a 16-row block of C and up to 4 of its column tiles at a time: the A operand is read once for all of
-    // them and the independent accumulator chains keep the matrix pipe busy between dependent k-steps
-    // (as many as it takes to give each of the 4 waves one unit of work: small matrices keep one tile per wave)
-    constexpr int NT = 4;
-    const int nte = min(NT, max(1, (tm * tn + 3) >> 2));
-    const int ngrp = (tn + nte - 1) / nte;
-    for (int unit = wave; unit < tm * ngrp; unit += 4) {
-        const int m0 = (unit / ngrp) * 16;
-        const int nb = (unit % ngrp) * nte;
-        const int cnt = min(tn, nb + nte) - nb;
-        if (tb) {
-            switch (cnt) {
-                case 1: lds_mm_unit<R, CX, 1, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                case 2: lds_mm_unit<R, CX, 2, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                case 3: lds_mm_unit<R, CX, 3, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                default: lds_mm_unit<R, CX, 4, true>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
+__device__ __forceinline__ void lds_tile_rows(typename Mx<R>::acc_t& cr, typename Mx<R>::acc_t& ci, Plane<R> A, int a_row0, Plane<R> B, int n0,
+                                              int ks, int ld) {
+    constexpr int VEC = 16 / (int)sizeof(R);
+    typedef R vec_t __attribute__((ext_vector_type(VEC)));
+    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int ia = (a_row0 + i16) * ld + kq * ks, ib = (n0 + i16) * ld + kq * ks;
+    const vec_t* Ar = reinterpret_cast<const vec_t*>(A.r + ia);
+    const vec_t* Br = reinterpret_cast<const vec_t*>(B.r + ib);
+    const vec_t* Ai = reinterpret_cast<const vec_t*>(A.i + ia);
+    const vec_t* Bi = reinterpret_cast<const vec_t*>(B.i + ib);
+    const int ng = ks / VEC;
+    for (int g = 0; g < ng; ++g) {
+        const vec_t ar = Ar[g], br = Br[g];
+        if constexpr (CX) {
+            const vec_t ai = Ai[g], bi = Bi[g];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                cr = Mx<R>::mma(ar[e], br[e], cr);
+                ci = Mx<R>::mma(ai[e], br[e], ci);
+                cr = Mx<R>::mma(ai[e], bi[e], cr);
+                ci = Mx<R>::mma(-ar[e], bi[e], ci);
             }
         } else {
-            switch (cnt) {
-                case 1: lds_mm_unit<R, CX, 1, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                case 2: lds_mm_unit<R, CX, 2, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                case 3: lds_mm_unit<R, CX, 3, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-                default: lds_mm_unit<R, CX, 4, false>(Cm, A, B, m0, nb, ks, ld, accumulate); break;
-            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) cr = Mx<R>::mma(ar[e], br[e], cr);
         }
     }
 }
-
-// one 16 x 16 tile C(m0.., n0..) (+)= A[m0.. rows] * B  or  A * B^H (TB: B holds the N x K operand), operands in LDS planes
-// with leading dimension ld, the accumulator stays with the caller
-template <typename R, bool CX, bool TB>
-__device__ __forceinline__ void lds_tile(typename Mx<R>::acc_t& accr, typename Mx<R>::acc_t& acci, Plane<R> A, int a_row0, Plane<R> B, int n0,
-                                         int ks, int ld) {
-    const int lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
-    const int ia0 = (a_row0 + i16) * ld + kq;
-    const int ib0 = TB ? (n0 + i16) * ld + kq : kq * ld + n0 + i16;
-    const int bstep = TB ? 4 : 4 * ld;
-    for (int u = 0; u < ks; ++u) {
-        const R ar = A.r[ia0 + 4 * u], br = B.r[ib0 + bstep * u];
-        accr = Mx<R>::mma(ar, br, accr);
-        if constexpr (CX) {
-            const R ai = A.i[ia0 + 4 * u], bi = B.i[ib0 + bstep * u];
-            acci = Mx<R>::mma(ai, br, acci);                 // the two accumulator chains alternate
-            accr = Mx<R>::mma(TB ? ai : -ai, bi, accr);
-            acci = Mx<R>::mma(TB ? -ar : ar, bi, acci);
-        }
-    }
-}
-
-// LDS holds the current environment R, the site matrix Ms and ONE 16-row block of T1 = Ms R; the new environment
-// R' = sum_s Ms R Ms^H never visits LDS while it is summed: wave w keeps column tile w of all (up to four) row blocks in
-// MFMA accumulators across the whole s loop.  2 x chi^2 + 16 chi elements instead of 4 x chi^2: two workgroups per CU at
-// chi = 64, which is what hides the site-tensor loads and the barriers of one workgroup behind the other's matrix work.
-template <typename R, bool CX>
-__global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
-                                                     int max_missing, int64_t i0, int rev) {
+template <typename R, bool CX, int IMR_T>
+__global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
+                                                      int max_missing, int64_t i0, int rev) {
     using acc_t = typename Mx<R>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
-    __shared__ double red[4];
+    __shared__ double red[IMR_T / 64];
+    constexpr int NW = IMR_T / 64, NQ = IMR_T == 512 ? 5 : 4;      // waves; site-matrix elements per thread (the host picks IMR_T)
     constexpr int ZW = CX ? 2 : 1;
-    const int64_t i = i0 + blockIdx.x;          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
+    const int64_t i = i0 + blockIdx.x;
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const uint8_t* mi = missing + i * T;
@@ -235,160 +166,154 @@ __global__ __launch_bounds__(IMP_T) void k_imp_right(ImpModel v, const uint8_t* 
     for (int j = 0; j < T; ++j) nm += mi[j] ? 1 : 0;
     if (nm == 0) return;
     const int cls = v.label[i];
-    const int cp = (cm + 15) & ~15;            // matrices are kept zero-padded to a multiple of 16 rows / columns
-    const int ld = cp + 2;                     // + 2: the 16 rows an MFMA operand read touches land on different banks
-    const int msz = cp * ld, bsz = 16 * ld;
-    const int tpr = cp >> 4;                                   // tiles per row of a padded matrix: 1, 2, 3 or 4
-    const int ngrp = tpr >= 3 ? 1 : (tpr == 2 ? 2 : 4);        // groups of waves that take row blocks in turn
-    const int ncol = 4 / ngrp;                                  // waves (column tiles) per group
-    const int grp = wave / ncol, wc = wave % ncol;              // this wave's group and column tile
-    const Plane<R> Rc{smem, smem + (ZW - 1) * msz};                                      // current environment matrix
-    const Plane<R> Ms{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};                // M_j or W_j[s] as an (out x in) matrix of this pass
-    const Plane<R> T1{smem + 2 * ZW * msz, smem + 2 * ZW * msz + (ZW - 1) * ngrp * bsz};  // one 16-row block of Ms * R per group
-    for (int e = tid; e < ZW * (2 * msz + ngrp * bsz); e += IMP_T) smem[e] = R(0);
+    const int cp = (cm + 15) & ~15;
+    const int ld = cp + 16 / (int)sizeof(R);       // rows 16-byte aligned and 4 banks apart: conflict-free 128-bit operand reads
+    const int msz = cp * ld;
+    const int tpr = cp >> 4, ntile = tpr * tpr, ks = cp >> 2;
+    const Plane<R> Rc{smem, smem + (ZW - 1) * msz};
+    const Plane<R> Ms{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};
+    const Plane<R> T1{smem + 2 * ZW * msz, smem + 2 * ZW * msz + (ZW - 1) * msz};
+    for (int e = tid; e < 3 * ZW * msz; e += IMR_T) smem[e] = R(0);
     __syncthreads();
     if (tid == 0) Rc.r[0] = R(1);
     __syncthreads();
+    // this wave's tiles of the tpr x tpr grid: wave (and wave + NW: only 9 tiles on 8 waves)
+    const bool h0 = wave < ntile, h1 = wave + NW < ntile;
+    const int rbA = h0 ? wave / tpr : 0, wcA = h0 ? wave % tpr : 0;
+    const int rbB = h1 ? (wave + NW) / tpr : rbA, wcB = h1 ? (wave + NW) % tpr : wcA;
     int slot = 0;
     for (int step = 0; step < T; ++step) {
-        // forwards imputation: this pass runs right to left and a site is entered through its RIGHT bond
         const int j = rev ? step : T - 1 - step;
         const SiteView<R> sv = site_view<R, CX>(v, j, cls, rev != 0);
-        const int Di = sv.Din, Do = sv.Dout;        // R is Di x Di, the new one Do x Do
+        const int Di = sv.Din, Do = sv.Dout;
         const bool miss = mi[j] != 0;
         if (miss) {
-            // the environment of the sites beyond j is what site j's density matrix needs
             R* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm * ZW;
-            for (int e = tid; e < Di * Di; e += IMP_T) {
+            for (int e = tid; e < Di * Di; e += IMR_T) {
                 const int at = (e / Di) * ld + (e % Di);
                 zstore<R, CX>(out, e, Rc.r[at], CX ? Rc.i[at] : R(0));
             }
             ++slot;
-            if (slot == nm) break;                 // nothing beyond the last missing site of this pass needs an environment
+            if (slot == nm) break;
         }
         const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
         const int ns = miss ? d : 1;
-        // consecutive threads walk the contiguous bond index of the stored tensor (its right bond)
         const bool in_fast = sv.si == 1;
         const int Df = in_fast ? Di : Do;
-        const int tmo = (Do + 15) >> 4, tni = (Di + 15) >> 4, ksi = (Di + 3) >> 2;
-        acc_t rnr[4], rni[4];                       // this wave's column tile of the new environment, its row blocks
+        const int tmo = (Do + 15) >> 4, tni = (Di + 15) >> 4;
+        // the (at most NQ) elements of the site matrix this thread carries
+        int64_t off[NQ];
+        int dst[NQ];
+        R fr[NQ], fi[NQ];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            rnr[rb] = acc_t{0, 0, 0, 0};
-            rni[rb] = acc_t{0, 0, 0, 0};
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + q * IMR_T;
+            const int slow = e / Df, fast = e - slow * Df;
+            const int ii = in_fast ? fast : slow, oo = in_fast ? slow : fast;
+            off[q] = (int64_t)ii * sv.si + (int64_t)oo * sv.so;
+            dst[q] = e < Di * Do ? oo * ld + ii : -1;
         }
+        auto fetch = [&](int s_) {          // Ms = W_j[s_] (missing) or sum_q conj(phi_q) W_j[q] (known)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                fr[q] = R(0);
+                fi[q] = R(0);
+            }
+            if (miss) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                    if (dst[q] >= 0) zload<R, CX>(sv.W, off[q] + (int64_t)s_ * sv.ss, fr[q], fi[q]);
+            } else {
+                for (int qq = 0; qq < d; ++qq) {
+                    R pr, pi;
+                    zload<R, CX>(ph, qq, pr, pi);
+                    R wr[NQ], wi[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        wr[q] = R(0);
+                        wi[q] = R(0);
+                        if (dst[q] >= 0) zload<R, CX>(sv.W, off[q] + (int64_t)qq * sv.ss, wr[q], wi[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        fr[q] = fma(pr, wr[q], fr[q]);
+                        if constexpr (CX) {
+                            fr[q] = fma(pi, wi[q], fr[q]);
+                            fi[q] = fma(pr, wi[q], fi[q]);
+                            fi[q] = fma(-pi, wr[q], fi[q]);
+                        }
+                    }
+                }
+            }
+        };
+        acc_t rnr[2], rni[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            rnr[t] = acc_t{0, 0, 0, 0};
+            rni[t] = acc_t{0, 0, 0, 0};
+        }
+        fetch(0);
         for (int s = 0; s < ns; ++s) {
-            // Ms[o][i] = M_j = sum_q conj(phi_q) W_j[q] (known) or W_j[s] (missing); 8 elements per thread per round trip
-            for (int e0 = tid; e0 < Di * Do; e0 += 8 * IMP_T) {
-                R accr[8], acci[8];
-                int64_t off[8];
-                int dst[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int e = e0 + q * IMP_T;
-                    const int slow = e / Df, fast = e - slow * Df;
-                    const int ii = in_fast ? fast : slow, oo = in_fast ? slow : fast;
-                    off[q] = (int64_t)ii * sv.si + (int64_t)oo * sv.so;
-                    dst[q] = oo * ld + ii;
-                    accr[q] = R(0);
-                    acci[q] = R(0);
+            for (int q = 0; q < NQ; ++q)
+                if (dst[q] >= 0) {
+                    Ms.r[dst[q]] = fr[q];
+                    if constexpr (CX) Ms.i[dst[q]] = fi[q];
                 }
-                if (miss) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (e0 + q * IMP_T < Di * Do) zload<R, CX>(sv.W, off[q] + (int64_t)s * sv.ss, accr[q], acci[q]);
-                } else {
-                    for (int qq = 0; qq < d; ++qq) {
-                        R pr, pi;
-                        zload<R, CX>(ph, qq, pr, pi);
-                        R wr[8], wi[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            wr[q] = R(0);
-                            wi[q] = R(0);
-                            if (e0 + q * IMP_T < Di * Do) zload<R, CX>(sv.W, off[q] + (int64_t)qq * sv.ss, wr[q], wi[q]);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            accr[q] = fma(pr, wr[q], accr[q]);
-                            if constexpr (CX) {
-                                accr[q] = fma(pi, wi[q], accr[q]);
-                                acci[q] = fma(pr, wi[q], acci[q]);
-                                acci[q] = fma(-pi, wr[q], acci[q]);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (e0 + q * IMP_T < Di * Do) {
-                        Ms.r[dst[q]] = accr[q];
-                        if constexpr (CX) Ms.i[dst[q]] = acci[q];
-                    }
-            }
             __syncthreads();
-            // row blocks are dealt out to `ngrp` groups of waves (4 / tiles-per-row groups: small matrices would leave
-            // most waves without a column tile); a group works on row block grp + it * ngrp in its own T1 block
+            if (s + 1 < ns) fetch(s + 1);          // in flight during both products (the barriers below order LDS only)
+            // T1 = Ms R^H (Do x Di)
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int rb = grp + it * ngrp;
-                if (it * ngrp < tmo) {                      // uniform over the workgroup: every group takes the barriers
-                    const Plane<R> Tg{T1.r + grp * bsz, T1.i + grp * bsz};
-                    if (rb < tmo && wc < tni) {
-                        // T1 block = Ms[16 rb .. 16 rb + 15][:] * R: this wave's column tile (R is Di x Di)
-                        acc_t tr = {0, 0, 0, 0}, ti = {0, 0, 0, 0};
-                        lds_tile<R, CX, false>(tr, ti, Ms, 16 * rb, Rc, 16 * wc, ksi, ld);
+            for (int t = 0; t < 2; ++t) {
+                const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
+                if ((t == 0 ? h0 : h1) && rb < tmo && wc < tni) {
+                    acc_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
+                    lds_tile_rows<R, CX>(ar, ai, Ms, 16 * rb, Rc, 16 * wc, ks, ld);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int at = Mx<R>::row(kq, r) * ld + 16 * wc + i16;
-                            Tg.r[at] = tr[r];
-                            if constexpr (CX) Tg.i[at] = ti[r];
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const int at = (16 * rb + Mx<R>::row(kq, r)) * ld + 16 * wc + i16;
+                        T1.r[at] = ar[r];
+                        if constexpr (CX) T1.i[at] = ai[r];
                     }
-                    __syncthreads();
-                    // R'[16 rb .., 16 wc2 ..] += T1 block * Ms[16 wc2 .. 16 wc2 + 15][:]^H - R' is Hermitian: only the tiles on and
-                    // above the diagonal are formed (10 of 16 at chi = 64), and the column tile a wave takes rotates with the
-                    // row block so that the idle turns are spread over the four SIMDs (the CU's other workgroup fills them)
-                    const int wc2 = (wc + rb) % ncol;
-                    if (rb < tmo && wc2 < tmo && wc2 >= rb) lds_tile<R, CX, true>(rnr[it], rni[it], Tg, 0, Ms, 16 * wc2, ksi, ld);
-                    __syncthreads();
                 }
             }
-        }
-        // the new environment replaces the old one in LDS (every read of R is behind the last barrier), rescaled by its trace
-        // (every density below is scale-free); rows / columns beyond Do must be zero for the next site
+            lds_barrier();
+            // R' += T1 Ms^H (Do x Do)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int rb = grp + it * ngrp, wc2 = (wc + rb) % ncol;
-            if (wc2 < rb) continue;                 // below the diagonal: written by the owner of the mirrored tile
+            for (int t = 0; t < 2; ++t) {
+                const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
+                if ((t == 0 ? h0 : h1) && rb < tmo && wc < tmo) lds_tile_rows<R, CX>(rnr[t], rni[t], T1, 16 * rb, Ms, 16 * wc, ks, ld);
+            }
+            lds_barrier();
+        }
+        // the new environment replaces the old one, rescaled by its trace; rows / columns beyond Do are zero for the next site
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool have = t == 0 ? h0 : h1;
+            const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
+            if (!have) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc2 + i16;
-                if (row < cp && col < cp) {
-                    const bool live = rb < tmo && wc2 < tmo && row < Do && col < Do;
-                    const R xr = live ? rnr[it][r] : R(0), xi = (CX && live) ? rni[it][r] : R(0);
-                    Rc.r[row * ld + col] = xr;
-                    if constexpr (CX) Rc.i[row * ld + col] = xi;
-                    if (wc2 > rb) {
-                        Rc.r[col * ld + row] = xr;
-                        if constexpr (CX) Rc.i[col * ld + row] = -xi;
-                    }
-                }
+                const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc + i16;
+                const bool live = row < Do && col < Do;
+                Rc.r[row * ld + col] = live ? rnr[t][r] : R(0);
+                if constexpr (CX) Rc.i[row * ld + col] = live ? rni[t][r] : R(0);
             }
         }
         __syncthreads();
         double tr = 0.0;
-        for (int a_ = tid; a_ < Do; a_ += IMP_T) tr += (double)Rc.r[a_ * ld + a_];
-        tr = blk_sum(tr, red);
+        for (int a_ = tid; a_ < Do; a_ += IMR_T) tr += (double)Rc.r[a_ * ld + a_];
+        tr = blk_sum_n<NW>(tr, red);
         const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
-        for (int e = tid; e < cp * cp; e += IMP_T) {
+        for (int e = tid; e < cp * cp; e += IMR_T) {
             const int a_ = e / cp, b2 = e - a_ * cp;
             Rc.r[a_ * ld + b2] *= sc;
             Ms.r[a_ * ld + b2] = R(0);
+            T1.r[a_ * ld + b2] = R(0);
             if constexpr (CX) {
                 Rc.i[a_ * ld + b2] *= sc;
                 Ms.i[a_ * ld + b2] = R(0);
+                T1.i[a_ * ld + b2] = R(0);
             }
         }
         __syncthreads();
@@ -1319,8 +1244,7 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
 
 static size_t right_lds_bytes(int cap, bool cx, bool f32) {
     const int cp = (cap + 15) & ~15;
-    const int ngrp = cp >= 48 ? 1 : (cp == 32 ? 2 : 4);
-    return (size_t)(cx ? 2 : 1) * (2 * cp + 16 * ngrp) * (cp + 2) * (f32 ? 4 : 8);
+    return (size_t)(cx ? 2 : 1) * 3 * cp * (cp + (f32 ? 4 : 2)) * (f32 ? 4 : 8);
 }
 static size_t left_lds_bytes(int cap, bool cx, bool f32) {
     return (size_t)(2 * cap + 2 * IMP_MAXD * cap + IMP_MAXD) * (cx ? 2 : 1) * (f32 ? 4 : 8);
@@ -1338,8 +1262,12 @@ hipError_t impute_init_attrs(int device) {
     if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
     hipError_t e;
 #define IMP_ATTR(R, CX, F32)                                                                                                       \
-    if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX>, hipFuncAttributeMaxDynamicSharedMemorySize,                      \
-                                 (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;           \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                 (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;          \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,                \
+                                 (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;          \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                 (int)right_lds_bytes(impute_lds_chi_limit(CX, F32), CX, F32))) != hipSuccess) return e;          \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
                                  (int)left_lds_bytes(CAP_LIMIT, CX, F32))) != hipSuccess) return e;                                \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, CX, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,                    \
@@ -1367,9 +1295,14 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     if (v.cap > impute_lds_chi_limit(CX, F32))
         hipLaunchKernelGGL((k_imp_right_big<R, CX>), dim3((unsigned)count), dim3(IMP_T), 0, s, v, q.missing, (R*)q.Rbuf, (R*)q.work,
                            q.max_missing, i0, q.rev);
-    else
-        hipLaunchKernelGGL((k_imp_right<R, CX>), dim3((unsigned)count), dim3(IMP_T), right_lds_bytes(v.cap, CX, F32), s, v, q.missing,
-                           (R*)q.Rbuf, q.max_missing, i0, q.rev);
+    else {
+        // a wave per 16 x 16 tile: 16, 9 (on 8 waves), 4 or 1 tiles
+        const int tpr = (v.cap + 15) >> 4;
+        const size_t lds = right_lds_bytes(v.cap, CX, F32);
+        if (tpr >= 4) hipLaunchKernelGGL((k_imp_right<R, CX, 1024>), dim3((unsigned)count), dim3(1024), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
+        else if (tpr == 3) hipLaunchKernelGGL((k_imp_right<R, CX, 512>), dim3((unsigned)count), dim3(512), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
+        else hipLaunchKernelGGL((k_imp_right<R, CX, 256>), dim3((unsigned)count), dim3(256), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
+    }
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0, q.x0, q.dxu};
