@@ -597,34 +597,60 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
         const int Di = sv.Din, Do = sv.Dout;
         const bool miss = mi[j] != 0;
         // LW[s][o] = sum_i L[i] W(i, s, o) for both kinds of site; a known site then contracts s with its encoded value.
-        // Forwards consecutive threads are consecutive o (contiguous in memory), backwards the 8 loads of a thread are.
-        for (int e = tid; e < d * Do; e += IMP_T) {
-            const int s_ = e / Do, o = e - s_ * Do;
-            const int64_t w0 = (int64_t)s_ * sv.ss + (int64_t)o * sv.so;
-            R tr = R(0), ti = R(0);
-            for (int a0 = 0; a0 < Di; a0 += 8) {
-                R wr[8], wi[8];
+        // Forwards consecutive threads are consecutive o (contiguous in memory), backwards the loads of a thread are.  Two
+        // outputs x 16 bond values = 32 loads in flight per thread: the loop is a chain of round trips to the L2 / memory-side
+        // cache (the 262 KB site tensor of configs[4] is re-read by every instance), so their number is what counts.
+        {
+            const int nout = d * Do;
+            auto lw_pass = [&](auto NOc) {
+                constexpr int NO = decltype(NOc)::value, LQ = TRIG ? 16 : 8;    // (the table kernels are at their register limit: 8 as before)
+                for (int e0 = tid; e0 < nout; e0 += NO * IMP_T) {
+                    const int e1 = e0 + IMP_T;
+                    const bool v1 = NO == 2 && e1 < nout;
+                    const int s0 = e0 / Do, o0 = e0 - s0 * Do, s1 = v1 ? e1 / Do : s0, o1 = v1 ? e1 - s1 * Do : o0;
+                    const int64_t w0 = (int64_t)s0 * sv.ss + (int64_t)o0 * sv.so, w1 = (int64_t)s1 * sv.ss + (int64_t)o1 * sv.so;
+                    R tr0 = R(0), ti0 = R(0), tr1 = R(0), ti1 = R(0);
+                    for (int a0 = 0; a0 < Di; a0 += LQ) {
+                        R wr0[LQ], wi0[LQ], wr1[NO == 2 ? LQ : 1], wi1[NO == 2 ? LQ : 1];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    wr[q] = R(0);
-                    wi[q] = R(0);
-                    if (a0 + q < Di) zload<R, CX>(sv.W, w0 + (int64_t)(a0 + q) * sv.si, wr[q], wi[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (a0 + q < Di) {
-                        const R lr = L.r[a0 + q];
-                        tr = fma(lr, wr[q], tr);
-                        if constexpr (CX) {
-                            const R li = L.i[a0 + q];
-                            tr = fma(-li, wi[q], tr);
-                            ti = fma(lr, wi[q], ti);
-                            ti = fma(li, wr[q], ti);
+                        for (int q = 0; q < LQ; ++q) {
+                            wr0[q] = wi0[q] = R(0);
+                            if constexpr (NO == 2) wr1[q] = wi1[q] = R(0);
+                            if (a0 + q < Di) {
+                                zload<R, CX>(sv.W, w0 + (int64_t)(a0 + q) * sv.si, wr0[q], wi0[q]);
+                                if constexpr (NO == 2)
+                                    if (v1) zload<R, CX>(sv.W, w1 + (int64_t)(a0 + q) * sv.si, wr1[q], wi1[q]);
+                            }
                         }
+#pragma unroll
+                        for (int q = 0; q < LQ; ++q)
+                            if (a0 + q < Di) {
+                                const R lr = L.r[a0 + q];
+                                tr0 = fma(lr, wr0[q], tr0);
+                                if constexpr (NO == 2) tr1 = fma(lr, wr1[q], tr1);
+                                if constexpr (CX) {
+                                    const R li = L.i[a0 + q];
+                                    tr0 = fma(-li, wi0[q], tr0);
+                                    ti0 = fma(lr, wi0[q], ti0);
+                                    ti0 = fma(li, wr0[q], ti0);
+                                    if constexpr (NO == 2) {
+                                        tr1 = fma(-li, wi1[q], tr1);
+                                        ti1 = fma(lr, wi1[q], ti1);
+                                        ti1 = fma(li, wr1[q], ti1);
+                                    }
+                                }
+                            }
                     }
-            }
-            LW.r[s_ * cm + o] = tr;
-            if constexpr (CX) LW.i[s_ * cm + o] = ti;
+                    LW.r[s0 * cm + o0] = tr0;
+                    if constexpr (CX) LW.i[s0 * cm + o0] = ti0;
+                    if (v1) {
+                        LW.r[s1 * cm + o1] = tr1;
+                        if constexpr (CX) LW.i[s1 * cm + o1] = ti1;
+                    }
+                }
+            };
+            if (nout > IMP_T) lw_pass(std::integral_constant<int, 2>{});
+            else lw_pass(std::integral_constant<int, 1>{});
         }
         __syncthreads();
         if (!miss) {
@@ -648,33 +674,63 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
         } else {
             const R* Rm = (const R*)g.Rbuf + ((int64_t)blockIdx.x * g.max_missing + (nm - 1 - seen)) * cm * cm * ZW;      // [Do][Do] compact
             ++seen;
-            // U = LW R;  rho = U LW^H
-            for (int e = tid; e < d * Do; e += IMP_T) {
-                const int s_ = e / Do, o = e - s_ * Do;
-                R tr = R(0), ti = R(0);
-                for (int q0 = 0; q0 < Do; q0 += 8) {
-                    R rr8[8], ri8[8];
+            // U = LW R;  rho = U LW^H   (R: this instance's environment of the site, read once from memory - same load pattern)
+            {
+                const int nout = d * Do;
+                auto u_pass = [&](auto NOc) {
+                    constexpr int NO = decltype(NOc)::value, LQ = TRIG ? 16 : 8;    // (the table kernels are at their register limit: 8 as before)
+                    for (int e0 = tid; e0 < nout; e0 += NO * IMP_T) {
+                        const int e1 = e0 + IMP_T;
+                        const bool v1 = NO == 2 && e1 < nout;
+                        const int s0 = e0 / Do, o0 = e0 - s0 * Do, s1 = v1 ? e1 / Do : s0, o1 = v1 ? e1 - s1 * Do : o0;
+                        const bool share = o1 == o0;      // (the usual case: the two outputs share the column of R)
+                        R tr0 = R(0), ti0 = R(0), tr1 = R(0), ti1 = R(0);
+                        for (int q0 = 0; q0 < Do; q0 += LQ) {
+                            R r0[LQ], j0[LQ], r1[NO == 2 ? LQ : 1], j1[NO == 2 ? LQ : 1];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        rr8[q] = R(0);
-                        ri8[q] = R(0);
-                        if (q0 + q < Do) zload<R, CX>(Rm, (int64_t)(q0 + q) * Do + o, rr8[q], ri8[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (q0 + q < Do) {
-                            const R ar = LW.r[s_ * cm + q0 + q];
-                            tr = fma(ar, rr8[q], tr);
-                            if constexpr (CX) {
-                                const R ai = LW.i[s_ * cm + q0 + q];
-                                tr = fma(-ai, ri8[q], tr);
-                                ti = fma(ar, ri8[q], ti);
-                                ti = fma(ai, rr8[q], ti);
+                            for (int q = 0; q < LQ; ++q) {
+                                r0[q] = j0[q] = R(0);
+                                if constexpr (NO == 2) r1[q] = j1[q] = R(0);
+                                if (q0 + q < Do) {
+                                    zload<R, CX>(Rm, (int64_t)(q0 + q) * Do + o0, r0[q], j0[q]);
+                                    if constexpr (NO == 2)
+                                        if (v1 && !share) zload<R, CX>(Rm, (int64_t)(q0 + q) * Do + o1, r1[q], j1[q]);
+                                }
                             }
+#pragma unroll
+                            for (int q = 0; q < LQ; ++q)
+                                if (q0 + q < Do) {
+                                    const R a0r = LW.r[s0 * cm + q0 + q];
+                                    tr0 = fma(a0r, r0[q], tr0);
+                                    if constexpr (CX) {
+                                        const R a0i = LW.i[s0 * cm + q0 + q];
+                                        tr0 = fma(-a0i, j0[q], tr0);
+                                        ti0 = fma(a0r, j0[q], ti0);
+                                        ti0 = fma(a0i, r0[q], ti0);
+                                    }
+                                    if constexpr (NO == 2) {
+                                        const R x1 = share ? r0[q] : r1[q], y1 = share ? j0[q] : j1[q];
+                                        const R a1r = LW.r[s1 * cm + q0 + q];
+                                        tr1 = fma(a1r, x1, tr1);
+                                        if constexpr (CX) {
+                                            const R a1i = LW.i[s1 * cm + q0 + q];
+                                            tr1 = fma(-a1i, y1, tr1);
+                                            ti1 = fma(a1r, y1, ti1);
+                                            ti1 = fma(a1i, x1, ti1);
+                                        }
+                                    }
+                                }
                         }
-                }
-                U.r[s_ * cm + o] = tr;
-                if constexpr (CX) U.i[s_ * cm + o] = ti;
+                        U.r[s0 * cm + o0] = tr0;
+                        if constexpr (CX) U.i[s0 * cm + o0] = ti0;
+                        if (v1) {
+                            U.r[s1 * cm + o1] = tr1;
+                            if constexpr (CX) U.i[s1 * cm + o1] = ti1;
+                        }
+                    }
+                };
+                if (nout > IMP_T) u_pass(std::integral_constant<int, 2>{});
+                else u_pass(std::integral_constant<int, 1>{});
             }
             __syncthreads();
             for (int e = tid; e < d * d; e += IMP_T) {
