@@ -683,7 +683,7 @@ def main():
                   "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
                   "split": "mpst::k_split", "env": "mpst::k_env_split" if fused else "mpst::k_env",
                   "grad_reduce+update": "mpst::k_fused_reduce" if fused else "mpst::k_grad_reduce"}
-        pmc_file = os.path.join("profiles", "r03_pmc_counters.json")
+        pmc_file = os.path.join("profiles", "r04_pmc_counters.json")
         pmc, pmc_quoted = {}, None
         try:
             pj = json.load(open(os.path.join(ROOT, pmc_file)))
