@@ -171,9 +171,10 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
     const int msz = cp * ld;
     const int tpr = cp >> 4, ntile = tpr * tpr, ks = cp >> 2;
     const Plane<R> Rc{smem, smem + (ZW - 1) * msz};
-    const Plane<R> Ms{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};
+    const Plane<R> Ms0{smem + ZW * msz, smem + ZW * msz + (ZW - 1) * msz};              // the site matrix, double-buffered
+    const Plane<R> Ms1{smem + 3 * ZW * msz, smem + 3 * ZW * msz + (ZW - 1) * msz};
     const Plane<R> T1{smem + 2 * ZW * msz, smem + 2 * ZW * msz + (ZW - 1) * msz};
-    for (int e = tid; e < 3 * ZW * msz; e += IMR_T) smem[e] = R(0);
+    for (int e = tid; e < 4 * ZW * msz; e += IMR_T) smem[e] = R(0);
     __syncthreads();
     if (tid == 0) Rc.r[0] = R(1);
     __syncthreads();
@@ -252,16 +253,20 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             rnr[t] = acc_t{0, 0, 0, 0};
             rni[t] = acc_t{0, 0, 0, 0};
         }
-        fetch(0);
-        for (int s = 0; s < ns; ++s) {
+        auto put = [&](const Plane<R>& M) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 if (dst[q] >= 0) {
-                    Ms.r[dst[q]] = fr[q];
-                    if constexpr (CX) Ms.i[dst[q]] = fi[q];
+                    M.r[dst[q]] = fr[q];
+                    if constexpr (CX) M.i[dst[q]] = fi[q];
                 }
-            __syncthreads();
-            if (s + 1 < ns) fetch(s + 1);          // in flight during both products (the barriers below order LDS only)
+        };
+        fetch(0);
+        put(Ms0);
+        __syncthreads();
+        if (ns > 1) fetch(1);                       // in flight during the first product
+        for (int s = 0; s < ns; ++s) {
+            const Plane<R>& Ms = (s & 1) ? Ms1 : Ms0;
             // T1 = Ms R^H (Do x Di)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -277,7 +282,11 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
                     }
                 }
             }
-            lds_barrier();
+            // the next site matrix goes into the other buffer (last read before the previous step's closing barrier): its
+            // load had a whole product to arrive, and the step needs two barriers instead of three
+            if (s + 1 < ns) put((s & 1) ? Ms0 : Ms1);
+            __syncthreads();
+            if (s + 2 < ns) fetch(s + 2);
             // R' += T1 Ms^H (Do x Do)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -308,11 +317,13 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
         for (int e = tid; e < cp * cp; e += IMR_T) {
             const int a_ = e / cp, b2 = e - a_ * cp;
             Rc.r[a_ * ld + b2] *= sc;
-            Ms.r[a_ * ld + b2] = R(0);
+            Ms0.r[a_ * ld + b2] = R(0);
+            Ms1.r[a_ * ld + b2] = R(0);
             T1.r[a_ * ld + b2] = R(0);
             if constexpr (CX) {
                 Rc.i[a_ * ld + b2] *= sc;
-                Ms.i[a_ * ld + b2] = R(0);
+                Ms0.i[a_ * ld + b2] = R(0);
+                Ms1.i[a_ * ld + b2] = R(0);
                 T1.i[a_ * ld + b2] = R(0);
             }
         }
@@ -1300,7 +1311,7 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
 
 static size_t right_lds_bytes(int cap, bool cx, bool f32) {
     const int cp = (cap + 15) & ~15;
-    return (size_t)(cx ? 2 : 1) * 3 * cp * (cp + (f32 ? 4 : 2)) * (f32 ? 4 : 8);
+    return (size_t)(cx ? 2 : 1) * 4 * cp * (cp + (f32 ? 4 : 2)) * (f32 ? 4 : 8);
 }
 static size_t left_lds_bytes(int cap, bool cx, bool f32) {
     return (size_t)(2 * cap + 2 * IMP_MAXD * cap + IMP_MAXD) * (cx ? 2 : 1) * (f32 ? 4 : 8);
