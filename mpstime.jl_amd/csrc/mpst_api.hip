@@ -1931,6 +1931,21 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         maxm = std::max(maxm, mm);
     }
     std::vector<double> xo((size_t)N * T, 0.0), eo((size_t)N * T, 0.0);
+    // Instances are dealt out to workgroups in the order of where their missing sites begin (in the direction of the sweep):
+    // workgroups that are resident together then walk the chain in step and find the site tensor the first of them fetched
+    // still in the L2 (a 262 KB tensor per site at configs[4], re-read by every instance).  Results do not depend on the order.
+    std::vector<int32_t> order((size_t)N);
+    {
+        std::vector<int32_t> key((size_t)N, T);
+        const bool backwards = o->order == MPST_IMPUTE_BACKWARDS;
+        for (int64_t i = 0; i < N; ++i) {
+            order[i] = (int32_t)i;
+            for (int j = 0; j < T; ++j)
+                if (missing[i * T + (backwards ? T - 1 - j : j)]) { key[i] = j; break; }
+        }
+        if (getenv("MPST_IMP_NO_ORDER") == nullptr)
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    }
     if (maxm > 0) {
         // instances are processed in chunks so that the per-instance scratch (environments of the missing sites, p_k and
         // its prefix sums) stays below ~8 GB
@@ -1938,16 +1953,19 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         const int64_t per = (int64_t)maxm * m.cap * m.cap * zw + welems + 2ll * ngrid;
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
         uint8_t *dmiss = nullptr, *dR = nullptr, *dW = nullptr;
+        int32_t* dord = nullptr;
         double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
         struct Temps {
-            uint8_t **m, **r, **w; double **b, **cc, **dd, **e, **f, **g, **h;
-            ~Temps() { dfree(m); dfree(r); dfree(w); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); }
-        } temps{&dmiss, &dR, &dW, &dgx, &dgp, &du, &dp, &dS, &dx, &de};
+            uint8_t **m, **r, **w; double **b, **cc, **dd, **e, **f, **g, **h; int32_t** o;
+            ~Temps() { dfree(m); dfree(r); dfree(w); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); dfree(o); }
+        } temps{&dmiss, &dR, &dW, &dgx, &dgp, &du, &dp, &dS, &dx, &de, &dord};
         int rc;
         if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, (int64_t)(chunk * maxm * m.cap * m.cap * zw * esz))) ||
             (rc = dalloc(c, &dgx, ngrid)) || (rc = dalloc(c, &dgp, (int64_t)ngrid * d * zw)) || (rc = dalloc(c, &dp, chunk * ngrid)) ||
             (rc = dalloc(c, &dS, chunk * ngrid)) || (rc = dalloc(c, &dx, N * T)) || (rc = dalloc(c, &de, N * T))) return rc;
         if (sampling && (rc = dalloc(c, &du, N * T * ntrial))) return rc;
+        if ((rc = dalloc(c, &dord, N))) return rc;
+        HIPC(c, hipMemcpy(dord, order.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice));
         if (welems && (rc = dalloc(c, &dW, (int64_t)(chunk * welems * esz)))) return rc;
         HIPC(c, hipMemcpy(dmiss, missing, (size_t)N * T, hipMemcpyHostToDevice));
         HIPC(c, hipMemcpy(dgx, grid_x, (size_t)ngrid * sizeof(double), hipMemcpyHostToDevice));
@@ -1960,7 +1978,7 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         const int trig = (m.is_complex && fourier_grid(grid_x, (const double*)grid_phi, ngrid, d, &gx0, &gdx)) ? 1 : 0;
         c->impute_trig = trig;
         const ImputeParams q{dmiss, dR, dW, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
-                             ntrial, o->mean_basis, o->rejection_threshold, trig, gx0, gdx};
+                             ntrial, o->mean_basis, o->rejection_threshold, trig, gx0, gdx, dord};
         // one event between the two kernels of every chunk: the split of the pass into its environment and density halves
         // (mpst_get_impute_phases) costs nothing against kernels of tens of milliseconds
         struct Evs {

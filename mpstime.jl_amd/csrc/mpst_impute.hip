@@ -151,14 +151,14 @@ __device__ __forceinline__ void lds_tile_rows(typename Mx<R>::acc_t& cr, typenam
 }
 template <typename R, bool CX, int IMR_T>
 __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
-                                                      int max_missing, int64_t i0, int rev) {
+                                                      int max_missing, const int32_t* __restrict__ ord, int rev) {
     using acc_t = typename Mx<R>::acc_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[IMR_T / 64];
     constexpr int NW = IMR_T / 64, NQ = IMR_T == 512 ? 5 : 4;      // waves; site-matrix elements per thread (the host picks IMR_T)
     constexpr int ZW = CX ? 2 : 1;
-    const int64_t i = i0 + blockIdx.x;
+    const int64_t i = ord[blockIdx.x];          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const uint8_t* mi = missing + i * T;
@@ -432,10 +432,10 @@ __device__ __forceinline__ void gmem_mm(R* __restrict__ Cm, int ldc, GMat<R> A, 
 
 template <typename R, bool CX>
 __global__ __launch_bounds__(IMP_T) void k_imp_right_big(ImpModel v, const uint8_t* __restrict__ missing, R* __restrict__ Rbuf,
-                                                         R* __restrict__ work /* [chunk][4][cap*cap] */, int max_missing, int64_t i0, int rev) {
+                                                         R* __restrict__ work /* [chunk][4][cap*cap] */, int max_missing, const int32_t* __restrict__ ord, int rev) {
     __shared__ double red[4];
     constexpr int ZW = CX ? 2 : 1;
-    const int64_t i = i0 + blockIdx.x;
+    const int64_t i = ord[blockIdx.x];          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
     const uint8_t* mi = missing + i * T;
     int nm = 0;
@@ -546,7 +546,7 @@ struct ImpArgs {
     double* err_out;            // [N][T]
     int max_missing, ngrid, method, get_wmad, rev, ntrial, mean_basis;
     double reject_thr;
-    int64_t i0;                 // first instance of this chunk
+    const int32_t* ord;         // the instances of this chunk (run_impute orders them by where their missing sites begin)
     double x0, dxu;             // TRIG kernels: the uniform grid x_k = x0 + k dxu
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
@@ -575,7 +575,7 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
     __shared__ int isel[4];
     __shared__ double tcr[TRIG ? IMP_MAXD : 1], tci[TRIG ? IMP_MAXD : 1], tbr[TRIG ? IMP_MAXD : 1], tbi[TRIG ? IMP_MAXD : 1];
     constexpr int ZW = CX ? 2 : 1;
-    const int64_t i = g.i0 + blockIdx.x;
+    const int64_t i = g.ord[blockIdx.x];
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
     const uint8_t* mi = g.missing + i * T;
     int nm = 0;
@@ -1361,18 +1361,18 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     constexpr bool F32 = std::is_same<R, float>::value;
     if (v.cap > impute_lds_chi_limit(CX, F32))
         hipLaunchKernelGGL((k_imp_right_big<R, CX>), dim3((unsigned)count), dim3(IMP_T), 0, s, v, q.missing, (R*)q.Rbuf, (R*)q.work,
-                           q.max_missing, i0, q.rev);
+                           q.max_missing, q.order + i0, q.rev);
     else {
         // a wave per 16 x 16 tile: 16, 9 (on 8 waves), 4 or 1 tiles
         const int tpr = (v.cap + 15) >> 4;
         const size_t lds = right_lds_bytes(v.cap, CX, F32);
-        if (tpr >= 4) hipLaunchKernelGGL((k_imp_right<R, CX, 1024>), dim3((unsigned)count), dim3(1024), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
-        else if (tpr == 3) hipLaunchKernelGGL((k_imp_right<R, CX, 512>), dim3((unsigned)count), dim3(512), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
-        else hipLaunchKernelGGL((k_imp_right<R, CX, 256>), dim3((unsigned)count), dim3(256), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, i0, q.rev);
+        if (tpr >= 4) hipLaunchKernelGGL((k_imp_right<R, CX, 1024>), dim3((unsigned)count), dim3(1024), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, q.order + i0, q.rev);
+        else if (tpr == 3) hipLaunchKernelGGL((k_imp_right<R, CX, 512>), dim3((unsigned)count), dim3(512), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, q.order + i0, q.rev);
+        else hipLaunchKernelGGL((k_imp_right<R, CX, 256>), dim3((unsigned)count), dim3(256), lds, s, v, q.missing, (R*)q.Rbuf, q.max_missing, q.order + i0, q.rev);
     }
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
-              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, i0, q.x0, q.dxu};
+              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, q.order + i0, q.x0, q.dxu};
     // two workgroups per CU (128 VGPRs each, 70-183 of them spilled) against one (256 VGPRs, no spill): the spilling
     // build wins where the density loop is latency-bound - real models and complex ones with d <= 5 - because a second
     // workgroup hides more than the scratch traffic costs (same-box A/B: profiles/r03_impute_occupancy_ab.txt;
