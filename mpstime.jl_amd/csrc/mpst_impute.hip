@@ -574,6 +574,7 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
     __shared__ double wtot[4];                              // totals of the four quarters of the grid (prefix sums)
     __shared__ int isel[4];
     __shared__ double tcr[TRIG ? IMP_MAXD : 1], tci[TRIG ? IMP_MAXD : 1], tbr[TRIG ? IMP_MAXD : 1], tbi[TRIG ? IMP_MAXD : 1];
+    __shared__ double tmr[TRIG ? IMP_MAXD * IMP_MAXD : 1], tmi[TRIG ? IMP_MAXD * IMP_MAXD : 1];      // rho^H rho
     constexpr int ZW = CX ? 2 : 1;
     const int64_t i = g.ord[blockIdx.x];
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x;
@@ -744,10 +745,13 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                 else u_pass(std::integral_constant<int, 1>{});
             }
             __syncthreads();
-            for (int e = tid; e < d * d; e += IMP_T) {
-                const int s_ = e / d, s2 = e - s_ * d;
+            // four threads per entry (a quad: every fourth bond value each, summed over the quad with DPP)
+            for (int e4 = tid; e4 < ((4 * d * d + 63) & ~63); e4 += IMP_T) {
+                const int e = e4 >> 2, part = e4 & 3;
+                const bool live = e < d * d;
+                const int s_ = live ? e / d : 0, s2 = live ? e - s_ * d : 0;
                 R tr = R(0), ti = R(0);
-                for (int k = 0; k < Do; ++k) {
+                for (int k = part; k < Do; k += 4) {
                     const R ur = U.r[s_ * cm + k], br = LW.r[s2 * cm + k];
                     tr = fma(ur, br, tr);
                     if constexpr (CX) {
@@ -757,8 +761,15 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                         ti = fma(-ur, bi, ti);
                     }
                 }
-                rho[s_ * IMP_MAXD + s2] = (double)tr;
-                if constexpr (CX) rhoi[s_ * IMP_MAXD + s2] = (double)ti;
+                double dr = (double)tr, di = (double)ti;
+                dr += dpp_mov<0xB1>(dr);               // quad_perm [1, 0, 3, 2]
+                di += dpp_mov<0xB1>(di);
+                dr += dpp_mov<0x4E>(dr);               // quad_perm [2, 3, 0, 1]
+                di += dpp_mov<0x4E>(di);
+                if (live && part == 0) {
+                    rho[s_ * IMP_MAXD + s2] = dr;
+                    if constexpr (CX) rhoi[s_ * IMP_MAXD + s2] = di;
+                }
             }
             __syncthreads();
             // normalise rho by its trace (p scales with the square, every quantity below is scale-free)
@@ -777,6 +788,20 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
             int kmax = 0;
             double tsum = 0.0, tbound = 0.0;                  // TRIG: sum_m Re(B_m); c_0 + sum_m |c_m| >= max p
             if constexpr (TRIG) {
+                // M = rho^H rho, an entry per thread; c_m sums the entries whose frequencies differ by m
+                for (int e = tid; e < d * d; e += IMP_T) {
+                    const int a = e / d, bx = e - a * d;
+                    double mr = 0.0, mi = 0.0;
+                    for (int s_ = 0; s_ < d; ++s_) {
+                        const double ar = rho[s_ * IMP_MAXD + a], ai = rhoi[s_ * IMP_MAXD + a];
+                        const double br = rho[s_ * IMP_MAXD + bx], bi = rhoi[s_ * IMP_MAXD + bx];
+                        mr = fma(ar, br, fma(ai, bi, mr));
+                        mi = fma(ar, bi, fma(-ai, br, mi));
+                    }
+                    tmr[a * IMP_MAXD + bx] = mr;
+                    tmi[a * IMP_MAXD + bx] = mi;
+                }
+                __syncthreads();
                 if (tid < d) {
                     const int m = tid;
                     double cr = 0.0, ci = 0.0;
@@ -784,12 +809,8 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                         const int fa = (a + 1) / 2 * ((a & 1) ? 1 : -1), fb = fa + m;
                         const int bx = fb == 0 ? 0 : (fb > 0 ? 2 * fb - 1 : -2 * fb);        // the state of frequency fb
                         if (bx >= d) continue;
-                        for (int s_ = 0; s_ < d; ++s_) {                                      // (rho^H rho)[a][bx]
-                            const double ar = rho[s_ * IMP_MAXD + a], ai = rhoi[s_ * IMP_MAXD + a];
-                            const double br = rho[s_ * IMP_MAXD + bx], bi = rhoi[s_ * IMP_MAXD + bx];
-                            cr = fma(ar, br, fma(ai, bi, cr));
-                            ci = fma(ar, bi, fma(-ai, br, ci));
-                        }
+                        cr += tmr[a * IMP_MAXD + bx];
+                        ci += tmi[a * IMP_MAXD + bx];
                     }
                     const double sc = (m == 0 ? 1.0 : 2.0) / (double)d;
                     cr *= sc;
@@ -1098,13 +1119,19 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                     klo = 64 * rc + __popcll(__ballot(le)) - 1;
                 }
                 if (klo < 0) klo = 0;
+                // (the six candidates on six lanes, then the first minimum in lane order = in grid order)
+                const int kfirst = max(0, klo - 2), klast = min(n - 1, klo + 3);
+                const int kk = kfirst + lane;
+                double a = 1e300;
+                if (lane < 6 && kk <= klast) a = fabs(cdf_at(kk) / Z - target);
                 int ks = klo;
                 double best = 1e300;
-                for (int k = max(0, klo - 2); k <= min(n - 1, klo + 3); ++k) {
-                    const double a = fabs(cdf_at(k) / Z - target);
-                    if (a < best) {
-                        best = a;
-                        ks = k;
+#pragma unroll
+                for (int l = 0; l < 6; ++l) {
+                    const double al = readlane_f64(a, l);
+                    if (al < best) {
+                        best = al;
+                        ks = kfirst + l;
                     }
                 }
                 return ks;
