@@ -1412,6 +1412,10 @@ hipError_t impute_init_attrs(int device) {
 #define IMP_ATTR_TRIG(R, F32)                                                                                                      \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                  (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;                              \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                 (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;                              \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                 (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;                              \
     if ((e = hipFuncSetAttribute((const void*)k_imp_left<R, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize,            \
                                  (int)left_lds_bytes(CAP_LIMIT, true, F32))) != hipSuccess) return e;
     IMP_ATTR_TRIG(double, false)
@@ -1451,8 +1455,12 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     if constexpr (CX) {
         if (q.trig) {
             // closed-form densities: no density loop, so no reason to keep the whole register file for one workgroup
+            // three workgroups per CU (170 VGPRs): same-box A/B at configs[4] with 16 / 8 loads per output in flight:
+            // OCC 2: 83.5 / 148 ms, OCC 3: 76.2 / 97 ms, OCC 4 (spilling): 121 / 102 ms
             if (force_occ == 1) hipLaunchKernelGGL((k_imp_left<R, CX, 1, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
-            else hipLaunchKernelGGL((k_imp_left<R, CX, 2, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+            else if (force_occ == 2) hipLaunchKernelGGL((k_imp_left<R, CX, 2, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+            else if (force_occ == 4) hipLaunchKernelGGL((k_imp_left<R, CX, 4, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+            else hipLaunchKernelGGL((k_imp_left<R, CX, 3, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
             return;
         }
     }
