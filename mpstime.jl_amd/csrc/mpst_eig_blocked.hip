@@ -21,6 +21,7 @@
 #include "mpst_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 namespace mpst {
 
@@ -738,14 +739,72 @@ __device__ __forceinline__ void st_c(double2* p, double2 v) {
     __hip_atomic_store(&p->x, v.x, __ATOMIC_RELAXED, SC_AGENT);
     __hip_atomic_store(&p->y, v.y, __ATOMIC_RELAXED, SC_AGENT);
 }
+// the same two through ONE XCD's L2 (all participants on that XCD - roll call): plain 128-bit store (the L1 writes through),
+// non-temporal load (never kept in the reader's L1, so always served by the L2); a line of these buffers is never touched any other way
+__device__ __forceinline__ double2 ld_x(const double2* p) {
+    u32x4 q;
+    asm volatile("global_load_dwordx4 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(p) : "memory");
+    return make_double2(__longlong_as_double((long long)((unsigned long long)q.x | ((unsigned long long)q.y << 32))),
+                        __longlong_as_double((long long)((unsigned long long)q.z | ((unsigned long long)q.w << 32))));
+}
+__device__ __forceinline__ void ld_x3(const double2* p0, const double2* p1, const double2* p2, double2& v0, double2& v1, double2& v2) {
+    u32x4 q0, q1, q2;
+    asm volatile("global_load_dwordx4 %0, %3, off nt\n\t"
+                 "global_load_dwordx4 %1, %4, off nt\n\t"
+                 "global_load_dwordx4 %2, %5, off nt\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+                 : "v"(p0), "v"(p1), "v"(p2)
+                 : "memory");
+    auto cv = [](const u32x4 q) {
+        return make_double2(__longlong_as_double((long long)((unsigned long long)q.x | ((unsigned long long)q.y << 32))),
+                            __longlong_as_double((long long)((unsigned long long)q.z | ((unsigned long long)q.w << 32))));
+    };
+    v0 = cv(q0);
+    v1 = cv(q1);
+    v2 = cv(q2);
+}
+__device__ __forceinline__ void st_x(double2* p, double2 v) {
+    const unsigned long long a = (unsigned long long)__double_as_longlong(v.x), b = (unsigned long long)__double_as_longlong(v.y);
+    const u32x4 q = {(unsigned int)a, (unsigned int)(a >> 32), (unsigned int)b, (unsigned int)(b >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+}
+// counting barrier inside one XCD: the arrivals are L2 atomics (no scope bits), the poll a non-temporal load
+__device__ __forceinline__ bool xcd_wait(const BtCoop& cp, unsigned int target, int* sh_ok) {
+    if (threadIdx.x == 0) {
+        int ok = 1, spins = 0;
+        for (;;) {
+            unsigned int c;
+            asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(c) : "v"(cp.counter) : "memory");
+            if (c >= target) break;
+            if ((++spins & 1023) == 0 &&
+                (spins > (1 << 21) || __hip_atomic_load(cp.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_fetch_or(cp.abort_flag, ABORT_PATIENCE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *sh_ok = ok;
+    }
+    __syncthreads();
+    return *sh_ok != 0;
+}
+__device__ __forceinline__ void xcd_arrive(const BtCoop& cp) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's stores have been taken by the L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cp.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 constexpr int BTC_NT = 512, BTC_NMAX = BT_NMAX / 2;
 // TAGGED: the XCD-local exchange of k_bt_coop<512, SC_XCD> (self-validating 16-byte entries - two per complex number -, polls through
 // the XCD's L2, no counter; every `stride`-th workgroup of the launch takes part, a roll call checks that they share an XCD), else
 // agent-scope atomics and the counting barrier.
-template <bool TAGGED>
+// XMODE 0: agent-scope atomics and the counting barrier (workgroups anywhere); 1: tagged entries inside one XCD; 3: the counting
+// barrier and plain data inside one XCD (st_x / ld_x / xcd_wait / xcd_arrive)
+template <int XMODE>
 __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
     if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NT = BTC_NT, NW = NT / 64;
+    constexpr bool TAGGED = XMODE == 1, XCNT = XMODE == 3;
     static_assert(BTC_NMAX <= NT, "one element of every length-n vector per thread");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_a[NW][2], red_b[NW];
@@ -786,14 +845,16 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
         st_tag(base, 2 * e, x.x, key);
         st_tag(base, 2 * e + 1, x.y, key);
     };
-    if (TAGGED && !bt_coop_roll_call(cp, G, &sh_ok)) return;          // leaves sh_ok = 1
+    if ((TAGGED || XCNT) && !bt_coop_roll_call(cp, G, &sh_ok)) return;          // leaves sh_ok = 1
     if (g == 0) {
         for (int c = tid; c < n; c += NT) {
             if constexpr (TAGGED) put_c(cp.rowbuf, c, rows[c], tag_key(seq, 2, 0));
+            else if constexpr (XCNT) st_x(rowbuf + c, rows[c]);
             else st_c(rowbuf + c, rows[c]);
         }
     }
-    if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
+    if constexpr (XCNT) xcd_arrive(cp);
+    else if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
     double2 tau_prev = make_double2(0.0, 0.0);
     for (int j = 0; j <= n - 2; ++j) {
         const int idx = j + tid;
@@ -815,9 +876,22 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
                     break;
                 }
             }
-            yp = (ok && j > 0) ? yp : zero;
-            aj = ok ? aj : zero;
-            yj = j > 0 ? yj : zero;
+            // (component by component: a ternary between two double2 LVALUES selects an address, and both operands then live
+            // in scratch - 80 bytes of it and a memory round trip per use made both XCD-local variants slower than the agent-scope one)
+            const bool oky = ok && j > 0;
+            yp = make_double2(oky ? yp.x : 0.0, oky ? yp.y : 0.0);
+            aj = make_double2(ok ? aj.x : 0.0, ok ? aj.y : 0.0);
+            yj = make_double2(j > 0 ? yj.x : 0.0, j > 0 ? yj.y : 0.0);
+        } else if constexpr (XCNT) {
+            if (!xcd_wait(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
+            const double2* yprev = ybuf + (int64_t)((j + 1) & 1) * ld;
+            const double2* rowj = rowbuf + (int64_t)(j & 1) * ld;
+            const int c0 = ok ? idx : j;
+            ld_x3(yprev + c0, rowj + c0, yprev + j, yp, aj, yj);       // (step 0 reads parity buffers nobody has written: dropped below)
+            const bool oky = ok && j > 0;
+            yp = make_double2(oky ? yp.x : 0.0, oky ? yp.y : 0.0);
+            aj = make_double2(ok ? aj.x : 0.0, ok ? aj.y : 0.0);
+            yj = make_double2(j > 0 ? yj.x : 0.0, j > 0 ? yj.y : 0.0);
         } else {
             if (!bt_coop_wait<SC_AGENT>(cp, (unsigned int)G * (unsigned int)(j + 1), &sh_ok)) return;
             const double2* yprev = ybuf + (int64_t)((j + 1) & 1) * ld;
@@ -933,6 +1007,7 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
                 si += pr.y;
                 if (pub) {
                     if constexpr (TAGGED) put_c(rownext_t, c, a_, key_r);
+                    else if constexpr (XCNT) st_x(rownext + c, a_);
                     else st_c(rownext + c, a_);
                 }
             }
@@ -940,10 +1015,12 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
             si = wave_sum_fast(si);
             if (lane == 0) {
                 if constexpr (TAGGED) put_c(ynew_t, r, c_mul(tau, make_double2(sr, si)), key_y);
+                else if constexpr (XCNT) st_x(ynew + r, c_mul(tau, make_double2(sr, si)));
                 else st_c(ynew + r, c_mul(tau, make_double2(sr, si)));
             }
         }
-        if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
+        if constexpr (XCNT) xcd_arrive(cp);
+        else if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
         bookkeeping();
     }
 }
@@ -1680,17 +1757,23 @@ static size_t coopc_lds(int ncap) {
     const int nc = ncap / 2, G = coopc_grid(ncap);
     return (size_t)(3 + (nc + G - 1) / G) * nc * sizeof(double2);
 }
-// XCD-local variant: 32 workgroups on one XCD, ceil(n / 32) complex rows each.  Measured slower than the agent-scope exchange at
-// both sizes tried (n_c = 256: 1.72 vs 1.21 ms per bond, n_c = 512: 4.58 vs 3.41): two tagged entries per complex element and,
-// at n_c = 512, twice the rows per workgroup.  Opt-in (MPST_BT_C_XCD=1) for measurements only.
+// XCD-local variants: 32 workgroups on one XCD, ceil(n / 32) complex rows each
 static size_t coopc_xcd_lds(int ncap) {
     const int nc = ncap / 2;
     return (size_t)(3 + (nc + XCD_G - 1) / XCD_G) * nc * sizeof(double2);
 }
-static bool cnative_xcd_usable(int ncap) {
-    static const bool on = getenv("MPST_BT_C_XCD") != nullptr && getenv("MPST_BT_NO_XCD") == nullptr;
-    return on && coopc_xcd_lds(ncap) <= 156 * 1024;
+// 0: across the XCDs; 1: one XCD, tagged entries (default where the rows fit); 3: one XCD, counting barrier.  Same box, c64, per bond
+// at n_c = 256 / 512: across the XCDs 1.23 / 3.41 ms, counted 1.10 / 3.32, tagged 1.01 / 3.07 (MPST_BT_C_XCD=0|counted|tagged)
+static int cnative_xcd_mode(int ncap) {
+    static const int pick = [] {
+        if (getenv("MPST_BT_NO_XCD") != nullptr) return 0;
+        const char* e = getenv("MPST_BT_C_XCD");
+        if (e && !strcmp(e, "0")) return 0;
+        return (e && !strcmp(e, "counted")) ? 3 : 1;
+    }();
+    return coopc_xcd_lds(ncap) <= 156 * 1024 ? pick : 0;
 }
+static bool cnative_xcd_usable(int ncap) { return cnative_xcd_mode(ncap) != 0; }
 static bool cnative_usable(const View& v, int ncap) {
     static const bool off = getenv("MPST_BT_NO_CNATIVE") != nullptr;
     return !off && v.zw == 2 && (ncap & 1) == 0 && ncap / 2 <= BTC_NMAX && coopc_lds(ncap) <= 150 * 1024;
@@ -1718,8 +1801,9 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
                  hipFuncSetAttribute((const void*)k_bt_coop<256, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_AGENT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop_c<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop_c<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -1782,10 +1866,12 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
-            if (mode == 4)
-                hipLaunchKernelGGL(k_bt_coop_c<true>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
+            if (mode == 4 && cnative_xcd_mode(ncap) == 3)
+                hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, 0u);
+            else if (mode == 4)
+                hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (mode == 3)
-                hipLaunchKernelGGL(k_bt_coop_c<false>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
+                hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
             else if (mode == 2)
                 hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (coop_threads() == 512)
@@ -1851,10 +1937,12 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
     bt.sticky = e->sticky;
     const bool nat = cnative_usable(v, ncap);
     bt.cnative = nat ? 1 : 0;
-    if (nat && cnative_xcd_usable(ncap))
-        hipLaunchKernelGGL(k_bt_coop_c<true>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
+    if (nat && cnative_xcd_mode(ncap) == 3)
+        hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, 0u);
+    else if (nat && cnative_xcd_mode(ncap) == 1)
+        hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
     else if (nat)
-        hipLaunchKernelGGL(k_bt_coop_c<false>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
+        hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
     else if (xcd_usable(ncap))
         hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
     else if (coop_threads() == 512)
