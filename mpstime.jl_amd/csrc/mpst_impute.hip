@@ -295,7 +295,8 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
         __syncthreads();
         if (ns > 1) fetch(1);                       // in flight during the first product
         for (int s = 0; s < ns; ++s) {
-            const Plane<R>& Ms = (s & 1) ? Ms1 : Ms0;
+            // (by value, pointer by pointer: a ternary between the two Plane lvalues selects an address and parks both in scratch)
+            const Plane<R> Ms{(s & 1) ? Ms1.r : Ms0.r, (s & 1) ? Ms1.i : Ms0.i};
             // T1 = Ms R^H (Do x Di)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             }
             // the next site matrix goes into the other buffer (last read before the previous step's closing barrier): its
             // load had a whole product to arrive, and the step needs two barriers instead of three
-            if (s + 1 < ns) put((s & 1) ? Ms0 : Ms1);
+            if (s + 1 < ns) put(Plane<R>{(s & 1) ? Ms0.r : Ms1.r, (s & 1) ? Ms0.i : Ms1.i});
             __syncthreads();
             if (s + 2 < ns) fetch(s + 2);
             // R' += T1 Ms^H (Do x Do)
