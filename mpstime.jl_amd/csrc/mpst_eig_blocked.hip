@@ -1044,8 +1044,8 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
     }
     const double2* Vc = (const double2*)b.Vall;
     const double2* tauc = (const double2*)b.tau;
-    // the next reflector's entries (and its tau) are requested before the current one is applied: the loop is a chain of L2 round
-    // trips otherwise (0.43 ms for 511 reflectors at n = 512)
+    // reflectors (and their tau) are requested ahead of their application: the loop is a chain of L2 round trips otherwise
+    // (0.43 ms for 511 reflectors at n = 512; one ahead 0.34)
     auto fetch = [&](int j, double2 (&dst)[QE], double2& tj) {
         const double2* vj = Vc + (int64_t)(j >= 0 ? j : 0) * ldc;
 #pragma unroll
@@ -1072,14 +1072,23 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
             z[q].y -= u.y;
         }
     };
-    double2 va[QE], vb[QE], ta, tb;
+    // four reflectors in flight (a ring of register buffers): with one ahead the loop waited an L2 round trip every other step
+    double2 va[QE], vb[QE], vc[QE], vd[QE], ta, tb, tc, td;
     fetch(n - 2, va, ta);
-    for (int j = n - 2; j >= 0; j -= 2) {
-        fetch(j - 1, vb, tb);
+    fetch(n - 3, vb, tb);
+    fetch(n - 4, vc, tc);
+    for (int j = n - 2; j >= 0; j -= 4) {
+        fetch(j - 3, vd, td);
         apply(va, ta);
         if (j - 1 < 0) break;
-        fetch(j - 2, va, ta);
+        fetch(j - 4, va, ta);
         apply(vb, tb);
+        if (j - 2 < 0) break;
+        fetch(j - 5, vb, tb);
+        apply(vc, tc);
+        if (j - 3 < 0) break;
+        fetch(j - 6, vc, tc);
+        apply(vd, td);
     }
     double* zp = zrow + ld;
 #pragma unroll

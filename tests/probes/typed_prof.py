@@ -5,7 +5,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R
 
