@@ -95,6 +95,26 @@ __device__ __forceinline__ void mstep(Cp<R> a, Cp<R> b, typename Mx<R>::acc_t& a
     }
 }
 
+// The same step for k_tyhat in the 3M form (k_tgrad is bound by forming its operand tiles, 3M bought it nothing): three real MFMAs
+// per complex step instead of four,
+//   K1 += (a.re + a.im) b.re,  K2 += a.re (b.im - b.re),  K3 += a.im (b.re + b.im);   re = K1 - K3,  im = K1 + K2
+// (the derived operands are three VALU adds beside three 32-cycle MFMAs; the accumulators are combined once, after the k-loops).
+template <typename R, bool CX>
+__device__ __forceinline__ void mstep3(Cp<R> a, Cp<R> b, typename Mx<R>::acc_t& k1, typename Mx<R>::acc_t& k2, typename Mx<R>::acc_t& k3) {
+    if constexpr (CX) {
+        k1 = Mx<R>::mma(a.re + a.im, b.re, k1);
+        k2 = Mx<R>::mma(a.re, b.im - b.re, k2);
+        k3 = Mx<R>::mma(a.im, b.re + b.im, k3);
+    } else {
+        k1 = Mx<R>::mma(a.re, b.re, k1);
+    }
+}
+template <typename A> __device__ __forceinline__ void combine3(A& k1_re, A& k2_im, const A& k3) {
+    const A k1 = k1_re;
+    k1_re = k1 - k3;
+    k2_im = k1 + k2_im;
+}
+
 // 16 x 16 tile of a product whose operands come from global memory through loaders (lane-local lambdas: fa(k) = A[m0 + i16][k],
 // fb(k) = B[k][n0 + i16], zero outside the matrix), accumulated on the fp64 MFMA whatever the storage type.
 template <bool CX, typename FA, typename FB>
@@ -358,11 +378,11 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
             const int cg = task % ncg, ks = task / ncg;
             const int kbeg = ks * Kc, kend = min(XP, kbeg + Kc);
             if (kbeg >= kend) continue;
-            acc_t aR[TY_MT][TY_NT], aI[TY_MT][TY_NT];
+            acc_t aR[TY_MT][TY_NT], aI[TY_MT][TY_NT], a3[TY_MT][CX ? TY_NT : 1];
 #pragma unroll
             for (int m = 0; m < TY_MT; ++m)
 #pragma unroll
-                for (int t = 0; t < TY_NT; ++t) aR[m][t] = aI[m][t] = acc_t{0, 0, 0, 0};
+                for (int t = 0; t < TY_NT; ++t) aR[m][t] = aI[m][t] = a3[m][CX ? t : 0] = acc_t{0, 0, 0, 0};
             int ka = (kbeg + kq) / d, ksx = (kbeg + kq) - ka * d;        // x = ka * d + ksx
             for (int kb = kbeg; kb < kend; kb += 4 * UB) {
                 Cp<R> bv[TY_NT][UB];
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
                             // rows beyond X: ka >= Dl reads a zero of the padded row (LS > cap >= Dl)
                             const Cp<R> a = cmulc(eld<R, CX>(Lf, (m * 16 + i16) * LS + min(ka, LS - 1)), eld<R, CX>(Pl, (m * 16 + i16) * DS + ksx));
 #pragma unroll
-                            for (int t = 0; t < TY_NT; ++t) mstep<R, CX>(a, bv[t][u], aR[m][t], aI[m][t]);
+                            for (int t = 0; t < TY_NT; ++t) mstep3<R, CX>(a, bv[t][u], aR[m][t], aI[m][t], a3[m][CX ? t : 0]);
                         }
                     }
                     ksx += dlo;
@@ -393,6 +413,12 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
                         ++ka;
                     }
                 }
+            }
+            if constexpr (CX) {
+#pragma unroll
+                for (int m = 0; m < TY_MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < TY_NT; ++t) combine3(aR[m][t], aI[m][t], a3[m][t]);
             }
 #pragma unroll
             for (int t = 0; t < TY_NT; ++t) {
