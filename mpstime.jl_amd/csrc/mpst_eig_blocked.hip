@@ -954,10 +954,16 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
             double2 scale = zero;
             const double xx = a0.x * a0.x + a0.y * a0.y + s;
             if ((s > 0.0 || a0.y != 0.0) && xx > 1e-280) {
-                const double nrm = sqrt(xx);
+                // (reciprocal square root + two Heron steps and Newton reciprocals, as bt_reflector_scalars: the divisions and the
+                // square root of the library forms sit on every workgroup's critical path, 511 times per solve)
+                const double rs = __builtin_amdgcn_rsq(xx), hrs = 0.5 * rs;
+                double nrm = xx * rs;
+                nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
+                nrm = fma(fma(-nrm, nrm, xx), hrs, nrm);
                 beta = -copysign(nrm, a0.x);
-                tau = make_double2((beta - a0.x) / beta, -a0.y / beta);
-                const double dr = a0.x - beta, di = a0.y, dn = 1.0 / (dr * dr + di * di);
+                const double rb = frcp(beta);
+                tau = make_double2((beta - a0.x) * rb, -a0.y * rb);
+                const double dr = a0.x - beta, di = a0.y, dn = frcp(dr * dr + di * di);
                 scale = make_double2(dr * dn, -di * dn);                                        // 1 / (a0 - beta)
             } else {
                 beta = a0.x;
