@@ -102,3 +102,52 @@ def test_sharded_sweep_equals_unsharded(tmp_path, loss, sep):
     yo = R.contract_mps(W, ds.phi)
     ys = R.contract_mps([outs[0][f"W{j}"] for j in range(len(W))], ds.phi)
     assert np.abs(yo - ys).max() < 1e-10 * np.abs(yo).max()
+
+
+def _worker_complex(rank, world, port, loss, out_dir):
+    """One bond of the legacy-engine (complex) gradient, sharded: local partial sums re-weighted to the global divisors + one
+    all-reduce of the interleaved (re, im) message = the unsharded gradient.  The message layout is the one the library
+    all-reduces ([loss, pad, grad as (re, im) pairs], fp64)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref_complex as RC
+    from oracle import ref_numpy as R
+
+    data, W = RC.make_problem(38, 5, 3, 4, 2, seed=4, balanced=False)
+    lid, rid = 2, 3
+    rng = np.random.default_rng(9)
+    N = data.phi.shape[0]
+    LEp = rng.standard_normal((N, W[lid].shape[0])) + 1j * rng.standard_normal((N, W[lid].shape[0]))
+    REp = rng.standard_normal((N, W[rid].shape[2])) + 1j * rng.standard_normal((N, W[rid].shape[2]))
+    C = 2
+    bt5 = rng.standard_normal((3, W[lid].shape[0], 3, W[rid].shape[2], C)) + 1j * rng.standard_normal((3, W[lid].shape[0], 3, W[rid].shape[2], C))
+    full_loss, full_grad = RC.loss_grad(bt5, LEp, REp, data, lid, rid, loss)
+    # class-even shard of the class-sorted set (what Shard.split does): every rank takes every world-th series of each class
+    idx, i0 = [], 0
+    counts = [int(x) for x in data.class_distribution]
+    for cn in counts:
+        idx.extend(range(i0 + rank, i0 + cn, world))
+        i0 += cn
+    idx = np.array(idx)
+    lc = np.array([np.sum(data.label_index[idx] == c) for c in range(C)])
+    loc = R.EncodedSet(data.phi[idx], data.label_index[idx], lc)
+    l_loc, g_loc = RC.loss_grad(bt5, LEp[idx], REp[idx], loc, lid, rid, loss)
+    wgt = len(idx) / N                                   # local divisor N_local -> global divisor N
+    msg = np.concatenate([[l_loc * wgt, 0.0], np.ascontiguousarray(g_loc * wgt).view(np.float64).reshape(-1)])
+    buf = torch.from_numpy(msg)
+    dist.all_reduce(buf)
+    g = buf[2:].numpy().view(np.complex128).reshape(bt5.shape)
+    np.savez(os.path.join(out_dir, f"crank{rank}.npz"), loss=float(buf[0]), full_loss=float(full_loss),
+             err=float(np.abs(g - full_grad).max() / np.abs(full_grad).max()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("loss", ["KLD", "MSE"])
+def test_complex_gradient_shards_over_two_ranks(tmp_path, loss):
+    port = _free_port()
+    mp.spawn(_worker_complex, args=(2, port, loss, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        z = np.load(tmp_path / f"crank{r}.npz")
+        assert abs(float(z["loss"]) - float(z["full_loss"])) <= 1e-12 * max(1.0, abs(float(z["full_loss"])))
+        assert float(z["err"]) < 1e-13
