@@ -971,7 +971,12 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                     case 4: evalc(std::integral_constant<int, 4>{}); break;
                     case 5: evalc(std::integral_constant<int, 5>{}); break;
                     case 6: evalc(std::integral_constant<int, 6>{}); break;
+                    case 7: evalc(std::integral_constant<int, 7>{}); break;
                     case 8: evalc(std::integral_constant<int, 8>{}); break;
+                    case 10: evalc(std::integral_constant<int, 10>{}); break;
+                    case 12: evalc(std::integral_constant<int, 12>{}); break;
+                    case 14: evalc(std::integral_constant<int, 14>{}); break;
+                    case 16: evalc(std::integral_constant<int, 16>{}); break;
                     default:
                         for (int k = tid; k < n; k += IMP_T) {
                             const double2* ph = gp + (int64_t)k * d;
@@ -999,7 +1004,7 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
             } else {
                 auto eval = [&](auto DD) {
                     constexpr int D = decltype(DD)::value;
-                    constexpr int Q = D <= 4 ? 4 : 2;                      // grid values per batch of loads
+                    constexpr int Q = D <= 4 ? 4 : (D <= 8 ? 2 : 1);       // grid values per batch of loads (d > 8: one - the batch is 2 d registers)
                     constexpr int DR = D <= 4 ? D : 1;                     // rho in registers for d <= 4, else read from LDS
                     double rr[DR * DR];                                    // (every lane reads the same entry: a broadcast)
 #pragma unroll
@@ -1051,6 +1056,15 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
                     case 6: eval(std::integral_constant<int, 6>{}); break;
                     case 7: eval(std::integral_constant<int, 7>{}); break;
                     case 8: eval(std::integral_constant<int, 8>{}); break;
+                    // (the reference's imputation examples use Legendre d = 10 ... 12: the generic loop below is 10-100x slower)
+                    case 9: eval(std::integral_constant<int, 9>{}); break;
+                    case 10: eval(std::integral_constant<int, 10>{}); break;
+                    case 11: eval(std::integral_constant<int, 11>{}); break;
+                    case 12: eval(std::integral_constant<int, 12>{}); break;
+                    case 13: eval(std::integral_constant<int, 13>{}); break;
+                    case 14: eval(std::integral_constant<int, 14>{}); break;
+                    case 15: eval(std::integral_constant<int, 15>{}); break;
+                    case 16: eval(std::integral_constant<int, 16>{}); break;
                     default:
                         for (int k = tid; k < n; k += IMP_T) {
                             const double* ph = g.grid_phi + (int64_t)k * d;
@@ -1465,7 +1479,9 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
             return;
         }
     }
-    if (force_occ == 1 || (force_occ != 2 && CX && v.d > 5))
+    // (real models with d > 8 - the reference's imputation examples use Legendre d = 10 ... 12 - likewise: d = 12, chi = 40: 147 ms with
+    // two spilling workgroups per CU, 44 ms with one; 774 ms before the density loop had unrolled forms beyond d = 8)
+    if (force_occ == 1 || (force_occ != 2 && ((CX && v.d > 5) || (!CX && v.d > 8))))
         hipLaunchKernelGGL((k_imp_left<R, CX, 1>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
     else
         hipLaunchKernelGGL((k_imp_left<R, CX, 2>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
