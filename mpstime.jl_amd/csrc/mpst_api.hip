@@ -1895,6 +1895,75 @@ static bool fourier_grid(const double* gx, const double* gp, int n, int d, doubl
     return true;
 }
 
+// Are the grid states one of the Legendre bases (bases.jl:70-108: sqrt((2s+1)/2) P_s(x), optionally over sqrt(sqrt((2d+1)/2) d)) on a
+// uniform grid inside [-1, 1]?  Then p(x) is a Legendre series of degree 2d - 2 and the kernels need no table of grid states
+// (k_imp_left<..., TRIG>, real models).  On success `lin` receives the linearisation table A[l][s][s'] = cn^2 kappa_s kappa_s'
+// a(s, s', l), P_s P_s' = sum_l a(s, s', l) P_l, by Gauss-Legendre quadrature (64 nodes: exact far beyond degree 3 x 30).
+static bool legendre_grid(const double* gx, const double* gp, int n, int d, double* x0, double* dxu, std::vector<double>* lin) {
+    if (getenv("MPST_IMP_NO_TRIG") || d < 1 || d > 16) return false;
+    const double a = gx[0], h = (gx[n - 1] - gx[0]) / (double)(n - 1);
+    if (!(h > 0.0) || a < -1.0 - 1e-12 || gx[n - 1] > 1.0 + 1e-12) return false;
+    const double tolx = 1e-12;
+    const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);
+    double cn = 0.0;
+    std::vector<double> P(d);
+    for (int k = 0; k < n; ++k) {
+        const double x = gx[k];
+        if (fabs(x - (a + k * h)) > tolx) return false;
+        P[0] = 1.0;
+        if (d > 1) P[1] = x;
+        for (int m = 1; m + 1 < d; ++m) P[m + 1] = ((2 * m + 1) * x * P[m] - m * P[m - 1]) / (m + 1);
+        if (k == 0) {
+            // the scale of the table: with or without the norm (state 0 is the constant sqrt(1/2) cn)
+            const double c0 = gp[0] / sqrt(0.5);
+            if (fabs(c0 - 1.0) < 1e-12) cn = 1.0;
+            else if (fabs(c0 - 1.0 / nrm) < 1e-12) cn = 1.0 / nrm;
+            else return false;
+        }
+        for (int s = 0; s < d; ++s)
+            if (fabs(gp[(size_t)k * d + s] - cn * sqrt((2.0 * s + 1.0) / 2.0) * P[s]) > 1e-12) return false;
+    }
+    // Gauss-Legendre nodes and weights (Newton on P_64)
+    const int NG = 64, L = 2 * d - 1;
+    std::vector<double> xg(NG), wg(NG);
+    for (int i = 0; i < NG; ++i) {
+        double x = cos(M_PI * (i + 0.75) / (NG + 0.5)), dp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p0 = 1.0, p1 = x;
+            for (int m = 1; m < NG; ++m) {
+                const double p2 = ((2 * m + 1) * x * p1 - m * p0) / (m + 1);
+                p0 = p1;
+                p1 = p2;
+            }
+            dp = NG * (x * p1 - p0) / (x * x - 1.0);
+            const double dxn = p1 / dp;
+            x -= dxn;
+            if (fabs(dxn) < 1e-16) break;
+        }
+        xg[i] = x;
+        wg[i] = 2.0 / ((1.0 - x * x) * dp * dp);
+    }
+    lin->assign((size_t)L * d * d, 0.0);
+    std::vector<double> Q(L);
+    for (int i = 0; i < NG; ++i) {
+        const double x = xg[i];
+        Q[0] = 1.0;
+        if (L > 1) Q[1] = x;
+        for (int m = 1; m + 1 < L; ++m) Q[m + 1] = ((2 * m + 1) * x * Q[m] - m * Q[m - 1]) / (m + 1);
+        for (int l = 0; l < L; ++l)
+            for (int s = 0; s < d; ++s)
+                for (int t = 0; t < d; ++t)
+                    (*lin)[((size_t)l * d + s) * d + t] += wg[i] * 0.5 * (2 * l + 1) * Q[l] * Q[s] * Q[t];
+    }
+    for (int l = 0; l < L; ++l)
+        for (int s = 0; s < d; ++s)
+            for (int t = 0; t < d; ++t)
+                (*lin)[((size_t)l * d + s) * d + t] *= cn * cn * sqrt((2.0 * s + 1.0) / 2.0) * sqrt((2.0 * t + 1.0) / 2.0);
+    *x0 = a;
+    *dxu = h;
+    return true;
+}
+
 // shared tail of the two imputation entry points: option checks, scratch, launches, results
 static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const double* grid_x, const void* grid_phi, int32_t ngrid,
                       const mpst_impute_opts* o, const double* u, double* x_out, double* err_out, double* seconds) {
@@ -1954,11 +2023,11 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
         uint8_t *dmiss = nullptr, *dR = nullptr, *dW = nullptr;
         int32_t* dord = nullptr;
-        double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr;
+        double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr, *dlin = nullptr;
         struct Temps {
-            uint8_t **m, **r, **w; double **b, **cc, **dd, **e, **f, **g, **h; int32_t** o;
-            ~Temps() { dfree(m); dfree(r); dfree(w); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); dfree(o); }
-        } temps{&dmiss, &dR, &dW, &dgx, &dgp, &du, &dp, &dS, &dx, &de, &dord};
+            uint8_t **m, **r, **w; double **b, **cc, **dd, **e, **f, **g, **h; int32_t** o; double** l;
+            ~Temps() { dfree(m); dfree(r); dfree(w); dfree(b); dfree(cc); dfree(dd); dfree(e); dfree(f); dfree(g); dfree(h); dfree(o); dfree(l); }
+        } temps{&dmiss, &dR, &dW, &dgx, &dgp, &du, &dp, &dS, &dx, &de, &dord, &dlin};
         int rc;
         if ((rc = dalloc(c, &dmiss, N * T)) || (rc = dalloc(c, &dR, (int64_t)(chunk * maxm * m.cap * m.cap * zw * esz))) ||
             (rc = dalloc(c, &dgx, ngrid)) || (rc = dalloc(c, &dgp, (int64_t)ngrid * d * zw)) || (rc = dalloc(c, &dp, chunk * ngrid)) ||
@@ -1975,10 +2044,16 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
         HIPC(c, hipMemset(de, 0, (size_t)N * T * sizeof(double)));
         HIPC(c, hipEventRecord(c->ev_start, c->stream));
         double gx0 = 0.0, gdx = 0.0;
-        const int trig = (m.is_complex && fourier_grid(grid_x, (const double*)grid_phi, ngrid, d, &gx0, &gdx)) ? 1 : 0;
+        std::vector<double> lin;
+        const int trig = m.is_complex ? (fourier_grid(grid_x, (const double*)grid_phi, ngrid, d, &gx0, &gdx) ? 1 : 0)
+                                      : (legendre_grid(grid_x, (const double*)grid_phi, ngrid, d, &gx0, &gdx, &lin) ? 1 : 0);
         c->impute_trig = trig;
+        if (!lin.empty()) {
+            if ((rc = dalloc(c, &dlin, (int64_t)lin.size()))) return rc;
+            HIPC(c, hipMemcpy(dlin, lin.data(), lin.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
         const ImputeParams q{dmiss, dR, dW, dgx, dgp, du, dp, dS, dx, de, maxm, ngrid, method, o->get_err, o->order == MPST_IMPUTE_BACKWARDS ? 1 : 0,
-                             ntrial, o->mean_basis, o->rejection_threshold, trig, gx0, gdx, dord};
+                             ntrial, o->mean_basis, o->rejection_threshold, trig, gx0, gdx, dord, dlin};
         // one event between the two kernels of every chunk: the split of the pass into its environment and density halves
         // (mpst_get_impute_phases) costs nothing against kernels of tens of milliseconds
         struct Evs {

@@ -629,6 +629,7 @@ struct ImputeParams {
     int trig;                   // the grid states are the Fourier basis on the uniform grid x0 + k dxu: densities in closed form
     double x0, dxu;
     const int32_t* order;       // device [N]: the order in which the instances are dealt out to workgroups
+    const double* lin;          // device [2d-1][d][d]: Legendre linearisation table (trig, real models), else null
 };
 int impute_chi_limit(bool cx, bool f32);
 int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scratch elements of the large-chi environment kernel

@@ -85,12 +85,14 @@ def test_complex_fourier_model_fp64(engine_cls, cfg, order):
 
 
 @pytest.mark.parametrize("compute", ["f64", "f32"])
-def test_closed_form_densities_equal_the_table_path(engine_cls, compute, monkeypatch):
-    """Fourier grid states on a uniform grid: densities and cumulative sums from 2d coefficients (k_imp_left<..., TRIG>) against
-    the same kernel streaming the table of grid states (MPST_IMP_NO_TRIG=1), every method, on the reference's 20 001-value
-    grid; a grid that is not uniform, or states that are not the Fourier basis, keep the table path."""
-    N, T, d, chi, C = 12, 16, 8, 12, 2
-    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=77, ngrid=20001, cx=True)
+@pytest.mark.parametrize("cx,d", [(True, 8), (False, 4), (False, 12)], ids=["fourier_d8", "legendre_d4", "legendre_d12"])
+def test_closed_form_densities_equal_the_table_path(engine_cls, compute, cx, d, monkeypatch):
+    """Fourier (complex models) or Legendre (real models) grid states on a uniform grid: densities and cumulative sums from 2d
+    coefficients (k_imp_left<..., TRIG>: geometric series / Euler-Maclaurin) against the same kernel streaming the table of
+    grid states (MPST_IMP_NO_TRIG=1), every method, on the reference's 20 001-value grid; a grid that is not uniform, or states
+    that are not the basis, keep the table path."""
+    N, T, chi, C = 12, 16, 12, 2
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=77, ngrid=20001, cx=cx)
     u = rng.uniform(0.02, 0.98, (N, T, 3))
     eng = engine_cls(0)
     try:
@@ -110,7 +112,7 @@ def test_closed_form_densities_equal_the_table_path(engine_cls, compute, monkeyp
         eng.impute_model(W, phi, y, m, xs2, grid_phi, 0, True, compute=compute)
         assert not eng.impute_info()["closed_form_densities"]
         gp2 = grid_phi.copy()
-        gp2[:, 3] = np.conj(gp2[:, 3])
+        gp2[:, 3] = np.conj(gp2[:, 3]) if cx else -gp2[:, 3]
         eng.impute_model(W, phi, y, m, xs, gp2, 0, True, compute=compute)
         assert not eng.impute_info()["closed_form_densities"]
     finally:
