@@ -203,6 +203,36 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
             "roofline": roof_env if dom_env else roof_den, "roofline_other_kernel": roof_den if dom_env else roof_env,
             "closed_form_densities": bool(closed_form),
             "wall_ms_per_step_incl_pcie_and_host_packing": 1e3 * wall / args.steps}
+    if rank == 0 and world == 1:
+        # side figure: a real model on the reference's default basis (Legendre, d = 12, chi = 40: the size of its imputation
+        # examples), same missing pattern and grid; its densities run in closed form as well (Legendre series, Euler-Maclaurin)
+        try:
+            N2, T2, d2, chi2 = 2048, 100, 12, 40
+            W2 = [np.ascontiguousarray(w.real) for w in random_chain(T2, d2, chi2, np.random.default_rng(11))]
+            for j in range(T2 - 1):                       # left-canonical again after dropping the imaginary parts
+                l_, dd_, r_ = W2[j].shape[:3]
+                q_, rr_ = np.linalg.qr(W2[j].reshape(l_ * dd_, r_))
+                W2[j] = q_.reshape(l_, dd_, q_.shape[1])
+                W2[j + 1] = np.einsum("kb,bsc...->ksc...", rr_ / np.linalg.norm(rr_), W2[j + 1])
+            W2[-1] = W2[-1] / np.linalg.norm(W2[-1])
+            enc2 = mt.model_encoding("Legendre")
+            rng2 = np.random.default_rng(12)
+            X2 = rng2.uniform(-0.95, 0.95, (N2, T2))
+            phi2 = np.ascontiguousarray(enc2.encode(X2, d2), dtype=np.float64)
+            g2 = np.ascontiguousarray(enc2.encode(xs, d2), dtype=np.float64)
+            m2 = np.zeros((N2, T2), dtype=np.uint8)
+            for i in range(N2):
+                s0 = rng2.integers(0, T2 - T2 // 2 + 1)
+                m2[i, s0:s0 + T2 // 2] = 1
+            eng2 = mt.SweepEngine(dev_index)
+            lab2 = np.zeros(N2, dtype=np.int32)
+            eng2.impute_model(W2, phi2[:8], lab2[:8], m2[:8], xs, g2, 0, True, compute="f32")
+            _, _, s2 = eng2.impute_model(W2, phi2, lab2, m2, xs, g2, 0, True, compute="f32")
+            line["legendre_side"] = {"config": f"real model, Legendre d={d2}, chi={chi2}, N={N2}, T={T2}, 50 % block, fp32 chain", "value": int(m2.sum()) / s2,
+                                     "unit": "site-imputations/s", "ms": 1e3 * s2, "closed_form_densities": eng2.impute_info()["closed_form_densities"]}
+            eng2.close()
+        except Exception as e:                            # a side figure never takes the line down
+            line["legendre_side"] = {"error": str(e)}
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import impute_numpy as I         # the checker, timed as the CPU baseline on a bounded sample
         cls = [w.reshape(w.shape[:3]) for w in W]
