@@ -379,3 +379,36 @@ def test_host_api_sahand_model_mean(engine_cls):
             continue
         xo, eo = I.impute(classes[yte[k]], phi[k], sites, xs, gphi, "mean", "forwards", True, None, encode=lambda v: enc.encode(np.asarray(v), d))
         assert np.abs(ts[k, sites] - xo).max() < 1e-9 and np.abs(sd[k, sites] - eo).max() < 1e-9
+
+
+@pytest.mark.parametrize("cx", [False, True], ids=["legendre", "fourier"])
+def test_closed_form_on_a_partial_grid(engine_cls, cx, monkeypatch):
+    """The closed forms do not assume the grid spans the basis' whole range: a uniform grid over [-0.7, 0.85] (1 501 values),
+    d = 6 (Legendre) / d = 5 (Fourier), median + WMAD and inverse-transform sampling, against the table path."""
+    N, T, chi, C = 10, 12, 7, 1
+    d = 5 if cx else 6
+    rng = np.random.default_rng(3)
+    W = _complex_mps(T, d, chi, C, rng) if cx else R.random_mps(T, d, chi, C, rng)
+    xs = -0.7 + (1.55 / 1500) * np.arange(1501)
+    enc = (lambda x: R.fourier_encode(x, d)) if cx else (lambda x: R.legendre_encode(x, d))
+    X = rng.uniform(-0.6, 0.8, (N, T))
+    y = np.zeros(N, dtype=np.int32)
+    m = (rng.uniform(size=(N, T)) < 0.5).astype(np.uint8)
+    u = rng.uniform(0.05, 0.95, (N, T, 1))
+    phi, grid_phi = enc(X), enc(xs)
+    eng = engine_cls(0)
+    try:
+        a = [eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True)[:2], eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u)[:2]]
+        assert eng.impute_info()["closed_form_densities"]
+        monkeypatch.setenv("MPST_IMP_NO_TRIG", "1")
+        b = [eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True)[:2], eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u)[:2]]
+        assert not eng.impute_info()["closed_form_densities"]
+    finally:
+        eng.close()
+    dx = xs[1] - xs[0]
+    for (xa, ea), (xb, eb) in zip(a, b):
+        bad = [i for i in range(N) if not np.array_equal(xa[i], xb[i])]
+        assert len(bad) <= 1, bad
+        for i in bad:
+            first = int(np.argmax(xa[i] != xb[i]))
+            assert abs(xa[i, first] - xb[i, first]) <= dx * 1.0000001
