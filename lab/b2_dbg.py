@@ -1,4 +1,4 @@
-"""Bring-up: per-phase stamps of k_yhat_s / k_grad_s (library built with scratch/build_dbg.sh b2dbg -DMPST_B2_DEBUG)."""
+"""Bring-up: per-phase stamps of k_yhat_s / k_grad_s (library built with lab/build_dbg.sh b2dbg -DMPST_B2_DEBUG)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds a bring-up variant of the library into scratch/ with extra -D flags: scratch/build_dbg.sh b2dbg -DMPST_B2_DEBUG
+# builds a bring-up variant of the library into lab/ with extra -D flags: lab/build_dbg.sh b2dbg -DMPST_B2_DEBUG
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -12,5 +12,5 @@ for f in mpst_kernels mpst_fused mpst_eig mpst_eig_blocked mpst_encode mpst_allr
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function "$@" $extra -c $f.hip -o $out/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $out/*.o -o $root/scratch/libmpstime_hip_$name.so -L/opt/rocm/lib -lrocsolver -lrocblas -ldl -Wl,-rpath,/opt/rocm/lib
-ls -la $root/scratch/libmpstime_hip_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $out/*.o -o $root/lab/libmpstime_hip_$name.so -L/opt/rocm/lib -lrocsolver -lrocblas -ldl -Wl,-rpath,/opt/rocm/lib
+ls -la $root/lab/libmpstime_hip_$name.so

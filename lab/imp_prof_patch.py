@@ -1,5 +1,5 @@
 """Temporary instrumentation of k_imp_left (wall_clock64 per phase, written to err_out[instance 0][0..7]); apply, build,
-run scratch/imp_phase.py, then restore the source."""
+run lab/imp_phase.py, then restore the source."""
 import sys
 p = 'mpstime.jl_amd/csrc/mpst_impute.hip'
 s = open(p).read()

@@ -1,6 +1,6 @@
 """Same-box A/B of k_imp_left's two builds: one workgroup per CU (256 VGPRs, no spill) against two (128 VGPRs each, 70-183
 spilled).  MPST_IMP_OCC is read once per process, so every arm runs in a child process.
-    python tests/probes/impute_occ_ab.py > profiles/r03_impute_occupancy_ab.txt"""
+    python lab/probes/impute_occ_ab.py > profiles/r03_impute_occupancy_ab.txt"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CHILD = r"""
@@ -10,7 +10,7 @@ import numpy as np
 import mpstime_jl_amd as mt
 sys.argv = ["x", "--quick"]
 import importlib.util
-spec = importlib.util.spec_from_file_location("ib", os.path.join(%r, "tests", "probes", "impute_bench.py"))
+spec = importlib.util.spec_from_file_location("ib", os.path.join(%r, "lab", "probes", "impute_bench.py"))
 src = open(spec.origin).read().split("res = []")[0]      # helpers only (random_chain, block_mask, problem)
 ns = {"__file__": spec.origin, "__name__": "impute_bench_helpers"}
 exec(compile(src, spec.origin, "exec"), ns)

@@ -4,8 +4,8 @@ sys.argv = ["x", "--quick"]
 import numpy as np
 import mpstime_jl_amd as mt
 from oracle import ref_numpy as R
-exec(open(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/tests/probes/impute_bench.py").read().split("res = []")[0].split("ap = argparse")[0])
-exec("def random_chain" + open(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/tests/probes/impute_bench.py").read().split("def random_chain")[1].split("def deviation")[0])
+exec(open(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/lab/probes/impute_bench.py").read().split("res = []")[0].split("ap = argparse")[0])
+exec("def random_chain" + open(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/lab/probes/impute_bench.py").read().split("def random_chain")[1].split("def deviation")[0])
 eng = mt.SweepEngine(0)
 for (N, T, d, chi) in [(4096, 100, 4, 32), (1024, 200, 8, 64), (2048, 100, 12, 40)]:
     for cx in (False, True):

@@ -1,6 +1,6 @@
 """SHA-256 of the MPS after two sweeps through the large-bond path (d*chi = 168 and 512-wide bonds are too slow here:
 d=12, chi_max=14).  Run once per exchange variant of the blocked tridiagonalisation and compare the digests:
-    python tests/probes/path_hash.py; MPST_BT_NO_XCD=1 python tests/probes/path_hash.py; MPST_BT_NO_COOP=1 python tests/probes/path_hash.py
+    python lab/probes/path_hash.py; MPST_BT_NO_XCD=1 python lab/probes/path_hash.py; MPST_BT_NO_COOP=1 python lab/probes/path_hash.py
 The arithmetic does not depend on which workgroup owns which row, so the three digests must be equal."""
 import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

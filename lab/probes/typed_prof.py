@@ -1,5 +1,5 @@
 """Probe (not a test): per-kernel-class device time of the element-typed sweep at a given shape.
-usage: python tests/probes/typed_prof.py N T chi d dtype [C] [sweeps]"""
+usage: python lab/probes/typed_prof.py N T chi d dtype [C] [sweeps]"""
 import sys
 import time
 

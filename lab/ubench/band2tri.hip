@@ -3,7 +3,7 @@
 // chasing, one workgroup, the matrix in LDS.  Sweep s annihilates column s below the first subdiagonal and chases
 // the bulge to the end of the matrix in steps of B rows; only the first column of each bulge is annihilated, so the
 // working band is 2B - 1 wide.  Sweep s + 1 may run step k as soon as sweep s has finished step k + 2 (stagger 3:
-// scratch/ubench/band_ref.py shows the result is bit-identical to the sequential order, and wrong with stagger 2),
+// lab/ubench/band_ref.py shows the result is bit-identical to the sequential order, and wrong with stagger 2),
 // so up to n / (3B) ... 16 sweeps are in flight, one wave each; they synchronise through progress counters in LDS
 // (DS operations of one wave are executed in order, the LDS unit serves the CU's waves from one queue, so a wave
 // that has seen the counter sees the data written before it) - no workgroup barrier inside the reduction.
@@ -13,8 +13,8 @@
 // so applying H = I - tau v v^T from the left / right / both sides is lane-local except for one group sum and the
 // broadcast of w inside the B lanes of the diagonal block (DPP for B <= 4).
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 scratch/ubench/band2tri.hip -o scratch/ubench/band2tri.bin
-//   scratch/ubench/band2tri.bin 128 200   -> gpurun_out/band2tri_T.txt, checked by scratch/ubench/band_check.py
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 lab/ubench/band2tri.hip -o lab/ubench/band2tri.bin
+//   lab/ubench/band2tri.bin 128 200   -> gpurun_out/band2tri_T.txt, checked by lab/ubench/band_check.py
 #include <hip/hip_runtime.h>
 #include "../../mpstime.jl_amd/csrc/mpst_internal.h"
 #include <cstdio>

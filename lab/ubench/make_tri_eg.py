@@ -1,4 +1,4 @@
-"""Generates scratch/ubench/tri_eg.hip: the product k_eig_tri (mpst_eig.hip) + a single-wave endgame for the last 32 x 32
+"""Generates lab/ubench/tri_eg.hip: the product k_eig_tri (mpst_eig.hip) + a single-wave endgame for the last 32 x 32
 trailing block.  Run from the repository root."""
 src = open('mpstime.jl_amd/csrc/mpst_eig.hip').read()
 a = src.index('__global__ __launch_bounds__(TRI_T) void k_eig_tri(')
@@ -204,13 +204,13 @@ new_loop = r'''    static_assert(NP == 8 && QN == 8, "the era loops assume 8 col
     }
 '''
 k = k.replace(old_loop, new_loop)
-hdr = '''// Prototype (generated by scratch/ubench/make_tri_eg.py from mpst_eig.hip): the product tridiagonalisation with a
+hdr = '''// Prototype (generated by lab/ubench/make_tri_eg.py from mpst_eig.hip): the product tridiagonalisation with a
 // single-wave endgame - the last 32 x 32 trailing block is handed to ONE wave (two lanes per row, 16 interleaved columns
 // per lane) that finishes the factorisation without a workgroup barrier.
 #pragma once
 namespace mpst {
 '''
-open('scratch/ubench/tri_eg.hip', 'w').write(hdr + k + '''
+open('lab/ubench/tri_eg.hip', 'w').write(hdr + k + '''
 static void launch_tri_eg(const double* G, int n, double* ws, unsigned long long* stamps, hipStream_t s) {
     View v{};
     static bool init = false;

@@ -1,7 +1,7 @@
 // Same-box A/B harness for the n <= 128 tridiagonalisation: runs the engine's k_eig_tri (included from the product
 // source) and the prototypes of tri_proto.hip on the same Gram matrix, times them with HIP events, dumps per-step cycle
 // stamps and writes (d, e) of each so that a Python check can compare the spectra.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMPST_TRI_STEPPROF scratch/ubench/tri_ab.hip -o scratch/ubench/tri_ab.bin -lrocsolver -lrocblas -ldl
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMPST_TRI_STEPPROF lab/ubench/tri_ab.hip -o lab/ubench/tri_ab.bin -lrocsolver -lrocblas -ldl
 #include "../../mpstime.jl_amd/csrc/mpst_eig.hip"
 #ifdef HAVE_PROTO
 #include "tri_proto_gen.hip"

@@ -2,7 +2,7 @@
 // x 16 columns): every LDS operand (v and p at a thread's columns) serves two rows, which halves the operand traffic that
 // bounds the first ~48 steps; the row sums are 16-lane instead of 8-lane reductions.  Everything else - helper wave,
 // look-ahead reflector, deferred stores - is the product kernel's (generated from mpst_eig.hip by the substitutions in
-// scratch/ubench/make_tri_rows2.py).
+// lab/ubench/make_tri_rows2.py).
 #pragma once
 namespace mpst {
 constexpr int QN2 = 16;        // threads per row pair

@@ -172,7 +172,7 @@ def test_full_size_config3_against_c_oracle(engine_cls, chi):
             # the first sweep is the chaotic one (-22.5 ... -24.9 for the same data, depending on the start and on the last bits
             # of the eigensolver); from then on all trajectories descend in parallel, about 0.5-0.9 per sweep.  After five sweeps:
             # three starting seeds x both eigensolver launch chains gave KLD -30.19 ... -30.97, accuracy 0.981 ... 0.992
-            # (scratch/plateau.py); a build that does not train like the others falls out of this band
+            # (lab/plateau.py); a build that does not train like the others falls out of this band
             for _ in range(4):
                 eng.sweep()
             _, kld5, acc5, _ = eng.eval(0)

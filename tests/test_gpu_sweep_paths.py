@@ -27,7 +27,7 @@ def test_graph_sweep_equals_bond_steps_at_the_benchmarked_shape():
     chained path forms T = bt_new E with the contraction split over four waves and feeds it on from the accumulators, the
     back-split stored the same product from one sequential accumulation); bonds therefore started from states differing in
     the last bits, and the sweep's own dynamics - a truncated SVD is discontinuous where sigma_chi ~ sigma_chi+1 - decided
-    how far that grew: 3e-13 ... 6e-3 after ONE sweep depending on the starting MPS (scratch/path_dev.py).  The back-split
+    how far that grew: 3e-13 ... 6e-3 after ONE sweep depending on the starting MPS (lab/path_dev.py).  The back-split
     now adds its partial products in the chained path's order (gemm_tile_g4), the stored site tensor IS the chained T, and
     the replayed graph equals the stepped sweep bit for bit - for every start tried."""
     N, T, d, chi = 4096, 100, 4, 32
