@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -196,7 +197,8 @@ struct Ctx {
     View* batch_views = nullptr;
     int batch_cap = 0;
     hipGraphExec_t batch_graph = nullptr;
-    std::vector<std::pair<void*, uint64_t>> batch_key;
+    std::vector<std::pair<uint64_t, uint64_t>> batch_key;   // (uid, epoch) per member: an address can be handed out again, a uid cannot
+    uint64_t uid = 0;              // process-wide, never reused (mpst_create)
 };
 
 int fail(Ctx* c, int code, const char* fmt, ...) {
@@ -880,6 +882,8 @@ int mpst_create(void** ctx, int device_id) {
         return fail(nullptr, MPST_ERR_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
     if (device_id < 0 || device_id >= ndev) return fail(nullptr, MPST_ERR_INVALID, "device %d out of range (%d devices)", device_id, ndev);
     Ctx* c = new Ctx();
+    static std::atomic<uint64_t> next_uid{1};
+    c->uid = next_uid.fetch_add(1);
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
         delete c;
@@ -1635,6 +1639,7 @@ int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
     if (!ctxs || K < 1 || K > 64) return fail(nullptr, MPST_ERR_INVALID, "mpst_sweep_batch: 1..64 contexts");
     Ctx* c0 = (Ctx*)ctxs[0];
     if (!c0) return MPST_ERR_INVALID;
+    if (hipSetDevice(c0->device) != hipSuccess) return fail(c0, MPST_ERR_DEVICE, "cannot select device %d", c0->device);
     int rc;
     for (int k = 0; k < K; ++k) {
         Ctx* c = (Ctx*)ctxs[k];
@@ -1666,8 +1671,8 @@ int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
         c0->batch_cap = K;
         c0->batch_key.clear();
     }
-    std::vector<std::pair<void*, uint64_t>> key;
-    for (int k = 0; k < K; ++k) key.push_back({ctxs[k], ((Ctx*)ctxs[k])->epoch});
+    std::vector<std::pair<uint64_t, uint64_t>> key;
+    for (int k = 0; k < K; ++k) key.push_back({((Ctx*)ctxs[k])->uid, ((Ctx*)ctxs[k])->epoch});
     const View v0 = make_view(c0, MPST_TRAIN);
     if (!c0->batch_graph || key != c0->batch_key) {
         if (c0->batch_graph) {

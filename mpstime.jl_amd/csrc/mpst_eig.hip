@@ -1407,8 +1407,8 @@ static size_t vec_lds_bytes() { return (size_t)(16384 + 272 + 128 * 6 + 144 + 48
 
 size_t eig_workspace_doubles() { return WS_TOTAL; }
 hipError_t eig_init_attrs(int device) {
-    static unsigned long long done = 0;
-    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};
+    if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
@@ -1417,7 +1417,7 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
-    if (device >= 0 && device < 64) done |= 1ull << device;
+    if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
 

@@ -1279,8 +1279,8 @@ int64_t b2_partial_elems(const View& v, int64_t max_pass) { return (int64_t)v.C 
 static size_t yhat_s_lds(const View& v) { return (size_t)128 * (v.cap + 1 + v.d + 1 + 17) * sizeof(double); }
 static size_t grad_s_lds(const View& v) { return std::max((size_t)GS_KC * (((2 * b2_aw(v) + 2 * v.d + 1) | 1) + 1), (size_t)4 * 256) * sizeof(double); }
 hipError_t b2_init_attrs(int device) {
-    static unsigned long long done = 0;
-    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};
+    if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
@@ -1294,7 +1294,7 @@ hipError_t b2_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if (device >= 0 && device < 64) done |= 1ull << device;
+    if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
 void launch_yhat_s(const View& v, int lid, hipStream_t s) {

@@ -1507,8 +1507,8 @@ int impute_chi_limit(bool, bool) { return CAP_LIMIT; }
 int64_t impute_work_elems(int cap, bool cx, bool f32) { return cap > impute_lds_chi_limit(cx, f32) ? 4ll * cap * cap * (cx ? 2 : 1) : 0; }
 
 hipError_t impute_init_attrs(int device) {
-    static unsigned long long done = 0;
-    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};
+    if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
 #define IMP_ATTR(R, CX, F32)                                                                                                       \
     if ((e = hipFuncSetAttribute((const void*)k_imp_right<R, CX, 256>, hipFuncAttributeMaxDynamicSharedMemorySize,                \
@@ -1548,7 +1548,7 @@ hipError_t impute_init_attrs(int device) {
     IMP_ATTR(float, false, true)
     IMP_ATTR(float, true, true)
 #undef IMP_ATTR
-    if (device >= 0 && device < 64) done |= 1ull << device;
+    if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "../../include/mpstime_hip.h"
@@ -327,7 +328,9 @@ struct DevScalars {
     int32_t status;     // sticky error flag (non-finite spectrum ...)
     int32_t eig_sweeps_total;
     int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
-    int32_t pad[2];
+    int32_t pad[2];             // one-shot all-reduce: time-out diagnostics (OneShotParams.dbg)
+    int32_t xref;               // typed MSE: largest overlap exponent of the bond's series (k_tbt_assemble resets, k_tyhat raises)
+    int32_t pad2;
     unsigned long long eig_stamps[64];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
 };
 

@@ -1011,8 +1011,8 @@ void launch_env(const View& v, int site, int left_side, const double* prev, int 
                        out_bond, out, bt_lid, bt_bx);
 }
 hipError_t init_kernel_attrs(int device) {
-    static unsigned long long done = 0;      // one bit per device: the attribute is per device and per process
-    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};      // one bit per device: the attribute is per device and per process
+    if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_grad, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)(2 * CHUNK_S * GB * sizeof(double)))) != hipSuccess) return e;
@@ -1022,7 +1022,7 @@ hipError_t init_kernel_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_yhat_gen<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat_gen<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_norm2, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
-    if (device >= 0 && device < 64) done |= 1ull << device;
+    if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
 void launch_eval_final(const View& v, const double* Lc, const double* Rc, double* yout, hipStream_t s) {

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_tbt_assemble(TView v, int lid) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
     const int ty = (b.Y + 15) >> 4, tx = (b.X + 15) >> 4;
     const int tile = blockIdx.x * 4 + wave, c = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) v.sc->xref = INT32_MIN;   // first launch of a bond's chain
     if (tile >= tx * ty) return;
     const int m0 = (tile / ty) * 16, n0 = (tile % ty) * 16;
     const int ls = *v.label_site;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
     if (tid < 64) {
         const int m = tid >> 4, i = tid & 15;
         double term = 0.0;
-        int c = 0;
+        int c = 0, xmax = INT32_MIN;
         if (m < ntl) {
             const Span tl = v.tiles[t0 + m];
             c = mse ? (int)blockIdx.y : tl.cls;
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
                 yo[0] = yr;
                 yo[1] = yi;
                 if (c == (mse ? 0 : tl.cls)) v.yexp[smp] = xs;
+                if (mse && c == 0) xmax = xs;
                 if (mse) {
                     const double mm = (tl.cls == c) ? 1.0 : 0.0;
                     const double tr_ = ldexp(yr, xs), ti_ = ldexp(yi, xs);
@@ -489,6 +491,10 @@ __global__ __launch_bounds__(64 * TY_W) void k_tyhat(TView v, int lid) {
         }
         term = sum16(term);
         if (i == 0 && m < ntl) v.tile_loss[(int64_t)(mse ? c : 0) * v.ntiles + t0 + m] = term;
+        if (mse && blockIdx.y == 0) {        // MSE weights are staged relative to the largest exponent (k_tgrad)
+            for (int o = 32; o; o >>= 1) xmax = max(xmax, __shfl_xor(xmax, o));
+            if (tid == 0 && xmax != INT32_MIN) atomicMax(&v.sc->xref, xmax);
+        }
     }
 }
 
@@ -567,9 +573,11 @@ __global__ __launch_bounds__(256) void k_tgrad(TView v, int lid, int nsplit) {
                             const double* yp = v.yhat + ((int64_t)c * v.N + smp) * 2;
                             const double yr = yp[0], yi = yp[1];
                             if (mse) {
-                                // u 2^xs with the true overlap yhat = (yr, yi) 2^xs: the operands below carry 2^-xs
-                                const int xs = v.yexp[smp];
-                                u = Cp<R>{(R)ldexp(ldexp(yr, xs) - ((ch.cls == c) ? 1.0 : 0.0), xs), (R)ldexp(yi, 2 * xs)};
+                                // u 2^xs with the true overlap yhat = (yr, yi) 2^xs: the operands below carry 2^-xs.  Staged
+                                // relative to the bond's largest exponent (2^xs leaves fp32's range after ~85 Fourier sites);
+                                // k_tgrad_reduce puts 2^xref back in fp64
+                                const int xs = v.yexp[smp], xr = xs - v.sc->xref;
+                                u = Cp<R>{(R)ldexp(ldexp(yr, xs) - ((ch.cls == c) ? 1.0 : 0.0), xr), (R)ldexp(yi, xs + xr)};
                             } else {
                                 const double q = 1.0 / (yr * yr + yi * yi);       // conj(1 / yhat) = yhat / |yhat|^2
                                 u = Cp<R>{(R)(yr * q), (R)(yi * q)};
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(256) void k_tgrad_reduce(TView v, int lid, int nspl
     if (idx < total) {
         const int c = (int)(idx / b.L);
         const int64_t e = idx - (int64_t)c * b.L;
-        const double scale = mse ? v.invN : -(v.train_sep ? v.inv_count[c] : v.invN);
+        const double scale = mse ? ldexp(v.invN, v.sc->xref) : -(v.train_sep ? v.inv_count[c] : v.invN);
         double sr = 0.0, si = 0.0;
         for (int k = 0; k < nsplit; ++k) {
             const Cp<R> p = eld<R, CX>(v.partial, ((int64_t)c * nsplit + k) * b.L + e);
@@ -694,7 +702,7 @@ __global__ __launch_bounds__(256) void k_tupdate(TView v, int lid, int first_ite
     double s = 0.0;
     for (int i = threadIdx.x; i < v.n_norm_part; i += 256) s += v.norm_part[i];
     const double nrm = sqrt(tblock_sum(s, red));
-    const double step = (v.optimiser == MPST_OPT_TSGO) ? v.eta / nrm : v.eta;
+    const double step = (v.optimiser == MPST_OPT_TSGO) ? (nrm > 0.0 ? v.eta / nrm : 0.0) : v.eta;   // a vanished gradient: no step
     R* p = (R*)v.bt;
     const double* g = v.gradbuf + 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = (R)((double)p[i] - step * g[i]);
@@ -1101,13 +1109,13 @@ void launch_tscale_sites(const TView& v, const double* norm2, hipStream_t s) { T
         if ((e = hipFuncSetAttribute((const void*)K<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) != hipSuccess) return e;  \
     } while (0)
 hipError_t typed_init_attrs(int device) {
-    static unsigned long long done = 0;
-    if (device >= 0 && device < 64 && (done >> device) & 1ull) return hipSuccess;
+    static std::atomic<unsigned long long> done{0};
+    if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
     TATTR(k_tenv, 144 * 1024);
     TATTR(k_tyhat, 144 * 1024);
     TATTR(k_tgrad, 144 * 1024);
-    if (device >= 0 && device < 64) done |= 1ull << device;
+    if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
 // LDS the three staged kernels ask for at this shape: the caller rejects shapes beyond the 144 KB opted into above

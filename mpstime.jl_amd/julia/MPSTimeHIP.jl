@@ -103,15 +103,37 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
     verbosity = opts.verbosity
     pos, label_idx = find_label(W)
     C = dim(label_idx)
-    loss = opts.loss_grad isa KLDLoss ? 0 : opts.loss_grad isa MSELoss ? 1 : -1
-    optim = opts.bbopt.name == "CustomGD" ? (uppercase(opts.bbopt.fl) == "TSGO" ? 0 : 1) : -1
+    nsweeps = opts.nsweeps
+    # a loss / an optimiser, or one per sweep (RealRealHighDimension.jl:693-713; same messages)
+    if opts.loss_grad isa AbstractArray
+        @assert length(opts.loss_grad) == nsweeps "loss_grad(...)::(loss,grad) must be a loss function or an array of loss functions with length nsweeps"
+        loss_grads = opts.loss_grad
+    elseif opts.loss_grad isa Function
+        loss_grads = [opts.loss_grad for _ in 1:nsweeps]
+    else
+        error("loss_grad(...)::(loss,grad) must be a loss function or an array of loss functions with length nsweeps")
+    end
+    if opts.train_classes_separately && !(eltype(loss_grads) <: KLDLoss)                                       # :702-704
+        @warn "Classes will be trained separately, but the cost function _may_ depend on measurements of multiple classes. Switch to a KLD style cost function or ensure your custom cost function depends only on one class at a time."
+    end
+    if opts.bbopt isa AbstractArray
+        @assert length(opts.bbopt) == nsweeps "bbopt must be an optimiser or an array of optimisers to use with length nsweeps"
+        bbopts = opts.bbopt
+    elseif opts.bbopt isa BBOpt
+        bbopts = [opts.bbopt for _ in 1:nsweeps]
+    else
+        error("bbopt must be an optimiser or an array of optimisers to use with length nsweeps")
+    end
+    loss_code(lg) = lg isa KLDLoss ? 0 : lg isa MSELoss ? 1 : -1            # -1: the library answers MPST_ERR_UNSUPPORTED
+    optim_code(bb) = bb.name == "CustomGD" ? (uppercase(bb.fl) == "TSGO" ? 0 : 1) : -1
+    sweep_options(its) = MpstOptions(opts.chi_max, opts.update_iters, loss_code(loss_grads[its]), optim_code(bbopts[its]), opts.rescale[1],
+                                     opts.rescale[2], opts.train_classes_separately, opts.svd_alg == "recursive" ? 1 : 0, 0,
+                                     opts.track_cost ? 1 : 0, opts.eta, opts.cutoff)
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     check(C_NULL, ccall((:mpst_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), ctx, device))
     c = ctx[]
     try
-        o = MpstOptions(opts.chi_max, opts.update_iters, loss, optim, opts.rescale[1], opts.rescale[2],
-                        opts.train_classes_separately, opts.svd_alg == "recursive" ? 1 : 0, 0, opts.track_cost ? 1 : 0, opts.eta, opts.cutoff)
-        check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, o))
+        check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, sweep_options(1)))
         for (which, ets) in ((0, train), (1, test))
             isempty(ets.timeseries) && continue
             phi, lab = pack_states(ets, d, T, E)
@@ -139,18 +161,27 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
                 check(c, ccall((:mpst_eval, LIB), Cint, (Ptr{Cvoid}, Cint, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Int64}), c, 1, mse, kld, acc, conf))
                 push!(info["test_loss"], mse[]); push!(info["test_acc"], acc[]); push!(info["test_KL_div"], kld[])
                 push!(info["test_conf"], permutedims(Float64.(conf)))     # C row-major [truth][pred] -> Julia [truth, pred]
-                verbosity > -1 && println("Test KL Div. $(kld[]) | Testing acc. $(acc[]).")
+                if verbosity > -1
+                    println("Test KL Div. $(kld[]) | Testing acc. $(acc[]).")
+                    println("")
+                    println("Test conf: $(info["test_conf"][end]).")                                          # :685
+                end
             end
             return acc[]
         end
         log!(0.0)
         nb = T - 1
         trace = zeros(Float64, opts.update_iters + 1, 2nb)
-        for its in 1:opts.nsweeps
-            verbosity > -1 && println("Using optimiser $(opts.bbopt.name) with the \"$(opts.bbopt.fl)\" algorithm")   # :728
-            verbosity > -1 && println("Starting backward sweeep: [$its/$(opts.nsweeps)]")                              # :729
+        for its in 1:nsweeps
+            verbosity > -1 && println("Using optimiser $(bbopts[its].name) with the \"$(bbopts[its].fl)\" algorithm")   # :728
+            verbosity > -1 && println("Starting backward sweeep: [$its/$nsweeps]")                                      # :729
+            # this sweep's loss / optimiser (:727-728 index loss_grads[itS], bbopts[itS])
+            its > 1 && check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, sweep_options(its)))
             st = Ref(MpstSweepStats(0, 0, 0, 0, 0))
             check(c, ccall((:mpst_sweep, LIB), Cint, (Ptr{Cvoid}, Ref{MpstSweepStats}), c, st))
+            # both half-sweeps run inside the one call: the reference's mid-sweep lines follow it
+            verbosity > -1 && println("Backward sweep finished.")                                                      # :766
+            verbosity > -1 && println("Starting forward sweep: [$its/$nsweeps]")                                       # :772
             if opts.track_cost && verbosity >= 1
                 # what custGD / TSGO (loss_functions.jl:50-52, :80-82) and apply_update (:181-184) print, bond by bond
                 check(c, ccall((:mpst_get_loss_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), c, trace))

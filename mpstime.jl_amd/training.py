@@ -143,6 +143,9 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
             if its > 0 and (isinstance(opts.loss_grad, tuple) or isinstance(opts.bbopt, tuple)):
                 eng.set_options(rebuild_caches=False, track_cost=opts.track_cost, **engine_options(opts, its))   # :727-728: this sweep's loss / optimiser
             st = eng.sweep()                                                     # :727-808
+            if verbosity > -1:        # both half-sweeps run inside the one call: the reference's mid-sweep lines follow it
+                print("Backward sweep finished.")                                # :766
+                print(f"Starting forward sweep: [{its + 1}/{opts.nsweeps}]")      # :772
             if opts.track_cost and verbosity >= 1:
                 # what custGD / TSGO (loss_functions.jl:50-52,80-82) and apply_update (:181-184) print, bond by bond
                 trace = eng.loss_trace()

@@ -13,7 +13,7 @@ from oracle import ref_numpy as R
 from tests.helpers import make_problem
 
 GOLDEN = [p for p in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
-          if not os.path.basename(p).startswith("ref_")]      # ref_*: reference-produced tensors (test_reference_fixture.py)
+          if not os.path.basename(p).startswith(("ref_", "juliaref_"))]      # ref_*: reference-produced tensors (test_reference_fixture.py)
 
 
 def load_golden(path):
@@ -25,6 +25,28 @@ def load_golden(path):
     opts = R.SweepOptions(nsweeps=nsw, chi_max=chimax, eta=float(g["eta"]), update_iters=iters,
                           loss_grad=str(g["loss"]), bbopt=str(g["bbopt"]), train_classes_separately=bool(sep))
     return g, ds, W0, opts
+
+
+JULIAREF = [p for p in GOLDEN if os.path.exists(os.path.join(os.path.dirname(p), "juliaref_" + os.path.basename(p)))]
+
+
+@pytest.mark.skipif(not JULIAREF, reason="no tests/golden/juliaref_*.npz: a maintainer with Julia writes them with "
+                                         "mpstime.jl_amd/julia/make_reference_goldens.jl (the pin of the sweep trajectory on the reference)")
+@pytest.mark.parametrize("path", JULIAREF, ids=[os.path.basename(p)[:-4] for p in JULIAREF])
+def test_oracle_against_reference_vectors(path):
+    """Per-bond {loss, ||grad||, chi, kept singular values} and the per-sweep KLD of the JULIA REFERENCE on the fixture's inputs."""
+    g, ds, W0, opts = load_golden(path)
+    ref = np.load(os.path.join(os.path.dirname(path), "juliaref_" + os.path.basename(path)))
+    rec = []
+    Wf, info = R.fit(W0, ds, None, opts, record=rec)
+    bonds = [b for sw in rec for b in sw]
+    assert len(bonds) == len(ref["bond_loss"])
+    assert np.array_equal([b["chi"] for b in bonds], ref["bond_chi"])
+    assert np.allclose([b["loss"] for b in bonds], ref["bond_loss"], rtol=1e-8, atol=1e-11)
+    assert np.allclose([b["grad_norm"] for b in bonds], ref["bond_grad_norm"], rtol=1e-8)
+    for i, b in enumerate(bonds):
+        assert np.allclose(b["S"], ref["bond_S"][i, :len(b["S"])], rtol=0, atol=1e-8 * b["S"][0])
+    assert np.allclose(info["train_KL_div"][:len(ref["train_KL_div"])], ref["train_KL_div"], rtol=1e-6)
 
 
 def test_golden_fixtures_present():
