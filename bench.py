@@ -431,7 +431,8 @@ def main():
     ap.add_argument("--rebuild-caches", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=24)
-    ap.add_argument("--cpu-full-sweep", action="store_true", help="also time ONE complete sweep of the CPU restatement (about half a minute at the headline shape)")
+    ap.add_argument("--cpu-full-sweep", action="store_true", help="(default since round 5; kept for old command lines) time ONE complete sweep of the CPU restatement")
+    ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline from the bounded bond sample only (extrapolated), skip the complete CPU sweep (~20 s)")
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
                          "and stream each (hyper-parameter search / CV folds); 0 = skip")
@@ -755,6 +756,18 @@ def main():
             "svd_group": {"algorithmic_flops_dense_svd": 4.0 * (chi * C * d) * (d * chi) ** 2 + 8.0 * (d * chi) ** 3,
                           "avg_us": round(sum(breakdown[k][0] / max(breakdown[k][1], 1) for k in ("gram", "eig_tri", "eig_vec", "eig_fin")
                                               if k in breakdown), 3)},
+            # SURVEY 8(d)'s per-sweep counts (all bonds at chi_max), for the region that was TIMED (rebuild_caches off: the two
+            # construct_caches passes the reference repeats are left out, A.6) and with them
+            "algorithmic_per_sweep": (lambda nb, w: (lambda byt, flo, rb, rf: {
+                "timed_region": {"bytes": byt + (rb if args.rebuild_caches else 0.0), "flops": flo + (rf if args.rebuild_caches else 0.0)},
+                "survey_8d_with_cache_rebuilds": {"bytes": byt + rb, "flops": flo + rf},
+                "whole_sweep_frac_of_fp64_mfma_peak": (flo + (rf if args.rebuild_caches else 0.0)) / (elapsed / args.steps) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                "whole_sweep_frac_of_hbm_peak": (byt + (rb if args.rebuild_caches else 0.0)) / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS,
+                "note": "N is the per-rank batch; bond terms: w N (3 chi + 2 d) + 2 w C d^2 chi^2 bytes, 4 N (d chi)^2 + 2 N d chi^2 + "
+                        "4 (chi C d)(d chi)^2 + 8 (d chi)^3 flops; rebuild terms: 2 w N T (d + chi) bytes, 4 N T d chi^2 flops"})(
+                    nb * (w * (N / world) * (3 * chi + 2 * d) + 2.0 * w * C * d * d * chi * chi),
+                    nb * (4.0 * (N / world) * (d * chi) ** 2 + 2.0 * (N / world) * d * chi * chi + 4.0 * (chi * C * d) * (d * chi) ** 2 + 8.0 * (d * chi) ** 3),
+                    2.0 * w * (N / world) * T * (d + chi), 4.0 * (N / world) * T * d * chi * chi))(2 * (T - 1), 8),
             "roofline": {"kernel": dominant, "kernel_symbol": kname, "bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_us": avg_us, "launches": cnt, "algorithmic_per_launch": alg,
@@ -931,7 +944,7 @@ def main():
             per_bond = r["seconds"] / max(r["bonds"], 1)
             sweep_s = per_bond * 2 * (T - 1) + 2 * t_cache
             full_sweep_s = None
-            if args.cpu_full_sweep:                   # ONE whole sweep on the host (all 2(T-1) bonds + both cache rebuilds), timed, no extrapolation
+            if not args.cpu_sample_only:              # ONE whole sweep on the host (all 2(T-1) bonds + both cache rebuilds), timed, no extrapolation
                 co2 = COracle(Wnow, full.phi, full.label_index, full.class_distribution, chi, eta=0.01, rebuild_caches=True, native=True)
                 t_f0 = time.perf_counter()
                 co2.build_caches()
@@ -961,15 +974,20 @@ def main():
                 np_per_bond = (time.perf_counter() - t_n0) / (skip + nb_np)
             except Exception:
                 pass
+            port = ("oracle/mps_oracle.c (-O3 -march=native -ffast-math, 1 thread for the per-series loops, SciPy OpenBLAS dgesdd); "
+                    "the Julia reference itself cannot run here")
+            extrap = {"value": 1.0 / sweep_s, "unit": "sweeps/s", "seconds_sampled": r["seconds"] + t_cache,
+                      "sample": f"{r['bonds']} steady-state bulk bond updates ({per_bond:.3f} s each) + one construct_caches ({t_cache:.2f} s), "
+                                f"extrapolated to 2(T-1)={2 * (T - 1)} bonds + 2 cache rebuilds"}
+            timed = full_sweep_s is not None
             out["cpu_baseline"] = {
-                "value": 1.0 / sweep_s, "unit": "sweeps/s", "cores": 1, "kind": "port",
-                "sample": f"oracle/mps_oracle.c (-O3 -march=native -ffast-math, 1 thread for the per-series loops, SciPy "
-                          f"OpenBLAS dgesdd): {r['bonds']} steady-state bulk bond updates ({per_bond:.3f} s each) + one "
-                          f"construct_caches ({t_cache:.2f} s) timed on this host, extrapolated to 2(T-1)={2 * (T - 1)} bonds "
-                          f"+ 2 cache rebuilds; the Julia reference itself cannot run here",
-                "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model(), "seconds_sampled": r["seconds"] + t_cache,
-                "full_sweep_timed": None if full_sweep_s is None else {"seconds": full_sweep_s, "value": 1.0 / full_sweep_s, "unit": "sweeps/s",
-                                                                          "note": "one complete sweep (198 bonds + cache rebuilds) timed on this host, --cpu-full-sweep"},
+                "value": 1.0 / (full_sweep_s if timed else sweep_s), "unit": "sweeps/s", "cores": 1, "kind": "port",
+                "sample": (f"{port}: ONE complete sweep from the steady-state MPS - all {2 * (T - 1)} bond updates + both cache rebuilds - "
+                           f"TIMED on this host ({full_sweep_s:.1f} s), no extrapolation") if timed else f"{port}: {extrap['sample']}",
+                "host_cpus": os.cpu_count(), "host_cpu_model": host_cpu_model(),
+                "seconds_sampled": full_sweep_s if timed else extrap["seconds_sampled"],
+                "full_sweep_timed": None if not timed else {"seconds": full_sweep_s, "value": 1.0 / full_sweep_s, "unit": "sweeps/s"},
+                "extrapolated_from_bond_sample": extrap,
                 "svd_gesdd_all_cores_ms": svd_ms,
                 "numpy_oracle": None if np_per_bond is None else {
                     "value": 1.0 / (np_per_bond * 2 * (T - 1)), "unit": "sweeps/s",
