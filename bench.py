@@ -410,6 +410,80 @@ def typed_workload(args, mt, torch, rank, dev_index):
     }
 
 
+def tolerance_study(args, mt):
+    """BASELINE configs[4]: "fp32 with tolerance study".  Two FREE-RUNNING fits from the same starting MPS and the same data, one in the
+    narrow element type (float32 / complex64) and one in its double-precision counterpart, through the whole public path (fitMPS ->
+    engine sweeps -> imputation): per-sweep train KLD / accuracy, test accuracy, bond dimensions, and the median imputation of a
+    held-out 50 % block from both models against the truth.  The reference's own statement of what spread is tolerable:
+    docs/src/imputation.md:62-64 (results vary by 1-2 % between machines)."""
+    cx = args.dtype in ("c64", "c128")
+    defaults = ap_defaults()
+    if all(getattr(args, k) == defaults[k] for k in defaults):
+        args.N, args.T, args.chi, args.d = 2048, 100, 32, 8
+    N, T, d, chi = args.N, args.T, args.d, args.chi
+    nsw = 5
+    rng = np.random.default_rng(11)
+    Nte = max(64, N // 4)
+    def gen(n):
+        h = n // 2
+        X1, _ = mt.trendy_sine(T, h, period=(12.0, 15.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+        X2, _ = mt.trendy_sine(T, n - h, period=(16.0, 19.0), slope=[-3.0, 0.0, 3.0], sigma=0.1, rng=rng)
+        return np.concatenate([X1, X2]), np.concatenate([np.ones(h, dtype=np.int64), 2 * np.ones(n - h, dtype=np.int64)])
+    Xtr, ytr = gen(N)
+    Xte, yte = gen(Nte)
+    mask = np.zeros((Nte, T), dtype=bool)
+    nm = T // 2
+    for i in range(Nte):
+        s0 = int(rng.integers(0, T - nm + 1))
+        mask[i, s0:s0 + nm] = True
+    names = {"f32": ("Float32", "Float64"), "c64": ("ComplexF32", "ComplexF64")}[args.dtype]
+    fits = {}
+    for name in names:
+        opts = mt.MPSOptions(d=d, chi_max=chi, nsweeps=nsw, eta=0.01, encoding="Fourier" if cx else "Legendre", dtype=name, verbosity=-1,
+                             chi_init=4, init_rng=1234, exit_early=False)
+        t0 = time.perf_counter()
+        trained, info, _ = mt.fitMPS(Xtr, ytr, Xte, yte, opts)
+        fit_s = time.perf_counter() - t0
+        imp = mt.init_imputation_problem(trained, Xte, yte, verbosity=0)
+        compute = "f32" if name in ("Float32", "ComplexF32") else "f64"
+        ts, err, secs = mt.impute_dataset(imp, mask, "median", compute=compute, return_seconds=True)
+        chis = [int(t.shape[2]) for t in trained.mps[:-1]]
+        fits[name] = dict(info=info, chis=chis, imputed=ts, fit_s=fit_s, impute_device_s=secs)
+    n_, w_ = names
+    a, b = fits[n_], fits[w_]
+    def col(k):
+        return [float(x) for x in a["info"][k]], [float(x) for x in b["info"][k]]
+    kn, kw = col("train_KL_div")
+    an, aw = col("train_acc")
+    tn, tw = col("test_acc")
+    mae_n = float(np.abs(a["imputed"] - Xte)[mask].mean())
+    mae_w = float(np.abs(b["imputed"] - Xte)[mask].mean())
+    dv = np.abs(a["imputed"] - b["imputed"])[mask]
+    flat = float(np.abs(np.mean(Xtr) - Xte)[mask].mean())
+    span = float(Xte.max() - Xte.min())
+    rows = [{"after_sweep": i, "train_KL_div": {n_: kn[i], w_: kw[i], "abs_diff": abs(kn[i] - kw[i])},
+             "train_acc": {n_: an[i], w_: aw[i]}, "test_acc": {n_: tn[i], w_: tw[i]}} for i in range(min(len(kn), nsw + 1))]
+    return {
+        "metric": f"tolerance study {n_} vs {w_}: free-running {nsw}-sweep fits + median imputation (N={N}, T={T}, chi={chi}, d={d}) - a side study, "
+                  "NOT the headline metric", "value": None, "unit": None, "n_gpus": 1, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"fitMPS(encoding={'Fourier' if cx else 'Legendre'}, d={d}, chi_max={chi}, nsweeps={nsw}, eta=0.01) on {N} noisy trendy sines "
+                               f"(2 classes), {Nte} held-out series, a contiguous 50 % block of each imputed (median) from the trained model; "
+                               "both fits start from generate_startingMPS(chi_init=4, init_rng=1234) and see the same encoded data"},
+        "per_sweep": rows,
+        "bond_dimensions": {"equal": a["chis"] == b["chis"], "max_abs_diff": int(np.abs(np.array(a["chis"]) - np.array(b["chis"])).max()),
+                            "sum": {n_: int(sum(a["chis"])), w_: int(sum(b["chis"]))}},
+        "imputation": {"missing_sites": int(mask.sum()), "mae_vs_truth": {n_: mae_n, w_: mae_w, "rel_diff": abs(mae_n - mae_w) / mae_w},
+                       "mae_flat_mean_baseline": flat, "data_span": span,
+                       "narrow_vs_wide_imputations": {"mean_abs": float(dv.mean()), "p50": float(np.quantile(dv, 0.5)), "p99": float(np.quantile(dv, 0.99)),
+                                                      "max": float(dv.max()), "mean_abs_over_span": float(dv.mean()) / span}},
+        "final": {"train_KL_div_rel_diff": abs(kn[-1] - kw[-1]) / max(1.0, abs(kw[-1])), "test_acc": {n_: tn[-1], w_: tw[-1]}},
+        "seconds": {n_: {"fit": a["fit_s"], "impute_device": a["impute_device_s"]}, w_: {"fit": b["fit_s"], "impute_device": b["impute_device_s"]}},
+        "reference_statement": "docs/src/imputation.md:62-64: the reference expects 1-2 % variation between machines",
+        "note": "free-running trajectories of a DMRG sweep are chaotic (oracle/sensitivity_study.py): the per-sweep differences are those of two "
+                "legitimate runs, not rounding errors of one; what is compared is the QUALITY of the two models",
+    }
+
+
 def ap_defaults():
     return {"N": 4096, "T": 100, "chi": 32, "d": 4}
 
@@ -448,6 +522,10 @@ def main():
                          "for the complex types, with a tolerance study against the double-precision type")
     ap.add_argument("--classes", type=int, default=0, help="--dtype side line: number of classes (default 1 for complex types, 2 for f32)")
     ap.add_argument("--study-bonds", type=int, default=6, help="--dtype side line: bonds of the tolerance study")
+    ap.add_argument("--study", action="store_true",
+                    help="with --dtype f32|c64: the tolerance study BASELINE configs[4] names - free-running 5-sweep fits from one start in the "
+                         "narrow and the wide element type (N=2048, T=100, chi=32, d=8), per-sweep KLD / accuracy, bond dimensions, and median "
+                         "imputation of a held-out 50 %% block from both models; never the headline value")
     ap.add_argument("--allreduce", choices=["auto", "rccl", "oneshot"], default="auto",
                     help="collective of the sharded sweep: RCCL, the one-shot direct-write kernel, or whichever one trial sweep shows faster")
     args = ap.parse_args()
@@ -520,7 +598,7 @@ def main():
         if world > 1:
             note("--dtype side line runs on one GPU")
             sys.exit(2)
-        line = typed_workload(args, mt, torch, rank, dev_index)
+        line = tolerance_study(args, mt) if args.study else typed_workload(args, mt, torch, rank, dev_index)
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
         return
     if args.workload == "impute":

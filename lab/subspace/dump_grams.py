@@ -16,7 +16,8 @@ every = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 C = 2 if mode == "f64" else 1
 ds_mt = bench.make_inputs(N, T, d) if mode == "f64" else bench.typed_inputs(N, T, d, C, mode == "fourier")
 ds = R.EncodedSet(np.asarray(ds_mt.phi), np.asarray(ds_mt.label_index), np.asarray(ds_mt.class_distribution), None, None)
-W = R.random_mps(T, d, 4, C, np.random.default_rng(1234), dtype=np.complex128 if mode == "fourier" else np.float64)
+import mpstime_jl_amd as mt
+W = mt.generate_startingMPS(4, T, d, C, 1234, np.complex128 if mode == "fourier" else np.float64)   # as bench.py
 Rm = RC if mode == "fourier" else R
 opts = R.SweepOptions(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1)
 rec, state, cnt = [], {}, [0]
