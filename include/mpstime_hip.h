@@ -222,6 +222,13 @@ int  mpst_sweep(void* ctx, mpst_sweep_stats* out);
  * update_iters = 1, no track_cost / rebuild_caches / profiling): MPST_ERR_UNSUPPORTED otherwise - drive such fits one by one.
  * `out` ([K], may be NULL): seconds = device time of the whole batch.  Errors are reported on ctxs[0]. */
 int  mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out);
+/* The same for fits dealt over SEVERAL devices of a node (what scales there: the batch-sharded sweep repeats its eigensolver on every
+ * rank, independent fits share nothing): the contexts are grouped - group[k] is an arbitrary id, NULL = one group per device -, a
+ * group must live on one device and hold fits of one shape (<= 64), and every group is advanced by ONE mpst_sweep_batch on its own
+ * host thread, concurrently with the others.  No collective, no data crosses devices.  Results are those of K mpst_sweep calls, bit
+ * for bit; out[k].seconds is the device time of fit k's group.  The reference's counterpart is the @distributed loop over candidate
+ * fits (hyperparameters/hyperopt_utils.jl:201, tuning.jl). */
+int  mpst_sweep_batch_multi(void* const* ctxs, int32_t K, const int32_t* group /* [K] or NULL */, mpst_sweep_stats* out);
 /* Optional, before the first sweep of a context: it will be advanced in batches of about K fits.  The engine then splits every
  * gradient block of THIS fit into fewer shares (K fits fill the chip together); the share count fixes the order of the partial
  * sums, so mpst_sweep on the same context gives the same bits as mpst_sweep_batch, while a context without the hint differs from

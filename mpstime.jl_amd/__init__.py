@@ -3,7 +3,7 @@ Encodings API.  The hot path lives in libmpstime_hip.so (csrc/); everything here
 host-side mirror of the reference's interface for that path."""
 from . import _lib
 from ._lib import MPSTError, SVDError
-from .engine import SweepEngine, comm_library, sweep_batch
+from .engine import SweepEngine, comm_library, sweep_batch, sweep_batch_multi
 from .options import MPSOptions, safe_options
 from .encodings import (EncodedTimeSeriesSet, Encoding, encode_dataset, model_encoding, symbolic_encoding,
                         transform_data, transform_train_data, transform_test_data, legendre_encode,
@@ -17,7 +17,7 @@ from .imputation import (ImputationProblem, init_imputation_problem, MPS_impute,
 from .jld2 import JLD2File, read_jld2, load_trained_mps_jld2
 from . import options
 
-__all__ = ["SweepEngine", "comm_library", "sweep_batch", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
+__all__ = ["SweepEngine", "comm_library", "sweep_batch", "sweep_batch_multi", "MPSOptions", "safe_options", "EncodedTimeSeriesSet", "Encoding", "encode_dataset",
            "model_encoding", "symbolic_encoding", "transform_data", "TrainedMPS", "fitMPS", "fit_encoded", "classify",
            "generate_startingMPS", "trendy_sine", "Shard", "split_encoded", "MPSTError", "SVDError", "ImputationProblem",
            "init_imputation_problem", "save_trained_mps", "load_trained_mps", "mps_content_digest", "MPS_impute", "impute_dataset", "kNN_impute", "mar", "invert_test_transform",

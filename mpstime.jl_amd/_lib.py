@@ -85,6 +85,7 @@ SYMBOLS = {
     "mpst_build_caches": (C.c_int, [_vp]),
     "mpst_sweep": (C.c_int, [_vp, C.POINTER(mpst_sweep_stats)]),
     "mpst_sweep_batch": (C.c_int, [C.POINTER(_vp), _i32, C.POINTER(mpst_sweep_stats)]),
+    "mpst_sweep_batch_multi": (C.c_int, [C.POINTER(_vp), _i32, C.POINTER(C.c_int32), C.POINTER(mpst_sweep_stats)]),
     "mpst_set_batch_hint": (C.c_int, [_vp, _i32]),
     "mpst_get_loss_trace": (C.c_int, [_vp, _dp]),
     "mpst_bond_step": (C.c_int, [_vp, _i32, _i32, C.POINTER(mpst_bond_debug)]),

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include "mpst_internal.h"
 
 using namespace mpst;
@@ -1755,6 +1756,60 @@ int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
         }
     }
     if (failed >= 0) return fail(c0, MPST_ERR_SVD, "bond-tensor decomposition failed in fit %d of the batch (its svd_status is set; the other fits are intact)", failed);
+    return 0;
+}
+
+// K fits dealt over several devices (or several groups on one device): every group is one mpst_sweep_batch on its own host
+// thread - no collective, nothing shared between groups.  What scales on a node: the sharded sweep replicates its eigensolver
+// (70 % of a bond) on every rank, independent fits do not.
+int mpst_sweep_batch_multi(void* const* ctxs, int32_t K, const int32_t* group, mpst_sweep_stats* out) {
+    if (!ctxs || K < 1 || K > 512) return fail(nullptr, MPST_ERR_INVALID, "mpst_sweep_batch_multi: 1..512 contexts");
+    for (int k = 0; k < K; ++k)
+        if (!ctxs[k]) return fail(nullptr, MPST_ERR_INVALID, "context %d is NULL", k);
+    // groups in order of first appearance; default: one group per device
+    std::vector<int> gid(K), keys;
+    for (int k = 0; k < K; ++k) {
+        const int key = group ? group[k] : ((Ctx*)ctxs[k])->device;
+        int g = -1;
+        for (size_t j = 0; j < keys.size(); ++j)
+            if (keys[j] == key) g = (int)j;
+        if (g < 0) {
+            keys.push_back(key);
+            g = (int)keys.size() - 1;
+        }
+        gid[k] = g;
+    }
+    const int G = (int)keys.size();
+    std::vector<std::vector<void*>> members(G);
+    std::vector<std::vector<int>> index(G);
+    for (int k = 0; k < K; ++k) {
+        members[gid[k]].push_back(ctxs[k]);
+        index[gid[k]].push_back(k);
+    }
+    for (int g = 0; g < G; ++g) {
+        if (members[g].size() > 64) return fail((Ctx*)ctxs[0], MPST_ERR_INVALID, "group %d holds %zu contexts (at most 64 per group)", keys[g], members[g].size());
+        for (void* m : members[g])
+            if (((Ctx*)m)->device != ((Ctx*)members[g][0])->device)
+                return fail((Ctx*)ctxs[0], MPST_ERR_INVALID, "group %d mixes devices %d and %d: a group is one launch chain on one device", keys[g],
+                            ((Ctx*)members[g][0])->device, ((Ctx*)m)->device);
+    }
+    std::vector<int> rc(G, 0);
+    std::vector<std::vector<mpst_sweep_stats>> st(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        st[g].resize(members[g].size());
+        th.emplace_back([&, g] { rc[g] = mpst_sweep_batch(members[g].data(), (int32_t)members[g].size(), st[g].data()); });
+    }
+    for (auto& t : th) t.join();
+    if (out)
+        for (int g = 0; g < G; ++g)
+            for (size_t j = 0; j < index[g].size(); ++j) out[index[g][j]] = st[g][j];
+    for (int g = 0; g < G; ++g)
+        if (rc[g]) {
+            Ctx* lead = (Ctx*)members[g][0];
+            if (lead != (Ctx*)ctxs[0]) ((Ctx*)ctxs[0])->err = lead->err;      // errors are reported on ctxs[0]
+            return rc[g];
+        }
     return 0;
 }
 

@@ -422,6 +422,21 @@ def sweep_batch(engines):
     return [{"seconds": s.seconds, "max_chi": s.max_chi, "eig_sweeps_total": s.eig_sweeps_total, "eig_fallbacks": s.eig_fallbacks} for s in st]
 
 
+def sweep_batch_multi(engines, groups=None):
+    """mpst_sweep_batch_multi: one sweep of K independent fits dealt over several devices - ``groups[k]`` names the group of engine k
+    (default: its device); every group is one ``sweep_batch`` launch chain on its own host thread, all groups run concurrently, no
+    collective.  Returns one stats dict per engine (``seconds`` = device time of its group)."""
+    lib = L.load()
+    K = len(engines)
+    arr = (C.c_void_p * K)(*[e.ctx.value for e in engines])
+    g = None if groups is None else (C.c_int32 * K)(*[int(x) for x in groups])
+    st = (L.mpst_sweep_stats * K)()
+    rc = lib.mpst_sweep_batch_multi(arr, K, g, st)
+    if rc:
+        engines[0]._chk(rc)
+    return [{"seconds": s.seconds, "max_chi": s.max_chi, "eig_sweeps_total": s.eig_sweeps_total, "eig_fallbacks": s.eig_fallbacks} for s in st]
+
+
 def comm_library():
     """Which librccl the HIP library has bound (it is loaded at run time, never linked): path + how it was found, the
     library's ncclGetVersion code and the NCCL_VERSION_CODE the HIP library was compiled against."""

@@ -3,7 +3,7 @@
 # reference's source (file:line below) for a maintainer who has MPSTime.jl checked out.  Needs MPSTime, ITensors (= 0.6.22, the
 # reference's pin), NPZ.
 #
-#   julia --project=<MPSTime.jl checkout> mpstime.jl_amd/julia/make_reference_goldens.jl <repo>/tests/golden
+#   julia --project=<MPSTime.jl checkout> tests/golden/make_reference_goldens.jl <repo>/tests/golden
 #
 # For every fixture tests/golden/<name>.npz (encoded inputs, initial MPS, options - written by tests/golden/make_golden.py) it
 # runs the REFERENCE's sweep body, bond by bond, with the reference's own functions

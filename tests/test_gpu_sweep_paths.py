@@ -109,3 +109,51 @@ def test_batched_sweep_of_independent_fits_is_bit_identical():
     finally:
         for e in solo + bat:
             e.close()
+
+
+def test_fits_dealt_over_groups_are_bit_identical_and_destroyed_members_do_not_alias():
+    """mpst_sweep_batch_multi: K fits dealt over G groups (on a node: one group per device; here two groups on the one GPU), every
+    group one launch chain on its own host thread, no collective: the bits of K separate mpst_sweep calls.  A group may hold fits
+    of another shape than its neighbour.  Then the graph-key regression: a member is destroyed and recreated (the allocator may
+    hand back its address) - the lead must not replay the graph captured for the dead context."""
+    import mpstime_jl_amd as mt
+    from tests.helpers import make_problem
+    K = 6
+    shapes = [(256, 12, 12)] * 3 + [(192, 10, 8)] * 3          # group 0 / group 1: different N, T, chi_max
+    probs = [make_problem(shapes[k][0], shapes[k][1], 4, 4, 2, seed=70 + k) for k in range(K)]
+
+    def fresh(k):
+        e = mt.SweepEngine(0)
+        e.set_batch_hint(3)
+        e.set_options(chi_max=shapes[k][2], eta=0.05)
+        ds, W = probs[k]
+        e.set_dataset(0, ds.phi, ds.label_index, 2)
+        e.set_mps(W)
+        e.build_caches()
+        return e
+
+    solo = [fresh(k) for k in range(K)]
+    bat = [fresh(k) for k in range(K)]
+    groups = [0, 0, 0, 1, 1, 1]
+    try:
+        for sweep in range(2):
+            for e in solo:
+                e.sweep()
+            st = mt.sweep_batch_multi(bat, groups)
+            assert len(st) == K and all(s["eig_fallbacks"] == 0 for s in st)
+            for a, b in zip(solo, bat):
+                assert all(np.array_equal(x, y) for x, y in zip(a.get_mps(), b.get_mps()))
+        with pytest.raises(mt.MPSTError, match="differs in shape"):
+            mt.sweep_batch_multi(bat, [0, 0, 0, 0, 1, 1])       # a group mixes the two shapes
+        # destroy and recreate a non-lead member of group 0 with the same call sequence, then batch again
+        for _ in range(3):
+            bat[1].close()
+            solo[1].close()
+            bat[1], solo[1] = fresh(1), fresh(1)
+            solo[0].sweep(); solo[1].sweep(); solo[2].sweep()
+            mt.sweep_batch(bat[:3])
+            for a, b in zip(solo[:3], bat[:3]):
+                assert all(np.array_equal(x, y) for x, y in zip(a.get_mps(), b.get_mps()))
+    finally:
+        for e in solo + bat:
+            e.close()

@@ -31,7 +31,7 @@ JULIAREF = [p for p in GOLDEN if os.path.exists(os.path.join(os.path.dirname(p),
 
 
 @pytest.mark.skipif(not JULIAREF, reason="no tests/golden/juliaref_*.npz: a maintainer with Julia writes them with "
-                                         "mpstime.jl_amd/julia/make_reference_goldens.jl (the pin of the sweep trajectory on the reference)")
+                                         "tests/golden/make_reference_goldens.jl (the pin of the sweep trajectory on the reference)")
 @pytest.mark.parametrize("path", JULIAREF, ids=[os.path.basename(p)[:-4] for p in JULIAREF])
 def test_oracle_against_reference_vectors(path):
     """Per-bond {loss, ||grad||, chi, kept singular values} and the per-sweep KLD of the JULIA REFERENCE on the fixture's inputs."""
