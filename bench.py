@@ -332,6 +332,7 @@ def typed_workload(args, mt, torch, rank, dev_index):
     mse, kld, acc, _ = eng.eval(0)
     chi_now, _ = eng.get_chi()
     Wend = eng.get_mps()
+    info = eng.info()              # after the timed sweeps: the counters of the eigensolver paths (subspace attempted / accepted, fall-backs)
     eng.set_profile(0x7FF)
     eng.sweep()
     breakdown = eng.get_profile()
@@ -825,7 +826,7 @@ def main():
                        "bond_dims_max": int(chi_now.max())},
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "train_KL_div_after": kld, "train_acc_after": acc,
-            "allreduce": dict(allreduce, us_per_optimiser_step=(breakdown["allreduce"][0] / max(breakdown["allreduce"][1], 1)
+            "allreduce": dict(allreduce, nranks_seen=int(info.get("ranks", 1)), us_per_optimiser_step=(breakdown["allreduce"][0] / max(breakdown["allreduce"][1], 1)
                                                                  if breakdown.get("allreduce", (0, 0))[1] else None), replicas=replicas),
             "eig_fallbacks_total": fallbacks, "eig_phases_us_last_bond": eng.eig_phases(), "launch_chain": info,
             "timed_region": "K sweeps with profiling off" + (" (hipGraph replay)" if info.get("graph") else " (plain stream)") +
@@ -939,6 +940,50 @@ def main():
                 pass
         if out is not None:
             out["sharded_n32768"] = sharded
+
+    # ---- extra with several ranks: what DOES scale on a node - independent fits (hyper-parameter candidates, CV folds, restarts: the
+    # reference's @distributed loops) dealt over the GPUs, K per GPU in one launch chain each (mpst_sweep_batch), no collective at all.
+    # Every fit is a complete headline-shape fit on the whole data set.  Never `value`.
+    if world > 1 and args.concurrent > 1:
+        indep = None
+        engs = []
+        try:
+            K = args.concurrent
+            for k in range(K):
+                e2 = mt.SweepEngine(dev_index)
+                e2.set_batch_hint(K)
+                e2.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True))
+                e2.set_dataset(0, full.phi, full.label_index, C)
+                e2.set_mps(W0)
+                e2.build_caches()
+                engs.append(e2)
+            for _ in range(2):
+                mt.sweep_batch(engs)                # capture + warm; bond dimensions reach chi_max
+            okk = 1.0
+        except Exception as e:
+            okk = 0.0
+            indep = {"error": str(e)}
+        if host_reduce([okk], dist.ReduceOp.MIN)[0] > 0:
+            nsw = 3
+            sync()
+            ti0 = time.perf_counter()
+            for _ in range(nsw):
+                mt.sweep_batch(engs)
+            torch.cuda.synchronize()
+            ti = host_reduce([time.perf_counter() - ti0], dist.ReduceOp.MAX)[0]
+            indep = {"fits_per_gpu": K, "gpus": world, "sweeps_each": nsw, "aggregate_sweeps_per_s": world * K * nsw / ti,
+                     "ratio_to_single_fit_single_gpu": None, "collective": "none",
+                     "note": "independent fits of the headline shape dealt over the ranks, K per GPU in one launch chain (mpst_sweep_batch; one process "
+                             "drives several GPUs with mpst_sweep_batch_multi); a side figure, never the headline metric"}
+        elif indep is None:
+            indep = {"error": "setup failed on another rank"}
+        for e2 in engs:
+            try:
+                e2.close()
+            except Exception:
+                pass
+        if out is not None:
+            out["independent_fits"] = indep
 
     # ---- extra: the same K sweeps WITH the reference's two cache rebuilds per sweep (RealRealHighDimension.jl:770,804), which the
     # headline leaves out (bit-identical results; tests/test_gpu_parity.py::test_rebuild_caches_is_bit_identical)

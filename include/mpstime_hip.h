@@ -356,7 +356,10 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * once per bond (no host synchronisation inside a sweep), out[15] 0, or 1 + dtype when the element-typed kernels
  * (csrc/mpst_typed.hip) run the sweep */
 int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
-/* the same, at most n entries: for callers compiled against another revision of this header */
+/* the same, at most n entries: for callers compiled against another revision of this header.  Entries beyond the 16 of mpst_get_info:
+ * out[16] large bonds the randomised subspace eigensolver attempted (real element types, d*chi_max > 128: top-chi_max singular
+ * triplets of the bond matrix by five GEMM half-steps + a (chi_max + 32)-dimensional Rayleigh-Ritz problem, certified on the device
+ * against the Gram matrix), out[17] those whose result was accepted - the others were solved by the exact Householder path. */
 int  mpst_get_info_n(void* ctx, int32_t* out, int32_t n);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader

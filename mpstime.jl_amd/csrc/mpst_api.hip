@@ -254,6 +254,7 @@ View make_view(Ctx* c, int which) {
     v.ntiles = s.ntiles; v.nchunks = s.nchunks;
     v.chi = c->chi; v.label_site = c->label_site; v.sites = c->sites; v.site_stride = c->site_stride;
     v.LE = c->LE; v.RE = c->RE; v.bt = c->bt; v.yhat = c->yhat; v.tile_loss = c->tile_loss;
+    v.ss_bt = c->bt; v.ss_f32 = 0;
     v.partial = c->partial; v.gradbuf = c->gradbuf; v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.eig_ws = c->eig_ws; v.sc = c->sc;
     v.loss = c->opt.loss; v.optimiser = c->opt.optimiser; v.rescale_before = c->opt.rescale_before;
     v.rescale_after = c->opt.rescale_after; v.train_sep = c->opt.train_classes_separately; v.svd_alg = c->opt.svd_alg;
@@ -316,6 +317,8 @@ View make_eig_view(Ctx* c) {
     v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.eig_ws = c->eig_ws; v.sc = c->sc;
     v.rescale_after = c->opt.rescale_after; v.svd_alg = c->opt.svd_alg; v.cutoff = c->opt.cutoff;
     v.zw = c->zw;
+    v.ss_bt = c->zw == 1 ? (const void*)c->bt : nullptr;        // the subspace eigensolver reads the bond tensor itself (real types)
+    v.ss_f32 = c->dtype == MPST_F32 ? 1 : 0;
     return v;
 }
 
@@ -386,6 +389,8 @@ int ensure_workspace_typed(Ctx* c) {
         const char* sel = getenv("MPST_BIG_EIG");
         if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, zw * dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        // real element types: the randomised subspace solver in front of the exact one (complex Gram matrices arrive as embeddings)
+        if (c->blk && zw == 1 && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
         if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);
     }
@@ -488,6 +493,7 @@ int ensure_workspace(Ctx* c) {
         if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         // MPST_BIG_SYNC=1: read the eigensolver's verdict after every bond (one host synchronisation per bond) instead of once per sweep
+        if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
         if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);       // test hook: the n-th solve of the context is marked failed
     }
@@ -2325,11 +2331,16 @@ int mpst_get_info(void* ctx, int32_t* out) {
 }
 
 int mpst_get_info_n(void* ctx, int32_t* out, int32_t n) {
-    int32_t full[16];
+    int32_t full[18];
     if (!out || n < 0) return MPST_ERR_INVALID;
     int rc = mpst_get_info(ctx, full);
     if (rc) return rc;
-    for (int i = 0; i < n && i < 16; ++i) out[i] = full[i];
+    full[16] = full[17] = 0;
+    if (n > 16) {       // bonds the subspace eigensolver attempted / whose result was accepted (the rest went to the exact solver)
+        Ctx* c = (Ctx*)ctx;
+        if (c->blk && blocked_eig_subspace_counts(c->blk, c->stream, &full[16], &full[17])) return fail(c, MPST_ERR_DEVICE, "reading the subspace eigensolver's counters failed");
+    }
+    for (int i = 0; i < n && i < 18; ++i) out[i] = full[i];
     return 0;
 }
 

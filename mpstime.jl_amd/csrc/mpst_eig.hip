@@ -244,7 +244,8 @@ __device__ __forceinline__ EigProblem resolve(const View& v, int lid, int going_
         p.n = rawn;
         p.rows = rawn;
         p.nspec = rawn;
-        p.K0 = rawn < RAW_KMAX ? rawn : RAW_KMAX;
+        const int kmax = (rawalg & 8) ? TRI_KMAX : RAW_KMAX;      // bit 3: all TRI_KMAX pairs (Rayleigh-Ritz of the subspace solver)
+        p.K0 = rawn < kmax ? rawn : kmax;
         p.pair = (rawalg & 4) != 0 && (rawn & 1) == 0;            // test hook: rawG is an embedding, one vector per pair
         if (p.pair) p.K0 &= ~1;
         p.tri = (rawalg & 3) != MPST_SVD_JACOBI && rawn >= 2;
@@ -551,9 +552,10 @@ __device__ __forceinline__ void tri_core(const double* __restrict__ G, const int
 // arrays the blocked path's later kernels read (Vall row j = reflector j, entries j .. n-1).
 __global__ __launch_bounds__(TRI_T) void k_eig_tail(View v, int lid, int going_left, int rawn, const double* __restrict__ Gt, int ld,
                                                           double* __restrict__ Vall, double* __restrict__ dd, double* __restrict__ ee,
-                                                          double* __restrict__ tau, const int32_t* abort_flag) {
+                                                          double* __restrict__ tau, const int32_t* abort_flag, const int32_t* skip) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (abort_flag && *(const volatile int32_t*)abort_flag != 0) return;
+    if (skip && *(const volatile int32_t*)skip != 0) return;          // the subspace solver's result stands (mpst_eig_subspace.inl)
     const EigProblem pb = resolve(v, lid, going_left, nullptr, rawn, 0);
     const int n = pb.n, tid = threadIdx.x;
     if (n <= EIG_TAIL_N) return;                   // the multi-workgroup reduction did all the steps itself
@@ -1114,6 +1116,13 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
                                                             int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
     trivec_body(v, lid, going_left, rawG, rawn, rawalg, ws, stamps);
 }
+// raw problem behind a gate word (v.label_site, 0 = leave at once): the Rayleigh-Ritz problem of the subspace solver
+// (mpst_eig_subspace.inl), which is enqueued whether or not the bond at hand is attempted.  A kernel of its own: the headline
+// kernel above keeps its register allocation.
+__global__ __launch_bounds__(TRI_T) void k_eig_trivec_g(View v, const double* rawG, int rawn, int rawalg, double* __restrict__ ws) {
+    if (*(const volatile int32_t*)v.label_site == 0) return;
+    trivec_body(v, 0, 0, rawG, rawn, rawalg, ws, nullptr);
+}
 // K independent fits per launch (blockIdx.z): see mpst_fused.hip.  The eigensolver reads a dozen scalar fields of the View: they
 // are copied into a local one (scalar registers after SROA) - through a reference into global memory the register-starved
 // reflector loop of trivec_body spilled 60 bytes per lane more and ran 55 us longer.
@@ -1346,6 +1355,13 @@ __device__ __forceinline__ void fin_body(const View& v, int lid, int going_left,
         if (tid < K0) lam_s[tid] = lam_in;
         __syncthreads();
         nk = truncate(lam_s, K0);
+        if (raw && (rawalg & 8)) {
+            // Rayleigh-Ritz problem of the subspace solver: a rank-deficient block (growth phase of a fit) has a cluster of zero
+            // eigenvalues whose vectors nobody reads - only the pairs above 1e-13 of the largest are verified and delivered
+            int cnt = 1;
+            while (cnt < K0 && lam_s[cnt] > 1e-13 * lam_s[0]) ++cnt;
+            nk = cnt;
+        }
         done = ks == 32 ? fin_tri<32>(smem, zin, n, nk, res_in, tnorm_in, Eout, ldE)
                         : fin_tri<64>(smem, zin, n, nk, res_in, tnorm_in, Eout, ldE);
     }
@@ -1395,6 +1411,11 @@ __global__ __launch_bounds__(EIG_THREADS) void k_eig_fin_b(const View* __restric
     fin_body(v, lid, going_left, nullptr, 0, 0, v.eig_ws, nullptr, nullptr, nullptr, v.sc->eig_stamps);
 }
 
+__global__ __launch_bounds__(EIG_THREADS) void k_eig_fin_g(View v, const double* rawG, int rawn, int rawalg, double* __restrict__ ws, double* rawlam,
+                                                           double* rawE, int32_t* rawinfo) {
+    if (*(const volatile int32_t*)v.label_site == 0) return;
+    fin_body(v, 0, 0, rawG, rawn, rawalg, ws, rawlam, rawE, rawinfo, nullptr);
+}
 // raw-mode helper: clear the outputs of the test entry point
 __global__ void k_eig_clear(double* lam, double* E, int n) {
     for (int i = threadIdx.x; i < n * n; i += blockDim.x) E[i] = 0.0;
@@ -1417,6 +1438,8 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_fin_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
@@ -1455,8 +1478,19 @@ void launch_eig_b(const View& v, const View* vs, int K, int lid, int going_left,
 }
 
 void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,
-                     double* tau, const int32_t* abort_flag, hipStream_t s) {
-    hipLaunchKernelGGL(k_eig_tail, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left, rawn, Gt, ld, Vall, dd, ee, tau, abort_flag);
+                     double* tau, const int32_t* abort_flag, const int32_t* skip, hipStream_t s) {
+    hipLaunchKernelGGL(k_eig_tail, dim3(1), dim3(TRI_T), eig_lds_bytes(), s, v, lid, going_left, rawn, Gt, ld, Vall, dd, ee, tau, abort_flag, skip);
+}
+
+// the TRI_KMAX largest eigenpairs of a symmetric n x n matrix (n <= 128) on the device, no host synchronisation; gate: device word,
+// 0 = every launch leaves at once.  E: n x n row-major, column k = vector k; lam descending.
+void launch_eig_raw_gated(const double* G, int n, double* lam, double* E, int32_t* info, double* ws, const int32_t* gate, hipStream_t s) {
+    View v{};
+    v.label_site = const_cast<int32_t*>(gate);
+    const int alg = 8;
+    const int K = n < TRI_KMAX ? (n < 32 ? 32 : n) : TRI_KMAX;
+    hipLaunchKernelGGL(k_eig_trivec_g, dim3(K), dim3(TRI_T), vec_lds_bytes(), s, v, G, n, alg, ws);
+    hipLaunchKernelGGL(k_eig_fin_g, dim3(1), dim3(EIG_THREADS), eig_lds_bytes(), s, v, G, n, alg, ws, lam, E, info);
 }
 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s) {

@@ -85,8 +85,16 @@ struct BtBufs {
                      // order n/2, Vall / tau hold complex reflectors (double2, row stride ncap/2), k_bt_back_c back-transforms
     const int32_t* abort;   // persistent tridiagonalisation's abort word (null on the launch-per-step path): when it is set,
                             // dd / ee / Vall are stale or partial and every kernel after it must leave without publishing
+    // subspace solver in front of the exact one (mpst_eig_subspace.inl):
+    const int32_t* skip;    // exact phase: word that says "the subspace result stands" - every kernel of the exact solve leaves at once
+    const int32_t* gate;    // subspace phase: word that says "this bond is attempted" - 0: the shared verification kernels leave at once
+    int ss;                 // 1: k_bt_gram / k_bt_decide / k_bt_polish run for the subspace phase (Z, lam, res, dd filled by k_ss_*)
 };
 __device__ __forceinline__ bool bt_aborted(const BtBufs& b) { return b.abort && *(const volatile int32_t*)b.abort != 0; }
+// the launch has nothing to do: the subspace result stands (exact phase), or the bond is not attempted (subspace phase)
+__device__ __forceinline__ bool bt_idle(const BtBufs& b) {
+    return (b.skip && *(const volatile int32_t*)b.skip != 0) || (b.gate && *(const volatile int32_t*)b.gate == 0);
+}
 
 // the sum a 512-thread workgroup (8 waves, added in wave order) forms, from 256 threads that each carry the partial sums of
 // two of its threads (t and t + 256)
@@ -113,6 +121,7 @@ __device__ __forceinline__ double bt_block_sum(double x, double* red) {
 }
 
 __global__ __launch_bounds__(BT_T) void k_bt_prep(View v, int lid, int going_left, const double* rawG, int rawn, BtBufs b) {
+    if (bt_idle(b)) return;
     const BtProblem pb = bt_resolve(v, lid, going_left, rawG, rawn);
     const int n = pb.n, ld = b.ncap;
     for (int64_t i = (int64_t)blockIdx.x * BT_T + threadIdx.x; i < (int64_t)n * n; i += (int64_t)gridDim.x * BT_T) {
@@ -156,6 +165,7 @@ __device__ __forceinline__ void bt_reflector_scalars(double a0, double s, double
 //   (c) its own rows r > j: A[r][:] -= v_prev[r] w^T + w[r] v_prev^T (full rows: both triangles stay consistent, and a
 //       row's product with v_j needs nothing from other workgroups), then y_r = tau_j A[r][:] v_j.
 __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_left, int rawn, BtBufs b, int j) {
+    if (bt_idle(b)) return;
     __shared__ double xs[BT_NMAX];      // row j with the pending update applied, then the reflector v_j
     __shared__ double vl[BT_NMAX];      // v_{j-1}
     __shared__ double wl[BT_NMAX];      // w_{j-1}
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_step(View v, int lid, int going_lef
 // alpha, w and element-wise update as step m would form (and as the persistent kernel forms at its hand-over), so both
 // paths hand identical bits to the tail kernel
 __global__ __launch_bounds__(BT_T) void k_bt_tail_prep(View v, int lid, int going_left, int rawn, BtBufs b) {
+    if (bt_idle(b)) return;
     __shared__ double vl[BT_NMAX];
     __shared__ double wl[BT_NMAX];
     __shared__ double red[8];
@@ -441,6 +452,7 @@ __device__ __forceinline__ bool bt_coop_roll_call(const BtCoop& cp, int G, int* 
 // over the 8 XCDs, so stride 8 puts the participants on one XCD - the roll call verifies it); the others leave at once.
 template <int NT, int SC>
 __global__ __launch_bounds__(NT) void k_bt_coop(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
+    if (bt_idle(b)) return;
     if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -802,6 +814,7 @@ constexpr int BTC_NT = 512, BTC_NMAX = BT_NMAX / 2;
 // barrier and plain data inside one XCD (st_x / ld_x / xcd_wait / xcd_arrive)
 template <int XMODE>
 __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
+    if (bt_idle(b)) return;
     if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NT = BTC_NT, NW = NT / 64;
     constexpr bool TAGGED = XMODE == 1, XCNT = XMODE == 3;
@@ -1035,6 +1048,7 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
 // vector (8 elements per lane at n = 512, reductions on DPP: no workgroup barrier), reflectors from L2 (the four waves of a
 // workgroup walk the same rows).  Writes (Re u, Im u) into row 2k and J u = (-Im u, Re u) into row 2k + 1.
 __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_left, BtBufs b) {
+    if (bt_idle(b)) return;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
     if (bt_aborted(b)) return;
     const int n = pb.n >> 1, ld = b.ncap, ldc = b.ncap >> 1, lane = threadIdx.x & 63;
@@ -1121,6 +1135,7 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
 // identities (tau = 0).
 constexpr int BT_NB = 16;
 __global__ __launch_bounds__(BT_T) void k_bt_larft(View v, int lid, int going_left, int rawn, BtBufs b) {
+    if (bt_idle(b)) return;
     __shared__ double part[4][256];
     __shared__ double S[16][17];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
@@ -1183,6 +1198,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_larft(View v, int lid, int going_le
 }
 
 __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left, int rawn, BtBufs b) {
+    if (bt_idle(b)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red[4];
     __shared__ int cnt_s[4];
@@ -1526,6 +1542,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_vec(View v, int lid, int going_left
 // ---- verification, re-orthonormalisation, publication -------------------------------------------------------------------
 // D = Z^T Z - I for all K0 candidate vectors: one 16 x 16 tile per workgroup, the n rows split over its 4 waves.
 __global__ __launch_bounds__(BT_T) void k_bt_gram(View v, int lid, int going_left, int rawn, BtBufs b, int second) {
+    if (bt_idle(b)) return;
     __shared__ double part[4][256];
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     if (bt_aborted(b) || (second && !b.ctl[2])) return;
@@ -1569,6 +1586,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_gram(View v, int lid, int going_lef
 // ctl: [0] vectors to publish, [1] verdict ok, [2] a second Loewdin round is needed, [3] first round needed at all
 __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_left, const double* rawG, int rawn, BtBufs b,
                                                    double* rawlam, int32_t* rawinfo, int second) {
+    if (bt_idle(b)) return;
     __shared__ double lam_s[CAP_LIMIT + 2];
     __shared__ double red[16];
     const BtProblem pb = bt_resolve(v, lid, going_left, rawG, rawn);
@@ -1637,6 +1655,16 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     rmax = 0.0;
     for (int i = 0; i < 8; ++i) rmax = fmax(rmax, red[i]);
     __syncthreads();
+    // subspace phase: res[k] = |G v_k - theta_k v_k| / sqrt(theta_k tr); the root of the sum of their squares bounds the error of the
+    // projected two-site tensor, ||M (P~ - P)||_F / ||M||_F (mpst_eig_subspace.inl); 1e300 marks a failed Frobenius certificate
+    double r2 = (b.ss && tid < kout) ? b.res[tid] * b.res[tid] : 0.0;
+    r2 = wave_sum(r2);
+    if ((tid & 63) == 0) red[tid >> 6] = r2;
+    __syncthreads();
+    r2 = 0.0;
+    for (int i = 0; i < 8; ++i) r2 += red[i];
+    __syncthreads();
+    const bool res_ok = b.ss ? (sqrt(r2) < 1e-9) : (rmax < 1e-8 && rmax == rmax);
     double emax = 0.0;
     for (int e = tid; e < kout * kout; e += 512) emax = fmax(emax, fabs(b.D[(int64_t)(e / kout) * CAP_LIMIT + (e % kout)]));
     emax = wave_max(emax);
@@ -1646,7 +1674,7 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
     for (int i = 0; i < 8; ++i) emax = fmax(emax, red[i]);
     // vectors of eigenvalues close to the cutoff come out of the twisted factorisation orthogonal to ~1e-6 only (two
     // Loewdin rounds take them to rounding); |D| > 1e-3 means a genuine cluster -> library solver
-    const bool ok = rmax < 1e-8 && rmax == rmax && emax < 1e-3 && emax == emax && trace_ok;
+    const bool ok = res_ok && emax < 1e-3 && emax == emax && trace_ok;
     if (tid == 0) {
         b.ctl[0] = kout;
         b.ctl[1] = ok ? 1 : 0;
@@ -1680,6 +1708,7 @@ __global__ __launch_bounds__(512) void k_bt_decide(View v, int lid, int going_le
 // E = Z (I - D/2) over the kept vectors (Loewdin: squares the deviation from orthonormality without leaving the subspace):
 // 16 x 16 tiles of E on the MFMA, A operand = Z^T, B operand = -D/2 + I.  second = 1: the input is the first round's E.
 __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_left, int rawn, BtBufs b, double* rawE, int second) {
+    if (bt_idle(b)) return;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     // the last launch of a solve: remember a failed verdict (verification, or the persistent kernel gave up) for callers that
     // look at it once per sweep instead of once per bond
@@ -1720,6 +1749,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_l
 
 // second round: the polished vectors become the input (Z <- E^T)
 __global__ __launch_bounds__(BT_T) void k_bt_copyback(View v, int lid, int going_left, int rawn, BtBufs b, const double* rawE) {
+    if (bt_idle(b)) return;
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     if (bt_aborted(b) || !b.ctl[2]) return;
     const bool raw = rawn > 0;
@@ -1732,6 +1762,8 @@ __global__ __launch_bounds__(BT_T) void k_bt_copyback(View v, int lid, int going
     }
 }
 
+#include "mpst_eig_subspace.inl"
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 struct BlockedEig {
     BtBufs b{};
@@ -1742,6 +1774,8 @@ struct BlockedEig {
     int xcd_misplaced = 0;             // solves whose XCD-local attempt found its workgroups on more than one XCD
     int cooldown = 0;                  // solves left that skip the persistent kernels after one of them gave up waiting
     int32_t* sticky = nullptr;         // device [1]: a solve enqueued by launch_eig_blocked_nosync failed since the last reset
+    SsBufs ss{};                       // subspace solver in front of the exact one (mpst_eig_subspace.inl); ss.Mw == nullptr: off
+    int32_t* host_st = nullptr;        // pinned [4]: copy of ss.st
 };
 static int coop_threads() {
     static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
@@ -1839,7 +1873,104 @@ void blocked_eig_destroy(BlockedEig* e) {
     if (e->cp.ybuf) (void)hipFree(e->cp.ybuf);
     if (e->cp.rowbuf) (void)hipFree(e->cp.rowbuf);
     if (e->cp.counter) (void)hipFree(e->cp.counter);
+    {
+        SsBufs& q = e->ss;
+        double* qs[] = {q.Mw, q.Lb[0], q.Lb[1], q.Rb[0], q.Rb[1], q.Sp, q.Tm, q.H, q.lamH, q.WH, q.wsH, q.part};
+        for (double* p : qs)
+            if (p) (void)hipFree(p);
+        if (q.infoH) (void)hipFree(q.infoH);
+        if (q.st) (void)hipFree(q.st);
+        if (e->host_st) (void)hipHostFree(e->host_st);
+    }
     delete e;
+}
+
+// Switch the subspace solver on for this workspace: mcap rows (C * d * cap), kcap = chi_max.  Off (and harmless) when the shape
+// leaves no room for it (block wider than SS_PMAX, or the matrix not at least twice as wide as the block) or MPST_NO_SUBSPACE is set.
+int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, std::string* err) {
+    if (!e || e->ss.Mw) return 0;
+    static const bool off = getenv("MPST_NO_SUBSPACE") != nullptr;
+    const int ncap = e->b.ncap;
+    if (off || kcap > 64 || C * kcap > SS_PMAX) return 0;      // the block holds rank(M0) <= C chi columns
+    const int pc = std::min(SS_PMAX, (C * kcap + SS_EXTRA + 15) & ~15);
+    if (ncap < 2 * pc || ncap <= MAX_DIM) return 0;
+    SsBufs& q = e->ss;
+    q.pc = pc;
+    q.mcap = mcap;
+    q.ncap = ncap;
+    auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess && hipMemset(*p, 0, n * sizeof(double)) == hipSuccess; };
+    const size_t tn = (size_t)(ncap + 15) / 16;
+    bool ok = al(&q.Mw, (size_t)mcap * ncap) && al(&q.Lb[0], (size_t)mcap * pc) && al(&q.Lb[1], (size_t)mcap * pc) && al(&q.Rb[0], (size_t)ncap * pc) &&
+              al(&q.Rb[1], (size_t)ncap * pc) && al(&q.Sp, (size_t)SS_KS * pc * pc) && al(&q.Tm, (size_t)pc * pc) && al(&q.H, (size_t)pc * pc) &&
+              al(&q.lamH, SS_PMAX) && al(&q.WH, (size_t)pc * pc) && al(&q.wsH, eig_workspace_doubles()) && al(&q.part, tn * CAP_LIMIT + tn + 16) &&
+              hipMalloc((void**)&q.infoH, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&q.st, 4 * sizeof(int32_t)) == hipSuccess &&
+              hipMemset(q.st, 0, 4 * sizeof(int32_t)) == hipSuccess && hipHostMalloc((void**)&e->host_st, 4 * sizeof(int32_t)) == hipSuccess;
+    if (!ok) {
+        if (err) *err = "allocation of the subspace eigensolver's workspace failed";
+        return MPST_ERR_NOMEM;
+    }
+    return 0;
+}
+bool blocked_eig_subspace_on(const BlockedEig* e) { return e && e->ss.Mw != nullptr; }
+// bonds the subspace solver attempted / whose result was accepted since creation (synchronises the stream)
+int blocked_eig_subspace_counts(BlockedEig* e, hipStream_t s, int32_t* attempted, int32_t* accepted) {
+    *attempted = *accepted = 0;
+    if (!blocked_eig_subspace_on(e)) return 0;
+    if (hipMemcpyAsync(e->host_st, e->ss.st, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+    if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
+    *accepted = e->host_st[2];
+    *attempted = e->host_st[3];
+    return 0;
+}
+
+// The subspace phase of a solve: ~30 launches, all leave at once on a bond that is not attempted.  Afterwards ss.st[0] says whether
+// E / lam / chi are published.
+static void enqueue_subspace(const View& v, int lid, int going_left, BlockedEig* e, hipStream_t s) {
+    const SsBufs& q = e->ss;
+    const int pc = q.pc, tp = pc / 16;
+    const int tm = (q.mcap + 15) / 16, tn = (q.ncap + 15) / 16;
+    const size_t chol_lds = 0;
+    const int kmax = std::min(v.chi_max, 64), tk = (kmax + 15) / 16;
+    hipLaunchKernelGGL(k_ss_load, dim3(256), dim3(256), 0, s, v, lid, going_left, q);
+    auto orth = [&](double* raw, double* out, int left) {          // out = cholqr(raw)
+        hipLaunchKernelGGL(k_ss_gram, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, left);
+        if (pc <= 96) hipLaunchKernelGGL(k_ss_chol<2>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
+        else hipLaunchKernelGGL(k_ss_chol<0>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
+        hipLaunchKernelGGL(k_ss_apply, dim3(((left ? tm : tn) * tp + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, out, left);
+    };
+    // X = cholqr(M^T Omega)
+    hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[0], q.Rb[0]);
+    orth(q.Rb[0], q.Rb[1], 0);
+    // Q = cholqr(M X); X = cholqr(M^T Q); Q = cholqr(M X)
+    hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
+    orth(q.Lb[0], q.Lb[1], 1);
+    hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[1], q.Rb[0]);
+    orth(q.Rb[0], q.Rb[1], 0);
+    hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
+    orth(q.Lb[0], q.Lb[1], 1);
+    // Z = M^T Q; H = Z^T Z; Rayleigh-Ritz
+    hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[1], q.Rb[0]);
+    hipLaunchKernelGGL(k_ss_gram, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[0], 0);
+    hipLaunchKernelGGL(k_ss_chol<1>, dim3((pc * pc + CH_T - 1) / CH_T), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
+    launch_eig_raw_gated(q.H, pc, q.lamH, q.WH, q.infoH, q.wsH, q.st + 1, s);
+    BtBufs b = e->b;
+    b.abort = nullptr;
+    b.sticky = nullptr;
+    b.skip = nullptr;
+    b.gate = q.st + 1;
+    b.ss = 1;
+    b.cnative = 0;
+    hipLaunchKernelGGL(k_ss_ritz, dim3((tn * tk + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, b, (const double*)q.Rb[0]);
+    hipLaunchKernelGGL(k_ss_resid, dim3(tn * tk), dim3(256), 0, s, v, lid, going_left, q, b);
+    hipLaunchKernelGGL(k_ss_collect, dim3(1), dim3(1024), 0, s, v, lid, going_left, q, b);
+    const int ncap = b.ncap, tkk = (std::min(v.chi_max, CAP_LIMIT) + 15) / 16, tnn = (ncap + 15) / 16;
+    for (int second = 0; second < 2; ++second) {
+        if (second) hipLaunchKernelGGL(k_bt_copyback, dim3(64), dim3(BT_T), 0, s, v, lid, going_left, 0, b, (const double*)nullptr);
+        hipLaunchKernelGGL(k_bt_gram, dim3(tkk * tkk), dim3(BT_T), 0, s, v, lid, going_left, 0, b, second);
+        hipLaunchKernelGGL(k_bt_decide, dim3(1), dim3(512), 0, s, v, lid, going_left, (const double*)nullptr, 0, b, (double*)nullptr, (int32_t*)nullptr, second);
+        hipLaunchKernelGGL(k_bt_polish, dim3(std::max(1, std::min(256, (tnn * tkk + 3) / 4))), dim3(BT_T), 0, s, v, lid, going_left, 0, b, (double*)nullptr, second);
+    }
+    hipLaunchKernelGGL(k_ss_verdict, dim3(1), dim3(64), 0, s, q, b);
 }
 
 // the launches that follow the tridiagonalisation: eigenvectors, verification, publication
@@ -1868,6 +1999,33 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
     const BtBufs& b = e->b;
     const int ncap = rawn > 0 ? rawn : b.ncap;
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
+    if (rawn == 0 && blocked_eig_subspace_on(e)) {
+        // the subspace solver first; its verdict is read here (this path synchronises per bond anyway), so the exact solve is
+        // enqueued only when it is needed
+        enqueue_subspace(v, lid, going_left, e, s);
+        if (hipMemcpyAsync(e->host_st, e->ss.st, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (hipStreamSynchronize(s) != hipSuccess) return MPST_ERR_DEVICE;
+        if (hipGetLastError() != hipSuccess) return MPST_ERR_DEVICE;
+        static const bool dbg = getenv("MPST_SS_DEBUG") != nullptr;
+        if (dbg && e->host_st[1]) {
+            double res[CAP_LIMIT], lam[CAP_LIMIT], D[CAP_LIMIT];
+            int32_t ctl[4], flag, info;
+            (void)hipMemcpy(res, b.res, sizeof res, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(lam, b.lam, sizeof lam, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(D, b.D, sizeof D, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ctl, b.ctl, sizeof ctl, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&flag, b.flag, sizeof flag, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&info, e->ss.infoH, sizeof info, hipMemcpyDeviceToHost);
+            double r2 = 0, rmax = 0; int bad = -1;
+            for (int i = 0; i < ctl[0] && i < CAP_LIMIT; ++i) { r2 += res[i] * res[i]; if (res[i] > rmax) { rmax = res[i]; bad = i; } }
+            double stamp[3];
+            (void)hipMemcpy(stamp, e->ss.lamH + SS_PMAX - 3, sizeof stamp, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ss] chol phases: load %.2f us, elimination %.2f us\n", stamp[0] * 0.01, stamp[1] * 0.01);
+            fprintf(stderr, "[ss] lid %d gl %d st %d %d ctl %d %d %d %d flag %d eiginfo %d est %.3e rmax %.3e at %d lam0 %.3e lam[k-1] %.3e D00 %.3e D01 %.3e\n", lid, going_left,
+                    e->host_st[0], e->host_st[1], ctl[0], ctl[1], ctl[2], ctl[3], flag, info, sqrt(r2), rmax, bad, lam[0], lam[ctl[0] > 0 ? ctl[0] - 1 : 0], D[0], D[1]);
+        }
+        if (e->host_st[0]) return 0;
+    }
     // mode 2: persistent kernel confined to one XCD; 1: persistent kernel across the XCDs; 0: one launch per step
     int mode = (rawn == 0 && !no_coop) ? (xcd_usable(ncap) ? 2 : 1) : 0;
     // pair mode: the Hermitian problem itself (k_bt_coop_c) - 4: confined to one XCD, 3: across the XCDs
@@ -1909,7 +2067,7 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (b.use_tail && mode < 3) {
             // the last BT_TAIL steps on one CU (the kernels above stopped at step n - BT_TAIL; nothing to do for n <= BT_TAIL)
             if (!mode) hipLaunchKernelGGL(k_bt_tail_prep, dim3(32), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
-            launch_eig_tail(v, lid, going_left, rawn, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
+            launch_eig_tail(v, lid, going_left, rawn, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, bt.skip, s);
         }
         enqueue_after_tridiag(v, lid, going_left, rawG, rawn, rawlam, rawE, rawinfo, bt, s);
         e->host_flag[1] = 0;
@@ -1946,10 +2104,13 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
     const int ncap = b.ncap;
     static const bool no_coop = getenv("MPST_BT_NO_COOP") != nullptr;
     if (no_coop) return MPST_ERR_UNSUPPORTED;
+    const bool ss = blocked_eig_subspace_on(e);
+    if (ss) enqueue_subspace(v, lid, going_left, e, s);      // the exact solve below leaves at once where its result stands
     if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
     BtBufs bt = b;
     bt.abort = e->cp.abort_flag;
     bt.sticky = e->sticky;
+    bt.skip = ss ? e->ss.st : nullptr;
     const bool nat = cnative_usable(v, ncap);
     bt.cnative = nat ? 1 : 0;
     if (nat && cnative_xcd_mode(ncap) == 3)
@@ -1964,7 +2125,7 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
         hipLaunchKernelGGL((k_bt_coop<512, SC_AGENT>), dim3(coop_grid(ncap)), dim3(512), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
     else
         hipLaunchKernelGGL((k_bt_coop<256, SC_AGENT>), dim3(coop_grid(ncap)), dim3(256), coop_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
-    if (b.use_tail && !nat) launch_eig_tail(v, lid, going_left, 0, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, s);
+    if (b.use_tail && !nat) launch_eig_tail(v, lid, going_left, 0, b.tailG, b.ncap, b.Vall, b.dd, b.ee, b.tau, bt.abort, bt.skip, s);
     enqueue_after_tridiag(v, lid, going_left, nullptr, 0, nullptr, nullptr, nullptr, bt, s);
     return 0;
 }

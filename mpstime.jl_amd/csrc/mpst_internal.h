@@ -409,6 +409,11 @@ struct View {
     // J u = (-u_im, u_re) next to it (columns 2k, 2k+1), the truncation rule runs on the de-duplicated spectrum and
     // chi_max / cap of this view are the doubled (real) counts.  0 / 1: plain real symmetric problem.
     int32_t zw;
+    // large bonds: the bond tensor as the subspace eigensolver reads it (mpst_eig_subspace.inl) - [C][X][Y] in fp64 (ss_f32 = 0) or
+    // fp32 (1); null: no subspace attempt (complex element types, small bonds).  Raw mode of the LDS-resident solver
+    // (launch_eig_raw_gated): label_site doubles as the gate word (0 = leave at once).
+    const void* ss_bt;
+    int32_t ss_f32;
 };
 __device__ __forceinline__ int view_zw(const View& v) { return v.zw == 2 ? 2 : 1; }
 
@@ -603,6 +608,9 @@ void blocked_eig_force_sticky(BlockedEig* e, hipStream_t s);
 int blocked_eig_coop_aborts(const BlockedEig* e);
 int blocked_eig_xcd_misplaced(const BlockedEig* e);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);
+int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, std::string* err);
+bool blocked_eig_subspace_on(const BlockedEig* e);
+int blocked_eig_subspace_counts(BlockedEig* e, hipStream_t s, int32_t* attempted, int32_t* accepted);
 void blocked_eig_destroy(BlockedEig* e);
 int launch_eig_blocked(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
                        int32_t* rawinfo, BlockedEig* e, hipStream_t s);
@@ -640,9 +648,10 @@ void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri (or tri + vec merged), 1 vec, 2 fin
 void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,
-                     double* tau, const int32_t* abort_flag, hipStream_t s);   // last 128 steps of a larger reduction on one CU
+                     double* tau, const int32_t* abort_flag, const int32_t* skip, hipStream_t s);   // last 128 steps of a larger reduction on one CU
 bool eig_merged();   // k_eig_trivec instead of k_eig_tri + k_eig_vec (default; MPST_EIG_SPLIT=1 restores the three-kernel chain)
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
+void launch_eig_raw_gated(const double* G, int n, double* lam, double* E, int32_t* info, double* ws, const int32_t* gate, hipStream_t s);
 size_t eig_workspace_doubles();
 // library slow path for d*chi_max > MAX_DIM (rocSOLVER dsyevd at the capacity size, see mpst_eig.hip)
 struct BigEig;

@@ -372,9 +372,9 @@ class SweepEngine:
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
 
     def info(self):
-        out = (C.c_int32 * 16)()
-        self._chk(self.lib.mpst_get_info(self.ctx, out))
-        return {"fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
+        out = (C.c_int32 * 18)()
+        self._chk(self.lib.mpst_get_info_n(self.ctx, out, 18))
+        return {"subspace_attempted": out[16], "subspace_accepted": out[17], "fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
                 "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11],
                 "eig_merged": bool(out[12]), "large_bond_sweep_redos": out[13], "large_bond_verdict_per_sweep": bool(out[14]),
