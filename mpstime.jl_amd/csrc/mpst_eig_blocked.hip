@@ -1896,6 +1896,7 @@ int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, std::s
     if (ncap < 2 * pc || ncap <= MAX_DIM) return 0;
     SsBufs& q = e->ss;
     q.pc = pc;
+    q.dbg = getenv("MPST_SS_DBG") ? atoi(getenv("MPST_SS_DBG")) : 0;
     q.mcap = mcap;
     q.ncap = ncap;
     auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess && hipMemset(*p, 0, n * sizeof(double)) == hipSuccess; };
@@ -1931,16 +1932,19 @@ static void enqueue_subspace(const View& v, int lid, int going_left, BlockedEig*
     const int tm = (q.mcap + 15) / 16, tn = (q.ncap + 15) / 16;
     const size_t chol_lds = 0;
     const int kmax = std::min(v.chi_max, 64), tk = (kmax + 15) / 16;
-    hipLaunchKernelGGL(k_ss_load, dim3(256), dim3(256), 0, s, v, lid, going_left, q);
+    const int short_start = v.ss_f32 ? 1 : 0;
+    hipLaunchKernelGGL(k_ss_load, dim3(256), dim3(256), 0, s, v, lid, going_left, q, short_start);
     auto orth = [&](double* raw, double* out, int left) {          // out = cholqr(raw)
         hipLaunchKernelGGL(k_ss_gram, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, left);
         if (pc <= 96) hipLaunchKernelGGL(k_ss_chol<2>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
         else hipLaunchKernelGGL(k_ss_chol<0>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
         hipLaunchKernelGGL(k_ss_apply, dim3(((left ? tm : tn) * tp + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, out, left);
     };
-    // X = cholqr(M^T Omega)
-    hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[0], q.Rb[0]);
-    orth(q.Rb[0], q.Rb[1], 0);
+    // X = cholqr(M^T Omega)  (fp32: X = Omega / sqrt(n), written by k_ss_load)
+    if (!short_start) {
+        hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[0], q.Rb[0]);
+        orth(q.Rb[0], q.Rb[1], 0);
+    }
     // Q = cholqr(M X); X = cholqr(M^T Q); Q = cholqr(M X)
     hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
     orth(q.Lb[0], q.Lb[1], 1);

@@ -10,6 +10,7 @@
 // on every one of the dumped bonds.  Every step is a GEMM on the fp64 MFMA:
 //     X = cholqr(M^H Omega);   Q = cholqr(M X);   X = cholqr(M^H Q);   Q = cholqr(M X);   Z = M^H Q;
 //     Z^H Z = W Theta W^H (p x p, the LDS-resident solver of mpst_eig.hip);   V = Z W Theta^-1/2,  sigma^2 = Theta.
+// (fp32 bond tensors, whose entries carry 6e-8 of rounding noise and whose bar is 3e-8: FOUR applications, X = Omega directly.)
 // The half-steps go through M, not G = M^H M: a Cholesky-QR of G X sees the SQUARED spectrum (condition 1e10 and more).
 // cholqr = Gram matrix (partials over row slices, summed in a fixed order), an in-place Gauss-Jordan elimination that leaves
 // L^-1 directly (one workgroup, p steps; pivots below 2e-15 of the column's own norm drop the column: rank-deficient blocks of
@@ -43,6 +44,7 @@ struct SsBufs {
                          // [2] bonds accepted, [3] bonds attempted (since creation)
     int pc;              // block width at capacity: multiple of 16, <= SS_PMAX
     int mcap, ncap;
+    int dbg;             // bring-up: MPST_SS_DBG bits switch parts of the elimination step off (timing only, results are wrong)
 };
 
 struct SsProblem {
@@ -73,7 +75,9 @@ __device__ __forceinline__ double ss_omega(int r, int j) {
 
 // M as decomposeBT sees it, in fp64: going left rows (c, x) | cols y; going right rows (c, y) | cols x  (bt = [C][X][Y]).
 // Omega into the first left block.  First launch of a solve: it also publishes whether the bond is attempted at all.
-__global__ __launch_bounds__(256) void k_ss_load(View v, int lid, int going_left, SsBufs s) {
+// start_right = 1 (fp32 bond tensors: one application of M fewer is enough for their 3e-8 bar): the start block is X = Omega / sqrt(n)
+// itself - independent +-1 columns are orthonormal to 1 / sqrt(n), which is all the first product needs - written to the right block.
+__global__ __launch_bounds__(256) void k_ss_load(View v, int lid, int going_left, SsBufs s, int start_right) {
     const SsProblem q = ss_resolve(v, lid, going_left, s);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         s.st[0] = 0;
@@ -97,10 +101,12 @@ __global__ __launch_bounds__(256) void k_ss_load(View v, int lid, int going_left
         }
         s.Mw[e] = v.ss_f32 ? (double)bf[src] : bd[src];
     }
-    const int64_t tot2 = (int64_t)m * q.p;
+    const int64_t tot2 = (int64_t)(start_right ? n : m) * q.p;
+    double* __restrict__ O = start_right ? s.Rb[1] : s.Lb[0];
+    const double sc = start_right ? 1.0 / sqrt((double)n) : 1.0;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot2; e += (int64_t)gridDim.x * 256) {
         const int r = (int)(e / q.p), j = (int)(e - (int64_t)r * q.p);
-        s.Lb[0][(int64_t)r * s.pc + j] = ss_omega(r, j);
+        O[(int64_t)r * s.pc + j] = sc * ss_omega(r, j);
     }
 }
 
@@ -202,7 +208,7 @@ struct CholShared {
     int dead[SS_PMAX];
 };
 template <int E, int S, int RU, int CT>      // steps 32 E + 8 S .. + 7: rows with u < E are finished; the pivot column sits in register t = 4 E + S
-__device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShared& sh, const int p, const int rg, const int cg) {
+__device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShared& sh, const int p, const int rg, const int cg, const int dbg) {
     constexpr int TP = 4 * E + S;
     const int j0 = 32 * E + 8 * S;
     const int jend = min(p, j0 + 8);
@@ -214,7 +220,7 @@ __device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShar
 #pragma unroll
         for (int u = E; u < RU; ++u) fc[u] = sh.colb[b][rg + 32 * u];
 #pragma unroll
-        for (int t = 0; t < CT; ++t) r[t] = sh.rowb[b][cg + 8 * t];
+        for (int t = 0; t < CT; ++t) r[t] = (dbg & 4) ? 1e-3 : sh.rowb[b][cg + 8 * t];
         const bool isdead = !(piv > 2e-15 * dj) || !(dj > 0.0);       // uniform
         if (rg == 0 && cg == 0) {
             sh.pivd[j] = piv;
@@ -230,8 +236,10 @@ __device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShar
         for (int u = E; u < RU; ++u) {
             const int i = rg + 32 * u;
             const double f = (u > E || i > j) ? fc[u] * rc : 0.0;
+            if (!(dbg & 1)) {
 #pragma unroll
-            for (int t = 0; t < CT; ++t) val[u][t] -= f * r[t];
+                for (int t = 0; t < CT; ++t) val[u][t] -= f * r[t];
+            } else val[u][TP] -= f * r[TP];
         }
         if (isdead && cg == (j & 7)) {  // ... and nothing of it survives below the diagonal
 #pragma unroll
@@ -239,8 +247,10 @@ __device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShar
                 if (rg + 32 * u > j) val[u][TP] = 0.0;
         }
         // publish row j + 1 and column j + 1 for the next step
+        // (tried: the next step's operands first, its LDS reads under the bulk of this step's update - 44 against 40 us per
+        // factorisation at p = 96: the second copy of the step's operands costs more registers than the overlap wins)
         const int jn = j + 1;
-        if (jn < p) {
+        if (jn < p && !(dbg & 2)) {
             if (rg == (jn & 31)) {
                 const bool same = (jn >> 5) == E;
 #pragma unroll
@@ -264,15 +274,15 @@ __device__ __forceinline__ void chol_piece(double (&val)[CH_RU][CH_CT], CholShar
                 }
             }
         }
-        __syncthreads();
+        if (!(dbg & 8)) __syncthreads();
     }
 }
 template <int E, int RU, int CT>
-__device__ __forceinline__ void chol_era(double (&val)[CH_RU][CH_CT], CholShared& sh, const int p, const int rg, const int cg) {
-    chol_piece<E, 0, RU, CT>(val, sh, p, rg, cg);
-    if (p > 32 * E + 8) chol_piece<E, 1, RU, CT>(val, sh, p, rg, cg);
-    if (p > 32 * E + 16) chol_piece<E, 2, RU, CT>(val, sh, p, rg, cg);
-    if (p > 32 * E + 24) chol_piece<E, 3, RU, CT>(val, sh, p, rg, cg);
+__device__ __forceinline__ void chol_era(double (&val)[CH_RU][CH_CT], CholShared& sh, const int p, const int rg, const int cg, const int dbg) {
+    chol_piece<E, 0, RU, CT>(val, sh, p, rg, cg, dbg);
+    if (p > 32 * E + 8) chol_piece<E, 1, RU, CT>(val, sh, p, rg, cg, dbg);
+    if (p > 32 * E + 16) chol_piece<E, 2, RU, CT>(val, sh, p, rg, cg, dbg);
+    if (p > 32 * E + 24) chol_piece<E, 3, RU, CT>(val, sh, p, rg, cg, dbg);
 }
 
 // MODE 0 / 2: the factorisation above -> Tm (2: block capacity <= 96).  MODE 1: H = sum of the partials, zero padded to pc x pc (the Rayleigh-Ritz matrix).
@@ -321,14 +331,14 @@ __global__ __launch_bounds__(CH_T) void k_ss_chol(View v, int lid, int going_lef
     __syncthreads();
     if (tid == 0) t1 = __builtin_amdgcn_s_memrealtime();
     if constexpr (MODE == 2) {          // block capacity <= 96: 3 x 12 of the 4 x 16 registers are live
-        chol_era<0, 3, 12>(val, sh, p, rg, cg);
-        if (p > 32) chol_era<1, 3, 12>(val, sh, p, rg, cg);
-        if (p > 64) chol_era<2, 3, 12>(val, sh, p, rg, cg);
+        chol_era<0, 3, 12>(val, sh, p, rg, cg, s.dbg);
+        if (p > 32) chol_era<1, 3, 12>(val, sh, p, rg, cg, s.dbg);
+        if (p > 64) chol_era<2, 3, 12>(val, sh, p, rg, cg, s.dbg);
     } else {
-        chol_era<0, 4, 16>(val, sh, p, rg, cg);
-        if (p > 32) chol_era<1, 4, 16>(val, sh, p, rg, cg);
-        if (p > 64) chol_era<2, 4, 16>(val, sh, p, rg, cg);
-        if (p > 96) chol_era<3, 4, 16>(val, sh, p, rg, cg);
+        chol_era<0, 4, 16>(val, sh, p, rg, cg, s.dbg);
+        if (p > 32) chol_era<1, 4, 16>(val, sh, p, rg, cg, s.dbg);
+        if (p > 64) chol_era<2, 4, 16>(val, sh, p, rg, cg, s.dbg);
+        if (p > 96) chol_era<3, 4, 16>(val, sh, p, rg, cg, s.dbg);
     }
     if (tid == 0) {         // phase stamps (100 MHz) of the last call: load, elimination
         t2 = __builtin_amdgcn_s_memrealtime();
