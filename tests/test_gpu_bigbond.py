@@ -276,3 +276,62 @@ def test_sweep_reads_the_verdict_once_and_redoes_a_failed_sweep(engine_cls):
     assert i_opt["large_bond_sweep_redos"] == 0 and i_redo["large_bond_sweep_redos"] == 1
     assert all(np.array_equal(a, b) for a, b in zip(W_sync, W_opt))
     assert all(np.array_equal(a, b) for a, b in zip(W_sync, W_redo))
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_subspace_eigensolver_is_used_certified_and_agrees_with_lapack(dtype):
+    """Large real bonds go through the randomised subspace solver first (csrc/mpst_eig_subspace.inl: GEMM half-steps through the bond
+    matrix + a (C chi + 32)-dimensional Rayleigh-Ritz problem), its result is certified on the device against the Gram matrix and the
+    exact Householder solver takes every bond the certificate rejects.  On structured data (the reference's noisy trendy sines,
+    toy_data.jl:68-71) after the growth phase nearly every bond must be ACCEPTED, and accepted or not every bond must agree with the
+    LAPACK-based restatement (decomposeBT, RealRealHighDimension.jl:146-203) to the usual tolerances: teacher forced, second sweep."""
+    from oracle import ref_complex as RC
+    from tests.test_gpu_typed import TOL, caches_around, two_site
+    from tests.helpers import bond_of
+    rng = np.random.default_rng(2)
+    N, T, d, chi = 768, 10, 8, 24                      # n = d chi = 192 >= 2 (C chi + 32) = 160
+    X, y = R.trendy_sine_dataset(N, T, rng)
+    Xs, _ = R.transform_train_data(X)
+    ds = R.encode_dataset(X, Xs, y, lambda x: R.legendre_encode(x, d), (-1, 1))
+    W = R.random_mps(T, d, 4, 2, np.random.default_rng(7))
+    opts = R.SweepOptions(chi_max=chi, eta=0.01)
+    dt = np.dtype(dtype)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=chi, eta=0.01)
+        eng.set_dataset(0, ds.phi.astype(dt), ds.label_index, 2, dtype=dt)
+        eng.set_mps([t.astype(dt) for t in W])
+        eng.build_caches()
+        eng.sweep()                                     # growth phase: the engine free-runs (rejections are expected here)
+        i0 = eng.info()
+        assert i0["large_bond"] and i0["subspace_attempted"] > 0
+        W1 = [np.asarray(t).astype(np.float64) for t in eng.get_mps()]
+        ds64 = R.EncodedSet(ds.phi.astype(dt).astype(np.float64), ds.label_index, ds.class_distribution)
+        tol = TOL["f32" if dtype == "float32" else "f64"]
+        worst = dict(loss=0.0, grad=0.0, S=0.0, bond=0.0)
+        Wo = [t.copy() for t in W1]
+        for q in range(2 * (T - 1)):
+            lid, gl = bond_of(q, T)
+            ls = lid + 1 if gl else lid
+            eng.set_mps([t.astype(dt) for t in Wo], label_site=ls)
+            eng.build_caches()
+            LE, RE = caches_around(Wo, ds64.phi, ls)
+            tr = {}
+            RC.bond_step(Wo, LE, RE, lid, ds64, opts, gl, tr)
+            got = eng.bond_step(lid, gl)
+            assert got["chi"] == tr["chi"], (q, got["chi"], tr["chi"])
+            worst["loss"] = max(worst["loss"], abs(got["loss"] - tr["loss"]) / max(1.0, abs(tr["loss"])))
+            worst["grad"] = max(worst["grad"], abs(got["grad_norm"] - tr["grad_norm"]) / tr["grad_norm"])
+            worst["S"] = max(worst["S"], np.abs(got["S"][:tr["chi"]] - tr["S"]).max() / tr["S"][0])
+            Wg = eng.get_mps()
+            a, b = two_site(Wg[lid], Wg[lid + 1]), two_site(Wo[lid], Wo[lid + 1])
+            worst["bond"] = max(worst["bond"], np.abs(a - b).max() / np.abs(b).max())
+        i1 = eng.info()
+        att, acc = i1["subspace_attempted"] - i0["subspace_attempted"], i1["subspace_accepted"] - i0["subspace_accepted"]
+        print(dtype, "second sweep: subspace attempted", att, "accepted", acc, worst)
+        assert att >= 2 * (T - 1) - 6 and acc >= att - 3, (att, acc)      # the bonds next to the chain's ends are small (exact solver)
+        assert i1["library_eig_fallbacks"] == 0
+        for k in tol:
+            assert worst[k] < tol[k], (k, worst)
+    finally:
+        eng.close()
