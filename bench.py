@@ -439,11 +439,18 @@ def tolerance_study(args, mt):
         mask[i, s0:s0 + nm] = True
     names = {"f32": ("Float32", "Float64"), "c64": ("ComplexF32", "ComplexF64")}[args.dtype]
     fits = {}
-    for name in names:
-        opts = mt.MPSOptions(d=d, chi_max=chi, nsweeps=nsw, eta=0.01, encoding="Fourier" if cx else "Legendre", dtype=name, verbosity=-1,
+    wide_np = np.complex128 if cx else np.float64
+    # control: the wide type once more from a start that differs by 1e-12 (relative, Gaussian) - the spread two legitimate double-precision
+    # runs show after the same number of sweeps (a DMRG sweep amplifies rounding-level differences: oracle/sensitivity_study.py)
+    W0 = mt.generate_startingMPS(4, T, d, 2, 1234, wide_np)
+    prng = np.random.default_rng(99)
+    W0p = [t * (1.0 + 1e-12 * prng.standard_normal(t.shape)) for t in W0]
+    for name in names + ("control",):
+        dname = names[1] if name == "control" else name
+        opts = mt.MPSOptions(d=d, chi_max=chi, nsweeps=nsw, eta=0.01, encoding="Fourier" if cx else "Legendre", dtype=dname, verbosity=-1,
                              chi_init=4, init_rng=1234, exit_early=False)
         t0 = time.perf_counter()
-        trained, info, _ = mt.fitMPS(Xtr, ytr, Xte, yte, opts)
+        trained, info, _ = mt.fitMPS(Xtr, ytr, Xte, yte, opts, W=(W0p if name == "control" else [t.astype(mt.options.numpy_dtype(dname)) for t in W0]))
         fit_s = time.perf_counter() - t0
         imp = mt.init_imputation_problem(trained, Xte, yte, verbosity=0)
         compute = "f32" if name in ("Float32", "ComplexF32") else "f64"
@@ -451,7 +458,7 @@ def tolerance_study(args, mt):
         chis = [int(t.shape[2]) for t in trained.mps[:-1]]
         fits[name] = dict(info=info, chis=chis, imputed=ts, fit_s=fit_s, impute_device_s=secs)
     n_, w_ = names
-    a, b = fits[n_], fits[w_]
+    a, b, ctl = fits[n_], fits[w_], fits["control"]
     def col(k):
         return [float(x) for x in a["info"][k]], [float(x) for x in b["info"][k]]
     kn, kw = col("train_KL_div")
@@ -459,11 +466,15 @@ def tolerance_study(args, mt):
     tn, tw = col("test_acc")
     mae_n = float(np.abs(a["imputed"] - Xte)[mask].mean())
     mae_w = float(np.abs(b["imputed"] - Xte)[mask].mean())
+    mae_c = float(np.abs(ctl["imputed"] - Xte)[mask].mean())
+    dvc = np.abs(ctl["imputed"] - b["imputed"])[mask]
+    kc = [float(x) for x in ctl["info"]["train_KL_div"]]
+    tc = [float(x) for x in ctl["info"]["test_acc"]]
     dv = np.abs(a["imputed"] - b["imputed"])[mask]
     flat = float(np.abs(np.mean(Xtr) - Xte)[mask].mean())
     span = float(Xte.max() - Xte.min())
-    rows = [{"after_sweep": i, "train_KL_div": {n_: kn[i], w_: kw[i], "abs_diff": abs(kn[i] - kw[i])},
-             "train_acc": {n_: an[i], w_: aw[i]}, "test_acc": {n_: tn[i], w_: tw[i]}} for i in range(min(len(kn), nsw + 1))]
+    rows = [{"after_sweep": i, "train_KL_div": {n_: kn[i], w_: kw[i], "abs_diff": abs(kn[i] - kw[i]), "control_abs_diff": abs(kc[i] - kw[i])},
+             "train_acc": {n_: an[i], w_: aw[i]}, "test_acc": {n_: tn[i], w_: tw[i], "control": tc[i]}} for i in range(min(len(kn), nsw + 1))]
     return {
         "metric": f"tolerance study {n_} vs {w_}: free-running {nsw}-sweep fits + median imputation (N={N}, T={T}, chi={chi}, d={d}) - a side study, "
                   "NOT the headline metric", "value": None, "unit": None, "n_gpus": 1, "dtype": args.dtype, "data": "synthetic",
@@ -473,6 +484,10 @@ def tolerance_study(args, mt):
         "per_sweep": rows,
         "bond_dimensions": {"equal": a["chis"] == b["chis"], "max_abs_diff": int(np.abs(np.array(a["chis"]) - np.array(b["chis"])).max()),
                             "sum": {n_: int(sum(a["chis"])), w_: int(sum(b["chis"]))}},
+        "control": {"what": f"{w_} again from a starting MPS perturbed by 1e-12 (relative): the spread of two legitimate double-precision runs",
+                    "final_train_KL_div_rel_diff": abs(kc[-1] - kw[-1]) / max(1.0, abs(kw[-1])), "mae_vs_truth": mae_c, "mae_rel_diff": abs(mae_c - mae_w) / mae_w,
+                    "imputations_mean_abs_diff_over_span": float(dvc.mean()) / span,
+                    "bond_dimensions_equal": ctl["chis"] == b["chis"]},
         "imputation": {"missing_sites": int(mask.sum()), "mae_vs_truth": {n_: mae_n, w_: mae_w, "rel_diff": abs(mae_n - mae_w) / mae_w},
                        "mae_flat_mean_baseline": flat, "data_span": span,
                        "narrow_vs_wide_imputations": {"mean_abs": float(dv.mean()), "p50": float(np.quantile(dv, 0.5)), "p99": float(np.quantile(dv, 0.99)),

@@ -317,8 +317,8 @@ View make_eig_view(Ctx* c) {
     v.gram = c->gram; v.lam = c->lam; v.E = c->E; v.eig_ws = c->eig_ws; v.sc = c->sc;
     v.rescale_after = c->opt.rescale_after; v.svd_alg = c->opt.svd_alg; v.cutoff = c->opt.cutoff;
     v.zw = c->zw;
-    v.ss_bt = c->zw == 1 ? (const void*)c->bt : nullptr;        // the subspace eigensolver reads the bond tensor itself (real types)
-    v.ss_f32 = c->dtype == MPST_F32 ? 1 : 0;
+    v.ss_bt = c->bt;                                             // the subspace eigensolver reads the bond tensor itself
+    v.ss_f32 = (c->dtype == MPST_F32 || c->dtype == MPST_C64) ? 1 : 0;
     return v;
 }
 
@@ -390,7 +390,7 @@ int ensure_workspace_typed(Ctx* c) {
         if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, zw * dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         // real element types: the randomised subspace solver in front of the exact one (complex Gram matrices arrive as embeddings)
-        if (c->blk && zw == 1 && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, zw * c->C * dm, c->cap, c->C, zw == 2, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
         if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);
     }
@@ -493,7 +493,7 @@ int ensure_workspace(Ctx* c) {
         if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         // MPST_BIG_SYNC=1: read the eigensolver's verdict after every bond (one host synchronisation per bond) instead of once per sweep
-        if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
+        if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, 0, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         c->big_opt = c->blk && getenv("MPST_BIG_SYNC") == nullptr && getenv("MPST_BT_NO_COOP") == nullptr;
         if (const char* ff = getenv("MPST_BIG_FORCE_FAIL")) c->big_force_fail = atoi(ff);       // test hook: the n-th solve of the context is marked failed
     }

@@ -813,7 +813,8 @@ constexpr int BTC_NT = 512, BTC_NMAX = BT_NMAX / 2;
 // XMODE 0: agent-scope atomics and the counting barrier (workgroups anywhere); 1: tagged entries inside one XCD; 3: the counting
 // barrier and plain data inside one XCD (st_x / ld_x / xcd_wait / xcd_arrive)
 template <int XMODE>
-__global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq) {
+__global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going_left, BtBufs b, BtCoop cp, int stride, unsigned int seq,
+                                                       const double* rawG, int rawn) {
     if (bt_idle(b)) return;
     if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NT = BTC_NT, NW = NT / 64;
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     __shared__ double red_a[NW][2], red_b[NW];
     __shared__ double2 bc[2];
     __shared__ int sh_ok;
-    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
+    const BtProblem pb = bt_resolve(v, lid, going_left, rawG, rawn);
     const int nf = pb.n, n = pb.n >> 1, ld = b.ncap >> 1, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int G = ((int)gridDim.x + stride - 1) / stride, g = (int)blockIdx.x / stride;
     double2* xs = (double2*)smem;        // [ld] the reflector v_j (v_{j-1} when a step starts)
@@ -1047,9 +1048,9 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
 // u = H_0 H_1 ... H_{n-2} z for the eigenvectors z of T that k_bt_vec left in rows 2k of Z (first n entries, real): one WAVE per
 // vector (8 elements per lane at n = 512, reductions on DPP: no workgroup barrier), reflectors from L2 (the four waves of a
 // workgroup walk the same rows).  Writes (Re u, Im u) into row 2k and J u = (-Im u, Re u) into row 2k + 1.
-__global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_left, BtBufs b) {
+__global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_left, int rawn, BtBufs b) {
     if (bt_idle(b)) return;
-    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
+    const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, rawn);
     if (bt_aborted(b)) return;
     const int n = pb.n >> 1, ld = b.ncap, ldc = b.ncap >> 1, lane = threadIdx.x & 63;
     const int k = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1776,6 +1777,7 @@ struct BlockedEig {
     int32_t* sticky = nullptr;         // device [1]: a solve enqueued by launch_eig_blocked_nosync failed since the last reset
     SsBufs ss{};                       // subspace solver in front of the exact one (mpst_eig_subspace.inl); ss.Mw == nullptr: off
     int32_t* host_st = nullptr;        // pinned [4]: copy of ss.st
+    BlockedEig* rr = nullptr;          // complex: workspace of the Hermitian Rayleigh-Ritz solve (order 2 pc, pair mode, raw)
 };
 static int coop_threads() {
     static const int nt = [] { const char* e = getenv("MPST_BT_COOP_T"); return e ? atoi(e) : 512; }();
@@ -1881,31 +1883,43 @@ void blocked_eig_destroy(BlockedEig* e) {
         if (q.infoH) (void)hipFree(q.infoH);
         if (q.st) (void)hipFree(q.st);
         if (e->host_st) (void)hipHostFree(e->host_st);
+        if (e->rr) blocked_eig_destroy(e->rr);
     }
     delete e;
 }
 
 // Switch the subspace solver on for this workspace: mcap rows (C * d * cap), kcap = chi_max.  Off (and harmless) when the shape
 // leaves no room for it (block wider than SS_PMAX, or the matrix not at least twice as wide as the block) or MPST_NO_SUBSPACE is set.
-int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, std::string* err) {
+int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, int cx, std::string* err) {
     if (!e || e->ss.Mw) return 0;
     static const bool off = getenv("MPST_NO_SUBSPACE") != nullptr;
-    const int ncap = e->b.ncap;
-    if (off || kcap > 64 || C * kcap > SS_PMAX) return 0;      // the block holds rank(M0) <= C chi columns
+    static const bool off_c = getenv("MPST_NO_SUBSPACE_C") != nullptr;
+    // complex: the workspace of the exact solver holds the 2n embedding; counts below are those of the complex matrix
+    const int ncap = cx ? e->b.ncap / 2 : e->b.ncap;
+    if (cx) mcap /= 2;
+    if (off || (cx && off_c) || kcap > 64 || C * kcap > SS_PMAX) return 0;      // the block holds rank(M0) <= C chi columns
     const int pc = std::min(SS_PMAX, (C * kcap + SS_EXTRA + 15) & ~15);
-    if (ncap < 2 * pc || ncap <= MAX_DIM) return 0;
+    if (ncap < 2 * pc || (cx ? 2 : 1) * ncap <= MAX_DIM) return 0;
+    if (cx && pc > 96) return 0;                                                 // the complex elimination keeps a 3 x 12 register tile
     SsBufs& q = e->ss;
     q.pc = pc;
+    q.cx = cx ? 1 : 0;
     q.dbg = getenv("MPST_SS_DBG") ? atoi(getenv("MPST_SS_DBG")) : 0;
     q.mcap = mcap;
     q.ncap = ncap;
+    const size_t z = cx ? 2 : 1;          // doubles per element
     auto al = [&](double** p, size_t n) { return hipMalloc((void**)p, n * sizeof(double)) == hipSuccess && hipMemset(*p, 0, n * sizeof(double)) == hipSuccess; };
-    const size_t tn = (size_t)(ncap + 15) / 16;
-    bool ok = al(&q.Mw, (size_t)mcap * ncap) && al(&q.Lb[0], (size_t)mcap * pc) && al(&q.Lb[1], (size_t)mcap * pc) && al(&q.Rb[0], (size_t)ncap * pc) &&
-              al(&q.Rb[1], (size_t)ncap * pc) && al(&q.Sp, (size_t)SS_KS * pc * pc) && al(&q.Tm, (size_t)pc * pc) && al(&q.H, (size_t)pc * pc) &&
-              al(&q.lamH, SS_PMAX) && al(&q.WH, (size_t)pc * pc) && al(&q.wsH, eig_workspace_doubles()) && al(&q.part, tn * CAP_LIMIT + tn + 16) &&
+    const size_t tn = (size_t)(z * ncap + 15) / 16;
+    bool ok = al(&q.Mw, z * mcap * ncap) && al(&q.Lb[0], z * mcap * pc) && al(&q.Lb[1], z * mcap * pc) && al(&q.Rb[0], z * ncap * pc) &&
+              al(&q.Rb[1], z * ncap * pc) && al(&q.Sp, z * SS_KS * pc * pc) && al(&q.Tm, z * pc * pc) && al(&q.H, z * z * pc * pc) &&
+              al(&q.lamH, SS_PMAX + 8) && al(&q.WH, z * z * pc * pc) && al(&q.wsH, eig_workspace_doubles()) && al(&q.part, tn * CAP_LIMIT + tn + 16) &&
               hipMalloc((void**)&q.infoH, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&q.st, 4 * sizeof(int32_t)) == hipSuccess &&
               hipMemset(q.st, 0, 4 * sizeof(int32_t)) == hipSuccess && hipHostMalloc((void**)&e->host_st, 4 * sizeof(int32_t)) == hipSuccess;
+    if (ok && cx) {
+        std::string e2;
+        ok = blocked_eig_create(&e->rr, 2 * pc, &e2) == 0;
+        if (ok) q.rrflag = e->rr->b.flag;
+    }
     if (!ok) {
         if (err) *err = "allocation of the subspace eigensolver's workspace failed";
         return MPST_ERR_NOMEM;
@@ -1926,7 +1940,87 @@ int blocked_eig_subspace_counts(BlockedEig* e, hipStream_t s, int32_t* attempted
 
 // The subspace phase of a solve: ~30 launches, all leave at once on a bond that is not attempted.  Afterwards ss.st[0] says whether
 // E / lam / chi are published.
+static void enqueue_after_tridiag(const View& v, int lid, int going_left, const double* rawG, int rawn, double* rawlam, double* rawE,
+                                  int32_t* rawinfo, const BtBufs& b, hipStream_t s);
+static int cnative_xcd_mode(int ncap);
+static size_t coopc_xcd_lds(int ncap);
+static size_t coopc_lds(int ncap);
+static int coopc_grid(int ncap);
+
+// complex element types: the same sequence with the complex kernels; the Hermitian Rayleigh-Ritz problem goes through the native
+// pair-mode chain (k_bt_coop_c ...) on the small workspace e->rr, raw mode, gated by st[1]
+static void enqueue_subspace_c(const View& v, int lid, int going_left, BlockedEig* e, hipStream_t s) {
+    const SsBufs& q = e->ss;
+    const int pc = q.pc, tp = pc / 16;
+    const int tm = (q.mcap + 15) / 16, tn = (q.ncap + 15) / 16;
+    const int kmax = std::min(v.chi_max / 2, 64), tk = (kmax + 15) / 16;
+    double2 *L0 = (double2*)q.Lb[0], *L1 = (double2*)q.Lb[1], *R0 = (double2*)q.Rb[0], *R1 = (double2*)q.Rb[1];
+    const int short_start = v.ss_f32 ? 1 : 0;
+    hipLaunchKernelGGL(k_ss_load_c, dim3(256), dim3(256), 0, s, v, lid, going_left, q, short_start);
+    auto orth = [&](double2* raw, double2* out, int left) {
+        hipLaunchKernelGGL(k_ss_gram_c, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double2*)raw, left);
+        hipLaunchKernelGGL(k_ss_chol_c<0>, dim3(1), dim3(CH_T), 0, s, v, lid, going_left, q);
+        hipLaunchKernelGGL(k_ss_apply_c, dim3(((left ? tm : tn) * tp + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, (const double2*)raw, out, left);
+    };
+    if (!short_start) {
+        hipLaunchKernelGGL(k_ss_mm_c<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double2*)L0, R0, 0);
+        orth(R0, R1, 0);
+    }
+    hipLaunchKernelGGL(k_ss_mm_c<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double2*)R1, L0, 0);
+    orth(L0, L1, 1);
+    hipLaunchKernelGGL(k_ss_mm_c<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double2*)L1, R0, 0);
+    orth(R0, R1, 0);
+    hipLaunchKernelGGL(k_ss_mm_c<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double2*)R1, L0, 0);
+    orth(L0, L1, 1);
+    hipLaunchKernelGGL(k_ss_mm_c<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double2*)L1, R0, 0);
+    hipLaunchKernelGGL(k_ss_gram_c, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double2*)R0, 0);
+    hipLaunchKernelGGL(k_ss_chol_c<1>, dim3((pc * pc + CH_T - 1) / CH_T), dim3(CH_T), 0, s, v, lid, going_left, q);
+    {   // Hermitian Rayleigh-Ritz: eigenpairs of the 2 pc x 2 pc embedding in pair mode -> lamH (each value twice), WH (vector k in column 2k)
+        BlockedEig* r = e->rr;
+        const int rn = 2 * pc;
+        (void)hipMemsetAsync(r->cp.counter, 0, 16, s);
+        BtBufs bt = r->b;
+        bt.abort = r->cp.abort_flag;
+        bt.sticky = nullptr;
+        bt.skip = nullptr;
+        bt.gate = q.st + 1;
+        bt.ss = 0;
+        bt.cnative = 1;
+        const int xm = cnative_xcd_mode(rn);
+        if (xm == 3)
+            hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(rn), s, v, 0, 0, bt, r->cp, XCD_STRIDE, 0u, (const double*)q.H, rn);
+        else if (xm == 1)
+            hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(rn), s, v, 0, 0, bt, r->cp, XCD_STRIDE, ++r->seq, (const double*)q.H, rn);
+        else
+            hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(rn)), dim3(BTC_NT), coopc_lds(rn), s, v, 0, 0, bt, r->cp, 1, 0u, (const double*)q.H, rn);
+        enqueue_after_tridiag(v, 0, 0, q.H, rn, q.lamH, q.WH, q.infoH, bt, s);
+    }
+    BtBufs b = e->b;
+    b.abort = nullptr;
+    b.sticky = nullptr;
+    b.skip = nullptr;
+    b.gate = q.st + 1;
+    b.ss = 1;
+    b.cnative = 0;
+    hipLaunchKernelGGL(k_ss_ritz_c, dim3((tn * tk + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, b, (const double2*)R0, 0);
+    const int tne = (2 * q.ncap + 15) / 16;
+    hipLaunchKernelGGL(k_ss_resid, dim3(tne * tk), dim3(256), 0, s, v, lid, going_left, q, b);
+    hipLaunchKernelGGL(k_ss_collect, dim3(1), dim3(1024), 0, s, v, lid, going_left, q, b);
+    const int ncap = b.ncap, tkk = (std::min(v.chi_max, CAP_LIMIT) + 15) / 16, tnn = (ncap + 15) / 16;
+    for (int second = 0; second < 2; ++second) {
+        if (second) hipLaunchKernelGGL(k_bt_copyback, dim3(64), dim3(BT_T), 0, s, v, lid, going_left, 0, b, (const double*)nullptr);
+        hipLaunchKernelGGL(k_bt_gram, dim3(tkk * tkk), dim3(BT_T), 0, s, v, lid, going_left, 0, b, second);
+        hipLaunchKernelGGL(k_bt_decide, dim3(1), dim3(512), 0, s, v, lid, going_left, (const double*)nullptr, 0, b, (double*)nullptr, (int32_t*)nullptr, second);
+        hipLaunchKernelGGL(k_bt_polish, dim3(std::max(1, std::min(256, (tnn * tkk + 3) / 4))), dim3(BT_T), 0, s, v, lid, going_left, 0, b, (double*)nullptr, second);
+    }
+    hipLaunchKernelGGL(k_ss_verdict, dim3(1), dim3(64), 0, s, q, b);
+}
+
 static void enqueue_subspace(const View& v, int lid, int going_left, BlockedEig* e, hipStream_t s) {
+    if (e->ss.cx) {
+        enqueue_subspace_c(v, lid, going_left, e, s);
+        return;
+    }
     const SsBufs& q = e->ss;
     const int pc = q.pc, tp = pc / 16;
     const int tm = (q.mcap + 15) / 16, tn = (q.ncap + 15) / 16;
@@ -1984,7 +2078,7 @@ static void enqueue_after_tridiag(const View& v, int lid, int going_left, const 
     const int kmax = rawn > 0 ? std::min(rawn, CAP_LIMIT) : std::min(v.chi_max, CAP_LIMIT);
     hipLaunchKernelGGL(k_bt_larft, dim3((ncap + BT_NB - 1) / BT_NB), dim3(BT_T), 0, s, v, lid, going_left, rawn, b);
     hipLaunchKernelGGL(k_bt_vec, dim3(kmax), dim3(BT_T), bt_vec_lds(), s, v, lid, going_left, rawn, b);
-    if (b.cnative) hipLaunchKernelGGL(k_bt_back_c, dim3((kmax / 2 + 3) / 4), dim3(256), 0, s, v, lid, going_left, b);
+    if (b.cnative) hipLaunchKernelGGL(k_bt_back_c, dim3((kmax / 2 + 3) / 4), dim3(256), 0, s, v, lid, going_left, rawn, b);
     const int tk = (kmax + 15) / 16, tn = (ncap + 15) / 16;
     for (int second = 0; second < 2; ++second) {
         if (second) hipLaunchKernelGGL(k_bt_copyback, dim3(64), dim3(BT_T), 0, s, v, lid, going_left, rawn, b, (const double*)rawE);
@@ -2023,7 +2117,7 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
             double r2 = 0, rmax = 0; int bad = -1;
             for (int i = 0; i < ctl[0] && i < CAP_LIMIT; ++i) { r2 += res[i] * res[i]; if (res[i] > rmax) { rmax = res[i]; bad = i; } }
             double stamp[3];
-            (void)hipMemcpy(stamp, e->ss.lamH + SS_PMAX - 3, sizeof stamp, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(stamp, e->ss.lamH + SS_PMAX, sizeof stamp, hipMemcpyDeviceToHost);
             fprintf(stderr, "[ss] chol phases: load %.2f us, elimination %.2f us\n", stamp[0] * 0.01, stamp[1] * 0.01);
             fprintf(stderr, "[ss] lid %d gl %d st %d %d ctl %d %d %d %d flag %d eiginfo %d est %.3e rmax %.3e at %d lam0 %.3e lam[k-1] %.3e D00 %.3e D01 %.3e\n", lid, going_left,
                     e->host_st[0], e->host_st[1], ctl[0], ctl[1], ctl[2], ctl[3], flag, info, sqrt(r2), rmax, bad, lam[0], lam[ctl[0] > 0 ? ctl[0] - 1 : 0], D[0], D[1]);
@@ -2044,11 +2138,11 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
         if (mode) {
             if (hipMemsetAsync(e->cp.counter, 0, 16, s) != hipSuccess) return MPST_ERR_DEVICE;
             if (mode == 4 && cnative_xcd_mode(ncap) == 3)
-                hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, 0u);
+                hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, 0u, (const double*)nullptr, 0);
             else if (mode == 4)
-                hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
+                hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq, (const double*)nullptr, 0);
             else if (mode == 3)
-                hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u);
+                hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, b, e->cp, 1, 0u, (const double*)nullptr, 0);
             else if (mode == 2)
                 hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, b, e->cp, XCD_STRIDE, ++e->seq);
             else if (coop_threads() == 512)
@@ -2118,11 +2212,11 @@ int launch_eig_blocked_nosync(const View& v, int lid, int going_left, BlockedEig
     const bool nat = cnative_usable(v, ncap);
     bt.cnative = nat ? 1 : 0;
     if (nat && cnative_xcd_mode(ncap) == 3)
-        hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, 0u);
+        hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, 0u, (const double*)nullptr, 0);
     else if (nat && cnative_xcd_mode(ncap) == 1)
-        hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
+        hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq, (const double*)nullptr, 0);
     else if (nat)
-        hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u);
+        hipLaunchKernelGGL(k_bt_coop_c<0>, dim3(coopc_grid(ncap)), dim3(BTC_NT), coopc_lds(ncap), s, v, lid, going_left, bt, e->cp, 1, 0u, (const double*)nullptr, 0);
     else if (xcd_usable(ncap))
         hipLaunchKernelGGL((k_bt_coop<512, SC_XCD>), dim3(XCD_G * XCD_STRIDE), dim3(512), xcd_lds(ncap), s, v, lid, going_left, bt, e->cp, XCD_STRIDE, ++e->seq);
     else if (coop_threads() == 512)

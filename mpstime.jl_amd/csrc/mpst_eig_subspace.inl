@@ -44,25 +44,31 @@ struct SsBufs {
                          // [2] bonds accepted, [3] bonds attempted (since creation)
     int pc;              // block width at capacity: multiple of 16, <= SS_PMAX
     int mcap, ncap;
+    int cx;              // 1: complex element type - Mw, the blocks, Sp, Tm are double2 arrays of the same element counts, H is the real
+                         //    embedding [[Hr, -Hi], [Hi, Hr]] (2 pc x 2 pc) the pair-mode Hermitian solver reads
+    const int32_t* rrflag;   // complex: verdict word of the Rayleigh-Ritz solve (0 = delivered)
     int dbg;             // bring-up: MPST_SS_DBG bits switch parts of the elimination step off (timing only, results are wrong)
 };
 
 struct SsProblem {
-    int n, m, K0, p;
+    int n, m, K0, p;     // columns, rows, wanted pairs, block width - of the COMPLEX matrix in pair mode
+    int st;              // 2: the Gram matrix / Z / lam / res are those of the real embedding (pair mode), else 1
     bool active;
 };
 __device__ __forceinline__ SsProblem ss_resolve(const View& v, int lid, int going_left, const SsBufs& s) {
     const BtProblem pb = bt_resolve(v, lid, going_left, nullptr, 0);
     SsProblem q;
-    q.n = pb.n;
-    q.m = pb.rows;
-    q.K0 = pb.K0;
+    q.st = pb.pair ? 2 : 1;
+    q.n = pb.n / q.st;
+    q.m = pb.rows / q.st;
+    q.K0 = pb.K0 / q.st;
     // the block has to hold what the matrix holds before the update - M0 = W[lid] W[rid] has rank <= C chi(lid, rid) - and the kept
     // values, plus the oversampling; where the capacity of the Rayleigh-Ritz solver cuts it short the oversampling goes first
-    const int r0 = min(pb.nspec, v.C * v.chi[lid + 1]);
-    const int want = max(pb.K0, r0);
+    const int r0 = min(pb.nspec / q.st, v.C * v.chi[lid + 1]);
+    const int want = max(q.K0, r0);
     q.p = min(s.pc, (want + SS_EXTRA + 15) & ~15);
-    q.active = !pb.pair && v.ss_bt != nullptr && want <= q.p && q.n >= 2 * q.p && q.n > MAX_DIM && q.m >= 1 && q.K0 >= 1 && q.K0 <= 64;
+    q.active = (pb.pair ? s.cx != 0 : s.cx == 0) && v.ss_bt != nullptr && want <= q.p && q.n >= 2 * q.p && q.st * q.n > MAX_DIM && q.m >= 1 &&
+               q.K0 >= 1 && q.K0 <= 64;
     return q;
 }
 __device__ __forceinline__ double ss_omega(int r, int j) {
@@ -342,8 +348,8 @@ __global__ __launch_bounds__(CH_T) void k_ss_chol(View v, int lid, int going_lef
     }
     if (tid == 0) {         // phase stamps (100 MHz) of the last call: load, elimination
         t2 = __builtin_amdgcn_s_memrealtime();
-        s.lamH[SS_PMAX - 3] = (double)(t1 - t0);
-        s.lamH[SS_PMAX - 2] = (double)(t2 - t1);
+        s.lamH[SS_PMAX] = (double)(t1 - t0);
+        s.lamH[SS_PMAX + 1] = (double)(t2 - t1);
     }
     // Tm[c][i] = Linv[i][c] = rsqrt(pivot_i) * (c == i ? 1 : c < i ? unit-lower inverse [i][c] : 0); dropped rows / columns are zero
 #pragma unroll
@@ -429,12 +435,13 @@ __global__ __launch_bounds__(256) void k_ss_ritz(View v, int lid, int going_left
 
 // Residuals of the Ritz pairs against G itself: part[rt][k] = sum over the 16 rows of row tile rt of (G v_k - theta_k v_k)^2, and
 // (k tile 0 only) part[tn*CAP_LIMIT + rt] = the rows' share of ||G||_F^2.  One tile per workgroup, contraction over its 4 waves.
+// Pair mode: G is the 2n x 2n embedding, vector k is row 2k of Z (its partner J u has the same residual).
 __global__ __launch_bounds__(256) void k_ss_resid(View v, int lid, int going_left, SsBufs s, BtBufs b) {
     __shared__ double part[4][256];
     __shared__ double fro[4];
     if (!s.st[1]) return;
     const SsProblem q = ss_resolve(v, lid, going_left, s);
-    const int n = q.n, K0 = q.K0;
+    const int st = q.st, n = st * q.n, K0 = q.K0;
     const int tk = (K0 + 15) >> 4, tn = (n + 15) >> 4;
     const int rt = (int)blockIdx.x / tk, kt = (int)blockIdx.x - rt * tk;
     if (rt >= tn) return;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void k_ss_resid(View v, int lid, int going_lef
             const int k = k0 + 4 * u + kq;
             const bool kv = k < kend;
             a[u] = (kv && row < n) ? G[(int64_t)row * n + k] : 0.0;
-            bb[u] = (kv && kc < K0) ? b.Z[(int64_t)kc * b.ncap + k] : 0.0;
+            bb[u] = (kv && kc < K0) ? b.Z[(int64_t)(st * kc) * b.ncap + k] : 0.0;
             f2 += a[u] * a[u];
         }
 #pragma unroll
@@ -465,13 +472,13 @@ __global__ __launch_bounds__(256) void k_ss_resid(View v, int lid, int going_lef
     if (lane == 0) fro[wave] = f2;
     __syncthreads();
     if (wave == 0) {
-        const double th = kc < K0 ? b.lam[kc] : 0.0;
+        const double th = kc < K0 ? b.lam[st * kc] : 0.0;
         double col2 = 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = rt * 16 + kq + 4 * r;
             const double gv = (part[0][r * 64 + lane] + part[1][r * 64 + lane]) + (part[2][r * 64 + lane] + part[3][r * 64 + lane]);
-            const double vk = (c < n && kc < K0) ? b.Z[(int64_t)kc * b.ncap + c] : 0.0;
+            const double vk = (c < n && kc < K0) ? b.Z[(int64_t)(st * kc) * b.ncap + c] : 0.0;
             const double rr = (c < n && kc < K0) ? gv - th * vk : 0.0;
             col2 += rr * rr;
         }
@@ -490,10 +497,11 @@ __global__ __launch_bounds__(1024) void k_ss_collect(View v, int lid, int going_
     __shared__ double red[3][16];
     if (!s.st[1]) return;
     const SsProblem q = ss_resolve(v, lid, going_left, s);
-    const int n = q.n, K0 = q.K0, tid = threadIdx.x;
+    const int st = q.st, n = st * q.n, K0 = q.K0, tid = threadIdx.x;
     const int tn = (n + 15) >> 4;
     const double* __restrict__ G = v.gram;
-    // three sums in one pass: trace of G, ||G||_F^2 (row-tile pieces of k_ss_resid), ||H||_F^2
+    // three sums in one pass: trace of G, ||G||_F^2 (row-tile pieces of k_ss_resid), ||H||_F^2 (pair mode: all three of the embeddings,
+    // i.e. twice those of the complex matrices)
     double tr = 0.0, fr = 0.0, h2 = 0.0;
     for (int i = tid; i < n; i += 1024) {
         const double g = G[(int64_t)i * n + i];
@@ -501,12 +509,12 @@ __global__ __launch_bounds__(1024) void k_ss_collect(View v, int lid, int going_
         tr += g;
     }
     for (int i = tid; i < tn; i += 1024) fr += s.part[(int64_t)tn * CAP_LIMIT + i];
-    const int pc = s.pc;
-    for (int e = tid; e < pc * pc; e += 1024) h2 += s.H[e] * s.H[e];
+    const int hn = st * s.pc;
+    for (int e = tid; e < hn * hn; e += 1024) h2 += s.H[e] * s.H[e];
     double r2 = 0.0, th = 0.0;
     if (tid < K0) {
         for (int t = 0; t < tn; ++t) r2 += s.part[(int64_t)t * CAP_LIMIT + tid];
-        th = b.lam[tid];
+        th = b.lam[st * tid];
     }
     tr = wave_sum(tr);
     fr = wave_sum(fr);
@@ -523,18 +531,25 @@ __global__ __launch_bounds__(1024) void k_ss_collect(View v, int lid, int going_
         fr += red[1][w];
         h2 += red[2][w];
     }
+    const double inv_st = 1.0 / (double)st;
+    tr *= inv_st;
+    fr *= inv_st;
+    h2 *= inv_st;
     // unseen part of the spectrum: ||G||_F^2 - ||H||_F^2 >= sum of the squares of what the block missed (H is a compression of
     // M M^H, whose non-zero spectrum is that of G); below the resolution of the subtraction (64 eps ||G||_F^2) nothing can be said
     // and nothing is claimed
     const double unseen2 = fmax(fr - h2, 0.0);
     const double floor2 = 64.0 * 2.2e-16 * fr;
+    const bool rr_failed = s.rrflag && *(const volatile int32_t*)s.rrflag != 0;      // complex: the Hermitian Rayleigh-Ritz solve gave up
     if (tid < K0) {
         // fp32 bond tensors carry 6e-8 of rounding noise per entry: 3e-8 of the tensor's norm is the bar there, 1e-9 in fp64
         // (k_bt_decide compares the root of the sum of squares with 1e-9)
         double rel = (th > 0.0 && tr > 0.0) ? sqrt(r2 / (th * tr)) * (v.ss_f32 ? 1.0 / 30.0 : 1.0) : 0.0;
         // an eigenvalue the block missed and that is larger than this kept one: the certificate fails for it
         if (unseen2 > floor2 && unseen2 > th * th) rel = th > 1e-10 * tr ? 1e300 : rel;
-        b.res[tid] = rel;
+        if (rr_failed) rel = 1e300;
+        b.res[st * tid] = rel;
+        if (st == 2) b.res[2 * tid + 1] = 0.0;          // the partner J u: its residual is the same one, counted once
     }
 }
 
@@ -545,4 +560,388 @@ __global__ void k_ss_verdict(SsBufs s, BtBufs b) {
     const int ok = (*b.flag == 0) ? 1 : 0;
     s.st[0] = ok;
     if (ok) s.st[2] += 1;
+}
+
+
+// =====================================================================================================================================
+// Complex element types (Fourier / Sahand / Stoudenmire encodings, BASELINE configs[4]): the same sequence on the complex m x n
+// matrix itself.  Blocks, Gram partials and the triangular factor are double2 arrays; a complex product is four real MFMAs.  The
+// Rayleigh-Ritz problem is Hermitian (p x p): its eigenpairs come from the pair-mode machinery of this file - k_bt_coop_c reduces
+// it with complex reflectors to a real tridiagonal matrix, k_bt_vec / k_bt_back_c deliver the vectors in the embedding layout -
+// on a small workspace of its own (raw mode, gated by st[1]).  What leaves this phase is what the exact pair-mode path leaves:
+// Z rows 2k = (Re v, Im v), 2k + 1 = J v; lam twice; the shared verification kernels run unchanged.
+// =====================================================================================================================================
+__device__ __forceinline__ void cmma(double ar, double ai, double br, double bi, d4& cR, d4& cI) {
+    cR = mfma_f64(ar, br, cR);
+    cR = mfma_f64(-ai, bi, cR);
+    cI = mfma_f64(ar, bi, cI);
+    cI = mfma_f64(ai, br, cI);
+}
+
+__global__ __launch_bounds__(256) void k_ss_load_c(View v, int lid, int going_left, SsBufs s, int start_right) {
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s.st[0] = 0;
+        s.st[1] = q.active ? 1 : 0;
+        if (q.active) s.st[3] += 1;
+    }
+    if (!q.active) return;
+    const int n = q.n, m = q.m;
+    const int Dl = v.chi[lid], Dr = v.chi[lid + 2];
+    const int X = Dl * v.d, Y = v.d * Dr;
+    const int64_t total = (int64_t)m * n;
+    const float2* bf = (const float2*)v.ss_bt;
+    const double2* bd = (const double2*)v.ss_bt;
+    double2* __restrict__ Mw = (double2*)s.Mw;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        int64_t src;
+        if (going_left) src = e;
+        else {
+            const int row = (int)(e / n), x = (int)(e - (int64_t)row * n);
+            const int c = row / Y, y = row - c * Y;
+            src = ((int64_t)c * X + x) * Y + y;
+        }
+        // going right the decomposed matrix is the plain transpose of the [X][Y] slices (rows (c, y), columns x), no conjugate:
+        // M^H M = sum_c conj(B_c) B_c^T is the Gram matrix k_tgram forms in that direction
+        Mw[e] = v.ss_f32 ? make_double2((double)bf[src].x, (double)bf[src].y) : bd[src];
+    }
+    const int64_t tot2 = (int64_t)(start_right ? n : m) * q.p;
+    double2* __restrict__ O = (double2*)(start_right ? s.Rb[1] : s.Lb[0]);
+    const double sc = start_right ? 1.0 / sqrt((double)n) : 1.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot2; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / q.p), j = (int)(e - (int64_t)r * q.p);
+        O[(int64_t)r * s.pc + j] = make_double2(sc * ss_omega(r, j), 0.0);
+    }
+}
+
+// dst = op(M) src.  TA = 0: M src;  TA = 1: M^H src.  cj = 1: M stands for conj(Mw) (going right, see k_ss_load_c).
+template <int TA>
+__global__ __launch_bounds__(256) void k_ss_mm_c(View v, int lid, int going_left, SsBufs s, const double2* __restrict__ src, double2* __restrict__ dst, int cj) {
+    __shared__ double part[2][4][256];
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int n = q.n, m = q.m, p = q.p, ld = s.pc;
+    const int R = TA ? n : m, K = TA ? m : n;
+    const int tp = p >> 4;
+    const int rt = (int)blockIdx.x / tp, ct = (int)blockIdx.x - rt * tp;
+    if (rt * 16 >= R) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int row = rt * 16 + i16, col = ct * 16 + i16;
+    const bool rv = row < R;
+    const int per = ((((K + 3) >> 2) + 3) >> 2) << 2;
+    const int kbeg = wave * per, kend = min(K, kbeg + per);
+    const double2* __restrict__ Mw = (const double2*)s.Mw;
+    const double sg = ((TA != 0) != (cj != 0)) ? -1.0 : 1.0;         // conjugate of the stored entry: M^H of M, or M of conj(M)
+    d4 cR = {0, 0, 0, 0}, cI = {0, 0, 0, 0};
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double2 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < kend;
+            a[u] = (kv && rv) ? (TA ? Mw[(int64_t)k * n + row] : Mw[(int64_t)row * n + k]) : make_double2(0.0, 0.0);
+            b[u] = kv ? src[(int64_t)k * ld + col] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 4 * u < kend) cmma(a[u].x, sg * a[u].y, b[u].x, b[u].y, cR, cI);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[0][wave][r * 64 + lane] = cR[r];
+        part[1][wave][r * 64 + lane] = cI[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int orow = rt * 16 + kq + 4 * r;
+            const double xr = (part[0][0][r * 64 + lane] + part[0][1][r * 64 + lane]) + (part[0][2][r * 64 + lane] + part[0][3][r * 64 + lane]);
+            const double xi = (part[1][0][r * 64 + lane] + part[1][1][r * 64 + lane]) + (part[1][2][r * 64 + lane] + part[1][3][r * 64 + lane]);
+            if (orow < R) dst[(int64_t)orow * ld + col] = make_double2(xr, xi);
+        }
+    }
+}
+
+// Gram partials S = A^H A of a complex block
+__global__ __launch_bounds__(256) void k_ss_gram_c(View v, int lid, int going_left, SsBufs s, const double2* __restrict__ A, int left) {
+    __shared__ double part[2][4][256];
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int p = q.p, ld = s.pc, R = left ? q.m : q.n;
+    const int tp = p >> 4;
+    const int ks = (int)blockIdx.x / (tp * tp), t = (int)blockIdx.x - ks * tp * tp;
+    if (ks >= SS_KS || tp == 0) return;
+    const int ti = t / tp, tj = t - ti * tp;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int per = ((((R + 4 * SS_KS - 1) / (4 * SS_KS)) + 3) >> 2) << 2;
+    const int kbeg = (ks * 4 + wave) * per, kend = min(R, kbeg + per);
+    d4 cR = {0, 0, 0, 0}, cI = {0, 0, 0, 0};
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double2 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < kend;
+            a[u] = kv ? A[(int64_t)k * ld + ti * 16 + i16] : make_double2(0.0, 0.0);
+            b[u] = kv ? A[(int64_t)k * ld + tj * 16 + i16] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 4 * u < kend) cmma(a[u].x, -a[u].y, b[u].x, b[u].y, cR, cI);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[0][wave][r * 64 + lane] = cR[r];
+        part[1][wave][r * 64 + lane] = cI[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double2* __restrict__ Sp = (double2*)s.Sp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti * 16 + kq + 4 * r, j = tj * 16 + i16;
+            const double xr = (part[0][0][r * 64 + lane] + part[0][1][r * 64 + lane]) + (part[0][2][r * 64 + lane] + part[0][3][r * 64 + lane]);
+            const double xi = (part[1][0][r * 64 + lane] + part[1][1][r * 64 + lane]) + (part[1][2][r * 64 + lane] + part[1][3][r * 64 + lane]);
+            Sp[(int64_t)ks * ld * ld + (int64_t)i * ld + j] = make_double2(xr, xi);
+        }
+    }
+}
+
+// The elimination for a Hermitian positive definite S (pivots real): 3 x 12 complex register tile per thread, block capacity <= 96.
+struct CholSharedC {
+    double2 rowb[2][96], colb[2][96];
+    double pivd[96], d0[96];
+    int dead[96];
+};
+template <int E, int S>
+__device__ __forceinline__ void chol_piece_c(double2 (&val)[3][12], CholSharedC& sh, const int p, const int rg, const int cg) {
+    constexpr int TP = 4 * E + S, RU = 3, CT = 12;
+    const int j0 = 32 * E + 8 * S;
+    const int jend = min(p, j0 + 8);
+    for (int j = j0; j < jend; ++j) {
+        const int b = j & 1;
+        const double piv = sh.rowb[b][j].x, dj = sh.d0[j];
+        double2 fc[RU], r[CT];
+#pragma unroll
+        for (int u = E; u < RU; ++u) fc[u] = sh.colb[b][rg + 32 * u];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) r[t] = sh.rowb[b][cg + 8 * t];
+        const bool isdead = !(piv > 2e-15 * dj) || !(dj > 0.0);
+        if (rg == 0 && cg == 0) {
+            sh.pivd[j] = piv;
+            sh.dead[j] = isdead ? 1 : 0;
+        }
+        double rc = __builtin_amdgcn_rcp(piv);
+        rc = rc * (2.0 - piv * rc);
+        rc = rc * (2.0 - piv * rc);
+        if (isdead) rc = 0.0;
+        if (cg == (j & 7)) r[TP] = make_double2(piv + 1.0, 0.0);      // val - f (piv + 1) = -f (the pivot itself is real: its rounding-level imaginary part goes)
+#pragma unroll
+        for (int u = E; u < RU; ++u) {
+            const int i = rg + 32 * u;
+            const bool on = u > E || i > j;
+            const double fr = on ? fc[u].x * rc : 0.0, fi = on ? fc[u].y * rc : 0.0;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                val[u][t].x -= fr * r[t].x - fi * r[t].y;
+                val[u][t].y -= fr * r[t].y + fi * r[t].x;
+            }
+        }
+        if (isdead && cg == (j & 7)) {
+#pragma unroll
+            for (int u = E; u < RU; ++u)
+                if (rg + 32 * u > j) val[u][TP] = make_double2(0.0, 0.0);
+        }
+        const int jn = j + 1;
+        if (jn < p) {
+            if (rg == (jn & 31)) {
+                const bool same = (jn >> 5) == E;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    double2 a = val[E][t];
+                    if constexpr (E + 1 < RU) {
+                        if (!same) a = make_double2(val[E + 1][t].x, val[E + 1][t].y);
+                    }
+                    sh.rowb[b ^ 1][cg + 8 * t] = a;
+                }
+            }
+            if (cg == (jn & 7)) {
+                const bool same = (jn >> 3) == TP;
+#pragma unroll
+                for (int u = E; u < RU; ++u) {
+                    double2 a = val[u][TP];
+                    if constexpr (TP + 1 < CT) {
+                        if (!same) a = make_double2(val[u][TP + 1].x, val[u][TP + 1].y);
+                    }
+                    sh.colb[b ^ 1][rg + 32 * u] = a;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+template <int E>
+__device__ __forceinline__ void chol_era_c(double2 (&val)[3][12], CholSharedC& sh, const int p, const int rg, const int cg) {
+    chol_piece_c<E, 0>(val, sh, p, rg, cg);
+    if (p > 32 * E + 8) chol_piece_c<E, 1>(val, sh, p, rg, cg);
+    if (p > 32 * E + 16) chol_piece_c<E, 2>(val, sh, p, rg, cg);
+    if (p > 32 * E + 24) chol_piece_c<E, 3>(val, sh, p, rg, cg);
+}
+// MODE 0: Tm = L^-H of S = sum of the partials = L L^H.  MODE 1: H = sum of the partials, written as the real embedding
+// [[Hr, -Hi], [Hi, Hr]] of order 2 pc (zero padded) - what the pair-mode Hermitian solver reads.
+template <int MODE>
+__global__ __launch_bounds__(CH_T) void k_ss_chol_c(View v, int lid, int going_left, SsBufs s) {
+    __shared__ CholSharedC sh;
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int p = q.p, ld = s.pc, tid = threadIdx.x;
+    const int64_t pp = (int64_t)ld * ld;
+    const double2* __restrict__ Sp = (const double2*)s.Sp;
+    if (MODE == 1) {
+        const int e = (int)blockIdx.x * CH_T + tid;
+        if (e < ld * ld) {
+            const int i = e / ld, j = e - i * ld;
+            double xr = 0.0, xi = 0.0;
+            if (i < p && j < p) {
+#pragma unroll
+                for (int k = 0; k < SS_KS; ++k) {
+                    xr += Sp[k * pp + e].x;
+                    xi += Sp[k * pp + e].y;
+                }
+                if (i == j) xi = 0.0;
+            }
+            const int hn = 2 * ld;
+            s.H[(int64_t)i * hn + j] = xr;
+            s.H[(int64_t)i * hn + ld + j] = -xi;
+            s.H[(int64_t)(ld + i) * hn + j] = xi;
+            s.H[(int64_t)(ld + i) * hn + ld + j] = xr;
+        }
+        return;
+    }
+    const int rg = tid >> 3, cg = tid & 7;
+    double2 val[3][12];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = rg + 32 * u;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const int c = cg + 8 * t;
+            double xr = 0.0, xi = 0.0;
+            if (i < p && c < p) {
+#pragma unroll
+                for (int k = 0; k < SS_KS; ++k) {
+                    xr += Sp[k * pp + (int64_t)i * ld + c].x;
+                    xi += Sp[k * pp + (int64_t)i * ld + c].y;
+                }
+            }
+            if (i == c) xi = 0.0;
+            val[u][t] = make_double2(xr, xi);
+            if (i == c) sh.d0[i] = xr;
+            if (i == 0) sh.rowb[0][c] = make_double2(xr, xi);
+            if (c == 0) sh.colb[0][i] = make_double2(xr, xi);
+        }
+    }
+    __syncthreads();
+    chol_era_c<0>(val, sh, p, rg, cg);
+    if (p > 32) chol_era_c<1>(val, sh, p, rg, cg);
+    if (p > 64) chol_era_c<2>(val, sh, p, rg, cg);
+    // Tm[c][i] = conj(Linv[i][c]),  Linv[i][c] = rsqrt(pivot_i) * (c == i ? 1 : c < i ? unit-lower inverse [i][c] : 0)
+    double2* __restrict__ Tm = (double2*)s.Tm;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int i = rg + 32 * u;
+        const bool live = i < p && !sh.dead[i];
+        const double sc = live ? 1.0 / sqrt(sh.pivd[i]) : 0.0;
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const int c = cg + 8 * t;
+            if (i < ld && c < ld) {
+                const bool on = live && c <= i && !sh.dead[c];
+                Tm[(int64_t)c * ld + i] = on ? (c == i ? make_double2(sc, 0.0) : make_double2(sc * val[u][t].x, -sc * val[u][t].y)) : make_double2(0.0, 0.0);
+            }
+        }
+    }
+}
+
+// dst = src Tm (complex)
+__global__ __launch_bounds__(256) void k_ss_apply_c(View v, int lid, int going_left, SsBufs s, const double2* __restrict__ src, double2* __restrict__ dst, int left) {
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int p = q.p, ld = s.pc, R = left ? q.m : q.n;
+    const int tp = p >> 4, tr = (R + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    const int t = (int)blockIdx.x * 4 + wave;
+    if (t >= tr * tp) return;
+    const int rt = t / tp, ct = t - rt * tp;
+    const int row = rt * 16 + i16, col = ct * 16 + i16;
+    const double2* __restrict__ Tm = (const double2*)s.Tm;
+    d4 cR = {0, 0, 0, 0}, cI = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < p; k0 += 32) {
+        double2 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < p;
+            a[u] = (kv && row < R) ? src[(int64_t)row * ld + k] : make_double2(0.0, 0.0);
+            b[u] = kv ? Tm[(int64_t)k * ld + col] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 4 * u < p) cmma(a[u].x, a[u].y, b[u].x, b[u].y, cR, cI);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int orow = rt * 16 + kq + 4 * r;
+        if (orow < R) dst[(int64_t)orow * ld + col] = make_double2(cR[r], cI[r]);
+    }
+}
+
+// Ritz vectors of the complex problem: v_k = Zb W[:, k] / sqrt(theta_k); (theta, W) from the pair-mode solve of the embedding of H
+// (rawlam[2k], vector k in column 2k of rawE: rows [0, pc) real parts, [pc, 2 pc) imaginary parts).  cj: the iteration ran on conj(M)
+// (going right): the eigenvectors of G = conj(M^H M) are the conjugates.  Z rows 2k = (Re v, Im v), 2k + 1 = (-Im v, Re v); lam twice.
+__global__ __launch_bounds__(256) void k_ss_ritz_c(View v, int lid, int going_left, SsBufs s, BtBufs b, const double2* __restrict__ Zb, int cj) {
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int p = q.p, ld = s.pc, n = q.n, K0 = q.K0, hn = 2 * s.pc;
+    const int tk = (K0 + 15) >> 4, tn = (n + 15) >> 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i16 = lane & 15, kq = lane >> 4;
+    if (blockIdx.x == 0 && threadIdx.x < K0) {
+        const double th = fmax(s.lamH[2 * threadIdx.x], 0.0);
+        b.lam[2 * threadIdx.x] = th;
+        b.lam[2 * threadIdx.x + 1] = th;
+    }
+    const int t = (int)blockIdx.x * 4 + wave;
+    if (t >= tn * tk) return;
+    const int rt = t / tk, kt = t - rt * tk;
+    const int row = rt * 16 + i16, kc = kt * 16 + i16;
+    d4 cR = {0, 0, 0, 0}, cI = {0, 0, 0, 0};
+    for (int k0 = 0; k0 < p; k0 += 32) {
+        double2 a[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq;
+            const bool kv = k < p;
+            a[u] = (kv && row < n) ? Zb[(int64_t)row * ld + k] : make_double2(0.0, 0.0);
+            w[u] = (kv && kc < K0) ? make_double2(s.WH[(int64_t)k * hn + 2 * kc], s.WH[(int64_t)(ld + k) * hn + 2 * kc]) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 4 * u < p) cmma(a[u].x, a[u].y, w[u].x, w[u].y, cR, cI);
+    }
+    const double th = kc < K0 ? s.lamH[2 * kc] : 0.0;
+    const double sc = th > 1e-13 * s.lamH[0] ? 1.0 / sqrt(th) : 0.0;
+    const double sgn = cj ? -1.0 : 1.0;
+    const int64_t ldz = b.ncap;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = rt * 16 + kq + 4 * r;
+        if (c < n && kc < K0) {
+            const double xr = cR[r] * sc, xi = sgn * cI[r] * sc;
+            b.Z[(int64_t)(2 * kc) * ldz + c] = xr;
+            b.Z[(int64_t)(2 * kc) * ldz + n + c] = xi;
+            b.Z[(int64_t)(2 * kc + 1) * ldz + c] = -xi;
+            b.Z[(int64_t)(2 * kc + 1) * ldz + n + c] = xr;
+        }
+    }
 }

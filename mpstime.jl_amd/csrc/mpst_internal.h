@@ -608,7 +608,7 @@ void blocked_eig_force_sticky(BlockedEig* e, hipStream_t s);
 int blocked_eig_coop_aborts(const BlockedEig* e);
 int blocked_eig_xcd_misplaced(const BlockedEig* e);
 int blocked_eig_create(BlockedEig** out, int ncap, std::string* err);
-int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, std::string* err);
+int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, int cx, std::string* err);
 bool blocked_eig_subspace_on(const BlockedEig* e);
 int blocked_eig_subspace_counts(BlockedEig* e, hipStream_t s, int32_t* attempted, int32_t* accepted);
 void blocked_eig_destroy(BlockedEig* e);
