@@ -96,7 +96,8 @@ def csrc_sha256():
     import glob
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.h"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "mpstime.jl_amd", "csrc", "*.inl"))):
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -522,6 +523,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bonds", type=int, default=24)
     ap.add_argument("--cpu-full-sweep", action="store_true", help="(default since round 5; kept for old command lines) time ONE complete sweep of the CPU restatement")
+    ap.add_argument("--pmc-file", default="", help="counter summary (profiles/aggregate_pmc.py) to quote HBM traffic / MFMA utilisation from; default: the "
+                                                   "newest profiles/rNN_pmc_counters.json whose csrc digest matches this tree")
     ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline from the bounded bond sample only (extrapolated), skip the complete CPU sweep (~20 s)")
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
@@ -808,14 +811,18 @@ def main():
                   "gram": "mpst::k_gram_upd" if fused else "mpst::k_gram",
                   "split": "mpst::k_split", "env": "mpst::k_env_split" if fused else "mpst::k_env",
                   "grad_reduce+update": "mpst::k_fused_reduce" if fused else "mpst::k_grad_reduce"}
-        pmc_file = os.path.join("profiles", "r04_pmc_counters.json")
-        pmc, pmc_quoted = {}, None
-        try:
-            pj = json.load(open(os.path.join(ROOT, pmc_file)))
-            if pj.get("csrc_sha256") == csrc_sha256():
-                pmc = pj["kernels"]
-        except Exception:
-            pass
+        # --pmc-file, else the newest committed profiles/r*_pmc_counters.json taken on THIS tree's kernel sources
+        import glob
+        cands = [args.pmc_file] if args.pmc_file else sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_counters.json")), reverse=True)
+        pmc_file, pmc, pmc_quoted = None, {}, None
+        for cf in cands:
+            try:
+                pj = json.load(open(cf if os.path.isabs(cf) else os.path.join(ROOT, cf) if not os.path.exists(cf) else cf))
+                if pj.get("csrc_sha256") == csrc_sha256():
+                    pmc, pmc_file = pj["kernels"], os.path.relpath(cf, ROOT) if os.path.isabs(cf) else cf
+                    break
+            except Exception:
+                pass
         headline = world == 1 and (N, T, chi, d) == (4096, 100, 32, 4)
         kname = knames.get(dominant)
         if headline and pmc:

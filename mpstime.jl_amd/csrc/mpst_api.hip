@@ -1969,6 +1969,11 @@ static bool legendre_grid(const double* gx, const double* gp, int n, int d, doub
     if (getenv("MPST_IMP_NO_TRIG") || d < 1 || d > 16) return false;
     const double a = gx[0], h = (gx[n - 1] - gx[0]) / (double)(n - 1);
     if (!(h > 0.0) || a < -1.0 - 1e-12 || gx[n - 1] > 1.0 + 1e-12) return false;
+    // the closed-form prefix sums are Euler-Maclaurin truncated after the h^3 (third derivative) term; the next one,
+    // h^5 / 30240 * delta p^(5), grows like (2d - 2)^10 for a Legendre series of degree 2d - 2: on a coarse grid it moves the cumulative
+    // trapezoid by whole grid steps (6e-4 relative at d = 16 with 101 points).  Only grids on which it stays below 1e-12 take the
+    // closed form, the rest the table path.
+    if (pow(h, 5.0) * pow(2.0 * d - 2.0, 10.0) / 1e8 >= 1e-12) return false;
     const double tolx = 1e-12;
     const double nrm = sqrt(sqrt((2 * d + 1) / 2.0) * d);
     double cn = 0.0;
