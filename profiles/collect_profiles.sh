@@ -11,7 +11,7 @@ rm -rf $out            # never leave an earlier run's kernel_stats.csv / pmc_cou
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python3 $prog "$@" > $out/stdout_under_rocprof.txt 2> $out/kt.err
-db=$(ls $out/kt/*results.db $out/kt/*/*results.db 2>/dev/null | head -1)
+db=$(ls $out/kt/*results.db $out/kt/*/*results.db 2>/dev/null | head -1 || true)
 test -n "$db" || { echo "collect_profiles: no rocprofv3 results for $tag" >&2; exit 1; }
 python3 $root/profiles/rocpd_stats.py $db $out/kernel_stats.csv > /dev/null
 test -s $out/kernel_stats.csv
@@ -21,9 +21,9 @@ if [ "$pmc" = "1" ]; then
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/pmc$i -o p -- python3 $prog "$@" > $out/pmc$i.stdout 2> $out/pmc$i.err
   done
-  f1=$(ls $out/pmc1/*counter_collection.csv $out/pmc1/*/*counter_collection.csv 2>/dev/null | head -1)
-  f2=$(ls $out/pmc2/*counter_collection.csv $out/pmc2/*/*counter_collection.csv 2>/dev/null | head -1)
-  f3=$(ls $out/pmc3/*counter_collection.csv $out/pmc3/*/*counter_collection.csv 2>/dev/null | head -1)
+  f1=$(ls $out/pmc1/*counter_collection.csv $out/pmc1/*/*counter_collection.csv 2>/dev/null | head -1 || true)
+  f2=$(ls $out/pmc2/*counter_collection.csv $out/pmc2/*/*counter_collection.csv 2>/dev/null | head -1 || true)
+  f3=$(ls $out/pmc3/*counter_collection.csv $out/pmc3/*/*counter_collection.csv 2>/dev/null | head -1 || true)
   cd $root
   test -n "$f1" -a -n "$f2" -a -n "$f3" || { echo "collect_profiles: a counter pass of $tag left no csv" >&2; exit 1; }
   python3 profiles/aggregate_pmc.py $f1 $f2 $f3 $out/pmc_counters.json " ($tag: $(basename $prog) $*)" > $out/pmc_summary.txt 2>&1

@@ -335,3 +335,58 @@ def test_subspace_eigensolver_is_used_certified_and_agrees_with_lapack(dtype):
             assert worst[k] < tol[k], (k, worst)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_subspace_eigensolver_complex_bonds(dtype):
+    """The same for a complex model (Fourier encoding, one class - BASELINE configs[4]'s kind of fit): complex GEMM half-steps, Hermitian
+    elimination, Rayleigh-Ritz through the native pair-mode chain; accepted bonds and handed-back bonds alike agree with the
+    double-precision restatement of the legacy engine (oracle/ref_complex.py), teacher forced over the second sweep."""
+    import bench
+    from oracle import ref_complex as RC
+    from tests.test_gpu_typed import TOL, caches_around, two_site
+    from tests.helpers import bond_of
+    N, T, d, chi = 512, 8, 8, 24                       # n = d chi = 192 complex columns, block 24 + 32 -> 64
+    full = bench.typed_inputs(N, T, d, 1, True)
+    dt = np.dtype(dtype)
+    W = mt.generate_startingMPS(4, T, d, 1, 1234, np.complex128)
+    opts = RC.SweepOptions(chi_max=chi, eta=0.01)
+    phi = np.asarray(full.phi).astype(dt)
+    eng = mt.SweepEngine(0)
+    try:
+        eng.set_options(chi_max=chi, eta=0.01)
+        eng.set_dataset(0, phi, full.label_index, 1, dtype=dt)
+        eng.set_mps([t.astype(dt) for t in W])
+        eng.build_caches()
+        eng.sweep()
+        i0 = eng.info()
+        assert i0["large_bond"] and i0["typed_kernels"] and i0["subspace_attempted"] > 0
+        Wo = [np.asarray(t).astype(np.complex128) for t in eng.get_mps()]
+        ds64 = RC.EncodedSet(phi.astype(np.complex128), np.asarray(full.label_index), np.asarray(full.class_distribution))
+        tol = TOL["f32" if dtype == "complex64" else "f64"]
+        worst = dict(loss=0.0, grad=0.0, S=0.0, bond=0.0)
+        for q in range(2 * (T - 1)):
+            lid, gl = bond_of(q, T)
+            ls = lid + 1 if gl else lid
+            eng.set_mps([t.astype(dt) for t in Wo], label_site=ls)
+            eng.build_caches()
+            LE, RE = caches_around(Wo, ds64.phi, ls)
+            tr = {}
+            RC.bond_step(Wo, LE, RE, lid, ds64, opts, gl, tr)
+            got = eng.bond_step(lid, gl)
+            assert got["chi"] == tr["chi"], (q, got["chi"], tr["chi"])
+            worst["loss"] = max(worst["loss"], abs(got["loss"] - tr["loss"]) / max(1.0, abs(tr["loss"])))
+            worst["grad"] = max(worst["grad"], abs(got["grad_norm"] - tr["grad_norm"]) / tr["grad_norm"])
+            worst["S"] = max(worst["S"], np.abs(got["S"][:tr["chi"]] - tr["S"]).max() / tr["S"][0])
+            Wg = eng.get_mps()
+            a, b = two_site(Wg[lid], Wg[lid + 1]), two_site(Wo[lid], Wo[lid + 1])
+            worst["bond"] = max(worst["bond"], np.abs(a - b).max() / np.abs(b).max())
+        i1 = eng.info()
+        att, acc = i1["subspace_attempted"] - i0["subspace_attempted"], i1["subspace_accepted"] - i0["subspace_accepted"]
+        print(dtype, "second sweep: subspace attempted", att, "accepted", acc, worst)
+        assert att >= 2 * (T - 1) - 6 and acc >= att - 4, (att, acc)
+        assert i1["library_eig_fallbacks"] == 0
+        for k in tol:
+            assert worst[k] < tol[k], (k, worst)
+    finally:
+        eng.close()
