@@ -66,7 +66,9 @@ __device__ __forceinline__ SsProblem ss_resolve(const View& v, int lid, int goin
     // values, plus the oversampling; where the capacity of the Rayleigh-Ritz solver cuts it short the oversampling goes first
     const int r0 = min(pb.nspec / q.st, v.C * v.chi[lid + 1]);
     const int want = max(q.K0, r0);
-    q.p = min(s.pc, (want + SS_EXTRA + 15) & ~15);
+    static_assert(SS_EXTRA == 32, "");
+    const int extra = (s.dbg & 16) ? 16 : SS_EXTRA;          // bring-up: MPST_SS_DBG=16 halves the oversampling
+    q.p = min(s.pc, (want + extra + 15) & ~15);
     q.active = (pb.pair ? s.cx != 0 : s.cx == 0) && v.ss_bt != nullptr && want <= q.p && q.n >= 2 * q.p && q.st * q.n > MAX_DIM && q.m >= 1 &&
                q.K0 >= 1 && q.K0 <= 64;
     return q;
