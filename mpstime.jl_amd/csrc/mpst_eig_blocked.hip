@@ -1903,6 +1903,7 @@ int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, int cx
     if (cx && pc > 96) return 0;                                                 // the complex elimination keeps a 3 x 12 register tile
     SsBufs& q = e->ss;
     q.pc = pc;
+    q.capped = (C * kcap + SS_EXTRA > pc) ? 1 : 0;
     q.cx = cx ? 1 : 0;
     q.dbg = getenv("MPST_SS_DBG") ? atoi(getenv("MPST_SS_DBG")) : 0;
     q.mcap = mcap;
@@ -1912,9 +1913,10 @@ int blocked_eig_enable_subspace(BlockedEig* e, int mcap, int kcap, int C, int cx
     const size_t tn = (size_t)(z * ncap + 15) / 16;
     bool ok = al(&q.Mw, z * mcap * ncap) && al(&q.Lb[0], z * mcap * pc) && al(&q.Lb[1], z * mcap * pc) && al(&q.Rb[0], z * ncap * pc) &&
               al(&q.Rb[1], z * ncap * pc) && al(&q.Sp, z * SS_KS * pc * pc) && al(&q.Tm, z * pc * pc) && al(&q.H, z * z * pc * pc) &&
-              al(&q.lamH, SS_PMAX + 8) && al(&q.WH, z * z * pc * pc) && al(&q.wsH, eig_workspace_doubles()) && al(&q.part, tn * CAP_LIMIT + tn + 16) &&
+              al(&q.lamH, SS_PMAX + 16) && al(&q.WH, z * z * pc * pc) && al(&q.wsH, eig_workspace_doubles()) && al(&q.part, tn * CAP_LIMIT + tn + 16) &&
               hipMalloc((void**)&q.infoH, sizeof(int32_t)) == hipSuccess && hipMalloc((void**)&q.st, 4 * sizeof(int32_t)) == hipSuccess &&
               hipMemset(q.st, 0, 4 * sizeof(int32_t)) == hipSuccess && hipHostMalloc((void**)&e->host_st, 4 * sizeof(int32_t)) == hipSuccess;
+    if (ok) ok = hipFuncSetAttribute((const void*)k_ss_cholb, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     if (ok && cx) {
         std::string e2;
         ok = blocked_eig_create(&e->rr, 2 * pc, &e2) == 0;
@@ -2028,9 +2030,12 @@ static void enqueue_subspace(const View& v, int lid, int going_left, BlockedEig*
     const int kmax = std::min(v.chi_max, 64), tk = (kmax + 15) / 16;
     const int short_start = v.ss_f32 ? 1 : 0;
     hipLaunchKernelGGL(k_ss_load, dim3(256), dim3(256), 0, s, v, lid, going_left, q, short_start);
+    static const bool pivotwise = getenv("MPST_SS_PIVOT") != nullptr;     // the pivot-by-pivot elimination instead of the blocked factorisation
+    const size_t cb_lds = ((size_t)pc * (pc + CB_LDPAD) + pc + (size_t)(pc / 16) * 256) * sizeof(double);
     auto orth = [&](double* raw, double* out, int left) {          // out = cholqr(raw)
         hipLaunchKernelGGL(k_ss_gram, dim3(tp * tp * SS_KS), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, left);
-        if (pc <= 96) hipLaunchKernelGGL(k_ss_chol<2>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
+        if (!pivotwise) hipLaunchKernelGGL(k_ss_cholb, dim3(1), dim3(CB_T), cb_lds, s, v, lid, going_left, q);
+        else if (pc <= 96) hipLaunchKernelGGL(k_ss_chol<2>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
         else hipLaunchKernelGGL(k_ss_chol<0>, dim3(1), dim3(CH_T), chol_lds, s, v, lid, going_left, q);
         hipLaunchKernelGGL(k_ss_apply, dim3(((left ? tm : tn) * tp + 3) / 4), dim3(256), 0, s, v, lid, going_left, q, (const double*)raw, out, left);
     };
@@ -2039,11 +2044,15 @@ static void enqueue_subspace(const View& v, int lid, int going_left, BlockedEig*
         hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[0], q.Rb[0]);
         orth(q.Rb[0], q.Rb[1], 0);
     }
-    // Q = cholqr(M X); X = cholqr(M^T Q); Q = cholqr(M X)
-    hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
-    orth(q.Lb[0], q.Lb[1], 1);
-    hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[1], q.Rb[0]);
-    orth(q.Rb[0], q.Rb[1], 0);
+    // Q = cholqr(M X); X = cholqr(M^T Q); Q = cholqr(M X)   (twice where the capacity of the Rayleigh-Ritz solver leaves the block no
+    // oversampling - two classes at chi_max = 64: rank(M0) = 128 = the block -: without it 15-20 % of such bonds end at 1e-9 ... 1e-8
+    // and go back to the exact solver)
+    for (int round = 0; round < (q.capped ? 2 : 1); ++round) {
+        hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
+        orth(q.Lb[0], q.Lb[1], 1);
+        hipLaunchKernelGGL(k_ss_mm<1>, dim3(tn * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Lb[1], q.Rb[0]);
+        orth(q.Rb[0], q.Rb[1], 0);
+    }
     hipLaunchKernelGGL(k_ss_mm<0>, dim3(tm * tp), dim3(256), 0, s, v, lid, going_left, q, (const double*)q.Rb[1], q.Lb[0]);
     orth(q.Lb[0], q.Lb[1], 1);
     // Z = M^T Q; H = Z^T Z; Rayleigh-Ritz
@@ -2116,9 +2125,10 @@ int launch_eig_blocked(const View& v, int lid, int going_left, const double* raw
             (void)hipMemcpy(&info, e->ss.infoH, sizeof info, hipMemcpyDeviceToHost);
             double r2 = 0, rmax = 0; int bad = -1;
             for (int i = 0; i < ctl[0] && i < CAP_LIMIT; ++i) { r2 += res[i] * res[i]; if (res[i] > rmax) { rmax = res[i]; bad = i; } }
-            double stamp[3];
+            double stamp[8];
             (void)hipMemcpy(stamp, e->ss.lamH + SS_PMAX, sizeof stamp, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[ss] chol phases: load %.2f us, elimination %.2f us\n", stamp[0] * 0.01, stamp[1] * 0.01);
+            fprintf(stderr, "[ss] chol phases: load %.2f us, elimination %.2f us | blocked: load %.2f, updates %.2f, diagonal blocks %.2f, panels %.2f, inverse %.2f, store %.2f us\n",
+                    stamp[0] * 0.01, stamp[1] * 0.01, stamp[2] * 0.01, stamp[3] * 0.01, stamp[4] * 0.01, stamp[5] * 0.01, stamp[6] * 0.01, stamp[7] * 0.01);
             fprintf(stderr, "[ss] lid %d gl %d st %d %d ctl %d %d %d %d flag %d eiginfo %d est %.3e rmax %.3e at %d lam0 %.3e lam[k-1] %.3e D00 %.3e D01 %.3e\n", lid, going_left,
                     e->host_st[0], e->host_st[1], ctl[0], ctl[1], ctl[2], ctl[3], flag, info, sqrt(r2), rmax, bad, lam[0], lam[ctl[0] > 0 ? ctl[0] - 1 : 0], D[0], D[1]);
         }

@@ -44,6 +44,7 @@ struct SsBufs {
                          // [2] bonds accepted, [3] bonds attempted (since creation)
     int pc;              // block width at capacity: multiple of 16, <= SS_PMAX
     int mcap, ncap;
+    int capped;          // 1: C chi_max + 32 exceeds the block capacity: no oversampling at full bond dimension, one more round of half-steps
     int cx;              // 1: complex element type - Mw, the blocks, Sp, Tm are double2 arrays of the same element counts, H is the real
                          //    embedding [[Hr, -Hi], [Hi, Hr]] (2 pc x 2 pc) the pair-mode Hermitian solver reads
     const int32_t* rrflag;   // complex: verdict word of the Rayleigh-Ritz solve (0 = delivered)
@@ -564,6 +565,180 @@ __global__ void k_ss_verdict(SsBufs s, BtBufs b) {
     if (ok) s.st[2] += 1;
 }
 
+
+// =====================================================================================================================================
+// Blocked form of the orthonormalisation's factorisation (real): S = L L^T with 16 x 16 blocks.  The pivot-by-pivot elimination above
+// pays a barrier, an LDS round trip and the reciprocal chain for each of p pivots (0.4 us each); here the dependent chain is the nb = p / 16
+// diagonal blocks, each factored AND inverted by ONE wave in registers (lane = row; v_readlane broadcasts, no LDS, no barrier:
+// ~1000 instructions), everything else - the updates of a block column and its scaling by L_JJ^-T - on the MFMA with operands from LDS.
+// What leaves is Tm = L^-T, formed by a block forward substitution on the MFMA as well (measured on the way: leaving L and doing the
+// substitution per row tile in the apply kernel made that kernel latency-bound, 15 against 7 us).
+// A pivot below 2e-15 of its column's own squared norm drops the column: its l_kk counts as infinite (inverse diagonal 0), its
+// sub-column as 0 - Q gets a zero column, as with the pivot-by-pivot kernel.
+// =====================================================================================================================================
+constexpr int CB_LDPAD = 4;        // LDS row stride = pc + 4 doubles: (4 row + k) mod 32 distinct over a wave's operand read
+
+// 16 x 16 block at LDS address T (row stride ldl): Cholesky factor into its lower triangle, inverse of the factor to Li (row stride 16,
+// lower triangle, zeros above).  One wave; lanes 0..15 own a row each.  d0: the block's original diagonal of S (drop criterion).
+__device__ __forceinline__ void cb_diag_block(double* __restrict__ T, int ldl, double* __restrict__ Li, const double* __restrict__ d0, int lane) {
+    const int r = lane & 15;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = T[r * ldl + c];
+    const double dr = d0[r];
+    double inv[16];                                          // 1 / l_kk (0: dropped)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double piv = readlane_f64(a[k], k);
+        const double dk = readlane_f64(dr, k);
+        const bool dead = !(piv > 2e-15 * dk) || !(dk > 0.0);
+        double rs = __builtin_amdgcn_rsq(piv);                  // v_rsq_f64 + two Newton steps: the IEEE sqrt and division cost 60 instructions a pivot
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        rs = rs * (1.5 - 0.5 * piv * rs * rs);
+        if (dead) rs = 0.0;
+        inv[k] = rs;
+        const double lk = a[k] * rs;                         // l_rk for r >= k (l_kk = sqrt(piv)); a dropped column is zero
+        a[k] = lk;
+#pragma unroll
+        for (int c = k + 1; c < 16; ++c) a[c] -= lk * readlane_f64(lk, c);
+    }
+    // inverse of the lower-triangular factor, column by column: lane c owns column c of X = L^-1
+    double x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = 0.0;
+    const int c = r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        // row q of X: x_qc = (delta_qc - sum_{j < q} l_qj x_jc) / l_qq
+        double sacc = (q == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < q; ++j) sacc -= readlane_f64(a[j], q) * x[j];
+        x[q] = (q >= c) ? sacc * inv[q] : 0.0;
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) T[r * ldl + cc] = cc <= r ? a[cc] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Li[q * 16 + c] = x[q];
+    }
+}
+
+// Tm = L^-T (as k_ss_chol leaves it: Tm[l][j] = Linv[j][l], l <= j, dropped columns zero) from the Gram partials.  One workgroup of
+// 16 waves (all of them load and store, up to nb of them work on a block column), the matrix in LDS.  After the factorisation the
+// inverse is formed block column by block column, X_IJ = -Linv_II sum_{K=J}^{I-1} L_IK X_KJ (a wave per block column, MFMA, operands
+// from LDS), and kept TRANSPOSED in the unused upper triangle - which is exactly the layout of Tm.
+constexpr int CB_T = 512;
+__global__ __launch_bounds__(CB_T) void k_ss_cholb(View v, int lid, int going_left, SsBufs s) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (!s.st[1]) return;
+    const SsProblem q = ss_resolve(v, lid, going_left, s);
+    const int p = q.p, ld = s.pc, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, i16 = lane & 15, kq = lane >> 4;
+    const int ldl = ld + CB_LDPAD, nb = p >> 4;
+    constexpr int NW = CB_T / 64;
+    double* A = sm;                                 // [pc][ldl]
+    double* d0 = A + (size_t)ld * ldl;              // [pc]
+    double* Ld = d0 + ld;                           // [nb][16][16] inverses of the diagonal blocks
+    const int64_t pp = (int64_t)ld * ld;
+    unsigned long long tq[6] = {0, 0, 0, 0, 0, 0}, tl = 0;
+    auto stamp = [&](int k) {
+        if (tid == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+            tq[k] += t - tl;
+            tl = t;
+        }
+    };
+    if (tid == 0) tl = __builtin_amdgcn_s_memrealtime();
+    {
+        const int j = tid & (SS_PMAX - 1);
+        for (int i = tid >> 7; i < p; i += CB_T / SS_PMAX) {
+            if (j < p) {
+                double x = 0.0;
+#pragma unroll
+                for (int k = 0; k < SS_KS; ++k) x += s.Sp[k * pp + (int64_t)i * ld + j];
+                A[i * ldl + j] = x;
+                if (i == j) d0[i] = x;
+            }
+        }
+    }
+    __syncthreads();
+    stamp(0);
+    for (int J = 0; J < nb; ++J) {
+        // (1) block column J, rows I >= J: T_IJ = S_IJ - sum_{K < J} L_IK L_JK^T   (left-looking; the waves share out the block rows)
+        for (int I = J + wave; I < nb; I += NW) {
+            d4 acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = A[(16 * I + kq + 4 * r) * ldl + 16 * J + i16];
+            for (int K = 0; K < J; ++K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double a = A[(16 * I + i16) * ldl + 16 * K + 4 * u + kq];
+                    const double b = A[(16 * J + i16) * ldl + 16 * K + 4 * u + kq];
+                    acc = mfma_f64(-a, b, acc);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(16 * I + kq + 4 * r) * ldl + 16 * J + i16] = acc[r];
+        }
+        __syncthreads();
+        stamp(1);
+        // (2) the diagonal block: factor + inverse, one wave
+        if (wave == 0) cb_diag_block(A + (16 * J) * ldl + 16 * J, ldl, Ld + J * 256, d0 + 16 * J, lane);
+        __syncthreads();
+        stamp(2);
+        // (3) L_IJ = T_IJ Linv_JJ^T for I > J
+        for (int I = J + 1 + wave; I < nb; I += NW) {
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double a = A[(16 * I + i16) * ldl + 16 * J + 4 * u + kq];
+                const double b = Ld[J * 256 + i16 * 16 + 4 * u + kq];              // (Linv^T)[k][c] = Linv[c][k]
+                acc = mfma_f64(a, b, acc);
+            }
+            // (in place: a wave's LDS operations execute in program order and the stores depend on every load through the MFMAs)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(16 * I + kq + 4 * r) * ldl + 16 * J + i16] = acc[r];
+        }
+        __syncthreads();
+        stamp(3);
+    }
+    // (4) X = L^-1, block column J on wave J: X_IJ^T goes to block (J, I) of the upper triangle
+    if (wave < nb) {
+        const int J = wave;
+        for (int I = J + 1; I < nb; ++I) {
+            d4 acc = {0, 0, 0, 0};
+            for (int K = J; K < I; ++K) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double a = A[(16 * I + i16) * ldl + 16 * K + 4 * u + kq];                        // L_IK[i][k]
+                    const double b = (K == J) ? Ld[J * 256 + (4 * u + kq) * 16 + i16]                       // X_JJ[k][c]
+                                              : A[(16 * J + i16) * ldl + 16 * K + 4 * u + kq];              // X_KJ[k][c], stored transposed
+                    acc = mfma_f64(a, b, acc);
+                }
+            }
+            d4 out = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) out = mfma_f64(-Ld[I * 256 + i16 * 16 + 4 * u + kq], acc[u], out);    // -Linv_II (.)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(16 * J + i16) * ldl + 16 * I + kq + 4 * r] = out[r];               // X_IJ[i = kq + 4r][c = i16], transposed
+        }
+    }
+    __syncthreads();
+    stamp(4);
+    // Tm[l][j] = Linv[j][l]: the upper triangle as it stands, the diagonal blocks from Ld (transposed), zeros below
+    {
+        const int j = tid & (SS_PMAX - 1);
+        for (int l = tid >> 7; l < ld; l += CB_T / SS_PMAX) {
+            if (j < ld) {
+                double x = 0.0;
+                if (l < p && j < p && l <= j) x = ((l >> 4) == (j >> 4)) ? Ld[(j >> 4) * 256 + (j & 15) * 16 + (l & 15)] : A[l * ldl + j];
+                s.Tm[(int64_t)l * ld + j] = x;
+            }
+        }
+    }
+    stamp(5);
+    if (tid == 0)
+        for (int k = 0; k < 6; ++k) s.lamH[SS_PMAX + 2 + k] = (double)tq[k];       // phase stamps (100 MHz) of the last call
+}
 
 // =====================================================================================================================================
 // Complex element types (Fourier / Sahand / Stoudenmire encodings, BASELINE configs[4]): the same sequence on the complex m x n
