@@ -819,6 +819,8 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     if ((int)blockIdx.x % stride != cp.xsel % stride) return;
     constexpr int NT = BTC_NT, NW = NT / 64;
     constexpr bool TAGGED = XMODE == 1, XCNT = XMODE == 3;
+    constexpr bool SOLO = XMODE == 4;         // ONE workgroup owns every row (order <= 96): y and the next row go through LDS, a step costs
+                                              // barriers instead of two round trips through the L2 (the Rayleigh-Ritz problem of the subspace solver)
     static_assert(BTC_NMAX <= NT, "one element of every length-n vector per thread");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double red_a[NW][2], red_b[NW];
@@ -832,6 +834,8 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     double2* wl = vl + ld;               // [ld] w_{j-1}
     double2* rows = wl + ld;             // [ceil(ld / G)][ld] this workgroup's rows g, g+G, ...
     const int nown = g < n ? (n - 1 - g) / G + 1 : 0;
+    double2* yl = rows + (size_t)(SOLO ? ld : 0) * ld;      // SOLO: [2][ld] y of the step before / at hand ...
+    double2* rl = yl + 2 * ld;                               // ... and [2][ld] the row the next step starts from
     if (b.sticky && *(const volatile int32_t*)b.sticky != 0) {       // the sweep is condemned already (see k_bt_coop)
         if (blockIdx.x == 0 && tid == 0) *cp.abort_flag = ABORT_PATIENCE;
         return;
@@ -862,12 +866,14 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
     if ((TAGGED || XCNT) && !bt_coop_roll_call(cp, G, &sh_ok)) return;          // leaves sh_ok = 1
     if (g == 0) {
         for (int c = tid; c < n; c += NT) {
-            if constexpr (TAGGED) put_c(cp.rowbuf, c, rows[c], tag_key(seq, 2, 0));
+            if constexpr (SOLO) rl[c] = rows[c];
+            else if constexpr (TAGGED) put_c(cp.rowbuf, c, rows[c], tag_key(seq, 2, 0));
             else if constexpr (XCNT) st_x(rowbuf + c, rows[c]);
             else st_c(rowbuf + c, rows[c]);
         }
     }
-    if constexpr (XCNT) xcd_arrive(cp);
+    if constexpr (SOLO) __syncthreads();
+    else if constexpr (XCNT) xcd_arrive(cp);
     else if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
     double2 tau_prev = make_double2(0.0, 0.0);
     for (int j = 0; j <= n - 2; ++j) {
@@ -875,7 +881,13 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
         const bool ok = idx < n;
         const double2 zero = make_double2(0.0, 0.0);
         double2 yp, aj, yj;
-        if constexpr (TAGGED) {
+        if constexpr (SOLO) {
+            const double2* yprev = yl + ((j + 1) & 1) * ld;
+            const double2* rowj = rl + (j & 1) * ld;
+            yp = (ok && j > 0) ? yprev[idx] : zero;
+            aj = ok ? rowj[idx] : zero;
+            yj = j > 0 ? yprev[j] : zero;
+        } else if constexpr (TAGGED) {
             const double* yprev = cp.ybuf + (int64_t)((j + 1) & 1) * 4 * ld;
             const double* rowj = cp.rowbuf + (int64_t)(j & 1) * 4 * ld;
             const unsigned long long kr = tag_key(seq, 2, j), ky = j > 0 ? tag_key(seq, 1, j - 1) : kr;
@@ -1026,7 +1038,8 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
                 sr += pr.x;
                 si += pr.y;
                 if (pub) {
-                    if constexpr (TAGGED) put_c(rownext_t, c, a_, key_r);
+                    if constexpr (SOLO) rl[((j + 1) & 1) * ld + c] = a_;
+                    else if constexpr (TAGGED) put_c(rownext_t, c, a_, key_r);
                     else if constexpr (XCNT) st_x(rownext + c, a_);
                     else st_c(rownext + c, a_);
                 }
@@ -1034,12 +1047,14 @@ __global__ __launch_bounds__(BTC_NT) void k_bt_coop_c(View v, int lid, int going
             sr = wave_sum_fast(sr);
             si = wave_sum_fast(si);
             if (lane == 0) {
-                if constexpr (TAGGED) put_c(ynew_t, r, c_mul(tau, make_double2(sr, si)), key_y);
+                if constexpr (SOLO) yl[(j & 1) * ld + r] = c_mul(tau, make_double2(sr, si));
+                else if constexpr (TAGGED) put_c(ynew_t, r, c_mul(tau, make_double2(sr, si)), key_y);
                 else if constexpr (XCNT) st_x(ynew + r, c_mul(tau, make_double2(sr, si)));
                 else st_c(ynew + r, c_mul(tau, make_double2(sr, si)));
             }
         }
-        if constexpr (XCNT) xcd_arrive(cp);
+        if constexpr (SOLO) __syncthreads();
+        else if constexpr (XCNT) xcd_arrive(cp);
         else if constexpr (!TAGGED) bt_coop_arrive<SC_AGENT>(cp);
         bookkeeping();
     }
@@ -1854,7 +1869,8 @@ int blocked_eig_create(BlockedEig** out, int ncap, std::string* err) {
                  hipFuncSetAttribute((const void*)k_bt_coop<512, SC_XCD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop_c<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
                  hipFuncSetAttribute((const void*)k_bt_coop_c<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
-                 hipFuncSetAttribute((const void*)k_bt_coop_c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess;
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) == hipSuccess &&
+                 hipFuncSetAttribute((const void*)k_bt_coop_c<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) == hipSuccess;
     if (!ok) {
         if (err) *err = "allocation of the blocked eigensolver's workspace failed";
         blocked_eig_destroy(e);
@@ -1989,7 +2005,14 @@ static void enqueue_subspace_c(const View& v, int lid, int going_left, BlockedEi
         bt.ss = 0;
         bt.cnative = 1;
         const int xm = cnative_xcd_mode(rn);
-        if (xm == 3)
+        // MPST_RR_SOLO=1: ONE workgroup with the exchange through LDS (XMODE 4).  Measured and rejected as the default: 95 steps of
+        // barriers instead of L2 round trips, but the row updates of a 96 x 96 complex matrix on one CU take 515 us against the 223 us
+        // of 32 workgroups (c64 at configs[4]'s shape: 1.30 against 1.53 sweeps/s)
+        static const bool solo = getenv("MPST_RR_SOLO") != nullptr;
+        const size_t solo_lds = ((size_t)(3 + pc) * pc + 4 * (size_t)pc) * sizeof(double2);
+        if (solo && solo_lds <= 158 * 1024)
+            hipLaunchKernelGGL(k_bt_coop_c<4>, dim3(1), dim3(BTC_NT), solo_lds, s, v, 0, 0, bt, r->cp, 1, 0u, (const double*)q.H, rn);
+        else if (xm == 3)
             hipLaunchKernelGGL(k_bt_coop_c<3>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(rn), s, v, 0, 0, bt, r->cp, XCD_STRIDE, 0u, (const double*)q.H, rn);
         else if (xm == 1)
             hipLaunchKernelGGL(k_bt_coop_c<1>, dim3(XCD_G * XCD_STRIDE), dim3(BTC_NT), coopc_xcd_lds(rn), s, v, 0, 0, bt, r->cp, XCD_STRIDE, ++r->seq, (const double*)q.H, rn);
