@@ -20,6 +20,10 @@ python bench.py --steps 20 --warmup 3 --pmc-file $out/${R}_pmc_counters.json > $
 MPST_B2=0 profiles/collect_profiles.sh headline_fused 0 bench.py --steps 3 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/collect_fused.log 2>&1
 cp gpurun_out/$R/headline_fused/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_bond_fused_ab.csv
 grep -v "^$" gpurun_out/$R/headline_fused/stdout_under_rocprof.txt | tail -1 > $out/${R}_bench_n1_bond_fused_ab_under_rocprofv3.json
+# the same kernels when the chip is fed: 8 independent fits per launch (mpst_sweep_batch) - per-kernel durations and MFMA utilisation of the _b variants
+profiles/collect_profiles.sh batched 1 bench.py --steps 2 --warmup 2 --no-cpu-baseline --concurrent 8 > $out/collect_batched.log 2>&1
+cp gpurun_out/$R/batched/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_batched8.csv
+cp gpurun_out/$R/batched/pmc_counters.json $out/${R}_pmc_counters_batched8.json
 profiles/collect_profiles.sh impute 1 bench.py --workload impute --steps 1 --warmup 1 --no-cpu-baseline > $out/collect_impute.log 2>&1
 cp gpurun_out/$R/impute/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_impute.csv
 cp gpurun_out/$R/impute/pmc_counters.json $out/${R}_pmc_counters_impute.json
