@@ -72,6 +72,10 @@ __device__ __forceinline__ SsProblem ss_resolve(const View& v, int lid, int goin
     q.p = min(s.pc, (want + extra + 15) & ~15);
     q.active = (pb.pair ? s.cx != 0 : s.cx == 0) && v.ss_bt != nullptr && want <= q.p && q.n >= 2 * q.p && q.st * q.n > MAX_DIM && q.m >= 1 &&
                q.K0 >= 1 && q.K0 <= 64;
+    // fp32 tensors while the bond between the two sites is still growing: the kept values reach down to the cutoff, i.e. into the
+    // rounding noise of the entries, whose spectrum does not decay - such a bond never passes (measured: every one of the first
+    // half-sweep), so it is not attempted
+    if (v.ss_f32 && q.st * v.chi[lid + 1] < v.chi_max && v.chi[lid + 1] < pb.nspec / q.st) q.active = false;
     return q;
 }
 __device__ __forceinline__ double ss_omega(int r, int j) {
