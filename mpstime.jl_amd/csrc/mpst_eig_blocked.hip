@@ -1071,6 +1071,7 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
     const int k = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= bt_nvec(pb)) return;
     constexpr int QE = BTC_NMAX / 64;
+    const int nq = (n + 63) >> 6;            // live 64-element slots (2 of 8 at n = 96: the Rayleigh-Ritz problem of the subspace solver)
     double* zrow = b.Z + (int64_t)(2 * k) * ld;
     double2 z[QE];
 #pragma unroll
@@ -1086,8 +1087,10 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
         const double2* vj = Vc + (int64_t)(j >= 0 ? j : 0) * ldc;
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
-            const int i = lane + 64 * q;
-            dst[q] = (j >= 0 && i > j && i < n) ? vj[i] : make_double2(0.0, 0.0);
+            if (q < nq) {
+                const int i = lane + 64 * q;
+                dst[q] = (j >= 0 && i > j && i < n) ? vj[i] : make_double2(0.0, 0.0);
+            }
         }
         tj = j >= 0 ? tauc[j] : make_double2(0.0, 0.0);
     };
@@ -1095,17 +1098,21 @@ __global__ __launch_bounds__(256) void k_bt_back_c(View v, int lid, int going_le
         double sr = 0.0, si = 0.0;
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
-            sr += vv[q].x * z[q].x + vv[q].y * z[q].y;                 // conj(v) z
-            si += vv[q].x * z[q].y - vv[q].y * z[q].x;
+            if (q < nq) {
+                sr += vv[q].x * z[q].x + vv[q].y * z[q].y;             // conj(v) z
+                si += vv[q].x * z[q].y - vv[q].y * z[q].x;
+            }
         }
         sr = wave_sum_fast(sr);
         si = wave_sum_fast(si);
         const double2 t = c_mul(tj, make_double2(sr, si));
 #pragma unroll
         for (int q = 0; q < QE; ++q) {
-            const double2 u = c_mul(t, vv[q]);
-            z[q].x -= u.x;
-            z[q].y -= u.y;
+            if (q < nq) {
+                const double2 u = c_mul(t, vv[q]);
+                z[q].x -= u.x;
+                z[q].y -= u.y;
+            }
         }
     };
     // four reflectors in flight (a ring of register buffers): with one ahead the loop waited an L2 round trip every other step

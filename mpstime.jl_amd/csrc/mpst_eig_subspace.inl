@@ -12,9 +12,11 @@
 //     Z^H Z = W Theta W^H (p x p, the LDS-resident solver of mpst_eig.hip);   V = Z W Theta^-1/2,  sigma^2 = Theta.
 // (fp32 bond tensors, whose entries carry 6e-8 of rounding noise and whose bar is 3e-8: FOUR applications, X = Omega directly.)
 // The half-steps go through M, not G = M^H M: a Cholesky-QR of G X sees the SQUARED spectrum (condition 1e10 and more).
-// cholqr = Gram matrix (partials over row slices, summed in a fixed order), an in-place Gauss-Jordan elimination that leaves
-// L^-1 directly (one workgroup, p steps; pivots below 2e-15 of the column's own norm drop the column: rank-deficient blocks of
-// the growth phase), and the product with L^-H.
+// cholqr = Gram matrix (partials over row slices, summed in a fixed order), the factor L^-H of it, and the product with it.  The
+// factorisation is one workgroup: real types blocked (k_ss_cholb: 16 x 16 diagonal blocks factored and inverted by one wave in
+// registers, everything else on the MFMA from LDS; 45 us at p = 96), complex types pivot by pivot with the matrix in registers
+// (k_ss_chol_c; 94 us; the real pivot-wise kernel k_ss_chol stays selectable, MPST_SS_PIVOT=1).  Pivots below 2e-15 of the column's own
+// squared norm drop the column (rank-deficient blocks of the growth phase).
 // The result is CERTIFIED on the device before it is used: residuals r_k = G v_k - theta_k v_k of the kept pairs against G itself,
 //     sqrt(sum_k |r_k|^2 / theta_k) <= 1e-9 ||M||_F      (the first-order bound of ||M (P~ - P)||_F: a residual lies outside the
 //     iterated block, where the spectrum is far below theta_k; checked against the true error on every dumped bond),
@@ -22,7 +24,8 @@
 // Frobenius certificate ||G||_F^2 - sum theta^2 (no eigenvalue above the kept ones was missed, down to the resolution of fp64).
 // A bond that fails any of them is solved by the exact path, whose launches follow in the same stream and leave at once when
 // the word st[0] says the result stands.  Deterministic: Omega is a hash of (row, column), all sums have a fixed order.
-// Real element types only so far (a complex Gram matrix arrives as its 2n x 2n embedding: st[1] = 0, exact path).
+// Real and complex element types (the complex kernels are at the end of the file); not attempted: d chi <= 128 (measured: no gain,
+// profiles/r05_subspace_feasibility.json), C chi_max > 128, complex blocks wider than 96, fp32 tensors whose bond is still growing.
 
 constexpr int SS_EXTRA = 32;      // oversampling: columns beyond chi_max
 constexpr int SS_PMAX = 128;      // block width limit = order limit of the LDS-resident Rayleigh-Ritz solver
@@ -67,7 +70,6 @@ __device__ __forceinline__ SsProblem ss_resolve(const View& v, int lid, int goin
     // values, plus the oversampling; where the capacity of the Rayleigh-Ritz solver cuts it short the oversampling goes first
     const int r0 = min(pb.nspec / q.st, v.C * v.chi[lid + 1]);
     const int want = max(q.K0, r0);
-    static_assert(SS_EXTRA == 32, "");
     const int extra = (s.dbg & 16) ? 16 : SS_EXTRA;          // bring-up: MPST_SS_DBG=16 halves the oversampling
     q.p = min(s.pc, (want + extra + 15) & ~15);
     q.active = (pb.pair ? s.cx != 0 : s.cx == 0) && v.ss_bt != nullptr && want <= q.p && q.n >= 2 * q.p && q.st * q.n > MAX_DIM && q.m >= 1 &&
