@@ -324,7 +324,9 @@ int  mpst_impute_model_run(void* ctx, const mpst_impute_model* m, const uint8_t*
 int  mpst_get_impute_phases(void* ctx, double* seconds_out /*[2]*/);
 /* How the last imputation call ran (at most n entries): out[0] = 1 when the grid states were recognised as the Fourier basis
  * (src/Encodings/bases.jl:23-42) on a uniform grid and the conditional densities |rho phi(x)|^2 and their cumulative trapezoid
- * (src/Imputation/sampling_utils.jl:162-199) were evaluated in closed form instead of from the table of grid states. */
+ * (src/Imputation/sampling_utils.jl:162-199) were evaluated in closed form instead of from the table of grid states;
+ * out[1] = 1 when the sweep over the sites (impute_at!, src/Imputation/MPS_methods.jl:103-177) ran for sixteen instances per
+ * workgroup (closed-form densities and panels that fit the LDS; otherwise one instance per workgroup - same results). */
 int  mpst_get_impute_info(void* ctx, int32_t* out, int32_t n);
 
 int  mpst_normalize(void* ctx);

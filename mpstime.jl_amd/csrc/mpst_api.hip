@@ -184,6 +184,7 @@ struct Ctx {
     size_t ev_used = 0;
     double prof_us[16] = {0};
     double impute_phase_s[2] = {0, 0};   // last imputation call: environment pass, density sweep
+    int impute_batched = 0;              // ... and whether its sweep ran sixteen instances per workgroup (k_imp_leftb)
     int impute_trig = 0;                 // ... and whether its densities were evaluated in closed form (Fourier states on a uniform grid)
     int64_t prof_cnt[16] = {0};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -2088,10 +2089,17 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
     }
     if (maxm > 0) {
         // instances are processed in chunks so that the per-instance scratch (environments of the missing sites, p_k and
-        // its prefix sums) stays below ~8 GB
+        // its prefix sums) stays below half of the free device memory, at most 48 GB (MPST_IMPUTE_CHUNK_GB overrides): the
+        // 27 GB of environments of configs[4] (8192 instances x 100 missing sites x 32 KB) are one chunk on a 288 GB device,
+        // 512 workgroups of the batched sweep instead of seven launches of 82
         const int64_t welems = impute_work_elems(m.cap, m.is_complex != 0, m.compute_f32 != 0);
-        const int64_t per = (int64_t)maxm * m.cap * m.cap * zw + welems + 2ll * ngrid;
-        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(1ll << 30) / per));
+        const int64_t per_bytes = ((int64_t)maxm * m.cap * m.cap * zw + welems) * (int64_t)esz + 2ll * ngrid * (int64_t)sizeof(double);
+        size_t free_b = 0, total_b = 0;
+        HIPC(c, hipMemGetInfo(&free_b, &total_b));
+        double budget = std::min(48.0 * (double)(1ull << 30), 0.5 * (double)free_b);
+        if (const char* e = getenv("MPST_IMPUTE_CHUNK_GB")) budget = std::max(0.001, atof(e)) * (double)(1ull << 30);
+        int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(budget / (double)per_bytes)));
+        if (chunk < N && chunk > 4096) chunk &= ~(int64_t)4095;      // whole rounds of 16-instance workgroups on 256 CUs
         uint8_t *dmiss = nullptr, *dR = nullptr, *dW = nullptr;
         int32_t* dord = nullptr;
         double *dgx = nullptr, *dgp = nullptr, *du = nullptr, *dp = nullptr, *dS = nullptr, *dx = nullptr, *de = nullptr, *dlin = nullptr;
@@ -2137,7 +2145,7 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
             evs.e.push_back(mid);
             HIPC(c, hipEventCreate(&end));
             evs.e.push_back(end);
-            launch_impute(m, q, i0, std::min(chunk, N - i0), c->stream, mid);
+            c->impute_batched = launch_impute(m, q, i0, std::min(chunk, N - i0), c->stream, mid);
             HIPC(c, hipEventRecord(end, c->stream));
         }
         HIPC(c, hipEventRecord(c->ev_stop, c->stream));
@@ -2153,6 +2161,14 @@ static int run_impute(Ctx* c, const ImpModel& m, const uint8_t* missing, const d
             HIPC(c, hipEventElapsedTime(&b, evs.e[k], evs.e[k + 1]));
             c->impute_phase_s[0] += 1e-3 * a;
             c->impute_phase_s[1] += 1e-3 * b;
+        }
+        if (const char* e = getenv("MPST_IMB_DBG")) {
+            if (atoi(e) & 8) {           // lab: phase clocks of the batched sweep (k_imp_leftb, workgroup 0 of the last chunk)
+                double ph[6] = {0, 0, 0, 0, 0, 0};
+                HIPC(c, hipMemcpy(ph, dp, sizeof(ph), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[imb] phase A %.0f us, barrier %.0f, B1 %.0f, B2 %.0f, barrier %.0f\n", ph[0] * 0.01, ph[1] * 0.01, ph[2] * 0.01,
+                        ph[3] * 0.01, ph[4] * 0.01);
+            }
         }
         HIPC(c, hipMemcpy(xo.data(), dx, xo.size() * sizeof(double), hipMemcpyDeviceToHost));
         HIPC(c, hipMemcpy(eo.data(), de, eo.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -2175,8 +2191,8 @@ int mpst_get_impute_phases(void* ctx, double* seconds_out) {
 int mpst_get_impute_info(void* ctx, int32_t* out, int32_t n) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !out || n < 0) return MPST_ERR_INVALID;
-    const int32_t full[1] = {c->impute_trig};
-    for (int i = 0; i < n && i < 1; ++i) out[i] = full[i];
+    const int32_t full[2] = {c->impute_trig, c->impute_batched};
+    for (int i = 0; i < n && i < 2; ++i) out[i] = full[i];
     return 0;
 }
 

@@ -593,6 +593,7 @@ struct ImpArgs {
     const int32_t* ord;         // the instances of this chunk (run_impute orders them by where their missing sites begin)
     double x0, dxu;             // TRIG kernels: the uniform grid x_k = x0 + k dxu
     const double* lin;          // TRIG, real models: [2d-1][d][d] Legendre linearisation table (scaled by the states' norms), else null
+    int dbg;                    // k_imp_leftb: parts switched off for timing (MPST_IMB_DBG, lab use)
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2, IMP_BASIS_STOUDENMIRE = 3, IMP_BASIS_SAHAND = 4,
@@ -1491,6 +1492,8 @@ template <typename R, bool CX, int OCC, bool TRIG = false> __global__ __launch_b
     }
 }
 
+#include "mpst_impute_batched.inl"
+
 static size_t right_lds_bytes(int cap, bool cx, bool f32) {
     const int cp = (cap + 15) & ~15;
     return (size_t)(cx ? 2 : 1) * 4 * cp * (cp + (f32 ? 4 : 2)) * (f32 ? 4 : 8);
@@ -1543,6 +1546,15 @@ hipError_t impute_init_attrs(int device) {
     IMP_ATTR_LEG(float, true, 2)
     IMP_ATTR_LEG(float, true, 3)
 #undef IMP_ATTR_LEG
+#define IMB_ATTR(R, CX, EMB)                                                                                                       \
+    if ((e = hipFuncSetAttribute((const void*)k_imp_leftb<R, CX, EMB>, hipFuncAttributeMaxDynamicSharedMemorySize, IMB_LDS_MAX)) != hipSuccess) return e;
+    IMB_ATTR(double, false, false)
+    IMB_ATTR(double, true, false)
+    IMB_ATTR(double, true, true)
+    IMB_ATTR(float, false, false)
+    IMB_ATTR(float, true, false)
+    IMB_ATTR(float, true, true)
+#undef IMB_ATTR
     IMP_ATTR(double, false, false)
     IMP_ATTR(double, true, false)
     IMP_ATTR(float, false, true)
@@ -1553,7 +1565,7 @@ hipError_t impute_init_attrs(int device) {
 }
 
 template <typename R, bool CX>
-static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
+static int launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
     constexpr bool F32 = std::is_same<R, float>::value;
     if (v.cap > impute_lds_chi_limit(CX, F32))
         hipLaunchKernelGGL((k_imp_right_big<R, CX>), dim3((unsigned)count), dim3(IMP_T), 0, s, v, q.missing, (R*)q.Rbuf, (R*)q.work,
@@ -1568,12 +1580,26 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
     }
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
-              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, q.order + i0, q.x0, q.dxu, q.lin};
+              q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, q.order + i0, q.x0, q.dxu, q.lin, 0};
+    static const int imb_dbg = [] { const char* e = getenv("MPST_IMB_DBG"); return e ? atoi(e) : 0; }();
+    g.dbg = imb_dbg;
     // two workgroups per CU (128 VGPRs each, 70-183 of them spilled) against one (256 VGPRs, no spill): the spilling
     // build wins where the density loop is latency-bound - real models and complex ones with d <= 5 - because a second
     // workgroup hides more than the scratch traffic costs (same-box A/B: profiles/r03_impute_occupancy_ab.txt;
     // MPST_IMP_OCC=1|2 forces either)
     static const int force_occ = [] { const char* e = getenv("MPST_IMP_OCC"); return e ? atoi(e) : 0; }();
+    // closed-form densities: sixteen instances per workgroup (MPST_IMP_NO_BATCH=1: the one-instance kernel, a test hook)
+    const bool no_batch = getenv("MPST_IMP_NO_BATCH") != nullptr;
+    const bool mean_ok = q.method != IMP_MEAN || (CX ? q.mean_basis == IMP_BASIS_FOURIER
+                                                     : (q.mean_basis == IMP_BASIS_LEGENDRE || q.mean_basis == IMP_BASIS_LEGENDRE_NO_NORM ||
+                                                        q.mean_basis == IMP_BASIS_UNIFORM));
+    if (q.trig && !no_batch && force_occ == 0 && mean_ok && imb_fits(v.cap, v.d, CX, F32)) {
+        const dim3 grid((unsigned)((count + IMB_B - 1) / IMB_B));
+        const size_t lds_b = imb_layout(v.cap, v.d, CX, F32).bytes;
+        if (CX && v.d <= 8) hipLaunchKernelGGL((k_imp_leftb<R, CX, CX>), grid, dim3(IMB_T), lds_b, s, v, g, (int)count);
+        else hipLaunchKernelGGL((k_imp_leftb<R, CX, false>), grid, dim3(IMB_T), lds_b, s, v, g, (int)count);
+        return 1;
+    }
     if constexpr (!CX) {
         if (q.trig) {
             // Legendre states on a uniform grid: the linearisation table rides in LDS behind the panels
@@ -1582,7 +1608,7 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
             if (force_occ == 1) hipLaunchKernelGGL((k_imp_left<R, CX, 1, true>), dim3((unsigned)count), dim3(IMP_T), lds_t, s, v, g);
             else if (force_occ == 2) hipLaunchKernelGGL((k_imp_left<R, CX, 2, true>), dim3((unsigned)count), dim3(IMP_T), lds_t, s, v, g);
             else hipLaunchKernelGGL((k_imp_left<R, CX, 3, true>), dim3((unsigned)count), dim3(IMP_T), lds_t, s, v, g);
-            return;
+            return 0;
         }
     }
     if constexpr (CX) {
@@ -1594,7 +1620,7 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
             else if (force_occ == 2) hipLaunchKernelGGL((k_imp_left<R, CX, 2, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
             else if (force_occ == 4) hipLaunchKernelGGL((k_imp_left<R, CX, 4, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
             else hipLaunchKernelGGL((k_imp_left<R, CX, 3, true>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
-            return;
+            return 0;
         }
     }
     // (real models with d > 8 - the reference's imputation examples use Legendre d = 10 ... 12 - likewise: d = 12, chi = 40: 147 ms with
@@ -1603,16 +1629,12 @@ static void launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0
         hipLaunchKernelGGL((k_imp_left<R, CX, 1>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
     else
         hipLaunchKernelGGL((k_imp_left<R, CX, 2>), dim3((unsigned)count), dim3(IMP_T), left_lds_bytes(v.cap, CX, F32), s, v, g);
+    return 0;
 }
 
-void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
-    if (v.is_complex) {
-        if (v.compute_f32) launch_impute_t<float, true>(v, q, i0, count, s, mid);
-        else launch_impute_t<double, true>(v, q, i0, count, s, mid);
-    } else {
-        if (v.compute_f32) launch_impute_t<float, false>(v, q, i0, count, s, mid);
-        else launch_impute_t<double, false>(v, q, i0, count, s, mid);
-    }
+int launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid) {
+    if (v.is_complex) return v.compute_f32 ? launch_impute_t<float, true>(v, q, i0, count, s, mid) : launch_impute_t<double, true>(v, q, i0, count, s, mid);
+    return v.compute_f32 ? launch_impute_t<float, false>(v, q, i0, count, s, mid) : launch_impute_t<double, false>(v, q, i0, count, s, mid);
 }
 
 }  // namespace mpst

@@ -644,7 +644,7 @@ struct ImputeParams {
 };
 int impute_chi_limit(bool cx, bool f32);
 int64_t impute_work_elems(int cap, bool cx, bool f32);     // per-instance scratch elements of the large-chi environment kernel
-void launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);
+int launch_impute(const ImpModel& v, const ImputeParams& q, int64_t i0, int64_t count, hipStream_t s, hipEvent_t mid = nullptr);   // 1: the sweep ran sixteen instances per workgroup (k_imp_leftb)
 // mpst_eig.hip
 void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s);   // stage 0 tri (or tri + vec merged), 1 vec, 2 fin
 void launch_eig_tail(const View& v, int lid, int going_left, int rawn, const double* Gt, int ld, double* Vall, double* dd, double* ee,

@@ -352,10 +352,11 @@ class SweepEngine:
         return float(out[0]), float(out[1])
 
     def impute_info(self):
-        """how the last imputation call ran: {"closed_form_densities": bool} (Fourier grid states on a uniform grid)"""
-        out = (C.c_int32 * 1)()
-        self._chk(self.lib.mpst_get_impute_info(self.ctx, out, 1))
-        return {"closed_form_densities": bool(out[0])}
+        """how the last imputation call ran: {"closed_form_densities": bool (Fourier / Legendre grid states on a uniform grid),
+        "batched_sweep": bool (sixteen instances per workgroup)}"""
+        out = (C.c_int32 * 2)()
+        self._chk(self.lib.mpst_get_impute_info(self.ctx, out, 2))
+        return {"closed_form_densities": bool(out[0]), "batched_sweep": bool(out[1])}
 
     def normalize(self):
         self._chk(self.lib.mpst_normalize(self.ctx))

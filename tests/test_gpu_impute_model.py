@@ -121,7 +121,9 @@ def test_closed_form_densities_equal_the_table_path(engine_cls, compute, cx, d, 
     dx = xs[1] - xs[0]
     for k, ((xa, ea), (xb, eb)) in enumerate(zip(runs["trig"], runs["table"])):
         if k == 3:          # mean: sums over the grid in another order
-            assert np.abs(xa - xb)[mask].max() < 1e-11 and np.abs(ea - eb)[mask].max() < 1e-11
+            # (fp32 chain: the closed-form sweep forms its products on the matrix pipe, the table kernel with FMAs - other sums)
+            tol = 1e-11 if compute == "f64" else 2e-4
+            assert np.abs(xa - xb)[mask].max() < tol and np.abs(ea - eb)[mask].max() < tol
             continue
         # selections: the same grid value, up to a cumulative sum that lands within rounding of a threshold (then one step, and
         # the conditioning carries the difference on: such instances are counted, not compared further)
@@ -429,3 +431,58 @@ def test_coarse_legendre_grids_take_the_table_path(engine_cls, d, ngrid):
     finally:
         eng.close()
     _check(W, xs, grid_phi, phi, y, m, x_g, e_g, "median")
+
+
+@pytest.mark.parametrize("order", [0, 1], ids=["forwards", "backwards"])
+@pytest.mark.parametrize("compute", ["f64", "f32"])
+@pytest.mark.parametrize("cx,d,chi", [(True, 8, 20), (True, 12, 9), (False, 12, 16), (False, 4, 33)],
+                         ids=["fourier_d8", "fourier_d12", "legendre_d12", "legendre_d4_chi33"])
+def test_batched_sweep_equals_the_one_instance_kernel(engine_cls, compute, cx, d, chi, order, monkeypatch):
+    """k_imp_leftb (sixteen instances per workgroup: the products with the site tensor and the environment on the matrix pipe, a wave
+    per instance for the selections) against k_imp_left<.., TRIG> (a workgroup per instance, MPST_IMP_NO_BATCH=1): 37 instances = two
+    full workgroups and a partial one, ragged missing patterns (one instance without a missing site, one with all of them), three
+    classes at the label site, every method, both orders.  fp64 chain: the same grid values up to a cumulative sum that lands within
+    rounding of a threshold; fp32 chain: the two kernels add their products in different orders, so one grid step."""
+    N, T, C = 37, 14, 3
+    W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=1000 + d + chi, ngrid=20001, cx=cx)
+    u = rng.uniform(0.02, 0.98, (N, T, 3))
+    eng = engine_cls(0)
+    try:
+        runs = {}
+        for tag in ("batched", "single"):
+            if tag == "single":
+                monkeypatch.setenv("MPST_IMP_NO_BATCH", "1")
+            runs[tag] = [eng.impute_model(W, phi, y, m, xs, grid_phi, 0, True, order=order, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 1, False, order=order, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 2, False, u[:, :, :1], order=order, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 3, True, order=order, compute=compute)[:2],
+                         eng.impute_model(W, phi, y, m, xs, grid_phi, 4, True, u, max_trials=3, rejection_threshold=1.0, order=order,
+                                          compute=compute)[:2]]
+            info = eng.impute_info()
+            assert info["closed_form_densities"] and info["batched_sweep"] == (tag == "batched")
+    finally:
+        eng.close()
+    mask = m.astype(bool)
+    dx = xs[1] - xs[0]
+    f64 = compute == "f64"
+    for k, ((xa, ea), (xb, eb)) in enumerate(zip(runs["batched"], runs["single"])):
+        assert np.all(xa[~mask] == 0.0) and np.all(np.isfinite(xa))
+        if k == 3:          # mean: sums over the grid in another order
+            tol = 1e-10 if f64 else 2e-4
+            assert np.abs(xa - xb)[mask].max() < tol and np.abs(ea - eb)[mask].max() < tol
+            continue
+        bad = [i for i in range(N) if not np.array_equal(xa[i], xb[i])]
+        if f64:
+            assert len(bad) <= 2, (k, bad)
+            for i in bad:
+                first = int(np.argmax(xa[i] != xb[i]))
+                assert abs(xa[i, first] - xb[i, first]) <= dx * 1.0000001
+        else:
+            # (the first site that differs: by a few of the 20 001 grid steps - fp32 products of up to 33 terms in two orders, a
+            # density as flat as a random model's; the conditioning carries the difference on)
+            for i in bad:
+                first = int(np.argmax(xa[i] != xb[i]))
+                assert abs(xa[i, first] - xb[i, first]) <= 10 * dx * 1.0000001, (k, i, xa[i, first], xb[i, first])
+        good = [i for i in range(N) if i not in bad]
+        if ea is not None and k in (0, 4) and f64:
+            assert np.abs(ea[good] - eb[good]).max() <= dx * 1.0000001
