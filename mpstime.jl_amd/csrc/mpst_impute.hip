@@ -185,6 +185,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
     R* smem = reinterpret_cast<R*>(smem_raw);
     __shared__ double red[IMR_T / 64];
     constexpr int NW = IMR_T / 64, NQ = IMR_T == 512 ? 5 : 4;      // waves; site-matrix elements per thread (the host picks IMR_T)
+    constexpr int NTW = IMR_T == 512 ? 2 : 1;                      // tiles per wave: 16 on 16 waves, 9 on 8, <= 4 on 4
     constexpr int ZW = CX ? 2 : 1;
     const int64_t i = ord[blockIdx.x];          // instance; scratch buffers are indexed by blockIdx.x (chunk-local)
     const int T = v.T, d = v.d, cm = v.cap, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
     if (tid == 0) Rc.r[0] = R(1);
     __syncthreads();
     // this wave's tiles of the tpr x tpr grid: wave (and wave + NW: only 9 tiles on 8 waves)
-    const bool h0 = wave < ntile, h1 = wave + NW < ntile;
+    const bool h0 = wave < ntile, h1 = NTW > 1 && wave + NW < ntile;
     const int rbA = h0 ? wave / tpr : 0, wcA = h0 ? wave % tpr : 0;
     const int rbB = h1 ? (wave + NW) / tpr : rbA, wcB = h1 ? (wave + NW) % tpr : wcA;
     int slot = 0;
@@ -230,6 +231,10 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
         const bool in_fast = sv.si == 1;
         const int Df = in_fast ? Di : Do;
         const int tmo = (Do + 15) >> 4, tni = (Di + 15) >> 4;
+        // the site after this one (the pass stops at the first missing site of the sweep, so there is one)
+        const int jn = rev ? j + 1 : j - 1;
+        const bool has_next = step + 1 < T;
+        const SiteView<R> svn = site_view<R, CX>(v, has_next ? jn : j, cls, rev != 0);
         // the (at most NQ) elements of the site matrix this thread carries
         int64_t off[NQ];
         int dst[NQ];
@@ -253,31 +258,41 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
                 for (int q = 0; q < NQ; ++q)
                     if (dst[q] >= 0) zload<R, CX>(sv.W, off[q] + (int64_t)s_ * sv.ss, fr[q], fi[q]);
             } else {
-                for (int qq = 0; qq < d; ++qq) {
-                    R pr, pi;
-                    zload<R, CX>(ph, qq, pr, pi);
-                    R wr[NQ], wi[NQ];
+                // complex models: two states per round trip to the L2 (four spill at 128 registers; real models lose a workgroup
+                // per CU to the extra registers and more than they gain: one)
+                constexpr int KB = CX ? 2 : 1;
+                for (int q0 = 0; q0 < d; q0 += KB) {
+                    R pr[KB], pi[KB], wr[KB][NQ], wi[KB][NQ];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        wr[q] = R(0);
-                        wi[q] = R(0);
-                        if (dst[q] >= 0) zload<R, CX>(sv.W, off[q] + (int64_t)qq * sv.ss, wr[q], wi[q]);
+                    for (int u = 0; u < KB; ++u) {
+                        pr[u] = pi[u] = R(0);
+                        const bool lq = q0 + u < d;
+                        if (lq) zload<R, CX>(ph, q0 + u, pr[u], pi[u]);
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            wr[u][q] = R(0);
+                            wi[u][q] = R(0);
+                            if (lq && dst[q] >= 0) zload<R, CX>(sv.W, off[q] + (int64_t)(q0 + u) * sv.ss, wr[u][q], wi[u][q]);
+                        }
                     }
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        fr[q] = fma(pr, wr[q], fr[q]);
-                        if constexpr (CX) {
-                            fr[q] = fma(pi, wi[q], fr[q]);
-                            fi[q] = fma(pr, wi[q], fi[q]);
-                            fi[q] = fma(-pi, wr[q], fi[q]);
+                    for (int u = 0; u < KB; ++u) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            fr[q] = fma(pr[u], wr[u][q], fr[q]);
+                            if constexpr (CX) {
+                                fr[q] = fma(pi[u], wi[u][q], fr[q]);
+                                fi[q] = fma(pr[u], wi[u][q], fi[q]);
+                                fi[q] = fma(-pi[u], wr[u][q], fi[q]);
+                            }
                         }
                     }
                 }
             }
         };
-        acc_t rnr[2], rni[2], rn3[2];
+        acc_t rnr[NTW], rni[NTW], rn3[NTW];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTW; ++t) {
             rnr[t] = acc_t{0, 0, 0, 0};
             rni[t] = acc_t{0, 0, 0, 0};
             rn3[t] = acc_t{0, 0, 0, 0};
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             const Plane<R> Ms{(s & 1) ? Ms1.r : Ms0.r, (s & 1) ? Ms1.i : Ms0.i};
             // T1 = Ms R^H (Do x Di)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NTW; ++t) {
                 const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
                 if ((t == 0 ? h0 : h1) && rb < tmo && wc < tni) {
                     acc_t ar = {0, 0, 0, 0}, ai = {0, 0, 0, 0};
@@ -326,7 +341,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             if (s + 2 < ns) fetch(s + 2);
             // R' += T1 Ms^H (Do x Do)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NTW; ++t) {
                 const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
                 if ((t == 0 ? h0 : h1) && rb < tmo && wc < tmo) {
                     if constexpr (CX) lds_tile_rows3<R>(rnr[t], rni[t], rn3[t], T1, 16 * rb, Ms, 16 * wc, ks, ld);      // K1, K2, K3
@@ -335,40 +350,49 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             }
             lds_barrier();
         }
-        // the new environment replaces the old one, rescaled by its trace; rows / columns beyond Do are zero for the next site
+        // the new environment replaces the old one, rescaled by its trace (taken from the accumulators: the diagonal tiles' lanes
+        // with row == column); rows / columns beyond Do are zero for the next site
+        double tr = 0.0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NTW; ++t) {
             const bool have = t == 0 ? h0 : h1;
             const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
-            if (!have) continue;
             if constexpr (CX) {                      // re = K1 - K3, im = K1 + K2
                 rni[t] = rnr[t] + rni[t];
                 rnr[t] = rnr[t] - rn3[t];
             }
+            if (have && rb == wc) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (Mx<R>::row(kq, r) == i16 && 16 * rb + i16 < Do) tr += (double)rnr[t][r];
+            }
+        }
+        tr = blk_sum_n<NW>(tr, red);
+        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const bool have = t == 0 ? h0 : h1;
+            const int rb = t == 0 ? rbA : rbB, wc = t == 0 ? wcA : wcB;
+            if (!have) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * rb + Mx<R>::row(kq, r), col = 16 * wc + i16;
                 const bool live = row < Do && col < Do;
-                Rc.r[row * ld + col] = live ? rnr[t][r] : R(0);
-                if constexpr (CX) Rc.i[row * ld + col] = live ? rni[t][r] : R(0);
+                Rc.r[row * ld + col] = live ? rnr[t][r] * sc : R(0);
+                if constexpr (CX) Rc.i[row * ld + col] = live ? rni[t][r] * sc : R(0);
             }
         }
-        __syncthreads();
-        double tr = 0.0;
-        for (int a_ = tid; a_ < Do; a_ += IMR_T) tr += (double)Rc.r[a_ * ld + a_];
-        tr = blk_sum_n<NW>(tr, red);
-        const R sc = tr > 0.0 ? (R)(1.0 / tr) : R(1);
-        for (int e = tid; e < cp * cp; e += IMR_T) {
-            const int a_ = e / cp, b2 = e - a_ * cp;
-            Rc.r[a_ * ld + b2] *= sc;
-            Ms0.r[a_ * ld + b2] = R(0);
-            Ms1.r[a_ * ld + b2] = R(0);
-            T1.r[a_ * ld + b2] = R(0);
-            if constexpr (CX) {
-                Rc.i[a_ * ld + b2] *= sc;
-                Ms0.i[a_ * ld + b2] = R(0);
-                Ms1.i[a_ * ld + b2] = R(0);
-                T1.i[a_ * ld + b2] = R(0);
+        // The site-matrix buffers keep their zeros outside the live block as long as the matrices do not shrink (`put` writes live
+        // elements only; T1 needs none: its stale rows / columns meet zeros of the site matrix or rows of R' that are masked above)
+        if (has_next && (svn.Dout < Do || svn.Din < Di)) {
+            for (int e = tid; e < cp * cp; e += IMR_T) {
+                const int a_ = e / cp, b2 = e - a_ * cp;
+                Ms0.r[a_ * ld + b2] = R(0);
+                Ms1.r[a_ * ld + b2] = R(0);
+                if constexpr (CX) {
+                    Ms0.i[a_ * ld + b2] = R(0);
+                    Ms1.i[a_ * ld + b2] = R(0);
+                }
             }
         }
         __syncthreads();
