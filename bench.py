@@ -163,6 +163,7 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
         dev_s += secs
     eng_phases = eng.impute_phases()
     closed_form = eng.impute_info()["closed_form_densities"]
+    batched = eng.impute_info()["batched_sweep"]
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     if world > 1:
@@ -195,6 +196,11 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
                     "unit": "GB/s", "frac": bytes_den / t_den / 1e9 / PEAK_HBM_GBS, "traffic": None, "avg_ms": 1e3 * t_den,
                     "note": "latency chain: one workgroup per instance walks its T sites (matrix-vector products against site tensors served by the L2, "
                             "then the selections on 2d Fourier coefficients); bytes = the environments of the missing sites + the encoded series"}
+        if batched:
+            roof_den["kernel"] = "k_imp_leftb<float, complex, [Re; Im] rows> (16 instances per workgroup, closed-form densities)"
+            roof_den["note"] = ("a workgroup walks the chain with 16 instances in step: L W_j for all of them and LW R_b per missing instance on the "
+                                "matrix pipe (operands straight from memory), a wave per instance for the closed-form selections; bytes = the "
+                                "environments of the missing sites (read once: the stream that bounds the kernel's product phase) + the encoded series")
     line = {"metric": "site-imputations/sec (imputation engine, BASELINE configs[4])", "value": value, "unit": "site-imputations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "c64 model; f32 chain contractions (MFMA f32 16x16x4), f64 densities",
@@ -202,7 +208,7 @@ def impute_workload(args, mt, torch, dist, world, rank, dev_index, host_reduce):
             "config": {"workload": f"median imputation + WMAD of a 50 % block, N={N} instances per GPU, T={T}, chi={chi}, d={d} Fourier "
                                    f"(complex random canonical MPS), 20001-value grid", "parallelism": f"instances sharded over {world} GPU(s), no collective"},
             "roofline": roof_env if dom_env else roof_den, "roofline_other_kernel": roof_den if dom_env else roof_env,
-            "closed_form_densities": bool(closed_form),
+            "closed_form_densities": bool(closed_form), "batched_sweep": bool(batched),
             "wall_ms_per_step_incl_pcie_and_host_packing": 1e3 * wall / args.steps}
     if rank == 0 and world == 1:
         # side figure: a real model on the reference's default basis (Legendre, d = 12, chi = 40: the size of its imputation
