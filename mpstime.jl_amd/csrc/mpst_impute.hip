@@ -212,20 +212,161 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
     const int rbA = h0 ? wave / tpr : 0, wcA = h0 ? wave % tpr : 0;
     const int rbB = h1 ? (wave + NW) / tpr : rbA, wcB = h1 ? (wave + NW) % tpr : wcA;
     int slot = 0;
-    for (int step = 0; step < T; ++step) {
+    // ---- the known sites the pass meets before its first missing one: R = r r^H stays an outer product ----------------------------
+    // r <- M_j r (M_j = sum_q conj(phi_q) W_j[q]) is one matrix-vector product against the site tensor where the matrix recursion
+    // forms M_j from d site matrices and multiplies twice (15 us a site, a third of the sites of a 50 % block in mid-chain).
+    // r and the partial sums live in the T1 planes.
+    int step0 = 0;
+    while (step0 < T && mi[rev ? step0 : T - 1 - step0] == 0) ++step0;        // (nm > 0: there is one)
+    if (step0 > 0) {
+        R* vr = T1.r;                       // r: [cp]; partial sums behind it: [IMR_T]
+        R* vi = T1.i;
+        R* pr_ = T1.r + cp;
+        R* pi_ = T1.i + cp;
+        if (tid < cp) {
+            vr[tid] = tid == 0 ? R(1) : R(0);
+            if constexpr (CX) vi[tid] = R(0);
+        }
+        __syncthreads();
+        int Dlast = 1;
+        for (int step = 0; step < step0; ++step) {
+            const int j = rev ? step : T - 1 - step;
+            const SiteView<R> sv = site_view<R, CX>(v, j, cls, rev != 0);
+            const int Di = sv.Din, Do = sv.Dout;
+            const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
+            // lanes along the index that is contiguous in memory: the input bond (this pass enters through the tensor's fast bond:
+            // a wave per output value, a wave-wide sum) or the output bond (a wave per input value, partial vectors summed in LDS)
+            constexpr int VB = 4;          // states per batch of loads
+            R nr = R(0), ni = R(0);
+            if (sv.si == 1) {
+                const R xr = lane < Di ? vr[lane] : R(0), xi = (CX && lane < Di) ? vi[lane] : R(0);
+                for (int o0 = wave; o0 < Do; o0 += 2 * NW) {
+                    const int o1 = o0 + NW;
+                    R a0r = R(0), a0i = R(0), a1r = R(0), a1i = R(0);
+                    for (int q0 = 0; q0 < d; q0 += VB) {
+                        R w0r[VB], w0i[VB], w1r[VB], w1i[VB], fr_[VB], fi_[VB];
+#pragma unroll
+                        for (int u = 0; u < VB; ++u) {
+                            w0r[u] = w0i[u] = w1r[u] = w1i[u] = fr_[u] = fi_[u] = R(0);
+                            if (q0 + u < d) {
+                                zload<R, CX>(ph, q0 + u, fr_[u], fi_[u]);
+                                if (lane < Di) {
+                                    zload<R, CX>(sv.W, (int64_t)lane + (int64_t)(q0 + u) * sv.ss + (int64_t)o0 * sv.so, w0r[u], w0i[u]);
+                                    if (o1 < Do) zload<R, CX>(sv.W, (int64_t)lane + (int64_t)(q0 + u) * sv.ss + (int64_t)o1 * sv.so, w1r[u], w1i[u]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < VB; ++u) {           // += conj(phi_q) W(i, q, o)
+                            a0r = fma(fr_[u], w0r[u], a0r);
+                            a1r = fma(fr_[u], w1r[u], a1r);
+                            if constexpr (CX) {
+                                a0r = fma(fi_[u], w0i[u], a0r);
+                                a0i = fma(fr_[u], w0i[u], a0i);
+                                a0i = fma(-fi_[u], w0r[u], a0i);
+                                a1r = fma(fi_[u], w1i[u], a1r);
+                                a1i = fma(fr_[u], w1i[u], a1i);
+                                a1i = fma(-fi_[u], w1r[u], a1i);
+                            }
+                        }
+                    }
+                    // times r_i, summed over the lanes
+                    const double s0r = wave_sum((double)(CX ? fma(a0r, xr, -a0i * xi) : a0r * xr));
+                    const double s1r = wave_sum((double)(CX ? fma(a1r, xr, -a1i * xi) : a1r * xr));
+                    double s0i = 0.0, s1i = 0.0;
+                    if constexpr (CX) {
+                        s0i = wave_sum((double)fma(a0r, xi, a0i * xr));
+                        s1i = wave_sum((double)fma(a1r, xi, a1i * xr));
+                    }
+                    if (lane == 0) {
+                        pr_[o0] = (R)s0r;
+                        if constexpr (CX) pi_[o0] = (R)s0i;
+                        if (o1 < Do) {
+                            pr_[o1] = (R)s1r;
+                            if constexpr (CX) pi_[o1] = (R)s1i;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid < Do) {
+                    nr = pr_[tid];
+                    if constexpr (CX) ni = pi_[tid];
+                }
+            } else {
+                // (so == 1) a wave per input value i, lanes along o; VB states in flight
+                R ar = R(0), ai = R(0);
+                for (int i_ = wave; i_ < Di; i_ += NW) {
+                    const R xr = vr[i_], xi = CX ? vi[i_] : R(0);
+                    for (int q0 = 0; q0 < d; q0 += VB) {
+                        R wr[VB], wi[VB], fr_[VB], fi_[VB];
+#pragma unroll
+                        for (int u = 0; u < VB; ++u) {
+                            wr[u] = wi[u] = fr_[u] = fi_[u] = R(0);
+                            if (q0 + u < d) {
+                                zload<R, CX>(ph, q0 + u, fr_[u], fi_[u]);
+                                if (lane < Do) zload<R, CX>(sv.W, (int64_t)i_ * sv.si + (int64_t)(q0 + u) * sv.ss + (int64_t)lane * sv.so, wr[u], wi[u]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < VB; ++u) {
+                            // conj(phi_q) r_i
+                            const R cr = CX ? fma(fr_[u], xr, fi_[u] * xi) : fr_[u] * xr;
+                            const R ci = CX ? fma(fr_[u], xi, -fi_[u] * xr) : R(0);
+                            ar = fma(cr, wr[u], ar);
+                            if constexpr (CX) {
+                                ar = fma(-ci, wi[u], ar);
+                                ai = fma(cr, wi[u], ai);
+                                ai = fma(ci, wr[u], ai);
+                            }
+                        }
+                    }
+                }
+                if (lane < Do) {
+                    pr_[wave * Do + lane] = ar;
+                    if constexpr (CX) pi_[wave * Do + lane] = ai;
+                }
+                __syncthreads();
+                if (tid < Do) {
+                    for (int w = 0; w < NW; ++w) {
+                        nr += pr_[w * Do + tid];
+                        if constexpr (CX) ni += pi_[w * Do + tid];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < cp) {
+                vr[tid] = tid < Do ? nr : R(0);
+                if constexpr (CX) vi[tid] = tid < Do ? ni : R(0);
+            }
+            // |r| = 1 (the trace of r r^H): every quantity downstream is scale-free
+            const double n2 = blk_sum_n<NW>(tid < Do ? (double)nr * (double)nr + (double)ni * (double)ni : 0.0, red);
+            const R sc = n2 > 0.0 ? (R)(1.0 / sqrt(n2)) : R(1);
+            if (tid < cp) {
+                vr[tid] *= sc;
+                if constexpr (CX) vi[tid] *= sc;
+            }
+            __syncthreads();
+            Dlast = Do;
+        }
+        for (int e = tid; e < cp * cp; e += IMR_T) {
+            const int a_ = e / cp, b2 = e - a_ * cp;
+            const bool live = a_ < Dlast && b2 < Dlast;
+            const R xr = vr[a_], yr = vr[b2];
+            if constexpr (CX) {
+                const R xi = vi[a_], yi = vi[b2];                       // r_a conj(r_b)
+                Rc.r[a_ * ld + b2] = live ? fma(xr, yr, xi * yi) : R(0);
+                Rc.i[a_ * ld + b2] = live ? fma(xi, yr, -xr * yi) : R(0);
+            } else {
+                Rc.r[a_ * ld + b2] = live ? xr * yr : R(0);
+            }
+        }
+        __syncthreads();
+    }
+    for (int step = step0; step < T; ++step) {
         const int j = rev ? step : T - 1 - step;
         const SiteView<R> sv = site_view<R, CX>(v, j, cls, rev != 0);
         const int Di = sv.Din, Do = sv.Dout;
         const bool miss = mi[j] != 0;
-        if (miss) {
-            R* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm * ZW;
-            for (int e = tid; e < Di * Di; e += IMR_T) {
-                const int at = (e / Di) * ld + (e % Di);
-                zstore<R, CX>(out, e, Rc.r[at], CX ? Rc.i[at] : R(0));
-            }
-            ++slot;
-            if (slot == nm) break;
-        }
         const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
         const int ns = miss ? d : 1;
         const bool in_fast = sv.si == 1;
@@ -305,7 +446,19 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
                     if constexpr (CX) M.i[dst[q]] = fi[q];
                 }
         };
-        fetch(0);
+        // a missing site: its environment goes to memory first - behind the request for the first site matrix, whose round trip
+        // the stores cover; the pass ends at the last missing site
+        const bool last = miss && slot + 1 == nm;
+        if (!last) fetch(0);
+        if (miss) {
+            R* out = Rbuf + ((int64_t)blockIdx.x * max_missing + slot) * cm * cm * ZW;
+            for (int e = tid; e < Di * Di; e += IMR_T) {
+                const int at = (e / Di) * ld + (e % Di);
+                zstore<R, CX>(out, e, Rc.r[at], CX ? Rc.i[at] : R(0));
+            }
+            ++slot;
+            if (last) break;
+        }
         put(Ms0);
         __syncthreads();
         if (ns > 1) fetch(1);                       // in flight during the first product
