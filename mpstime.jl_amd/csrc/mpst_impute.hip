@@ -10,10 +10,13 @@
 //     rho = (L W_j) R_{j+1} (L W_j)^T,
 // with L the left environment VECTOR of the known / already imputed sites and R_{j+1} the right environment MATRIX in
 // which known sites are projected and missing sites are traced out.  That turns one instance into two sweeps over the
-// chain with chi x chi state, and the batch into two launches of one persistent workgroup per instance:
-//   k_imp_right : R_T = 1, R_j = M_j R_{j+1} M_j^T (known, M_j = sum_s phi_s W_j[s]) or sum_s W_j[s] R_{j+1} W_j[s]^T
-//                 (missing); R_{j+1} is stored for every missing j.  Rescaled by its trace at every site.
-//   k_imp_left  : L_0 = 1; known site: L <- L M_j; missing site: rho, p_k = |rho phi_k|^2 over the grid (the value the
+// chain with chi x chi state, and the batch into two launches:
+//   k_imp_right : a workgroup per instance.  R_T = 1, R_j = M_j R_{j+1} M_j^T (known, M_j = sum_s phi_s W_j[s]) or
+//                 sum_s W_j[s] R_{j+1} W_j[s]^T (missing); R_{j+1} is stored for every missing j.  Rescaled by its trace at
+//                 every site.  While the pass has met known sites only, R = r r^H: a vector recursion r <- M_j r.
+//   k_imp_leftb : sixteen instances per workgroup (mpst_impute_batched.inl) where the densities are closed-form (TRIG below)
+//                 and the panels fit the LDS; the same steps as
+//   k_imp_left  : a workgroup per instance.  L_0 = 1; known site: L <- L M_j; missing site: rho, p_k = |rho phi_k|^2 over the grid (the value the
 //                 reference computes: rdm is a plain Matrix there, so get_conditional_probability(state, rdm) takes the
 //                 (state, A::Matrix) method, sampling_utils.jl:19-41, and returns |state' * rdm|^2, not state' rdm state), block-wide prefix sums, selection,
 //                 weighted median absolute deviation, L <- phi* (L W_j).
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(IMR_T) void k_imp_right(ImpModel v, const uint8_t* 
             const R* ph = (const R*)v.phi + ((int64_t)j * v.N + i) * d * ZW;
             // lanes along the index that is contiguous in memory: the input bond (this pass enters through the tensor's fast bond:
             // a wave per output value, a wave-wide sum) or the output bond (a wave per input value, partial vectors summed in LDS)
-            constexpr int VB = 4;          // states per batch of loads
+            constexpr int VB = 4;          // states per batch of loads (eight: registers - a workgroup per CU less in the smaller forms - for 1 %)
             R nr = R(0), ni = R(0);
             if (sv.si == 1) {
                 const R xr = lane < Di ? vr[lane] : R(0), xi = (CX && lane < Di) ? vi[lane] : R(0);
