@@ -1116,6 +1116,50 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
                                                             int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
     trivec_body(v, lid, going_left, rawG, rawn, rawalg, ws, stamps);
 }
+// The same for SEVERAL eigenpairs per workgroup: blockIdx.x, + gridDim.x, ... - one reduction, then the vector phase once per pair
+// (30 us each).  For mpst_sweep_batch beyond 8 fits: 32 workgroups per fit repeat the 114 us reduction 32 times, K x 32 > 256
+// workgroups run in rounds; 16 (8) workgroups per fit with 2 (4) pairs each keep 16 (32) fits in one round.  A body of its own:
+// the single-fit kernels keep their register allocation.
+__device__ __forceinline__ void trivec_body_multi(const View& v, int lid, int going_left, const double* rawG, int rawn, int rawalg,
+                                                  double* __restrict__ ws, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int cnt_s[8];
+    __shared__ double red_s[8];
+    __shared__ int arg_s[8];
+    const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
+    const int k = blockIdx.x, tid = threadIdx.x;
+    if (!pb.tri) {
+        if (k == 0 && tid == 0) ws[WS_MISC + 3] = 0.0;
+        return;
+    }
+    const int nvec = eig_nvec(pb);
+    if (k >= nvec) return;
+    double* Vd = smem;
+    double* de = Vd + 16384;
+    double* Tb = de + 272 + 128 * 6 + 8 + 128 + 8 + 24 + 24;
+    TriShared t{};
+    t.de = de;
+    t.es = de + 272;
+    t.taus = t.es + 128;
+    t.xs = Tb;
+    t.ps = Tb + 256;
+    t.Z = Tb + 512;
+    t.misc = Tb + 768;
+    unsigned long long* st = k == 0 ? stamps : nullptr;
+    tri_core<true>(pb.G, pb.n, t, Vd, st);
+    const double lo = t.misc[0], hi = t.misc[1], tnorm = t.misc[2];
+    if (k == 0 && tid == 0) {
+        ws[WS_MISC + 0] = lo;
+        ws[WS_MISC + 1] = hi;
+        ws[WS_MISC + 2] = tnorm;
+        ws[WS_MISC + 3] = 1.0;
+    }
+    if (tid >= VEC_THREADS) return;
+    for (int kk = k; kk < nvec; kk += (int)gridDim.x) {
+        vec_core<true>(pb, kk, smem, cnt_s, red_s, arg_s, ws, kk == 0 ? st : nullptr, lo, hi, tnorm);
+        lds_barrier();                  // (the scratch of the vector phase is reused by the next pair)
+    }
+}
 // raw problem behind a gate word (v.label_site, 0 = leave at once): the Rayleigh-Ritz problem of the subspace solver
 // (mpst_eig_subspace.inl), which is enqueued whether or not the bond at hand is attempted.  A kernel of its own: the headline
 // kernel above keeps its register allocation.
@@ -1139,6 +1183,11 @@ __device__ __forceinline__ View eig_fields(const View& s) {
 __global__ __launch_bounds__(TRI_T) void k_eig_trivec_b(const View* __restrict__ vs, int lid, int going_left, const double* rawG, int rawn, int rawalg) {
     const View v = eig_fields(vs[blockIdx.z]);
     trivec_body(v, lid, going_left, rawG, rawn, rawalg, v.eig_ws, v.sc->eig_stamps);
+}
+
+__global__ __launch_bounds__(TRI_T) void k_eig_trivec_bm(const View* __restrict__ vs, int lid, int going_left, const double* rawG, int rawn, int rawalg) {
+    const View v = eig_fields(vs[blockIdx.z]);
+    trivec_body_multi(v, lid, going_left, rawG, rawn, rawalg, v.eig_ws, v.sc->eig_stamps);
 }
 
 // =====================================================================================
@@ -1437,6 +1486,7 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_bm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
@@ -1473,6 +1523,15 @@ void launch_eig(const View& v, int lid, int going_left, int stage, hipStream_t s
 // the merged chain for K fits of one shape (mpst_sweep_batch): stage 0 k_eig_trivec_b, stage 2 k_eig_fin_b
 void launch_eig_b(const View& v, const View* vs, int K, int lid, int going_left, int stage, hipStream_t s) {
     const dim3 gvec(v.chi_max < TRI_KMAX ? (v.chi_max < 32 ? 32 : v.chi_max) : TRI_KMAX, 1, K);
+    // more workgroups than CUs (one workgroup per CU: 157 KB of LDS): several eigenpairs per workgroup instead of rounds of workgroups
+    // that repeat the reduction (MPST_EIG_BM=0: never)
+    static const bool bm_on = [] { const char* e = getenv("MPST_EIG_BM"); return !(e && e[0] == '0'); }();
+    const int rounds = ((int)gvec.x * K + 255) / 256;
+    if (stage == 0 && bm_on && rounds > 1) {
+        const int nb = std::max(8, ((int)gvec.x + rounds - 1) / rounds);
+        hipLaunchKernelGGL(k_eig_trivec_bm, dim3(nb, 1, K), dim3(TRI_T), vec_lds_bytes(), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
+        return;
+    }
     if (stage == 0) hipLaunchKernelGGL(k_eig_trivec_b, gvec, dim3(TRI_T), vec_lds_bytes(), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
     else hipLaunchKernelGGL(k_eig_fin_b, dim3(1, 1, K), dim3(EIG_THREADS), eig_lds_bytes(), s, vs, lid, going_left);
 }

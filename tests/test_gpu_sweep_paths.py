@@ -65,14 +65,15 @@ def test_graph_sweep_equals_bond_steps_at_the_benchmarked_shape():
         assert kla == klb and msa == msb and aca == acb and np.array_equal(cfa, cfb)
 
 
-def test_batched_sweep_of_independent_fits_is_bit_identical():
+@pytest.mark.parametrize("K", [4, 12, 20])
+def test_batched_sweep_of_independent_fits_is_bit_identical(K):
     """mpst_sweep_batch: K fits of one shape (different data, starting MPS, eta and cutoff) advanced by one launch chain give the
-    bits of K separate mpst_sweep calls, sweep after sweep; a fit of another shape is refused."""
+    bits of K separate mpst_sweep calls, sweep after sweep; a fit of another shape is refused.  K = 12 and 20: more eigensolver
+    workgroups than CUs, so every workgroup takes 2 (3, unevenly) eigenpairs (k_eig_trivec_bm)."""
     import mpstime_jl_amd as mt
     from tests.helpers import make_problem
-    K = 4
     probs = [make_problem(256, 12, 4, 4, 2, seed=50 + k) for k in range(K)]
-    etas = [0.05, 0.02, 0.05, 0.1]
+    etas = [[0.05, 0.02, 0.05, 0.1][k % 4] for k in range(K)]
 
     def fresh(k, chi=12):
         e = mt.SweepEngine(0)
