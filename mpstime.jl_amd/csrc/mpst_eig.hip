@@ -1116,6 +1116,10 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
                                                             int rawalg, double* __restrict__ ws, unsigned long long* stamps) {
     trivec_body(v, lid, going_left, rawG, rawn, rawalg, ws, stamps);
 }
+__device__ __noinline__ void vec_core_call(const EigProblem& pb, const int k, double* smem, int* cnt_s, double* red_s, int* arg_s,
+                                           double* __restrict__ ws, unsigned long long* stamps, const double lo, const double hi, const double tnorm) {
+    vec_core<true>(pb, k, smem, cnt_s, red_s, arg_s, ws, stamps, lo, hi, tnorm);
+}
 // The same for SEVERAL eigenpairs per workgroup: blockIdx.x, + gridDim.x, ... - one reduction, then the vector phase once per pair
 // (30 us each).  For mpst_sweep_batch beyond 8 fits: 32 workgroups per fit repeat the 114 us reduction 32 times, K x 32 > 256
 // workgroups run in rounds; 16 (8) workgroups per fit with 2 (4) pairs each keep 16 (32) fits in one round.  A body of its own:
@@ -1156,7 +1160,7 @@ __device__ __forceinline__ void trivec_body_multi(const View& v, int lid, int go
     }
     if (tid >= VEC_THREADS) return;
     for (int kk = k; kk < nvec; kk += (int)gridDim.x) {
-        vec_core<true>(pb, kk, smem, cnt_s, red_s, arg_s, ws, kk == 0 ? st : nullptr, lo, hi, tnorm);
+        vec_core_call(pb, kk, smem, cnt_s, red_s, arg_s, ws, kk == 0 ? st : nullptr, lo, hi, tnorm);
         lds_barrier();                  // (the scratch of the vector phase is reused by the next pair)
     }
 }
