@@ -57,7 +57,8 @@ def _check(W, xs, grid_phi, phi, y, m, x_g, e_g, method, order="forwards", wmad=
 
 
 @pytest.mark.parametrize("order", ["forwards", "backwards"])
-@pytest.mark.parametrize("cfg", [(14, 9, 3, 5, 2), (10, 12, 4, 9, 3), (6, 10, 8, 20, 1)], ids=["d3chi5", "d4chi9C3", "d8chi20"])
+@pytest.mark.parametrize("cfg", [(14, 9, 3, 5, 2), (10, 12, 4, 9, 3), (6, 10, 8, 20, 1), (3, 5, 2, 3, 2), (35, 7, 16, 6, 2)],
+                         ids=["d3chi5", "d4chi9C3", "d8chi20", "d2chi3_N3", "d16chi6_N35"])
 def test_complex_fourier_model_fp64(engine_cls, cfg, order):
     N, T, d, chi, C = cfg
     W, xs, enc, grid_phi, X, y, phi, m, rng = _problem(N, T, d, chi, C, seed=5 * N + T, ngrid=1201, cx=True)
