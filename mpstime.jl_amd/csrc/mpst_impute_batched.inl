@@ -252,10 +252,28 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
         const int ks2 = (Do + 3) >> 2, ntile2 = (Do + 15) >> 4, nkb2 = (ks2 + KU - 1) / KU, nun = nms * ntile2 * nkb2;
         const R* Rm0 = mis0 ? RmS0 : RmS1;
         const R* Rm1 = RmS1;
-        auto issueR = [&](R (&br)[KU], R (&bi)[KU], int u) {
-            if (u >= nun) return;
-            const int qq = u / (ntile2 * nkb2), rem = u - qq * ntile2 * nkb2, nt = rem / nkb2, kb = rem - nt * nkb2;
+        // (a unit is named by a cursor (instance, tile, batch) that is advanced, not decoded from a running number; when every lane
+        // and k-slot of every unit is live - bond dimensions that are multiples of 16 and of 4 KU - the loads carry no predicates)
+        const bool fullR = (Do & 15) == 0 && ks2 % KU == 0 && !(g.dbg & 2);
+        const int64_t laneR = (int64_t)(kq * ks2) * Do + i16;
+        auto advR = [&](int& qq, int& nt, int& kb) {
+            if (++kb == nkb2) {
+                kb = 0;
+                if (++nt == ntile2) {
+                    nt = 0;
+                    ++qq;
+                }
+            }
+        };
+        auto issueR = [&](R (&br)[KU], R (&bi)[KU], int qq, int nt, int kb) {
+            if (qq >= nms) return;
             const R* Rm = qq == 0 ? Rm0 : Rm1;
+            if (fullR) {
+                const int64_t so = (int64_t)(kb * KU) * Do + 16 * nt;
+#pragma unroll
+                for (int uu = 0; uu < KU; ++uu) zload<R, CX>(Rm, laneR + so + (int64_t)uu * Do, br[uu], bi[uu]);
+                return;
+            }
             const int ncol = 16 * nt + i16;
 #pragma unroll
             for (int uu = 0; uu < KU; ++uu) {
@@ -265,7 +283,9 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
             }
         };
         R rbA_r[KU], rbA_i[KU], rbB_r[KU], rbB_i[KU];
-        issueR(rbA_r, rbA_i, 0);
+        int iq = 0, it = 0, ib = 0;                  // the cursor of the loads
+        issueR(rbA_r, rbA_i, iq, it, ib);
+        advR(iq, it, ib);
 
         // ---- phase A: LW[b][s][o] = sum_i L[b][i] W(i, s, o), all instances at once ------------------------------------------
         // (the label site has one tensor per class: one product per class present, every instance keeps the rows of its own)
@@ -280,12 +300,25 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
             const SiteView<R> sv = site_view<R, CX>(v, j, cls, g.rev == 0);
             const int ncol = d * Do, ntile = (ncol + 15) >> 4, ks = (Di + 3) >> 2, nkb = (ks + KU - 1) / KU;
             const int ntw = ntile > wave ? (ntile - wave + IMB_NW - 1) / IMB_NW : 0, nua = ntw * nkb;
-            auto issueW = [&](R (&wr)[KU], R (&wi)[KU], int u) {
-                if (u >= nua) return;
-                const int m = u / nkb, kb = u - m * nkb, c = 16 * (wave + IMB_NW * m) + i16;
+            const bool fullW = (ncol & 15) == 0 && ks % KU == 0 && 4 * ks == Di && !(g.dbg & 4);
+            auto advW = [&](int& m, int& kb) {
+                if (++kb == nkb) {
+                    kb = 0;
+                    ++m;
+                }
+            };
+            auto issueW = [&](R (&wr)[KU], R (&wi)[KU], int m, int kb) {
+                if (m >= ntw) return;
+                const int c = 16 * (wave + IMB_NW * m) + i16;
                 const bool cl = c < ncol;
                 const int s_ = cl ? c / Do : 0, o_ = cl ? c - s_ * Do : 0;
                 const int64_t wcol = (int64_t)s_ * sv.ss + (int64_t)o_ * sv.so;
+                if (fullW) {
+                    const int64_t w0 = wcol + (int64_t)(kq * ks + kb * KU) * sv.si;
+#pragma unroll
+                    for (int uu = 0; uu < KU; ++uu) zload<R, CX>(sv.W, w0 + (int64_t)uu * sv.si, wr[uu], wi[uu]);
+                    return;
+                }
 #pragma unroll
                 for (int uu = 0; uu < KU; ++uu) {
                     const int k = kq * ks + kb * KU + uu;
@@ -294,9 +327,8 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
                 }
             };
             acc_t k1 = {0, 0, 0, 0}, k2 = {0, 0, 0, 0}, k3 = {0, 0, 0, 0};
-            auto consumeW = [&](const R (&wr)[KU], const R (&wi)[KU], int u) {
-                if (u >= nua) return;
-                const int m = u / nkb, kb = u - m * nkb;
+            auto consumeW = [&](const R (&wr)[KU], const R (&wi)[KU], int m, int kb) {
+                if (m >= ntw) return;
                 if (kb == 0) {
                     k1 = acc_t{0, 0, 0, 0};
                     k2 = acc_t{0, 0, 0, 0};
@@ -341,12 +373,18 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
                 }
             };
             R wA_r[KU], wA_i[KU], wB_r[KU], wB_i[KU];
-            issueW(wA_r, wA_i, 0);
+            int im = 0, ikb = 0, cm_ = 0, ckb = 0;      // cursors of the loads / of the products
+            issueW(wA_r, wA_i, im, ikb);
+            advW(im, ikb);
             for (int u = 0; u < nua; u += 2) {
-                issueW(wB_r, wB_i, u + 1);
-                consumeW(wA_r, wA_i, u);
-                issueW(wA_r, wA_i, u + 2);
-                consumeW(wB_r, wB_i, u + 1);
+                issueW(wB_r, wB_i, im, ikb);
+                advW(im, ikb);
+                consumeW(wA_r, wA_i, cm_, ckb);
+                advW(cm_, ckb);
+                issueW(wA_r, wA_i, im, ikb);
+                advW(im, ikb);
+                consumeW(wB_r, wB_i, cm_, ckb);
+                advW(cm_, ckb);
             }
         }
         IMB_STAMP(0)
@@ -359,9 +397,8 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
 #pragma unroll
             for (int q = 0; q < NE; ++q) rr[q] = ri[q] = 0.0;
             acc_t ur = {0, 0, 0, 0}, ui = {0, 0, 0, 0};
-            auto consumeR = [&](const R (&br)[KU], const R (&bi)[KU], int u) {
-                if (u >= nun) return;
-                const int qq = u / (ntile2 * nkb2), rem = u - qq * ntile2 * nkb2, nt = rem / nkb2, kb = rem - nt * nkb2;
+            auto consumeR = [&](const R (&br)[KU], const R (&bi)[KU], int qq, int nt, int kb) {
+                if (qq >= nms) return;
                 const int slot = qq == 0 ? slotA : 1;
                 const int b = wave + IMB_NW * slot;
                 const R* lw = LW.r + b * lay.ldw;             // (+ (ZW - 1) * nw: the imaginary plane)
@@ -451,11 +488,16 @@ __global__ __launch_bounds__(IMB_T, 1) void k_imp_leftb(ImpModel v, ImpArgs g, i
                     rr[q] = ri[q] = 0.0;
                 }
             };
+            int cq = 0, ct = 0, cb = 0;                 // the cursor of the products
             for (int u = 0; u < nun; u += 2) {
-                issueR(rbB_r, rbB_i, u + 1);
-                consumeR(rbA_r, rbA_i, u);
-                issueR(rbA_r, rbA_i, u + 2);
-                consumeR(rbB_r, rbB_i, u + 1);
+                issueR(rbB_r, rbB_i, iq, it, ib);
+                advR(iq, it, ib);
+                consumeR(rbA_r, rbA_i, cq, ct, cb);
+                advR(cq, ct, cb);
+                issueR(rbA_r, rbA_i, iq, it, ib);
+                advR(iq, it, ib);
+                consumeR(rbB_r, rbB_i, cq, ct, cb);
+                advR(cq, ct, cb);
             }
             wave_lds_sync();
         }
