@@ -535,6 +535,8 @@ def main():
     ap.add_argument("--concurrent", type=int, default=8,
                     help="extra figure (never `value`): aggregate sweeps/s of this many INDEPENDENT fits sharing the GPU, one context "
                          "and stream each (hyper-parameter search / CV folds); 0 = skip")
+    ap.add_argument("--fits-per-gpu", type=int, default=32,
+                    help="with --gpus N > 1: independent fits per GPU of the `independent_fits` side figure (32: 8x a single fit per GPU)")
     ap.add_argument("--no-sharded-extra", action="store_true",
                     help="with --gpus N > 1: skip the configs[3] (N = 32768 sharded) side measurement")
     ap.add_argument("--sharded-N", type=int, default=32768)
@@ -976,7 +978,7 @@ def main():
         indep = None
         engs = []
         try:
-            K = args.concurrent
+            K = max(1, args.fits_per_gpu)
             for k in range(K):
                 e2 = mt.SweepEngine(dev_index)
                 e2.set_batch_hint(K)
