@@ -361,12 +361,23 @@ int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
 /* the same, at most n entries: for callers compiled against another revision of this header.  Entries beyond the 16 of mpst_get_info:
  * out[16] large bonds the randomised subspace eigensolver attempted (real element types, d*chi_max > 128: top-chi_max singular
  * triplets of the bond matrix by five GEMM half-steps + a (chi_max + 32)-dimensional Rayleigh-Ritz problem, certified on the device
- * against the Gram matrix), out[17] those whose result was accepted - the others were solved by the exact Householder path. */
+ * against the Gram matrix), out[17] those whose result was accepted - the others were solved by the exact Householder path (real and
+ * complex bonds), out[18] the bonds of a sweep run FOUR launches (k_grad_s, k_gram_upd, k_eig_trivec, k_bond_tail: verification +
+ * polish of the eigenvectors, back-split, update_caches!, the next bond's tensor and the next bond's overlaps in the last one;
+ * Float64, KLD, d*chi_max <= 128, chi_max <= 32, one rank, update_iters = 1, no track_cost), out[19] sweeps / bond steps in which a
+ * tail launch's verification failed and the rest ran on the six-launch chain (whose k_eig_fin has the Jacobi fallback). */
 int  mpst_get_info_n(void* ctx, int32_t* out, int32_t n);
 /* in-kernel phase times (us) of the last eigensolver launch: tridiagonalisation, bisection,
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */
 int  mpst_get_eig_phases(void* ctx, double* us /*[6]*/);
+/* in-kernel phase stamps (us since its first tile workgroup started) of the last k_bond_tail launch - the four-launch chain's last
+ * launch, which stands for k_eig_fin + update_caches! + the back-split (RealRealHighDimension.jl:107-203) and the next bond's
+ * yhat pass (loss_functions.jl:248-262): us[0..10] the first tile workgroup (start, requests issued, factors in LDS, overlap product
+ * issued, truncation rule, candidate vectors in LDS, verified + polished, published, new environment rows, z + row dot, stores
+ * drained), us[11..19] the first workgroup of the next bond's tensor, us[20..28] the first back-split workgroup (start, ..., role
+ * done); -1 where a stamp was not taken */
+int  mpst_get_tail_phases(void* ctx, double* us /*[29]*/);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ SYMBOLS = {
     "mpst_set_profile": (C.c_int, [_vp, C.c_uint32]),
     "mpst_get_profile": (C.c_int, [_vp, _dp, C.POINTER(_i64)]),
     "mpst_get_eig_phases": (C.c_int, [_vp, _dp]),
+    "mpst_get_tail_phases": (C.c_int, [_vp, _dp]),
     "mpst_get_info": (C.c_int, [_vp, C.POINTER(_i32)]),
     "mpst_get_info_n": (C.c_int, [_vp, C.POINTER(_i32), _i32]),
 }

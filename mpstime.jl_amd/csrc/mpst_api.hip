@@ -128,6 +128,14 @@ struct Ctx {
     double *bt = nullptr, *yhat = nullptr, *tile_loss = nullptr, *partial = nullptr, *gradbuf = nullptr;
     double *gram = nullptr, *lam = nullptr, *E = nullptr, *eig_ws = nullptr;
     double *btn = nullptr, *norm_part = nullptr;
+    // four-launch chain (k_grad_s, k_gram_upd, k_eig_trivec, k_bond_tail): bt_new once more as [c][y][x] for the tail's contraction going
+    // right; which bond's overlaps the last tail launch left in b2_ypart (valid while nothing else touched the context: bond_seq / epoch);
+    // a tail whose on-device verification failed marks the sweep (DevScalars::redo) and the rest of it is redone on the six-launch chain
+    double* btnT = nullptr;
+    bool chain4_ok = false, chain4_hold = false;
+    int ynext_lid = -1;
+    uint64_t ynext_epoch = 0, ynext_seq = 0, bond_seq = 0;
+    int tail_redos = 0;
     // sliced bond GEMMs (k_yhat_s / k_grad_s): slice contributions to yhat, loss pieces, arrival tickets
     double *b2_ypart = nullptr, *b2_lossp = nullptr;
     unsigned int* b2_tick = nullptr;
@@ -263,6 +271,7 @@ View make_view(Ctx* c, int which) {
     const int pk = c->opt.loss == MPST_LOSS_MSE ? 1 : 0;
     v.parts = s.parts[pk]; v.part_off = s.part_off[pk]; v.nparts = s.nparts[pk];
     v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
+    v.btnT = (which == MPST_TRAIN && c->chain4_ok && !c->chain4_hold) ? c->btnT : nullptr;
     v.trace = nullptr; v.trace_it = 0; v.yhat_scaled = 0;
     v.cls_off = s.cls_off; v.ypart = c->b2_ypart; v.lossp = c->b2_lossp; v.tick = c->b2_tick; v.b2_ksplit = c->b2_ksplit; v.dbg = c->b2_dbg;
     {
@@ -472,6 +481,14 @@ int ensure_workspace(Ctx* c) {
     }
     if ((rc = dalloc(c, &c->partial, c->partial_elems))) return rc;
     if ((rc = dalloc(c, &c->btn, c->C * Lmax))) return rc;
+    {
+        const char* e4 = getenv("MPST_CHAIN4");
+        // (a context that is advanced in batches keeps the six-launch chain mpst_sweep_batch runs: its solo and its batched sweeps agree bit for bit)
+        c->chain4_ok = c->fused && c->b2 && c->batch_hint <= 1 && !(e4 && e4[0] == '0');
+        c->ynext_lid = -1;
+        dfree(&c->btnT);
+        if (c->chain4_ok && (rc = dalloc(c, &c->btnT, c->C * Lmax))) return rc;
+    }
     c->n_norm_part = (int)((c->C * Lmax + 63) / 64);      // RED_E entries per workgroup of k_fused_reduce
     if ((rc = dalloc(c, &c->loss_trace, (int64_t)2 * (c->T - 1) * (c->opt.update_iters + 1)))) return rc;
     HIPC(c, hipMemset(c->loss_trace, 0, (size_t)2 * (c->T - 1) * (c->opt.update_iters + 1) * sizeof(double)));
@@ -519,6 +536,7 @@ int ensure_workspace(Ctx* c) {
 int enqueue_reset_status(Ctx* c) {
     static_assert(offsetof(DevScalars, eig_fallbacks) == offsetof(DevScalars, status) + 8, "status / eig_sweeps_total / eig_fallbacks adjacent");
     HIPC(c, hipMemsetAsync((char*)c->sc + offsetof(DevScalars, status), 0, 12, c->stream));
+    HIPC(c, hipMemsetAsync((char*)c->sc + offsetof(DevScalars, redo), 0, 4, c->stream));
     return 0;
 }
 
@@ -707,16 +725,22 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
         return 0;
     };
     const int rid = lid + 1;
+    const uint64_t seq_before = c->bond_seq++;
     if (c->fused) {
         const int iters = c->opt.update_iters;
         // the next bond's tensor is assembled by this bond's last launch when the sweep moves on in the same direction
         const int chain = (next_bt_lid >= 0 && next_bt_lid == (going_left ? lid - 1 : lid + 1)) ? 1 : 0;
+        // four launches per bond: k_eig_fin, k_env_split and the NEXT bond's k_yhat_s in one (k_bond_tail, mpst_fused.hip)
+        const bool use4 = c->chain4_ok && !c->chain4_hold && c->b2 && !multi(c) && iters == 1 && !v.trace && eig_merged() && bond_tail_supported(v);
+        // ... whose overlaps are this bond's if the launch before this one was the neighbouring bond's tail
+        const bool y_ready = use4 && c->ynext_lid == lid && c->ynext_epoch == c->epoch && c->ynext_seq == seq_before;
+        c->ynext_lid = -1;
         if (!have_bt) { ProfScope p(c, K_BT); launch_bt_assemble(v, lid, s); }   // flatten_bt :733/:777
         View vl = v;                      // after k_grad_s on one rank the loss is still in pieces (bond_loss)
         vl.n_lossp = c->b2 ? c->b2_ksplit : 0;
         for (int it = 0; it < iters; ++it) {                                     // TSGO/custGD :44,:75
             if (c->b2) {
-                { ProfScope p(c, K_YHAT); launch_yhat_s(v, lid, s); }           // yhat, by column slices of B_c
+                if (!(y_ready && it == 0)) { ProfScope p(c, K_YHAT); launch_yhat_s(v, lid, s); }           // yhat, by column slices of B_c
                 { ProfScope p(c, K_GRAD); launch_grad_s(v, lid, s); }           // gradient blocks, reduced by their last arriver
                 if (multi(c)) launch_loss_sum(vl, s);                      // the loss travels in gradbuf[0]
             } else {
@@ -743,9 +767,22 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             if (c->b2 && !multi(c)) vg.n_lossp = c->b2_ksplit;
             // pieces of ||grad||^2: one per gradient block from k_grad_s; after an all-reduce k_grad_norm has rewritten them
             if (c->b2 && !multi(c)) vg.n_norm_part = c->b2_norm_parts;
+            if (!use4) vg.btnT = nullptr;
             launch_gram_upd(vg, lid, going_left, iters == 1, s);
         }
         { ProfScope p(c, K_EIG_TRI); launch_eig(v, lid, going_left, 0, s); }
+        if (use4) {
+            ProfScope p(c, K_ENV);                                                // verification, back-split, update_caches!, next yhat
+            const int nxt = going_left ? lid - 1 : lid + 1;
+            const int want = (nxt >= 0 && nxt <= c->T - 2) ? 1 : 0;
+            launch_bond_tail(v, lid, going_left, chain, want, s);
+            if (want) {
+                c->ynext_lid = nxt;
+                c->ynext_epoch = c->epoch;
+                c->ynext_seq = c->bond_seq;
+            }
+            return 0;
+        }
         if (!eig_merged()) { ProfScope p(c, K_EIG_VEC); launch_eig(v, lid, going_left, 1, s); }
         { ProfScope p(c, K_EIG_FIN); launch_eig(v, lid, going_left, 2, s); }
         { int rc = trace_final(c->btn); if (rc) return rc; }
@@ -923,6 +960,7 @@ void mpst_destroy(void* ctx) {
     for (int k = 0; k < 2; ++k) { dfree(&c->xchainL[k]); dfree(&c->xchainR[k]); }
     dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
+    dfree(&c->btnT);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1494,6 +1532,7 @@ int mpst_build_caches(void* ctx) {
     HIPC(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
     c->caches_valid = true;
+    c->ynext_lid = -1;
     return 0;
 }
 
@@ -1506,19 +1545,21 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     if (c->host_label_site != c->T - 1)
         return fail(c, MPST_ERR_INVALID, "a sweep starts with the label index on the last site (RealRealHighDimension.jl:19-29), it is on site %d", c->host_label_site);
     View v = make_view(c, MPST_TRAIN);
-    auto enqueue_sweep = [&]() -> int {
+    // k0 > 0: the rest of a sweep from its k0-th bond on (the state is that after bond k0 - 1: mpst_sweep's tail recovery)
+    auto enqueue_sweep = [&](int k0 = 0) -> int {
         int r0 = enqueue_reset_status(c);
         if (r0) return r0;
+        c->ynext_lid = -1;
         // bond order of one sweep (:731, :776); unless the tensor is rescaled first or the caches are
         // rebuilt in between, bond k+1's tensor is assembled by bond k's environment kernel
         const int nb = c->T - 1;
         const bool chain = !v.rescale_before;
         int r;
-        for (int k = 0; k < 2 * nb; ++k) {
+        for (int k = k0; k < 2 * nb; ++k) {
             const int lid = k < nb ? nb - 1 - k : k - nb, left = k < nb;
             const bool boundary_before = c->opt.rebuild_caches && (k == nb);
             const bool boundary_after = c->opt.rebuild_caches && (k == nb - 1);
-            bool have = chain && k > 0 && !boundary_before;
+            bool have = chain && k > k0 && !boundary_before;
             if (c->fused && k == nb) have = false;      // turning point: the same bond again, nothing was chained
             int next = -1;
             if (chain && k + 1 < 2 * nb && !boundary_after) next = (k + 1) < nb ? nb - 1 - (k + 1) : (k + 1) - nb;
@@ -1592,6 +1633,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         return rc;
     }
     HIPC(c, hipGetLastError());         // launch-time failures of the ~2000 enqueues above
+    c->ynext_lid = -1;
     if (optimistic) {
         c->big_opt_active = false;
         const int st = blocked_eig_take_sticky(c->blk, c->stream);        // the one synchronisation of the sweep
@@ -1617,6 +1659,28 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
     prof_collect(c);
     DevScalars sc;
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    int tail_fallbacks = 0;
+    if (sc.redo > 0 && !c->chain4_hold) {
+        // four-launch chain: a tail launch whose verification failed (clustered kept eigenvalues: the case k_eig_fin hands to its Jacobi
+        // solver) has marked the sweep and left the MPS, the caches and the chained tensor as the bond before it left them; so did every
+        // tail launch after it.  The rest of the sweep runs on the six-launch chain, plain stream.
+        c->tail_redos++;
+        tail_fallbacks = sc.eig_fallbacks;
+        c->chain4_hold = true;
+        struct Hold { bool& h; ~Hold() { h = false; } } hold{c->chain4_hold};
+        v = make_view(c, MPST_TRAIN);
+        HIPC(c, hipEventRecord(c->ev_start, c->stream));
+        if ((rc = enqueue_sweep(sc.redo - 1))) return rc;
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipEventRecord(c->ev_stop, c->stream));
+        HIPC(c, hipEventSynchronize(c->ev_stop));
+        float ms2 = 0.f;
+        HIPC(c, hipEventElapsedTime(&ms2, c->ev_start, c->ev_stop));
+        ms += ms2;
+        prof_collect(c);
+        HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+        sc.eig_fallbacks += tail_fallbacks;
+    }
     std::vector<int32_t> chi(c->T + 1);
     HIPC(c, hipMemcpy(chi.data(), c->chi, chi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out) {
@@ -1854,11 +1918,23 @@ int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* 
     if ((rc = enqueue_reset_status(c))) return rc;
     if ((rc = enqueue_bond(c, v, lid, going_left ? 1 : 0))) return rc;
     HIPC(c, hipGetLastError());
-    c->host_label_site = going_left ? lid : lid + 1;
     HIPC(c, hipStreamSynchronize(c->stream));
-    prof_collect(c);
     DevScalars sc;
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    if (sc.redo > 0) {
+        // the tail launch of the four-launch chain left the bond alone (its verification failed): once more on the six-launch chain
+        c->tail_redos++;
+        c->chain4_hold = true;
+        struct Hold { bool& h; ~Hold() { h = false; } } hold{c->chain4_hold};
+        View v6 = make_view(c, MPST_TRAIN);
+        if ((rc = enqueue_reset_status(c))) return rc;
+        if ((rc = enqueue_bond(c, v6, lid, going_left ? 1 : 0))) return rc;
+        HIPC(c, hipGetLastError());
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    }
+    c->host_label_site = going_left ? lid : lid + 1;
+    prof_collect(c);
     if (dbg) {
         std::vector<double> lam((size_t)std::max(sc.n_spec, 1));
         HIPC(c, hipMemcpy(lam.data(), c->lam, lam.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -2302,6 +2378,7 @@ int mpst_normalize(void* ctx) {
         launch_norm2(v, c->norm2, c->norm_scratch, c->stream);
         launch_scale_sites(v, c->norm2, c->stream);
     }
+    c->ynext_lid = -1;
     HIPC(c, hipGetLastError());
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
@@ -2352,16 +2429,23 @@ int mpst_get_info(void* ctx, int32_t* out) {
 }
 
 int mpst_get_info_n(void* ctx, int32_t* out, int32_t n) {
-    int32_t full[18];
+    int32_t full[20];
     if (!out || n < 0) return MPST_ERR_INVALID;
     int rc = mpst_get_info(ctx, full);
     if (rc) return rc;
     full[16] = full[17] = 0;
+    {
+        Ctx* c4 = (Ctx*)ctx;
+        View v4 = make_view(c4, MPST_TRAIN);
+        // [18] the bonds of a sweep run the four-launch chain (k_bond_tail); [19] sweeps / bond steps whose tail was redone on the six-launch chain
+        full[18] = (c4->chain4_ok && c4->b2 && !multi(c4) && c4->opt.update_iters == 1 && !c4->opt.track_cost && eig_merged() && bond_tail_supported(v4)) ? 1 : 0;
+        full[19] = c4->tail_redos;
+    }
     if (n > 16) {       // bonds the subspace eigensolver attempted / whose result was accepted (the rest went to the exact solver)
         Ctx* c = (Ctx*)ctx;
         if (c->blk && blocked_eig_subspace_counts(c->blk, c->stream, &full[16], &full[17])) return fail(c, MPST_ERR_DEVICE, "reading the subspace eigensolver's counters failed");
     }
-    for (int i = 0; i < n && i < 18; ++i) out[i] = full[i];
+    for (int i = 0; i < n && i < 20; ++i) out[i] = full[i];
     return 0;
 }
 
@@ -2379,6 +2463,24 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     us[3] = 0.01 * (double)(t[5] - t[4]);                     //                    back-transformation
     us[4] = 0.01 * (double)(t[9] - t[8]);                     // k_eig_fin: truncation, verification, Loewdin
     us[5] = (double)(t[7] - t[6]);                            // shader cycles spent in the tridiagonalisation
+    return 0;
+}
+
+// phase stamps of the last k_bond_tail launch (us since its first tile workgroup started): out[0..10] that workgroup (requests issued,
+// factors in LDS, P issued, truncation rule, candidates in LDS, polished, published, environment rows, z + row dot, stores drained),
+// out[11..19] the first chain workgroup (start .. role done), out[20..28] the first split workgroup
+int mpst_get_tail_phases(void* ctx, double* us) {
+    Ctx* c = (Ctx*)ctx;
+    if (!c || !c->sc || !us) return MPST_ERR_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    DevScalars sc;
+    HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+    const unsigned long long* t = sc.eig_stamps;
+    const double t0 = (double)t[16];
+    for (int i = 0; i < 11; ++i) us[i] = t[16 + i] ? 0.01 * ((double)t[16 + i] - t0) : -1.0;
+    for (int i = 0; i < 9; ++i) us[11 + i] = t[32 + i] ? 0.01 * ((double)t[32 + i] - t0) : -1.0;
+    for (int i = 0; i < 9; ++i) us[20 + i] = t[40 + i] ? 0.01 * ((double)t[40 + i] - t0) : -1.0;
     return 0;
 }
 

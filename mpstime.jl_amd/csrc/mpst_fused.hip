@@ -12,7 +12,9 @@
 //   k_env_split    update_caches! (:107-144) and the back-split of decomposeBT (:172-176,190-194) in one launch:
 //                  both depend only on the kept eigenvectors E and bt_new
 #include "mpst_internal.h"
+#include "mpst_eig_common.inl"
 #include <algorithm>
+#include <cstring>
 
 namespace mpst {
 
@@ -417,6 +419,11 @@ __device__ __forceinline__ void gram_upd_body(const View& v, int lid, int going_
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
                     if (mv && k0 + 4 * u + kq < kend) v.btn[ia[u]] = a[u];
+                if (v.btnT && !going_left) {        // (m = x, k = y): the same entries as [c][y][x] for k_bond_tail
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (mv && k0 + 4 * u + kq < kend) v.btnT[base + (int64_t)(k0 + 4 * u + kq) * b.X + m] = a[u];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
@@ -503,11 +510,11 @@ __device__ __forceinline__ d4 gemm_tile_g4(const double* __restrict__ A, int64_t
 }
 
 // decomposeBT back-split from the kept eigenvectors E (as k_split, reading bt_new from v.btn); `blk` of `nblk` workgroups
-__device__ __forceinline__ void split_block(const View& v, int lid, int going_left, int blk, int nblk) {
+// (Ev / ldE / nk / inv: the kept eigenvectors, their row stride, how many were kept and 1/||bt_new|| - from memory as k_eig_fin left them,
+// or from the workgroup's own LDS copy in k_bond_tail)
+__device__ __forceinline__ void split_block(const View& v, int lid, int going_left, int blk, int nblk, const double* __restrict__ Ev, const int ldE,
+                                            const int nk, const double inv) {
     const BondDimsF b = bond_dims_f(v, lid);
-    const int nk = v.sc->n_keep;
-    const int ldE = v.cap;
-    const double inv = v.sc->inv_norm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* Wl = v.sites + (int64_t)lid * v.site_stride;
     double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
@@ -520,7 +527,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
             const int c = tile / (tx * tk), rem = tile - c * tx * tk;
             const int m0 = (rem / tk) * 16, n0 = (rem % tk) * 16;
             const double* Bc = v.btn + (int64_t)c * b.L;
-            const d4 acc = gemm_tile_g4(Bc, b.Y, 1, b.X, v.E, ldE, 1, nk, b.Y, m0, n0);
+            const d4 acc = gemm_tile_g4(Bc, b.Y, 1, b.X, Ev, ldE, 1, nk, b.Y, m0, n0);
             double* out = Wl + (int64_t)c * b.X * nk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -530,7 +537,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
         }
         for (int i = blk * 256 + threadIdx.x; i < nk * b.Y; i += nblk * 256) {
             const int k = i / b.Y, y = i - k * b.Y;
-            Wr[i] = v.E[(int64_t)y * ldE + k];
+            Wr[i] = Ev[(int64_t)y * ldE + k];
         }
         if (blk == 0 && threadIdx.x == 0) *v.label_site = lid;
     } else {
@@ -540,7 +547,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
             const int c = tile / (tk * ty), rem = tile - c * tk * ty;
             const int m0 = (rem / ty) * 16, n0 = (rem % ty) * 16;
             const double* Bc = v.btn + (int64_t)c * b.L;
-            const d4 acc = gemm_tile_g4(v.E, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0);
+            const d4 acc = gemm_tile_g4(Ev, 1, ldE, nk, Bc, b.Y, 1, b.Y, b.X, m0, n0);
             double* out = Wr + (int64_t)c * nk * b.Y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -550,7 +557,7 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
         }
         for (int i = blk * 256 + threadIdx.x; i < b.X * nk; i += nblk * 256) {
             const int x = i / nk, k = i - x * nk;
-            Wl[i] = v.E[(int64_t)x * ldE + k];
+            Wl[i] = Ev[(int64_t)x * ldE + k];
         }
         if (blk == 0 && threadIdx.x == 0) *v.label_site = lid + 1;
     }
@@ -565,11 +572,10 @@ __device__ __forceinline__ void split_block(const View& v, int lid, int going_le
 // accumulator tile holds rows 4r .. 4r+3 (lane>>4) of the tile, which is exactly the B (or, transposed, the A) operand
 // of k-step r - then the waves share out the row (column) tiles of bt'.
 constexpr int CHAIN_J = 4;      // 16-row blocks of the contracted bond: chi <= 64 whenever d*chi <= 128 and d >= 2
-__device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going_left, int job, double* __restrict__ cpart /* [4][CHAIN_J][256] */) {
+__device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going_left, int job, double* __restrict__ cpart /* [4][CHAIN_J][256] */,
+                                               const double* __restrict__ Ev, const int ldE, const int nk, const double inv) {
     const BondDimsF b = bond_dims_f(v, lid);
-    const int nk = v.sc->n_keep;
-    const double inv = v.sc->inv_norm;
-    const int ldE = v.cap, d = v.d;
+    const int d = v.d;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ktc = (v.cap + 15) >> 4;                 // jobs are laid out for the capacity
@@ -619,7 +625,7 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
                 for (int u = 0; u < 8; ++u) {
                     const int q = q0 + 4 * u + kq;
                     av[u] = (row < Dc && q < kend) ? ap[(int64_t)q * astr] : 0.0;
-                    bv[u] = (kv && q < kend) ? v.E[(int64_t)q * ldE + kcol] : 0.0;
+                    bv[u] = (kv && q < kend) ? Ev[(int64_t)q * ldE + kcol] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -693,11 +699,11 @@ __device__ __forceinline__ void env_split_body(const View& v, int lid, int going
                                                double* __restrict__ out, int nsplit, int ntb, int tp) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if ((int)blockIdx.x >= ntb + nsplit) {
-        chain_bt_block(v, lid, going_left, (int)blockIdx.x - ntb - nsplit, smem);
+        chain_bt_block(v, lid, going_left, (int)blockIdx.x - ntb - nsplit, smem, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
         return;
     }
     if ((int)blockIdx.x >= ntb) {
-        split_block(v, lid, going_left, (int)blockIdx.x - ntb, nsplit);
+        split_block(v, lid, going_left, (int)blockIdx.x - ntb, nsplit, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
         return;
     }
     // new environment rows out_i = Z_i E.  A wave owns one 16-column tile of the output; with fewer than four column tiles
@@ -1212,6 +1218,311 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
     GSTAMP(4);
 }
 
+// =====================================================================================================================
+// k_bond_tail (round 6): everything of a bond that follows the eigenvectors, in ONE launch - the four-launch chain
+//   k_grad_s -> k_gram_upd -> k_eig_trivec -> k_bond_tail.
+// What used to be three dependent launches (k_eig_fin, k_env_split, the next bond's k_yhat_s: 33 us, of which about 12 are
+// three cold starts and first round trips to memory) is one:
+//  * every workgroup repeats k_eig_fin's work for itself - truncation rule (NDTensors truncate!), verification of the candidate
+//    vectors, Loewdin polish (verify_and_polish, the same code: the same bits in every workgroup) - and keeps the kept
+//    eigenvectors E in ITS LDS: 512 MFMAs of redundant work per CU (1.7 us) against a launch boundary and a trip through memory;
+//  * tile workgroups (16 series each): the new environment rows env' = S E (update_caches!, the very sums of k_env_split / k_env:
+//    a sweep with the reference's cache rebuilds stays bit-identical), and the NEXT bond's overlaps
+//        yhat_i = <B'_c, X'_i (x) Y'_i>,  B' = W[neighbour] * T_c,  T_c = bt_new_c E / ||bt_new||   (flatten_bt, RealRealHighDimension.jl:221-238)
+//               = O_i^T bt_new_c (E (E^T S_i)) / ||bt_new||
+//    with S_i / O_i the Khatri-Rao vectors of this bond on the side the eigenvectors live on / the other side (the environment of
+//    the other side is the next bond's outer environment contracted with the neighbouring site: it exists in the cache).  The
+//    product P = O bt_new (256 MFMAs per tile) needs neither E nor the new environment and runs before the polish; a wave owns 16
+//    columns of it and forms z = E env' for the same 16 columns in the accumulator layout, so the row dot needs no exchange;
+//  * split / chain workgroups: the back-split and the next bond's tensor as in k_env_split, with E from LDS.
+// A failed verification (genuinely clustered kept eigenvalues: k_eig_fin would fall through to its Jacobi solver) sets the sticky
+// DevScalars::redo and leaves the MPS alone; every later tail launch of the sweep leaves at once, and the host redoes the sweep
+// from its snapshot on the six-launch chain (mpst_sweep).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
+// =====================================================================================================================
+constexpr int BT_T = EIG_THREADS;            // verify_and_polish is written for 8 waves
+constexpr int BT_ENVS = 34;                  // LDS row stride of the 16 x 32 tile of new environment rows
+constexpr int BT_ELS = 37, BT_PLS = 21;      // LDS row strides of the staged factors (odd: the 16 rows a wave reads hit 16 bank pairs): 32 bond
+                                             // entries / 16 site states and zeros behind them (the padded K extent reads up to 4 beyond the live ones)
+constexpr int BT_FAC = 16 * (BT_ELS + BT_PLS);
+constexpr int BT_LDS_DOUBLES = 128 * 32 + 32 * 32 + 1024 + 128 + 2 * BT_FAC + 16 * BT_ENVS + 128;     // 70 KB: two workgroups per CU
+
+// One side's Khatri-Rao vectors of a 16-series tile, kept as their FACTORS in LDS (environment row, site vector); entry z of row i
+// is formed where the MFMA wants it: left  z = a d + s: prev_i[a] phi_i[s];  right  z = s Dp + b: phi_i[s] prev_i[b]
+// (the one product stage16 forms: the same bits).  Division by d / Dp with a multiply (z < 1024).
+struct KrSide {
+    const double* env;      // [16][BT_ELS]
+    const double* ph;       // [16][BT_PLS]
+    unsigned magic, div;
+    bool left;
+};
+__device__ __forceinline__ KrSide kr_side(const double* fac, int Dp, int d, bool left) {
+    KrSide k;
+    k.env = fac;
+    k.ph = fac + 16 * BT_ELS;
+    k.div = (unsigned)(left ? d : Dp);
+    k.magic = (65536u + k.div - 1u) / k.div;
+    k.left = left;
+    return k;
+}
+__device__ __forceinline__ double kr_at(const KrSide& k, int row, unsigned z) {
+    const unsigned q = (z * k.magic) >> 16, r = z - q * k.div;
+    const unsigned ie = k.left ? q : r, ip = k.left ? r : q;
+    return k.env[row * BT_ELS + ie] * k.ph[row * BT_PLS + ip];
+}
+
+// D4: d == 4 (the headline shapes): on the left side a = u, s = kq are immediates
+template <bool D4>
+__device__ __forceinline__ void bond_tail_body(const View& v, const int lid, const int going_left, const int nsplit, const int nchain, const int want_next_) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double lam_s[TRI_KMAX + 2];
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rid = lid + 1, d = v.d;
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
+    const double* __restrict__ ws = v.eig_ws;
+    // blocks [0, nchain): the next bond's tensor (the longest dependent chain: first to be dispatched); [nchain, nchain + nsplit): the
+    // back-split; the rest: tiles of series
+    const int bid = (int)blockIdx.x;
+    const int role = bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 0);
+    // phase stamps (100 MHz) of one workgroup per role: DevScalars::eig_stamps[16..] first tile workgroup, [32..] chain, [40..] split
+    unsigned long long* stp = nullptr;
+    const int want_next = want_next_ & 1;
+    if (tid == 0 && (want_next_ & 2)) {
+        if (bid == nchain + nsplit) stp = v.sc->eig_stamps + 16;
+        else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
+        else if (bid == nchain) stp = v.sc->eig_stamps + 40;
+    }
+    int sti = 0;
+#define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    TSTAMP();
+    FinShared f = fin_carve<32>(smem);
+    double* Sf = f.misc + 128;                     // factors of the S side, then of the O side
+    double* Of = Sf + BT_FAC;
+    double* envs = Of + BT_FAC;                    // [16][BT_ENVS] new environment rows of the tile
+    double* redy = envs + 16 * BT_ENVS;            // [8][16] the waves' pieces of yhat
+    const double* __restrict__ Ef = f.Z;           // after the polish: the kept eigenvectors [z][32], zero beyond the live rows / kept columns
+    const int64_t cs = (int64_t)v.N * v.cap;
+    // S: the side the kept eigenvectors live on (Y going left, X going right); O: the other side
+    const double* Sprev = going_left ? (rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr) : (lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr);
+    const double* Oprev = going_left ? (lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr) : (rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr);
+    const int DS = Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = Oprev ? (going_left ? b.Dl : b.Dr) : 1;
+    const double* phS = v.phi + (int64_t)(going_left ? rid : lid) * v.N * d;
+    const double* phO = v.phi + (int64_t)(going_left ? lid : rid) * v.N * d;
+    double* __restrict__ out = going_left ? v.RE + (int64_t)rid * cs : v.LE + (int64_t)lid * cs;
+    const KrSide ks = kr_side(Sf, DS, d, !going_left), ko = kr_side(Of, DO, d, going_left != 0);
+    const int KO = going_left ? b.X : b.Y, NS = going_left ? b.Y : b.X;      // bt_new as [k = O index][n = S index]
+    const int KP = (KO + 3) & ~3, ZP = (DS * d + 3) & ~3;
+    const double* Mbase = going_left ? v.btn : v.btnT;
+    // the loader role of a thread: threads [0, 256) the S side, [256, 512) the O side; 16 threads per series row, two bond entries and
+    // one site state each
+    const bool lower = tid < 256;
+    const int lrow = (tid & 255) >> 4, lj = tid & 15;
+    // ONE tile per tile workgroup, no loop around any of this: a loop invites the compiler to hoist the address arithmetic of every
+    // phase - polish, roles, products - in front of it, and the kernel then lives in scratch memory (400 bytes per lane, measured)
+    {
+        const int t = bid - nchain - nsplit;
+        // ---- requests: the tile's factors and its slice of bt_new, then (first pass) what k_eig_fin reads --------------------------
+        Span tl{0, 0, 0, 0};
+        d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
+        double bm[32];
+        double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
+        if (role == 0) {
+            tl = tile_span_k(v, t);
+            if (lower || want_next) {
+                const double* prev = lower ? Sprev : Oprev;
+                const double* ph = lower ? phS : phO;
+                const int Dp = lower ? DS : DO;
+                const bool valid = lrow < tl.count;
+                const int64_t smp = tl.start + (valid ? lrow : 0);
+                fe0 = (valid && lj < Dp) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
+                fe1 = (valid && lj + 16 < Dp) ? prev[smp * v.cap + lj + 16] : 0.0;
+                fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
+            }
+            if (want_next) {
+                // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
+                // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
+                // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
+                const unsigned col = (unsigned)min(16 * wave + i16, NS - 1);
+                const double* __restrict__ M = Mbase + (int64_t)tl.cls * b.L;        // (uniform base + 32-bit lane offsets)
+#pragma unroll
+                for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
+            }
+        }
+        double gdiag = 0.0, triflag = 0.0, tnorm_in = 0.0, lam_in = 0.0, res_in = 0.0;
+        int redo_in = 0;
+        double zin[8];
+        {
+            gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
+            triflag = ws[WS_MISC + 3];
+            tnorm_in = ws[WS_MISC + 2];
+            lam_in = tid < K0 ? ws[WS_LAM + tid] : 0.0;
+            res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+            redo_in = v.sc->redo;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
+        }
+        TSTAMP();      // [1] everything requested
+        if (role == 0) {
+            double* fac = lower ? Sf : Of;
+            fac[lrow * BT_ELS + lj] = fe0;
+            fac[lrow * BT_ELS + lj + 16] = fe1;
+            if (lj < BT_ELS - 32) fac[lrow * BT_ELS + 32 + lj] = 0.0;
+            fac[16 * BT_ELS + lrow * BT_PLS + lj] = fp;
+            if (lj < BT_PLS - 16) fac[16 * BT_ELS + lrow * BT_PLS + 16 + lj] = 0.0;
+            __syncthreads();
+            TSTAMP();  // [2] factors in LDS
+            if (want_next) {
+                // P = O bt_new, this wave's 16 columns (two accumulation chains)
+                if (D4 && ko.left) {
+                    const double ph = ko.ph[i16 * BT_PLS + kq];
+                    const double* er = ko.env + i16 * BT_ELS;
+#pragma unroll
+                    for (int u = 0; u < 32; u += 2) {
+                        if (4 * u < KP) pacc0 = mfma_f64(er[u] * ph, bm[u], pacc0);
+                        if (4 * u + 4 < KP) pacc1 = mfma_f64(er[u + 1] * ph, bm[u + 1], pacc1);
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 32; u += 2) {
+                        if (4 * u < KP) pacc0 = mfma_f64(kr_at(ko, i16, 4u * u + kq), bm[u], pacc0);
+                        if (4 * u + 4 < KP) pacc1 = mfma_f64(kr_at(ko, i16, 4u * u + 4u + kq), bm[u + 1], pacc1);
+                    }
+                }
+            }
+        }
+        TSTAMP();      // [3] P issued (tile workgroups)
+        int nk;
+        double inv;
+        {
+            // ---- k_eig_fin's work, by every workgroup for itself (fin_body / fin_tri<32>: the same operations in the same order) ----
+            double tr = wave_sum(gdiag);
+            if (lane == 0) red[wave] = tr;
+            __syncthreads();
+            tr = 0.0;
+            for (int i = 0; i < BT_T / 64; ++i) tr += red[i];
+            inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+            if (tid < K0) lam_s[tid] = lam_in;
+            __syncthreads();
+            nk = truncate_rule(lam_s, K0, nspec, tr, inv * inv, v.cutoff, false);
+            TSTAMP();  // [4] trace, truncation rule
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int i = tid + m * BT_T;
+                const int c = i >> 5, kk = i & 31;
+                f.Z[i] = (c < n && kk < nk) ? zin[m] : 0.0;
+            }
+            if (tid < 32) f.misc[32 + tid] = tid < nk ? res_in : 0.0;
+            if (tid == 0) f.misc[2] = tnorm_in;
+            __syncthreads();
+            TSTAMP();  // [5] candidates in LDS
+            bool ok = triflag == 1.0 && redo_in == 0;
+            if (ok) ok = verify_and_polish<32>(f, n, nk);
+            TSTAMP();  // [6] verified + polished
+            if (!ok) {
+                if (bid == 0 && tid == 0 && redo_in == 0) {
+                    v.sc->redo = 1 + (going_left ? v.T - 2 - lid : v.T - 1 + lid);      // 1 + the bond's position in the sweep
+                    v.sc->eig_fallbacks += 1;
+                }
+                return;
+            }
+            if (bid == 0) {                                 // publication (fin_body)
+                if (tid < K0) v.lam[tid] = lam_s[tid];
+                if (tid == 0) {
+                    bool bad = !(tr == tr) || tr > 1e300;
+                    for (int i = 0; i < K0; ++i) {
+                        const double P = lam_s[i] * inv * inv;
+                        if (!(P == P) || P > 1e300) bad = true;
+                    }
+                    v.sc->n_keep = nk;
+                    v.sc->n_spec = K0;
+                    v.sc->bt_norm2 = tr;
+                    v.sc->inv_norm = inv;
+                    v.sc->eig_sweeps = 0;
+                    if (bad) v.sc->status = MPST_ERR_SVD;
+                    v.chi[lid + 1] = nk;
+                }
+            }
+            __syncthreads();                                // the polish scratch is free, E is final
+            TSTAMP();  // [7] published
+            if (role != 0) {
+                if (!lower) return;                         // (a retired wave no longer counts at the barriers of the 256-thread bodies)
+                if (role == 2) chain_bt_block(v, lid, going_left, bid, f.D, Ef, 32, nk, inv);
+                else split_block(v, lid, going_left, bid - nchain, nsplit, Ef, 32, nk, inv);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TSTAMP();  // [8] role done, stores drained
+                return;
+            }
+        }
+        // env' = S E: one chain of MFMAs per 16-column tile, in the order of k_env / k_env_split (at most 32 vectors are kept here)
+        if (wave < 2) {
+            const int col = wave * 16 + i16;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            if (wave * 16 < nk) {
+                if (D4 && ks.left) {
+                    const double ph = ks.ph[i16 * BT_PLS + kq];
+                    const double* er = ks.env + i16 * BT_ELS;
+#pragma unroll
+                    for (int u = 0; u < 32; ++u)
+                        if (4 * u < ZP) acc = mfma_f64(er[u] * ph, Ef[(4 * u + kq) * 32 + col], acc);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u)
+                        if (4 * u < ZP) acc = mfma_f64(kr_at(ks, i16, 4u * u + kq), Ef[(4 * u + kq) * 32 + col], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = kq + 4 * r;
+                    if (i < tl.count && col < nk) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) envs[(kq + 4 * r) * BT_ENVS + col] = acc[r];
+        }
+        TSTAMP();      // [8] new environment rows
+        if (!want_next) return;
+        __syncthreads();
+        {
+            // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
+            d4 zacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) zacc = mfma_f64(envs[i16 * BT_ENVS + 4 * u + kq], Ef[(16 * wave + i16) * 32 + 4 * u + kq], zacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
+                if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
+            }
+        }
+        __syncthreads();
+        TSTAMP();      // [9] z, row dot
+        if (tid < 16 && tid < tl.count) {
+            const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
+                              ((redy[64 + tid] + redy[80 + tid]) + (redy[96 + tid] + redy[112 + tid]))) * inv;
+            // the reader (k_grad_s) adds the eight slice slots of a series in order: the overlap in slot 0, zeros behind it
+            double2* yp = (double2*)(v.ypart + (int64_t)(tl.start + tid) * YS_MAXSL);
+            yp[0] = make_double2(y, 0.0);
+            yp[1] = make_double2(0.0, 0.0);
+            yp[2] = make_double2(0.0, 0.0);
+            yp[3] = make_double2(0.0, 0.0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP();      // [10] stores drained
+    }
+#undef TSTAMP
+}
+// two register budgets of the same body: 128 VGPRs (two workgroups per CU: the chain / split workgroups find room beside the tile
+// workgroups; 57 dwords of private segment) or whatever the body wants (162: one workgroup per CU)
+template <bool D4>
+__global__ __launch_bounds__(BT_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bond_tail(View v, int lid, int going_left, int nsplit, int nchain, int want_next) {
+    bond_tail_body<D4>(v, lid, going_left, nsplit, nchain, want_next);
+}
+template <bool D4>
+__global__ __launch_bounds__(BT_T) void k_bond_tail_w(View v, int lid, int going_left, int nsplit, int nchain, int want_next) {
+    bond_tail_body<D4>(v, lid, going_left, nsplit, nchain, want_next);
+}
+
 // ---- the kernels proper: one fit per launch (View in the kernel arguments), or K independent fits of the same shape per
 // launch (blockIdx.z picks the fit's View from a device array - mpst_sweep_batch): the command processor dispatches about
 // 70 k kernels a second however many queues feed it, which caps K concurrent single-fit chains at 2.3x one chain; one
@@ -1294,6 +1605,10 @@ hipError_t b2_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bond_tail<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bond_tail<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bond_tail_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bond_tail_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
     if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
@@ -1350,6 +1665,29 @@ void launch_grad_s(const View& v, int lid, hipStream_t s) {
     if (aw > 8) hipLaunchKernelGGL((k_grad_s<2, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);         // d = 2, 3
     else if (v.d > 8) hipLaunchKernelGGL((k_grad_s<1, 2>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);   // d = 9..16
     else hipLaunchKernelGGL((k_grad_s<1, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
+}
+// the four-launch chain: real fp64, KLD, at most 32 kept vectors (the 32-column layout of the eigenvector block), tridiagonal solver
+bool bond_tail_supported(const View& v) {
+    return v.zw != 2 && v.loss == MPST_LOSS_KLD && v.chi_max <= 32 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.svd_alg != MPST_SVD_JACOBI && v.d >= 2 && v.d <= 16;
+}
+void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, hipStream_t s) {
+    const int dm = v.d * v.cap;
+    const int nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
+    const int nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
+    static const bool wide = [] { const char* e = getenv("MPST_TAIL_WIDE"); return e && e[0] == '1'; }();
+    // which bond's tail leaves its phase stamps (mpst_get_tail_phases): MPST_TAIL_STAMP="lid,going_left", default the middle bond going left
+    static const int stamp_lid = [] { const char* e = getenv("MPST_TAIL_STAMP"); return e ? atoi(e) : -1; }();
+    static const int stamp_dir = [] { const char* e = getenv("MPST_TAIL_STAMP"); const char* q = e ? strchr(e, ',') : nullptr; return q ? atoi(q + 1) : 1; }();
+    if (lid == (stamp_lid >= 0 ? stamp_lid : (v.T - 1) / 2) && (going_left != 0) == (stamp_dir != 0)) want_next |= 2;
+    const size_t lds = (size_t)BT_LDS_DOUBLES * sizeof(double);
+    const dim3 grid(nchain + nsplit + v.ntiles);          // one 16-series tile per tile workgroup
+    if (wide) {
+        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail_w<true>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+        else hipLaunchKernelGGL(k_bond_tail_w<false>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+    } else {
+        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+        else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+    }
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);

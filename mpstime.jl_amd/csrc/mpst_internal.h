@@ -330,7 +330,8 @@ struct DevScalars {
     int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
     int32_t pad[2];             // one-shot all-reduce: time-out diagnostics (OneShotParams.dbg)
     int32_t xref;               // typed MSE: largest overlap exponent of the bond's series (k_tbt_assemble resets, k_tyhat raises)
-    int32_t pad2;
+    int32_t redo;               // k_bond_tail: a bond's on-device verification failed - every later tail launch of the sweep leaves at once and the
+                                // host redoes the sweep from its snapshot on the chain that has the Jacobi fallback (sticky until the host clears it)
     unsigned long long eig_stamps[64];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
 };
 
@@ -382,6 +383,7 @@ struct View {
     int32_t nparts, n_norm_part;
     double* norm_part;  // [n_norm_part] pieces of ||grad||^2
     double* btn;        // bt_new, written by k_gram_upd
+    double* btnT;       // going right on the four-launch chain: bt_new once more as [c][y][x] (k_bond_tail contracts it along y), else null
     // sliced bond GEMMs (k_yhat_s / k_grad_s, mpst_fused.hip)
     const int32_t* cls_off;   // [C+1] first series of every class
     int32_t kcls_off[MAX_C + 1];    // the same table, and the first 16-series tile of every class, in the kernel arguments:
@@ -530,6 +532,10 @@ hipError_t b2_init_attrs(int device);
 void launch_gram_upd(const View& v, int lid, int going_left, int first_iter, hipStream_t s);
 void launch_env_split(const View& v, int lid, int going_left, int site, int left_side, const double* prev, int prev_bond,
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);
+// the four-launch chain's last launch (k_bond_tail): k_eig_fin's verification + polish, environment update, back-split, the next
+// bond's tensor (chain) and the next bond's overlaps (want_next) in one
+void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, hipStream_t s);
+bool bond_tail_supported(const View& v);
 // the headline chain for K independent fits of one shape per launch (blockIdx.z selects the fit's View in the device array vs)
 void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);
 void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);

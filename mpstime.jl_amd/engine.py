@@ -373,9 +373,10 @@ class SweepEngine:
         return {k: (us[i], int(cnt[i])) for i, k in enumerate(L.KERNEL_CLASSES)}
 
     def info(self):
-        out = (C.c_int32 * 18)()
-        self._chk(self.lib.mpst_get_info_n(self.ctx, out, 18))
-        return {"subspace_attempted": out[16], "subspace_accepted": out[17], "fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
+        out = (C.c_int32 * 20)()
+        self._chk(self.lib.mpst_get_info_n(self.ctx, out, 20))
+        return {"four_launch_chain": bool(out[18]), "tail_redos": out[19],
+                "subspace_attempted": out[16], "subspace_accepted": out[17], "fused": bool(out[0]), "large_bond": bool(out[1]), "nparts": out[2], "nchunks": out[3], "cap": out[4],
                 "ranks": out[5], "graph": bool(out[6]), "library_eig_fallbacks": out[7], "persistent_tridiag_aborts": out[8],
                 "xcd_local_misplaced": out[9], "sliced_bond_gemms": bool(out[10]), "grad_shares": out[11],
                 "eig_merged": bool(out[12]), "large_bond_sweep_redos": out[13], "large_bond_verdict_per_sweep": bool(out[14]),
@@ -385,6 +386,14 @@ class SweepEngine:
         us = np.zeros(6)
         self._chk(self.lib.mpst_get_eig_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
         return dict(zip(("tridiag", "bisect", "eigvec", "backtransform", "verify", "tridiag_cycles"), us.tolist()))
+
+    def tail_phases(self):
+        """Stamps (us) of the last k_bond_tail launch: the first tile workgroup, the first chain and the first split workgroup."""
+        us = np.zeros(29)
+        self._chk(self.lib.mpst_get_tail_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
+        names = ("start", "requested", "factors_in_lds", "overlap_product_issued", "truncation", "candidates_in_lds", "polished", "published",
+                 "env_rows", "z_rowdot", "stores_drained")
+        return {"tile": dict(zip(names, us[:11].tolist())), "chain": us[11:20].tolist(), "split": us[20:29].tolist()}
 
     def selftest_mfma(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)

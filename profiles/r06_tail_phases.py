@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""In-kernel phase stamps of the four-launch chain's last launch (k_bond_tail) and of the eigensolver at the headline shape, from the
+replayed sweep graph (the middle bond of the backward half-sweep; MPST_TAIL_STAMP="lid,going_left" picks another).
+From the repo root on the GPU box: python profiles/r06_tail_phases.py [N] [chi]"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mpstime_jl_amd as mt
+import bench
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+chi = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+T, d, C = 100, 4, 2
+full = bench.make_inputs(N, T, d)
+W0 = mt.generate_startingMPS(4, T, d, C, 1234)
+eng = mt.SweepEngine(0)
+eng.set_options(chi_max=chi, eta=0.01, cutoff=1e-10, update_iters=1, loss="KLD", bbopt="TSGO", rescale=(False, True))
+eng.set_dataset(0, full.phi, full.label_index, C)
+eng.set_mps(W0)
+eng.build_caches()
+secs = []
+for _ in range(6):
+    secs.append(eng.sweep()["seconds"])
+out = {"N": N, "chi": chi, "sweep_ms": [round(1e3 * s, 3) for s in secs], "info": eng.info(), "eig_phases_us": eng.eig_phases()}
+if out["info"].get("four_launch_chain"):
+    ph = eng.tail_phases()
+    out["tail_tile_us"] = {k: round(v, 2) for k, v in ph["tile"].items()}
+    out["tail_chain_us"] = [round(x, 2) for x in ph["chain"]]
+    out["tail_split_us"] = [round(x, 2) for x in ph["split"]]
+eng.set_profile(0x7FF)
+eng.sweep()
+out["event_profile_us_per_launch"] = {k: (round(v[0] / max(v[1], 1), 2), v[1]) for k, v in eng.get_profile().items() if v[1]}
+print(json.dumps(out))
