@@ -1239,15 +1239,19 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
 // DevScalars::redo and leaves the MPS alone; every later tail launch of the sweep leaves at once, and the host redoes the sweep
 // from its snapshot on the six-launch chain (mpst_sweep).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
 // =====================================================================================================================
-constexpr int BT_T = EIG_THREADS;            // verify_and_polish is written for 8 waves
+constexpr int BT_T = 512;                    // 8 waves
+constexpr int BT_ZS = 36;                    // LDS row stride of the candidate / kept eigenvectors: rows 16 apart in 16 different bank pairs
+                                             // (with the 32 of k_eig_fin's layout the A operand of Z D is a 16-way conflict: 3 us per polish)
 constexpr int BT_ENVS = 34;                  // LDS row stride of the 16 x 32 tile of new environment rows
 constexpr int BT_ELS = 37, BT_PLS = 21;      // LDS row strides of the staged factors (odd: the 16 rows a wave reads hit 16 bank pairs): 32 bond
                                              // entries / 16 site states and zeros behind them (the padded K extent reads up to 4 beyond the live ones)
 constexpr int BT_FAC = 16 * (BT_ELS + BT_PLS);
-constexpr int BT_LDS_DOUBLES = 128 * 32 + 32 * 32 + 1024 + 128 + 2 * BT_FAC + 16 * BT_ENVS + 128;     // 70 KB: two workgroups per CU
+constexpr int BT_SS = 129;                   // row stride of the dense S tile (over D / Dh / misc once the polish is done)
+constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2 * BT_FAC + 16 * BT_ENVS + 128;     // 74.5 KB: two workgroups per CU
+static_assert(16 * BT_SS <= 32 * 32 + 1024 + 128, "the dense S tile lives in the polish scratch");
 
 // One side's Khatri-Rao vectors of a 16-series tile, kept as their FACTORS in LDS (environment row, site vector); entry z of row i
-// is formed where the MFMA wants it: left  z = a d + s: prev_i[a] phi_i[s];  right  z = s Dp + b: phi_i[s] prev_i[b]
+// is formed where it is wanted: left  z = a d + s: prev_i[a] phi_i[s];  right  z = s Dp + b: phi_i[s] prev_i[b]
 // (the one product stage16 forms: the same bits).  Division by d / Dp with a multiply (z < 1024).
 struct KrSide {
     const double* env;      // [16][BT_ELS]
@@ -1270,27 +1274,150 @@ __device__ __forceinline__ double kr_at(const KrSide& k, int row, unsigned z) {
     return k.env[row * BT_ELS + ie] * k.ph[row * BT_PLS + ip];
 }
 
+// what the host knows of a tail launch: no pointer arithmetic on the device's scalar unit in front of the first request
+struct TailArgs {
+    const double *Sprev, *Oprev;    // environment rows of the side the eigenvectors live on / of the other side (null: chain end)
+    const double *phS, *phO;        // the two sites' encoded series
+    const double* M;                // bt_new as [c][k = O index][n = S index]: btn going left, btnT going right
+    double* out;                    // the new environment rows
+    int32_t lid, going_left, nsplit, nchain, flags;     // flags: 1 the next bond's overlaps are wanted, 2 leave phase stamps
+};
+
+// Verification + re-orthonormalisation of the K candidate vectors Z ([c * BT_ZS + k], zero beyond the live rows / columns), all 8 waves:
+// D = Z^T Z - I on the MFMA; |D| >= 1e-4 or a residual ||T z - lambda z|| above 1e-8 ||T|| (rres: this thread's, threads < K): the
+// caller's fallback.  |D| < 1e-13: nothing to do.  |D| < 1e-8: Z <- Z (I - D/2) (Loewdin, first order: the deviation is squared).
+// Else Z <- Z (I - D/2 + 3 D^2 / 8): the deviation becomes 5/8 |D|^3 <= 1.7e-14 for |D| <= 3e-5 - ONE pass over Z where
+// k_eig_fin's verify_and_polish forms D twice (D^2 is a 32^3 product); beyond 3e-5 a second, first-order pass follows.
+__device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __restrict__ D, double* __restrict__ Dh, double* __restrict__ misc,
+                                            const int n, const int K, const double rres) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jl = lane & 15, q4 = lane >> 4;
+    for (int pass = 0; pass < 2; ++pass) {
+        // ---- D: wave w owns the 16 x 16 tile (w & 3) over rows [64 (w >> 2), +64) ----
+        const int a0 = 16 * ((wave & 3) >> 1), b0 = 16 * (wave & 1), kb = 64 * (wave >> 2);
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int s4 = 0; s4 < 16; ++s4) {
+            const double* zr = Z + (kb + 4 * s4 + q4) * BT_ZS;
+            acc = mfma_f64(zr[a0 + jl], zr[b0 + jl], acc);
+        }
+        if (wave >= 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dh[(wave & 3) * 256 + (q4 + 4 * r) * 16 + jl] = acc[r];
+        }
+        __syncthreads();
+        double err = 0.0;
+        if (wave < 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int aa = a0 + q4 + 4 * r, bb = b0 + jl;
+                double dv = 0.0;
+                if (aa < K && bb < K) {
+                    dv = (acc[r] + Dh[wave * 256 + (q4 + 4 * r) * 16 + jl]) - (aa == bb ? 1.0 : 0.0);
+                    err = fmax(err, fabs(dv));
+                }
+                D[aa * 32 + bb] = dv;
+            }
+        }
+        err = wave_max(err);
+        const double rr = wave_max(rres);
+        if (lane == 0) {
+            misc[8 + wave] = err;
+            misc[16 + wave] = rr;
+        }
+        __syncthreads();
+        double emax = 0.0, rmax = 0.0;
+#pragma unroll
+        for (int w = 0; w < BT_T / 64; ++w) {
+            emax = fmax(emax, misc[8 + w]);
+            rmax = fmax(rmax, misc[16 + w]);
+        }
+        if (!(rmax < 1e-8) || !(emax < 1e-4)) return false;        // (NaN fails both)
+        if (emax < 1e-13) return true;
+        if (pass == 1 && !(emax < 1e-8)) return false;             // the second pass starts below 1e-12: anything else is not a rounding effect
+        const bool second = pass == 0 && !(emax < 1e-8);
+        const double* Cm = D;
+        if (second) {
+            // Cm = D - 3/4 D^2 (the update below takes half of it): four tiles, waves 0..3
+            if (wave < 4) {
+                d4 c2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c2 = mfma_f64(D[(a0 + jl) * 32 + 4 * u + q4], D[(4 * u + q4) * 32 + b0 + jl], c2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int aa = a0 + q4 + 4 * r, bb = b0 + jl;
+                    Dh[aa * 32 + bb] = fma(-0.75, c2[r], D[aa * 32 + bb]);
+                }
+            }
+            Cm = Dh;
+            __syncthreads();
+        }
+        // ---- Z <- Z - (Z Cm) / 2: 8 row tiles x 2 column tiles, two per wave ----
+        d4 upd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tile = wave * 2 + h;
+            const int c0 = 16 * (tile >> 1), ca = 16 * (tile & 1);
+            d4 a = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) a = mfma_f64(Z[(c0 + jl) * BT_ZS + 4 * s4 + q4], Cm[(4 * s4 + q4) * 32 + ca + jl], a);
+            upd[h] = a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int tile = wave * 2 + h;
+            const int c0 = 16 * (tile >> 1), ca = 16 * (tile & 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = c0 + q4 + 4 * r, aa = ca + jl;
+                if (c < n && aa < K) Z[c * BT_ZS + aa] -= 0.5 * upd[h][r];
+            }
+        }
+        __syncthreads();
+        if (emax < 3e-5) return true;
+    }
+    return true;
+}
+
+// NDTensors truncate! as truncate_rule() applies it (the same operations in the same order), with the K0 <= 32 eigenvalues in the lanes
+// of the calling wave instead of an array in LDS every thread walks (1 us of dependent LDS reads)
+__device__ __forceinline__ int truncate_rule_lanes(const double lam_lane, const int K, const int ns, const double tr, const double inv2, const double cutoff) {
+    const double scale0 = tr * inv2;
+    const double scale = scale0 == 0.0 ? 1.0 : scale0;
+    double kept = 0.0;
+    for (int i = 0; i < K; ++i) kept += readlane_f64(lam_lane, i) * inv2;
+    int nk = K;
+    double truncerr = scale0 - kept;
+    if (truncerr < 0.0 || ns <= K) truncerr = 0.0;
+    if (ns > 1) {
+        while (nk > 1) {
+            const double p = readlane_f64(lam_lane, nk - 1) * inv2;
+            if (!(truncerr + p <= cutoff * scale)) break;
+            truncerr += p;
+            --nk;
+        }
+    }
+    return nk;
+}
+
 // D4: d == 4 (the headline shapes): on the left side a = u, s = kq are immediates
 template <bool D4>
-__device__ __forceinline__ void bond_tail_body(const View& v, const int lid, const int going_left, const int nsplit, const int nchain, const int want_next_) {
+__device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double lam_s[TRI_KMAX + 2];
     __shared__ double red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int rid = lid + 1, d = v.d;
-    const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
-    const BondDimsF b = bond_dims_f(v, lid);
-    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
-    const double* __restrict__ ws = v.eig_ws;
+    const int lid = ta.lid, going_left = ta.going_left, nsplit = ta.nsplit, nchain = ta.nchain;
+    const int want_next = ta.flags & 1;
+    const int d = v.d;
     // blocks [0, nchain): the next bond's tensor (the longest dependent chain: first to be dispatched); [nchain, nchain + nsplit): the
-    // back-split; the rest: tiles of series
+    // back-split; the rest: one 16-series tile each
     const int bid = (int)blockIdx.x;
     const int role = bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 0);
     // phase stamps (100 MHz) of one workgroup per role: DevScalars::eig_stamps[16..] first tile workgroup, [32..] chain, [40..] split
     unsigned long long* stp = nullptr;
-    const int want_next = want_next_ & 1;
-    if (tid == 0 && (want_next_ & 2)) {
+    if (tid == 0 && (ta.flags & 2)) {
         if (bid == nchain + nsplit) stp = v.sc->eig_stamps + 16;
         else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
         else if (bid == nchain) stp = v.sc->eig_stamps + 40;
@@ -1298,229 +1425,213 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const int lid, con
     int sti = 0;
 #define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TSTAMP();
-    FinShared f = fin_carve<32>(smem);
-    double* Sf = f.misc + 128;                     // factors of the S side, then of the O side
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
+    const double* __restrict__ ws = v.eig_ws;
+    double* Zl = smem;                             // [128][BT_ZS] candidates, then the kept eigenvectors E (zero beyond the live rows / kept columns)
+    double* Dl = Zl + 128 * BT_ZS;                 // [32][32]
+    double* Dh = Dl + 1024;                        // [1024]
+    double* misc = Dh + 1024;                      // [128]
+    double* Sf = misc + 128;                       // factors of the S side, then of the O side
     double* Of = Sf + BT_FAC;
     double* envs = Of + BT_FAC;                    // [16][BT_ENVS] new environment rows of the tile
     double* redy = envs + 16 * BT_ENVS;            // [8][16] the waves' pieces of yhat
-    const double* __restrict__ Ef = f.Z;           // after the polish: the kept eigenvectors [z][32], zero beyond the live rows / kept columns
-    const int64_t cs = (int64_t)v.N * v.cap;
+    double* St = Dl;                               // [16][BT_SS] the dense S tile, once the polish is done
     // S: the side the kept eigenvectors live on (Y going left, X going right); O: the other side
-    const double* Sprev = going_left ? (rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr) : (lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr);
-    const double* Oprev = going_left ? (lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr) : (rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr);
-    const int DS = Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = Oprev ? (going_left ? b.Dl : b.Dr) : 1;
-    const double* phS = v.phi + (int64_t)(going_left ? rid : lid) * v.N * d;
-    const double* phO = v.phi + (int64_t)(going_left ? lid : rid) * v.N * d;
-    double* __restrict__ out = going_left ? v.RE + (int64_t)rid * cs : v.LE + (int64_t)lid * cs;
+    const int DS = ta.Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = ta.Oprev ? (going_left ? b.Dl : b.Dr) : 1;
     const KrSide ks = kr_side(Sf, DS, d, !going_left), ko = kr_side(Of, DO, d, going_left != 0);
     const int KO = going_left ? b.X : b.Y, NS = going_left ? b.Y : b.X;      // bt_new as [k = O index][n = S index]
-    const int KP = (KO + 3) & ~3, ZP = (DS * d + 3) & ~3;
-    const double* Mbase = going_left ? v.btn : v.btnT;
+    const int KP = (KO + 3) & ~3, ZS = DS * d, ZP = (ZS + 3) & ~3;
     // the loader role of a thread: threads [0, 256) the S side, [256, 512) the O side; 16 threads per series row, two bond entries and
     // one site state each
     const bool lower = tid < 256;
     const int lrow = (tid & 255) >> 4, lj = tid & 15;
     // ONE tile per tile workgroup, no loop around any of this: a loop invites the compiler to hoist the address arithmetic of every
     // phase - polish, roles, products - in front of it, and the kernel then lives in scratch memory (400 bytes per lane, measured)
-    {
-        const int t = bid - nchain - nsplit;
-        // ---- requests: the tile's factors and its slice of bt_new, then (first pass) what k_eig_fin reads --------------------------
-        Span tl{0, 0, 0, 0};
-        d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
-        double bm[32];
-        double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
-        if (role == 0) {
-            tl = tile_span_k(v, t);
-            if (lower || want_next) {
-                const double* prev = lower ? Sprev : Oprev;
-                const double* ph = lower ? phS : phO;
-                const int Dp = lower ? DS : DO;
-                const bool valid = lrow < tl.count;
-                const int64_t smp = tl.start + (valid ? lrow : 0);
-                fe0 = (valid && lj < Dp) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
-                fe1 = (valid && lj + 16 < Dp) ? prev[smp * v.cap + lj + 16] : 0.0;
-                fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
-            }
-            if (want_next) {
-                // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
-                // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
-                // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
-                const unsigned col = (unsigned)min(16 * wave + i16, NS - 1);
-                const double* __restrict__ M = Mbase + (int64_t)tl.cls * b.L;        // (uniform base + 32-bit lane offsets)
+    // ---- requests: the tile's factors and its slice of bt_new, then what k_eig_fin reads ---------------------------------------
+    Span tl{0, 0, 0, 0};
+    d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
+    double bm[32];
+    double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
+    if (role == 0) {
+        tl = tile_span_k(v, bid - nchain - nsplit);
+        if (want_next) {
+            // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
+            // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
+            // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
+            const unsigned col = (unsigned)min(16 * wave + i16, NS - 1);
+            const double* __restrict__ M = ta.M + (int64_t)tl.cls * b.L;        // (uniform base + 32-bit lane offsets)
 #pragma unroll
-                for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
-            }
+            for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
         }
-        double gdiag = 0.0, triflag = 0.0, tnorm_in = 0.0, lam_in = 0.0, res_in = 0.0;
-        int redo_in = 0;
-        double zin[8];
-        {
-            gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
-            triflag = ws[WS_MISC + 3];
-            tnorm_in = ws[WS_MISC + 2];
-            lam_in = tid < K0 ? ws[WS_LAM + tid] : 0.0;
-            res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
-            redo_in = v.sc->redo;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
+        if (lower || want_next) {
+            const double* prev = lower ? ta.Sprev : ta.Oprev;
+            const double* ph = lower ? ta.phS : ta.phO;
+            const int Dp = lower ? DS : DO;
+            const bool valid = lrow < tl.count;
+            const int64_t smp = tl.start + (valid ? lrow : 0);
+            fe0 = (valid && lj < Dp) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
+            fe1 = (valid && lj + 16 < Dp) ? prev[smp * v.cap + lj + 16] : 0.0;
+            fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
         }
-        TSTAMP();      // [1] everything requested
-        if (role == 0) {
-            double* fac = lower ? Sf : Of;
-            fac[lrow * BT_ELS + lj] = fe0;
-            fac[lrow * BT_ELS + lj + 16] = fe1;
-            if (lj < BT_ELS - 32) fac[lrow * BT_ELS + 32 + lj] = 0.0;
-            fac[16 * BT_ELS + lrow * BT_PLS + lj] = fp;
-            if (lj < BT_PLS - 16) fac[16 * BT_ELS + lrow * BT_PLS + 16 + lj] = 0.0;
-            __syncthreads();
-            TSTAMP();  // [2] factors in LDS
-            if (want_next) {
-                // P = O bt_new, this wave's 16 columns (two accumulation chains)
-                if (D4 && ko.left) {
-                    const double ph = ko.ph[i16 * BT_PLS + kq];
-                    const double* er = ko.env + i16 * BT_ELS;
+    }
+    const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
+    const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
+    const double lam_in = lane < K0 ? ws[WS_LAM + lane] : 0.0;           // every wave: the truncation rule runs in its lanes
+    const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+    const int redo_in = v.sc->redo;
+    double zin[8];
 #pragma unroll
-                    for (int u = 0; u < 32; u += 2) {
-                        if (4 * u < KP) pacc0 = mfma_f64(er[u] * ph, bm[u], pacc0);
-                        if (4 * u + 4 < KP) pacc1 = mfma_f64(er[u + 1] * ph, bm[u + 1], pacc1);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 32; u += 2) {
-                        if (4 * u < KP) pacc0 = mfma_f64(kr_at(ko, i16, 4u * u + kq), bm[u], pacc0);
-                        if (4 * u + 4 < KP) pacc1 = mfma_f64(kr_at(ko, i16, 4u * u + 4u + kq), bm[u + 1], pacc1);
-                    }
-                }
-            }
-        }
-        TSTAMP();      // [3] P issued (tile workgroups)
-        int nk;
-        double inv;
-        {
-            // ---- k_eig_fin's work, by every workgroup for itself (fin_body / fin_tri<32>: the same operations in the same order) ----
-            double tr = wave_sum(gdiag);
-            if (lane == 0) red[wave] = tr;
-            __syncthreads();
-            tr = 0.0;
-            for (int i = 0; i < BT_T / 64; ++i) tr += red[i];
-            inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
-            if (tid < K0) lam_s[tid] = lam_in;
-            __syncthreads();
-            nk = truncate_rule(lam_s, K0, nspec, tr, inv * inv, v.cutoff, false);
-            TSTAMP();  // [4] trace, truncation rule
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int i = tid + m * BT_T;
-                const int c = i >> 5, kk = i & 31;
-                f.Z[i] = (c < n && kk < nk) ? zin[m] : 0.0;
-            }
-            if (tid < 32) f.misc[32 + tid] = tid < nk ? res_in : 0.0;
-            if (tid == 0) f.misc[2] = tnorm_in;
-            __syncthreads();
-            TSTAMP();  // [5] candidates in LDS
-            bool ok = triflag == 1.0 && redo_in == 0;
-            if (ok) ok = verify_and_polish<32>(f, n, nk);
-            TSTAMP();  // [6] verified + polished
-            if (!ok) {
-                if (bid == 0 && tid == 0 && redo_in == 0) {
-                    v.sc->redo = 1 + (going_left ? v.T - 2 - lid : v.T - 1 + lid);      // 1 + the bond's position in the sweep
-                    v.sc->eig_fallbacks += 1;
-                }
-                return;
-            }
-            if (bid == 0) {                                 // publication (fin_body)
-                if (tid < K0) v.lam[tid] = lam_s[tid];
-                if (tid == 0) {
-                    bool bad = !(tr == tr) || tr > 1e300;
-                    for (int i = 0; i < K0; ++i) {
-                        const double P = lam_s[i] * inv * inv;
-                        if (!(P == P) || P > 1e300) bad = true;
-                    }
-                    v.sc->n_keep = nk;
-                    v.sc->n_spec = K0;
-                    v.sc->bt_norm2 = tr;
-                    v.sc->inv_norm = inv;
-                    v.sc->eig_sweeps = 0;
-                    if (bad) v.sc->status = MPST_ERR_SVD;
-                    v.chi[lid + 1] = nk;
-                }
-            }
-            __syncthreads();                                // the polish scratch is free, E is final
-            TSTAMP();  // [7] published
-            if (role != 0) {
-                if (!lower) return;                         // (a retired wave no longer counts at the barriers of the 256-thread bodies)
-                if (role == 2) chain_bt_block(v, lid, going_left, bid, f.D, Ef, 32, nk, inv);
-                else split_block(v, lid, going_left, bid - nchain, nsplit, Ef, 32, nk, inv);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                TSTAMP();  // [8] role done, stores drained
-                return;
-            }
-        }
-        // env' = S E: one chain of MFMAs per 16-column tile, in the order of k_env / k_env_split (at most 32 vectors are kept here)
-        if (wave < 2) {
-            const int col = wave * 16 + i16;
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            if (wave * 16 < nk) {
-                if (D4 && ks.left) {
-                    const double ph = ks.ph[i16 * BT_PLS + kq];
-                    const double* er = ks.env + i16 * BT_ELS;
-#pragma unroll
-                    for (int u = 0; u < 32; ++u)
-                        if (4 * u < ZP) acc = mfma_f64(er[u] * ph, Ef[(4 * u + kq) * 32 + col], acc);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 32; ++u)
-                        if (4 * u < ZP) acc = mfma_f64(kr_at(ks, i16, 4u * u + kq), Ef[(4 * u + kq) * 32 + col], acc);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = kq + 4 * r;
-                    if (i < tl.count && col < nk) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) envs[(kq + 4 * r) * BT_ENVS + col] = acc[r];
-        }
-        TSTAMP();      // [8] new environment rows
-        if (!want_next) return;
+    for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
+    TSTAMP();      // [1] everything requested
+    if (role == 0) {
+        double* fac = lower ? Sf : Of;
+        fac[lrow * BT_ELS + lj] = fe0;
+        fac[lrow * BT_ELS + lj + 16] = fe1;
+        if (lj < BT_ELS - 32) fac[lrow * BT_ELS + 32 + lj] = 0.0;
+        fac[16 * BT_ELS + lrow * BT_PLS + lj] = fp;
+        if (lj < BT_PLS - 16) fac[16 * BT_ELS + lrow * BT_PLS + 16 + lj] = 0.0;
         __syncthreads();
-        {
-            // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
-            d4 zacc = {0.0, 0.0, 0.0, 0.0};
+        TSTAMP();  // [2] factors in LDS
+        if (want_next) {
+            // P = O bt_new, this wave's 16 columns (two accumulation chains)
+            if (D4 && ko.left) {
+                const double ph = ko.ph[i16 * BT_PLS + kq];
+                const double* er = ko.env + i16 * BT_ELS;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) zacc = mfma_f64(envs[i16 * BT_ENVS + 4 * u + kq], Ef[(16 * wave + i16) * 32 + 4 * u + kq], zacc);
+                for (int u = 0; u < 32; u += 2) {
+                    if (4 * u < KP) pacc0 = mfma_f64(er[u] * ph, bm[u], pacc0);
+                    if (4 * u + 4 < KP) pacc1 = mfma_f64(er[u + 1] * ph, bm[u + 1], pacc1);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 32; u += 2) {
+                    if (4 * u < KP) pacc0 = mfma_f64(kr_at(ko, i16, 4u * u + kq), bm[u], pacc0);
+                    if (4 * u + 4 < KP) pacc1 = mfma_f64(kr_at(ko, i16, 4u * u + 4u + kq), bm[u + 1], pacc1);
+                }
+            }
+        }
+    }
+    TSTAMP();      // [3] P issued (tile workgroups)
+    // ---- k_eig_fin's work, by every workgroup for itself: trace, truncation rule, verification, polish ---------------------------------
+    double tr = wave_sum(gdiag);
+    if (lane == 0) red[wave] = tr;
+    __syncthreads();
+    tr = 0.0;
+    for (int i = 0; i < BT_T / 64; ++i) tr += red[i];
+    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+    const int nk = truncate_rule_lanes(lam_in, K0, nspec, tr, inv * inv, v.cutoff);
+    TSTAMP();      // [4] trace, truncation rule
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int i = tid + m * BT_T;
+        const int c = i >> 5, kk = i & 31;
+        Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
+    }
+    __syncthreads();
+    TSTAMP();      // [5] candidates in LDS
+    bool ok = triflag == 1.0 && redo_in == 0;
+    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0));
+    TSTAMP();      // [6] verified + polished
+    if (!ok) {
+        if (bid == 0 && tid == 0 && redo_in == 0) {
+            v.sc->redo = 1 + (going_left ? v.T - 2 - lid : v.T - 1 + lid);      // 1 + the bond's position in the sweep
+            v.sc->eig_fallbacks += 1;
+        }
+        return;
+    }
+    if (bid == 0 && wave == 0) {                    // publication (fin_body)
+        if (lane < K0) v.lam[lane] = lam_in;
+        bool bad = !(tr == tr) || tr > 1e300;
+        const double P = lam_in * inv * inv;
+        if (__ballot(lane < K0 && (!(P == P) || P > 1e300))) bad = true;
+        if (lane == 0) {
+            v.sc->n_keep = nk;
+            v.sc->n_spec = K0;
+            v.sc->bt_norm2 = tr;
+            v.sc->inv_norm = inv;
+            v.sc->eig_sweeps = 0;
+            if (bad) v.sc->status = MPST_ERR_SVD;
+            v.chi[lid + 1] = nk;
+        }
+    }
+    const double* __restrict__ Ef = Zl;
+    if (role != 0) {
+        if (!lower) return;                         // (a retired wave no longer counts at the barriers of the 256-thread bodies)
+        if (role == 2) chain_bt_block(v, lid, going_left, bid, Dl, Ef, BT_ZS, nk, inv);
+        else split_block(v, lid, going_left, bid - nchain, nsplit, Ef, BT_ZS, nk, inv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TSTAMP();  // [7] role done, stores drained
+        return;
+    }
+    // ---- the dense S tile, by all waves (the single chain of env' then pays one LDS read per MFMA, whichever side S is) ------------
+    {
+        const int row = tid >> 5, z0 = tid & 31;    // 4 entries per thread: z0, z0 + 32, ...
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int z = z0 + 32 * m;
+            St[row * BT_SS + z] = z < ZS ? kr_at(ks, row, (unsigned)z) : 0.0;
+        }
+    }
+    __syncthreads();
+    TSTAMP();      // [7] S tile formed
+    // env' = S E: one chain of MFMAs per 16-column tile, in the order of k_env / k_env_split (at most 32 vectors are kept here)
+    if (wave < 2) {
+        const int col = wave * 16 + i16;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (wave * 16 < nk) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (4 * u < ZP) acc = mfma_f64(St[i16 * BT_SS + 4 * u + kq], Ef[(4 * u + kq) * BT_ZS + col], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
-                if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
+                const int i = kq + 4 * r;
+                if (i < tl.count && col < nk) ta.out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
             }
         }
-        __syncthreads();
-        TSTAMP();      // [9] z, row dot
-        if (tid < 16 && tid < tl.count) {
-            const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
-                              ((redy[64 + tid] + redy[80 + tid]) + (redy[96 + tid] + redy[112 + tid]))) * inv;
-            // the reader (k_grad_s) adds the eight slice slots of a series in order: the overlap in slot 0, zeros behind it
-            double2* yp = (double2*)(v.ypart + (int64_t)(tl.start + tid) * YS_MAXSL);
-            yp[0] = make_double2(y, 0.0);
-            yp[1] = make_double2(0.0, 0.0);
-            yp[2] = make_double2(0.0, 0.0);
-            yp[3] = make_double2(0.0, 0.0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TSTAMP();      // [10] stores drained
+#pragma unroll
+        for (int r = 0; r < 4; ++r) envs[(kq + 4 * r) * BT_ENVS + col] = acc[r];
     }
+    TSTAMP();      // [8] new environment rows
+    if (!want_next) return;
+    __syncthreads();
+    {
+        // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
+        d4 zacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zacc = mfma_f64(envs[i16 * BT_ENVS + 4 * u + kq], Ef[(16 * wave + i16) * BT_ZS + 4 * u + kq], zacc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
+            if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
+        }
+    }
+    __syncthreads();
+    TSTAMP();      // [9] z, row dot
+    if (tid < 16 && tid < tl.count) {
+        const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
+                          ((redy[64 + tid] + redy[80 + tid]) + (redy[96 + tid] + redy[112 + tid]))) * inv;
+        // the reader (k_grad_s) adds the eight slice slots of a series in order: the overlap in slot 0, zeros behind it
+        double2* yp = (double2*)(v.ypart + (int64_t)(tl.start + tid) * YS_MAXSL);
+        yp[0] = make_double2(y, 0.0);
+        yp[1] = make_double2(0.0, 0.0);
+        yp[2] = make_double2(0.0, 0.0);
+        yp[3] = make_double2(0.0, 0.0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP();      // [10] stores drained
 #undef TSTAMP
 }
 // two register budgets of the same body: 128 VGPRs (two workgroups per CU: the chain / split workgroups find room beside the tile
-// workgroups; 57 dwords of private segment) or whatever the body wants (162: one workgroup per CU)
+// workgroups) or whatever the body wants (one workgroup per CU)
 template <bool D4>
-__global__ __launch_bounds__(BT_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bond_tail(View v, int lid, int going_left, int nsplit, int nchain, int want_next) {
-    bond_tail_body<D4>(v, lid, going_left, nsplit, nchain, want_next);
+__global__ __launch_bounds__(BT_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bond_tail(View v, TailArgs ta) {
+    bond_tail_body<D4>(v, ta);
 }
 template <bool D4>
-__global__ __launch_bounds__(BT_T) void k_bond_tail_w(View v, int lid, int going_left, int nsplit, int nchain, int want_next) {
-    bond_tail_body<D4>(v, lid, going_left, nsplit, nchain, want_next);
+__global__ __launch_bounds__(BT_T) void k_bond_tail_w(View v, TailArgs ta) {
+    bond_tail_body<D4>(v, ta);
 }
 
 // ---- the kernels proper: one fit per launch (View in the kernel arguments), or K independent fits of the same shape per
@@ -1671,22 +1782,37 @@ bool bond_tail_supported(const View& v) {
     return v.zw != 2 && v.loss == MPST_LOSS_KLD && v.chi_max <= 32 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.svd_alg != MPST_SVD_JACOBI && v.d >= 2 && v.d <= 16;
 }
 void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, hipStream_t s) {
-    const int dm = v.d * v.cap;
-    const int nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
-    const int nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
+    const int dm = v.d * v.cap, rid = lid + 1;
+    TailArgs ta;
+    ta.lid = lid;
+    ta.going_left = going_left;
+    ta.nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
+    ta.nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
+    ta.flags = want_next ? 1 : 0;
+    const int64_t cs = (int64_t)v.N * v.cap;
+    const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr;
+    const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr;
+    const double* phl = v.phi + (int64_t)lid * v.N * v.d;
+    const double* phr = v.phi + (int64_t)rid * v.N * v.d;
+    ta.Sprev = going_left ? REn : LEp;
+    ta.Oprev = going_left ? LEp : REn;
+    ta.phS = going_left ? phr : phl;
+    ta.phO = going_left ? phl : phr;
+    ta.M = going_left ? v.btn : v.btnT;
+    ta.out = going_left ? v.RE + (int64_t)rid * cs : v.LE + (int64_t)lid * cs;
     static const bool wide = [] { const char* e = getenv("MPST_TAIL_WIDE"); return e && e[0] == '1'; }();
     // which bond's tail leaves its phase stamps (mpst_get_tail_phases): MPST_TAIL_STAMP="lid,going_left", default the middle bond going left
     static const int stamp_lid = [] { const char* e = getenv("MPST_TAIL_STAMP"); return e ? atoi(e) : -1; }();
     static const int stamp_dir = [] { const char* e = getenv("MPST_TAIL_STAMP"); const char* q = e ? strchr(e, ',') : nullptr; return q ? atoi(q + 1) : 1; }();
-    if (lid == (stamp_lid >= 0 ? stamp_lid : (v.T - 1) / 2) && (going_left != 0) == (stamp_dir != 0)) want_next |= 2;
+    if (lid == (stamp_lid >= 0 ? stamp_lid : (v.T - 1) / 2) && (going_left != 0) == (stamp_dir != 0)) ta.flags |= 2;
     const size_t lds = (size_t)BT_LDS_DOUBLES * sizeof(double);
-    const dim3 grid(nchain + nsplit + v.ntiles);          // one 16-series tile per tile workgroup
+    const dim3 grid(ta.nchain + ta.nsplit + v.ntiles);          // one 16-series tile per tile workgroup
     if (wide) {
-        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail_w<true>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
-        else hipLaunchKernelGGL(k_bond_tail_w<false>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail_w<true>, grid, dim3(BT_T), lds, s, v, ta);
+        else hipLaunchKernelGGL(k_bond_tail_w<false>, grid, dim3(BT_T), lds, s, v, ta);
     } else {
-        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
-        else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_T), lds, s, v, lid, going_left, nsplit, nchain, want_next);
+        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_T), lds, s, v, ta);
+        else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_T), lds, s, v, ta);
     }
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
