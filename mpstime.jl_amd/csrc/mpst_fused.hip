@@ -725,12 +725,15 @@ __device__ __forceinline__ void env_split_body(const View& v, int lid, int going
     const int slot = wave / (4 / tp), nt = wave % (4 / tp);
     const int col = nt * 16 + i16;
     const bool cv = nt < nt_out && col < Dout;
-    double bv[32];
+    const int nsteps = ZP >> 2, ks4 = env_ks4(nsteps);          // four chains over the quarters of the contraction (mpst_internal.h)
+    double bv[4][8];                                            // quarter-major: d*chi <= 128 here, at most 8 k-steps per quarter
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const int z = 4 * u + kq;
-        bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = 4 * (q * ks4 + u) + kq;
+            bv[q][u] = (cv && u < ks4 && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
+        }
     for (int t0 = (int)blockIdx.x * tp; t0 < v.ntiles; t0 += ntb * tp) {
         if (t0 != (int)blockIdx.x * tp) __syncthreads();          // the previous pass has been consumed
         for (int sl = 0; sl < tp; ++sl) {
@@ -743,14 +746,20 @@ __device__ __forceinline__ void env_split_body(const View& v, int lid, int going
         if (t0 + slot < v.ntiles && nt < nt_out) {
             const Span tl = v.tiles[t0 + slot];
             const double* Xs = smem + slot * 16 * FXS;
-            d4 acc = {0, 0, 0, 0};
+            d4 p[4];
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if (4 * u < ZP) acc = mfma_f64(Xs[i16 * FXS + 4 * u + kq], bv[u], acc);
+            for (int q = 0; q < 4; ++q) p[q] = d4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int step = q * ks4 + u;
+                    if (u < ks4 && step < nsteps) p[q] = mfma_f64(Xs[i16 * FXS + 4 * step + kq], bv[q][u], p[q]);
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = kq + 4 * r;
-                if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+                if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
             }
         }
     }
@@ -1247,7 +1256,8 @@ constexpr int BT_ELS = 37, BT_PLS = 21;      // LDS row strides of the staged fa
                                              // entries / 16 site states and zeros behind them (the padded K extent reads up to 4 beyond the live ones)
 constexpr int BT_FAC = 16 * (BT_ELS + BT_PLS);
 constexpr int BT_SS = 129;                   // row stride of the dense S tile (over D / Dh / misc once the polish is done)
-constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2 * BT_FAC + 16 * BT_ENVS + 128;     // 74.5 KB: two workgroups per CU
+constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2048 + 16 * BT_ENVS + 128;     // 76 KB: two workgroups per CU
+static_assert(2 * BT_FAC <= 2048, "the factors live where the pieces of env' go later");
 static_assert(16 * BT_SS <= 32 * 32 + 1024 + 128, "the dense S tile lives in the polish scratch");
 
 // One side's Khatri-Rao vectors of a 16-series tile, kept as their FACTORS in LDS (environment row, site vector); entry z of row i
@@ -1274,6 +1284,238 @@ __device__ __forceinline__ double kr_at(const KrSide& k, int row, unsigned z) {
     return k.env[row * BT_ELS + ie] * k.ph[row * BT_PLS + ip];
 }
 
+// ---- the back-split and the next bond's tensor inside k_bond_tail: split_block / chain_bt_block (the same products, the same order
+// of operations: the same bits) cut in two - what does not depend on the eigenvectors is REQUESTED at the head of the kernel and
+// arrives under the polish; what follows the polish is MFMAs and stores.  Capacity <= 32 on this path: the shared bond has at most two
+// 16-row blocks, a wave's share of a contraction is one batch of 8 k-steps.
+// (the three roles' requested operands share ONE array of 32 registers per lane - a workgroup has one role; three arrays would all be
+// live across the polish as far as the register allocator can tell.)  Chain role: [0, 16) wpre[it][j][r], the neighbouring site's tensor
+// (operand of the second product); [16, 32) av[j][u], this wave's share of bt_new for the two row blocks of T.
+#define TC_WPRE(it, j, r) R[((it) * 2 + (j)) * 4 + (r)]
+#define TC_AV(j, u) R[16 + (j) * 8 + (u)]
+__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32]) {
+    const int d = v.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int ktc = (v.cap + 15) >> 4;
+    const int s = (job / ktc) % d, c = job / (ktc * d);
+    const double* Bc = v.btn + (int64_t)c * b.L;
+    const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
+    const int nj = (Dc + 15) >> 4;
+    const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];
+    const double* Wn = v.sites + (int64_t)(going_left ? lid - 1 : lid + 2) * v.site_stride;
+    const int Xn = Dnb * d;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int tl = 16 * (wave + 4 * it) + i16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * j + 4 * r + kq;
+                const bool ok = j < nj && tl < Xn && a < Dc;
+                TC_WPRE(it, j, r) = ok ? (going_left ? Wn[(int64_t)tl * b.Dl + a] : Wn[(int64_t)a * Xn + tl]) : 0.0;
+            }
+    }
+    const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
+    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * j + i16;
+        const double* ap = going_left ? Bc + (int64_t)(row * d + s) * b.Y : Bc + s * b.Dr + row;
+        const int64_t astr = going_left ? 1 : b.Y;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = kbeg + 4 * u + kq;
+            TC_AV(j, u) = (j < nj && row < Dc && q < kend) ? ap[(int64_t)q * astr] : 0.0;
+        }
+    }
+}
+__device__ __forceinline__ void tail_chain_finish(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
+                                                  double* __restrict__ cpart /* [4][2][256] */, const double* __restrict__ Ev, const int ldE, const int nk,
+                                                  const double inv) {
+    const int d = v.d;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int ktc = (v.cap + 15) >> 4;
+    const int kt = job % ktc, s = (job / ktc) % d, c = job / (ktc * d);
+    const int k0 = 16 * kt;
+    if (k0 >= nk) return;
+    const int kcol = k0 + i16;
+    const bool kv = kcol < nk;
+    const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
+    const int nj = (Dc + 15) >> 4;
+    const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];
+    const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
+    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        d4 t = {0, 0, 0, 0};
+        if (j < nj) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = kbeg + 4 * u + kq;
+                const double bv = (kv && q < kend) ? Ev[(int64_t)q * ldE + kcol] : 0.0;
+                if (kbeg + 4 * u < kend) t = mfma_f64(TC_AV(j, u), bv, t);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart[(wave * 2 + j) * 256 + r * 64 + lane] = t[r];
+    }
+    __syncthreads();
+    d4 T[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = j * 256 + r * 64 + lane;
+            T[j][r] = ((cpart[o] + cpart[2 * 256 + o]) + (cpart[4 * 256 + o] + cpart[6 * 256 + o])) * inv;
+        }
+    if (going_left) {
+        const int Xp = Dnb * d, Yp = d * nk;
+        double* out = v.bt + (int64_t)c * Xp * Yp;
+        const int ntx = (Xp + 15) >> 4;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int mt = wave + 4 * it;
+            if (mt >= ntx) break;
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (j < nj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(TC_WPRE(it, j, r), T[j][r], acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xr = 16 * mt + kq + 4 * r;
+                if (xr < Xp && kv) out[(int64_t)xr * Yp + s * nk + kcol] = acc[r];
+            }
+        }
+    } else {
+        const int Ypp = d * Dnb, Xp = nk * d;
+        double* out = v.bt + (int64_t)c * Xp * Ypp;
+        const int nty = (Ypp + 15) >> 4;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int nt = wave + 4 * it;
+            if (nt >= nty) break;
+            const int y = 16 * nt + i16;
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (j < nj) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], TC_WPRE(it, j, r), acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + kq + 4 * r;
+                if (k < nk && y < Ypp) out[(int64_t)(k * d + s) * Ypp + y] = acc[r];
+            }
+        }
+    }
+}
+// back-split: tile = (class, row / column tile of the site that keeps the label, kept-column tile) laid out for the CAPACITY (how many
+// vectors are kept is not known when the operands are requested); one tile per wave
+// (registers: a[w][u] = R[8 w + u], the bt_new operand of the wave's tile by contraction range)
+__device__ __forceinline__ void tail_split_tile(const View& v, const BondDimsF& b, int going_left, int tile, int& c, int& m0, int& n0) {
+    const int tkc = (v.cap + 15) >> 4;
+    if (going_left) {
+        const int tx = (b.X + 15) >> 4;
+        c = tile / (tx * tkc);
+        const int rem = tile - c * tx * tkc;
+        m0 = (rem / tkc) * 16;      // row tile of T (x)
+        n0 = (rem % tkc) * 16;      // kept columns
+    } else {
+        const int ty = (b.Y + 15) >> 4;
+        c = tile / (tkc * ty);
+        const int rem = tile - c * tkc * ty;
+        m0 = (rem / ty) * 16;       // kept rows
+        n0 = (rem % ty) * 16;       // column tile of T (y)
+    }
+}
+__device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& b, int going_left, int tile, double (&R)[32]) {
+    const int lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    int c, m0, n0;
+    tail_split_tile(v, b, going_left, tile, c, m0, n0);
+    const bool live = c < v.C;
+    const double* Bc = v.btn + (int64_t)(live ? c : 0) * b.L;
+    // going left  T[x][k] = sum_y bt_new[x][y] E[y][k]: A operand bt_new[m = x][kk = y];  going right T[k][y] = sum_x E[x][k] bt_new[x][y]: B operand bt_new[kk = x][n = y]
+    const int K = going_left ? b.Y : b.X;
+    const int ks4 = (((K + 3) >> 2) + 3) >> 2;
+    const int mm = (going_left ? m0 : n0) + i16;
+    const bool mv = live && mm < (going_left ? b.X : b.Y);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = kbeg + 4 * u + kq;
+            R[8 * w + u] = (mv && k < kend) ? (going_left ? Bc[(int64_t)mm * b.Y + k] : Bc[(int64_t)k * b.Y + mm]) : 0.0;
+        }
+    }
+}
+__device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF& b, int lid, int going_left, int blk, int nblk, double (&R)[32],
+                                                  const double* __restrict__ Ev, const int ldE, const int nk, const double inv) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    double* Wl = v.sites + (int64_t)lid * v.site_stride;
+    double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
+    const int tkc = (v.cap + 15) >> 4;
+    const int K = going_left ? b.Y : b.X;
+    const int ks4 = (((K + 3) >> 2) + 3) >> 2;
+    const int ntile = v.C * tkc * (((going_left ? b.X : b.Y) + 15) >> 4);
+    // (the launcher gives every wave of the split workgroups one tile of the capacity layout: no loop - see k_bond_tail on loops)
+    const int tile = blk * 4 + wave;
+    int c, m0, n0;
+    tail_split_tile(v, b, going_left, tile, c, m0, n0);
+    const int kn0 = going_left ? n0 : m0;           // first kept vector of the tile
+    if (tile < ntile && kn0 < nk) {
+        const int kcol = kn0 + i16;
+        d4 p[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            p[w] = d4{0, 0, 0, 0};
+            const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = kbeg + 4 * u + kq;
+                const double e = (kcol < nk && k < kend) ? Ev[(int64_t)k * ldE + kcol] : 0.0;
+                if (kbeg + 4 * u < kend) p[w] = going_left ? mfma_f64(R[8 * w + u], e, p[w]) : mfma_f64(e, R[8 * w + u], p[w]);
+            }
+        }
+        if (going_left) {
+            double* out = Wl + (int64_t)c * b.X * nk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + kq + 4 * r;
+                if (row < b.X && n0 + i16 < nk) out[(int64_t)row * nk + n0 + i16] = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) * inv;
+            }
+        } else {
+            double* out = Wr + (int64_t)c * nk * b.Y;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + kq + 4 * r;
+                if (row < nk && n0 + i16 < b.Y) out[(int64_t)row * b.Y + n0 + i16] = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) * inv;
+            }
+        }
+    }
+    // the other site: the kept eigenvectors themselves
+    // (two-dimensional walks: an integer division per element costs more than the copy)
+    if (going_left) {
+        for (int k = blk; k < nk; k += nblk)
+            for (int y = threadIdx.x; y < b.Y; y += 256) Wr[(int64_t)k * b.Y + y] = Ev[(int64_t)y * ldE + k];
+        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid;
+    } else {
+        const int k = threadIdx.x & 31;
+        for (int x = blk * 8 + ((int)threadIdx.x >> 5); x < b.X; x += nblk * 8)
+            if (k < nk) Wl[(int64_t)x * nk + k] = Ev[(int64_t)x * ldE + k];
+        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid + 1;
+    }
+}
+
 // what the host knows of a tail launch: no pointer arithmetic on the device's scalar unit in front of the first request
 struct TailArgs {
     const double *Sprev, *Oprev;    // environment rows of the side the eigenvectors live on / of the other side (null: chain end)
@@ -1289,7 +1531,7 @@ struct TailArgs {
 // Else Z <- Z (I - D/2 + 3 D^2 / 8): the deviation becomes 5/8 |D|^3 <= 1.7e-14 for |D| <= 3e-5 - ONE pass over Z where
 // k_eig_fin's verify_and_polish forms D twice (D^2 is a 32^3 product); beyond 3e-5 a second, first-order pass follows.
 __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __restrict__ D, double* __restrict__ Dh, double* __restrict__ misc,
-                                            const int n, const int K, const double rres) {
+                                            const int n, const int K, const double rres, double& emax0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jl = lane & 15, q4 = lane >> 4;
     for (int pass = 0; pass < 2; ++pass) {
@@ -1332,6 +1574,7 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
             emax = fmax(emax, misc[8 + w]);
             rmax = fmax(rmax, misc[16 + w]);
         }
+        if (pass == 0) emax0 = emax;
         if (!(rmax < 1e-8) || !(emax < 1e-4)) return false;        // (NaN fails both)
         if (emax < 1e-13) return true;
         if (pass == 1 && !(emax < 1e-8)) return false;             // the second pass starts below 1e-12: anything else is not a rounding effect
@@ -1380,25 +1623,24 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
     return true;
 }
 
-// NDTensors truncate! as truncate_rule() applies it (the same operations in the same order), with the K0 <= 32 eigenvalues in the lanes
-// of the calling wave instead of an array in LDS every thread walks (1 us of dependent LDS reads)
+// NDTensors truncate! (relative cutoff, mindim 1) with the K <= 32 largest eigenvalues in the lanes of the calling wave (lane k:
+// lam_k, zero beyond K) instead of an array in LDS every thread walks (1.3 us of dependent reads).  The rule drops values from the small end
+// while the discarded weight stays within cutoff * scale; the weight behind value m is base + sum_{i >= m} P_i (base: what lies beyond the K
+// values, trace - sum), so the answer is the smallest m >= 1 whose tail qualifies - one prefix scan and one ballot.  The sums are taken in
+// another order than truncate_rule()'s loop: the two can differ where a tail equals the threshold to the last bit.
 __device__ __forceinline__ int truncate_rule_lanes(const double lam_lane, const int K, const int ns, const double tr, const double inv2, const double cutoff) {
+    const int lane = threadIdx.x & 63;
     const double scale0 = tr * inv2;
     const double scale = scale0 == 0.0 ? 1.0 : scale0;
-    double kept = 0.0;
-    for (int i = 0; i < K; ++i) kept += readlane_f64(lam_lane, i) * inv2;
-    int nk = K;
-    double truncerr = scale0 - kept;
-    if (truncerr < 0.0 || ns <= K) truncerr = 0.0;
-    if (ns > 1) {
-        while (nk > 1) {
-            const double p = readlane_f64(lam_lane, nk - 1) * inv2;
-            if (!(truncerr + p <= cutoff * scale)) break;
-            truncerr += p;
-            --nk;
-        }
-    }
-    return nk;
+    const double P = lane < K ? lam_lane * inv2 : 0.0;
+    const double pre = wave_incl_scan(P);
+    const double kept = readlane_f64(pre, 63);
+    double base = scale0 - kept;
+    if (base < 0.0 || ns <= K) base = 0.0;
+    const double tail = base + ((kept - pre) + P);
+    const unsigned long long ok = __ballot(lane >= 1 && lane < K && tail <= cutoff * scale);
+    if (ns <= 1 || ok == 0ull) return K;
+    return __ffsll((long long)ok) - 1;
 }
 
 // D4: d == 4 (the headline shapes): on the left side a = u, s = kq are immediates
@@ -1420,71 +1662,87 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     if (tid == 0 && (ta.flags & 2)) {
         if (bid == nchain + nsplit) stp = v.sc->eig_stamps + 16;
         else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
-        else if (bid == nchain) stp = v.sc->eig_stamps + 40;
+        else if (bid == nchain) stp = v.sc->eig_stamps + 48;
     }
     int sti = 0;
 #define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TSTAMP();
-    const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
-    const BondDimsF b = bond_dims_f(v, lid);
-    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
-    const double* __restrict__ ws = v.eig_ws;
     double* Zl = smem;                             // [128][BT_ZS] candidates, then the kept eigenvectors E (zero beyond the live rows / kept columns)
     double* Dl = Zl + 128 * BT_ZS;                 // [32][32]
     double* Dh = Dl + 1024;                        // [1024]
     double* misc = Dh + 1024;                      // [128]
-    double* Sf = misc + 128;                       // factors of the S side, then of the O side
+    double* Sf = misc + 128;                       // factors of the S side, then of the O side ...
     double* Of = Sf + BT_FAC;
-    double* envs = Of + BT_FAC;                    // [16][BT_ENVS] new environment rows of the tile
+    double* part = Sf;                             // ... and, once both are consumed, [4 quarters][2 column tiles][256] pieces of env'
+    double* envs = part + 2048;                    // [16][BT_ENVS] new environment rows of the tile
     double* redy = envs + 16 * BT_ENVS;            // [8][16] the waves' pieces of yhat
     double* St = Dl;                               // [16][BT_SS] the dense S tile, once the polish is done
-    // S: the side the kept eigenvectors live on (Y going left, X going right); O: the other side
-    const int DS = ta.Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = ta.Oprev ? (going_left ? b.Dl : b.Dr) : 1;
-    const KrSide ks = kr_side(Sf, DS, d, !going_left), ko = kr_side(Of, DO, d, going_left != 0);
-    const int KO = going_left ? b.X : b.Y, NS = going_left ? b.Y : b.X;      // bt_new as [k = O index][n = S index]
-    const int KP = (KO + 3) & ~3, ZS = DS * d, ZP = (ZS + 3) & ~3;
+    const double* __restrict__ ws = v.eig_ws;
     // the loader role of a thread: threads [0, 256) the S side, [256, 512) the O side; 16 threads per series row, two bond entries and
     // one site state each
     const bool lower = tid < 256;
     const int lrow = (tid & 255) >> 4, lj = tid & 15;
     // ONE tile per tile workgroup, no loop around any of this: a loop invites the compiler to hoist the address arithmetic of every
     // phase - polish, roles, products - in front of it, and the kernel then lives in scratch memory (400 bytes per lane, measured)
-    // ---- requests: the tile's factors and its slice of bt_new, then what k_eig_fin reads ---------------------------------------
-    Span tl{0, 0, 0, 0};
-    d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
-    double bm[32];
-    double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
-    if (role == 0) {
-        tl = tile_span_k(v, bid - nchain - nsplit);
-        if (want_next) {
-            // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
-            // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
-            // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
-            const unsigned col = (unsigned)min(16 * wave + i16, NS - 1);
-            const double* __restrict__ M = ta.M + (int64_t)tl.cls * b.L;        // (uniform base + 32-bit lane offsets)
-#pragma unroll
-            for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
-        }
-        if (lower || want_next) {
-            const double* prev = lower ? ta.Sprev : ta.Oprev;
-            const double* ph = lower ? ta.phS : ta.phO;
-            const int Dp = lower ? DS : DO;
-            const bool valid = lrow < tl.count;
-            const int64_t smp = tl.start + (valid ? lrow : 0);
-            fe0 = (valid && lj < Dp) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
-            fe1 = (valid && lj + 16 < Dp) ? prev[smp * v.cap + lj + 16] : 0.0;
-            fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
-        }
-    }
-    const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
-    const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
-    const double lam_in = lane < K0 ? ws[WS_LAM + lane] : 0.0;           // every wave: the truncation rule runs in its lanes
-    const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
-    const int redo_in = v.sc->redo;
+    // ---- requests, first those that need nothing but the kernel arguments: the bond dimensions are a dependent (scalar) load from memory,
+    // about a microsecond on a cold start, and everything asked for before their first use is in flight by the time they arrive ----
     double zin[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
-    TSTAMP();      // [1] everything requested
+    const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
+    double lam_in = lane < 32 ? ws[WS_LAM + lane] : 0.0;                 // every wave: the truncation rule runs in its lanes
+    const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+    const int redo_in = v.sc->redo;
+    TSTAMP();      // [1] candidates requested
+    Span tl{0, 0, 0, 0};
+    double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
+    if (role == 0) {
+        tl = tile_span_k(v, bid - nchain - nsplit);
+        if (lower || want_next) {
+            // whole rows (the capacity is a kernel argument); what lies beyond the live bond is dropped when the dimensions are known
+            const double* prev = lower ? ta.Sprev : ta.Oprev;
+            const double* ph = lower ? ta.phS : ta.phO;
+            const bool valid = lrow < tl.count;
+            const int64_t smp = tl.start + (valid ? lrow : 0);
+            fe0 = (valid && lj < v.cap) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
+            fe1 = (valid && lj + 16 < v.cap) ? (prev ? prev[smp * v.cap + lj + 16] : 1.0) : 0.0;
+            fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
+        }
+    }
+    TSTAMP();      // [2] factors requested
+    // ---- ... then those that need the bond dimensions -----------------------------------------------------------------------
+    const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
+    const BondDimsF b = bond_dims_f(v, lid);
+    const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
+    // S: the side the kept eigenvectors live on (Y going left, X going right); O: the other side
+    const int DS = ta.Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = ta.Oprev ? (going_left ? b.Dl : b.Dr) : 1;
+    const KrSide ks = kr_side(Sf, DS, d, !going_left), ko = kr_side(Of, DO, d, going_left != 0);
+    const int KO = going_left ? b.X : b.Y, NS = going_left ? b.Y : b.X;      // bt_new as [k = O index][n = S index]
+    const int KP = (KO + 3) & ~3, ZS = DS * d, ZP = (ZS + 3) & ~3;
+    if (stp) { asm volatile("" :: "s"(KO), "s"(NS)); }
+    TSTAMP();      // [3] bond dimensions known
+    d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
+    double bm[32];          // requested operands of the workgroup's role: the tile's slice of bt_new / see tail_chain_request, tail_split_load
+    if (role == 0 && want_next) {
+        // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
+        // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
+        // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
+        const unsigned col = (unsigned)min(16 * wave + i16, NS - 1);
+        const double* __restrict__ M = ta.M + (int64_t)tl.cls * b.L;        // (uniform base + 32-bit lane offsets)
+#pragma unroll
+        for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
+    }
+    if (role == 2 && lower) tail_chain_request(v, b, lid, going_left, bid, bm);
+    if (role == 1 && lower) tail_split_load(v, b, going_left, (bid - nchain) * 4 + wave, bm);
+    const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
+    lam_in = lane < K0 ? lam_in : 0.0;
+    {
+        const int Dp = lower ? DS : DO;
+        const bool bnd = (lower ? ta.Sprev : ta.Oprev) == nullptr;      // chain end: the one live entry is 1
+        fe0 = lj < Dp ? fe0 : 0.0;
+        fe1 = (lj + 16 < Dp && !bnd) ? fe1 : 0.0;
+    }
+    TSTAMP();      // [4] everything requested
     if (role == 0) {
         double* fac = lower ? Sf : Of;
         fac[lrow * BT_ELS + lj] = fe0;
@@ -1492,8 +1750,41 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         if (lj < BT_ELS - 32) fac[lrow * BT_ELS + 32 + lj] = 0.0;
         fac[16 * BT_ELS + lrow * BT_PLS + lj] = fp;
         if (lj < BT_PLS - 16) fac[16 * BT_ELS + lrow * BT_PLS + 16 + lj] = 0.0;
-        __syncthreads();
-        TSTAMP();  // [2] factors in LDS
+    }
+    {
+        const double trw = wave_sum(gdiag);         // pieces of the trace: they meet at the barrier the factors need anyway
+        if (lane == 0) red[wave] = trw;
+    }
+    __syncthreads();
+    TSTAMP();      // [5] factors in LDS, trace pieces published
+    // ---- k_eig_fin's work, by every workgroup for itself: trace, truncation rule, verification, polish ---------------------------------
+    double tr = 0.0;
+    for (int i = 0; i < BT_T / 64; ++i) tr += red[i];
+    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
+    const int nk = truncate_rule_lanes(lam_in, K0, nspec, tr, inv * inv, v.cutoff);
+    TSTAMP();      // [4] trace, truncation rule
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int i = tid + m * BT_T;
+        const int c = i >> 5, kk = i & 31;
+        Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
+    }
+    __syncthreads();
+    TSTAMP();      // [5] candidates in LDS
+    bool ok = triflag == 1.0 && redo_in == 0;
+    double emax0 = 0.0;
+    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0);
+    TSTAMP();      // [6] verified + polished
+    if (!ok) {
+        if (bid == 0 && tid == 0 && redo_in == 0) {
+            v.sc->redo = 1 + (going_left ? v.T - 2 - lid : v.T - 1 + lid);      // 1 + the bond's position in the sweep
+            v.sc->eig_fallbacks += 1;
+        }
+        return;
+    }
+    // P = O bt_new AFTER the polish: its operand (128 KB of bt_new per workgroup: the CU's L1 moves 64 bytes a cycle) has arrived by now,
+    // the candidates came first
+    if (role == 0) {
         if (want_next) {
             // P = O bt_new, this wave's 16 columns (two accumulation chains)
             if (D4 && ko.left) {
@@ -1513,40 +1804,15 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             }
         }
     }
-    TSTAMP();      // [3] P issued (tile workgroups)
-    // ---- k_eig_fin's work, by every workgroup for itself: trace, truncation rule, verification, polish ---------------------------------
-    double tr = wave_sum(gdiag);
-    if (lane == 0) red[wave] = tr;
-    __syncthreads();
-    tr = 0.0;
-    for (int i = 0; i < BT_T / 64; ++i) tr += red[i];
-    const double inv = v.rescale_after ? 1.0 / sqrt(tr) : 1.0;
-    const int nk = truncate_rule_lanes(lam_in, K0, nspec, tr, inv * inv, v.cutoff);
-    TSTAMP();      // [4] trace, truncation rule
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        const int i = tid + m * BT_T;
-        const int c = i >> 5, kk = i & 31;
-        Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
-    }
-    __syncthreads();
-    TSTAMP();      // [5] candidates in LDS
-    bool ok = triflag == 1.0 && redo_in == 0;
-    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0));
-    TSTAMP();      // [6] verified + polished
-    if (!ok) {
-        if (bid == 0 && tid == 0 && redo_in == 0) {
-            v.sc->redo = 1 + (going_left ? v.T - 2 - lid : v.T - 1 + lid);      // 1 + the bond's position in the sweep
-            v.sc->eig_fallbacks += 1;
-        }
-        return;
-    }
+    TSTAMP();      // [10] P issued (tile workgroups)
     if (bid == 0 && wave == 0) {                    // publication (fin_body)
         if (lane < K0) v.lam[lane] = lam_in;
         bool bad = !(tr == tr) || tr > 1e300;
         const double P = lam_in * inv * inv;
         if (__ballot(lane < K0 && (!(P == P) || P > 1e300))) bad = true;
         if (lane == 0) {
+            // how far from orthonormal the candidates were, by class (diagnostics: mpst_get_tail_phases)
+            v.sc->eig_stamps[60 + (emax0 < 1e-13 ? 0 : emax0 < 1e-8 ? 1 : emax0 < 3e-5 ? 2 : 3)] += 1ull;
             v.sc->n_keep = nk;
             v.sc->n_spec = K0;
             v.sc->bt_norm2 = tr;
@@ -1559,13 +1825,15 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     const double* __restrict__ Ef = Zl;
     if (role != 0) {
         if (!lower) return;                         // (a retired wave no longer counts at the barriers of the 256-thread bodies)
-        if (role == 2) chain_bt_block(v, lid, going_left, bid, Dl, Ef, BT_ZS, nk, inv);
-        else split_block(v, lid, going_left, bid - nchain, nsplit, Ef, BT_ZS, nk, inv);
+        if (role == 2) tail_chain_finish(v, b, lid, going_left, bid, bm, Dl, Ef, BT_ZS, nk, inv);
+        else tail_split_finish(v, b, lid, going_left, bid - nchain, nsplit, bm, Ef, BT_ZS, nk, inv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TSTAMP();  // [7] role done, stores drained
         return;
     }
-    // ---- the dense S tile, by all waves (the single chain of env' then pays one LDS read per MFMA, whichever side S is) ------------
+    // ---- the dense S tile, by all waves (env' then pays one LDS read per MFMA, whichever side S is).  It goes over the polish scratch:
+    // the barrier keeps it off the error pieces a slower wave may still be reading (tail_polish returns without one when nothing is to do)
+    __syncthreads();
     {
         const int row = tid >> 5, z0 = tid & 31;    // 4 entries per thread: z0, z0 + 32, ...
 #pragma unroll
@@ -1576,22 +1844,30 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     __syncthreads();
     TSTAMP();      // [7] S tile formed
-    // env' = S E: one chain of MFMAs per 16-column tile, in the order of k_env / k_env_split (at most 32 vectors are kept here)
-    if (wave < 2) {
-        const int col = wave * 16 + i16;
+    // env' = S E, the sums of k_env / k_env_split (mpst_internal.h: four chains over the quarters of the contraction): wave = (column tile,
+    // quarter), the quarters meet in LDS as (q0 + q1) + (q2 + q3).  At most 32 vectors are kept here: two column tiles.
+    {
+        const int nsteps = ZP >> 2, ks4 = env_ks4(nsteps);
+        const int nt = wave & 1, q = wave >> 1;
+        const int col = nt * 16 + i16;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (wave * 16 < nk) {
+        if (nt * 16 < nk) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if (4 * u < ZP) acc = mfma_f64(St[i16 * BT_SS + 4 * u + kq], Ef[(4 * u + kq) * BT_ZS + col], acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = kq + 4 * r;
-                if (i < tl.count && col < nk) ta.out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+            for (int u = 0; u < 8; ++u) {
+                const int step = q * ks4 + u;
+                if (u < ks4 && step < nsteps) acc = mfma_f64(St[i16 * BT_SS + 4 * step + kq], Ef[(4 * step + kq) * BT_ZS + col], acc);
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) envs[(kq + 4 * r) * BT_ENVS + col] = acc[r];
+        for (int r = 0; r < 4; ++r) part[(q * 2 + nt) * 256 + r * 64 + lane] = acc[r];      // (both factor sets are consumed: P is issued, S is dense)
+    }
+    __syncthreads();
+    {
+        const int nt = tid >> 8, e = tid & 255;
+        const double sum = (part[nt * 256 + e] + part[(2 + nt) * 256 + e]) + (part[(4 + nt) * 256 + e] + part[(6 + nt) * 256 + e]);
+        const int i = ((e >> 4) & 3) + 4 * (e >> 6), col = nt * 16 + (e & 15);
+        if (i < tl.count && col < nk) ta.out[(int64_t)(tl.start + i) * v.cap + col] = sum;
+        envs[i * BT_ENVS + col] = sum;
     }
     TSTAMP();      // [8] new environment rows
     if (!want_next) return;

@@ -443,6 +443,12 @@ __device__ __forceinline__ int truncate_rule(const double* lam, int K0, int nspe
     return nk;
 }
 
+// The environment products out_i = Z_i M (update_caches!, construct_caches) are FOUR chains of MFMAs over consecutive quarters of the
+// contraction, added as (q0 + q1) + (q2 + q3): one wave runs the four chains side by side (k_env, k_env_split: four independent
+// accumulators instead of one dependent chain of 32), or four waves run one each (k_bond_tail) - the same bits either way, which is
+// what keeps a sweep with the reference's cache rebuilds identical to one without.  k-steps (of 4 entries) per quarter:
+__device__ __forceinline__ int env_ks4(int nsteps) { return (nsteps + 3) >> 2; }
+
 // loss of the current bond: gradbuf[0], or - after k_grad_s on a single rank - the sum of its pieces (fixed order)
 __device__ __forceinline__ double bond_loss(const View& v) {
     if (v.n_lossp <= 0) return v.gradbuf[0];

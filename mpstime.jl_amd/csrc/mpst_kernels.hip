@@ -769,27 +769,34 @@ __global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, co
     __syncthreads();
     const int i16 = lane & 15, kq = lane >> 4;
     const int nt_out = (Dout + 15) >> 4;
+    const int nsteps = ZP >> 2, ks4 = env_ks4(nsteps);          // four chains over the quarters of the contraction (mpst_internal.h)
     for (int nt = wave; nt < nt_out; nt += 4) {
         const int col = nt * 16 + i16;
         const bool cv = col < Dout;
-        d4 acc = {0, 0, 0, 0};
-        for (int kb = 0; kb < ZP; kb += 128) {
-            double bv[32];
+        d4 p[4];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int z = kb + 4 * u + kq;
-                bv[u] = (cv && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
-            }
+        for (int q = 0; q < 4; ++q) p[q] = d4{0, 0, 0, 0};
+        for (int s0 = 0; s0 < ks4; s0 += 8) {
+            double bv[4][8];
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                const int k0 = kb + 4 * u;
-                if (k0 < ZP) acc = mfma_f64(smem[i16 * ZS + k0 + kq], bv[u], acc);
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int step = q * ks4 + s0 + u, z = 4 * step + kq;
+                    bv[q][u] = (cv && s0 + u < ks4 && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int step = q * ks4 + s0 + u;
+                    if (s0 + u < ks4 && step < nsteps) p[q] = mfma_f64(smem[i16 * ZS + 4 * step + kq], bv[q][u], p[q]);
+                }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = kq + 4 * r;
-            if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = acc[r];
+            if (i < tl.count && cv) out[(int64_t)(tl.start + i) * v.cap + col] = (p[0][r] + p[1][r]) + (p[2][r] + p[3][r]);
         }
     }
 }

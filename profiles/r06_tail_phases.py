@@ -26,9 +26,10 @@ for _ in range(6):
 out = {"N": N, "chi": chi, "sweep_ms": [round(1e3 * s, 3) for s in secs], "info": eng.info(), "eig_phases_us": eng.eig_phases()}
 if out["info"].get("four_launch_chain"):
     ph = eng.tail_phases()
-    out["tail_tile_us"] = {k: round(v, 2) for k, v in ph["tile"].items()}
-    out["tail_chain_us"] = [round(x, 2) for x in ph["chain"]]
-    out["tail_split_us"] = [round(x, 2) for x in ph["split"]]
+    out["tail_tile_us"] = ph["tile"]
+    out["tail_chain_us"] = ph["chain"]
+    out["tail_split_us"] = ph["split"]
+    out["bonds_by_candidate_orthogonality"] = ph["bonds_by_candidate_orthogonality"]
 eng.set_profile(0x7FF)
 eng.sweep()
 out["event_profile_us_per_launch"] = {k: (round(v[0] / max(v[1], 1), 2), v[1]) for k, v in eng.get_profile().items() if v[1]}
