@@ -379,8 +379,9 @@ int  mpst_get_eig_phases(void* ctx, double* us /*[6]*/);
  * polished, dense S tile, new environment rows, z + row dot, stores drained; us[16..31] the first workgroup of the next bond's tensor,
  * us[32..47] the first back-split workgroup: start, the same four request stamps, barrier, truncation rule, candidates in LDS,
  * polished, role done (stores drained); us[48..51] bonds since the context was created by how far from orthonormal their candidate
- * vectors were: |Z^T Z - I| below 1e-13 (nothing to do), below 1e-8 (first-order polish), below 3e-5 (second-order), above (two passes) */
-int  mpst_get_tail_phases(void* ctx, double* us /*[52]*/);
+ * vectors were: |Z^T Z - I| below 1e-13 (nothing to do), below 1e-8 (first-order polish), below 3e-5 (second-order), above (two passes);
+ * us[52], us[53], us[54] the earliest start, the latest end and the latest start over ALL workgroups of the stamped launch */
+int  mpst_get_tail_phases(void* ctx, double* us /*[55]*/);
 
 #ifdef __cplusplus
 }

@@ -132,6 +132,7 @@ struct Ctx {
     // right; which bond's overlaps the last tail launch left in b2_ypart (valid while nothing else touched the context: bond_seq / epoch);
     // a tail whose on-device verification failed marks the sweep (DevScalars::redo) and the rest of it is redone on the six-launch chain
     double* btnT = nullptr;
+    unsigned long long* tail_span = nullptr;    // diagnostics: (start, end) stamps of every workgroup of the stamped k_bond_tail launch
     bool chain4_ok = false, chain4_hold = false;
     int ynext_lid = -1;
     uint64_t ynext_epoch = 0, ynext_seq = 0, bond_seq = 0;
@@ -488,6 +489,8 @@ int ensure_workspace(Ctx* c) {
         c->ynext_lid = -1;
         dfree(&c->btnT);
         if (c->chain4_ok && (rc = dalloc(c, &c->btnT, c->C * Lmax))) return rc;
+        if (c->chain4_ok && (rc = dalloc(c, &c->tail_span, 2 * 2048))) return rc;
+        if (c->chain4_ok) HIPC(c, hipMemset(c->tail_span, 0, 2 * 2048 * sizeof(unsigned long long)));
     }
     c->n_norm_part = (int)((c->C * Lmax + 63) / 64);      // RED_E entries per workgroup of k_fused_reduce
     if ((rc = dalloc(c, &c->loss_trace, (int64_t)2 * (c->T - 1) * (c->opt.update_iters + 1)))) return rc;
@@ -775,7 +778,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             ProfScope p(c, K_ENV);                                                // verification, back-split, update_caches!, next yhat
             const int nxt = going_left ? lid - 1 : lid + 1;
             const int want = (nxt >= 0 && nxt <= c->T - 2) ? 1 : 0;
-            launch_bond_tail(v, lid, going_left, chain, want, s);
+            launch_bond_tail(v, lid, going_left, chain, want, c->tail_span, s);
             if (want) {
                 c->ynext_lid = nxt;
                 c->ynext_epoch = c->epoch;
@@ -837,6 +840,12 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
     return 0;
 }
 
+// MPST_ENV_WALK=0: construct_caches as one k_env launch per site (the same bits)
+bool env_walk_on(const Ctx* c, const View& v) {
+    const char* e = getenv("MPST_ENV_WALK");
+    return !c->typed && !(e && e[0] == '0') && env_walk_supported(v);
+}
+
 // construct_caches (RealRealHighDimension.jl:45-103)
 void enqueue_caches(Ctx* c, const View& v, int going_left) {
     if (c->typed) {
@@ -846,6 +855,10 @@ void enqueue_caches(Ctx* c, const View& v, int going_left) {
     }
     const int64_t cs = (int64_t)v.N * v.cap;
     ProfScope p(c, K_ENV);
+    if (env_walk_on(c, v)) {           // one launch: every workgroup walks the chain with its 16 series (k_env_walk, the bits of the per-site launches)
+        launch_env_walk(v, going_left, c->T - 1, c->stream);
+        return;
+    }
     if (going_left) {
         for (int j = 0; j <= c->T - 2; ++j)
             launch_env(v, j, 1, j > 0 ? c->LE + (int64_t)(j - 1) * cs : nullptr, j, ENV_M_SITE, j + 1,
@@ -960,7 +973,7 @@ void mpst_destroy(void* ctx) {
     for (int k = 0; k < 2; ++k) { dfree(&c->xchainL[k]); dfree(&c->xchainR[k]); }
     dfree(&c->btn); dfree(&c->norm_part); dfree(&c->loss_trace);
     dfree(&c->b2_ypart); dfree(&c->b2_lossp); dfree(&c->b2_tick); dfree(&c->b2_dbg);
-    dfree(&c->btnT);
+    dfree(&c->btnT); dfree(&c->tail_span);
     dfree(&c->E); dfree(&c->eig_ws); dfree(&c->sc); dfree(&c->norm2); dfree(&c->yeval); dfree(&c->out3); dfree(&c->conf); dfree(&c->pred);
     for (int k = 0; k < 2; ++k) { dfree(&c->chainL[k]); dfree(&c->chainR[k]); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1519,6 +1532,10 @@ int mpst_build_caches(void* ctx) {
     const int64_t cs = (int64_t)v.N * v.cap;
     if (c->typed) {
         enqueue_caches_typed(c, ls, ls);
+    } else if (env_walk_on(c, v)) {
+        ProfScope p(c, K_ENV);
+        launch_env_walk(v, 1, std::min(ls, c->T - 1), c->stream);
+        launch_env_walk(v, 0, c->T - 1 - ls, c->stream);
     } else {
         ProfScope p(c, K_ENV);
         for (int j = 0; j < ls && j <= c->T - 2; ++j)
@@ -1707,7 +1724,11 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
 // K independent fits of one shape advanced by ONE launch chain (hyper-parameter candidates, CV folds, restarts: what the
 // reference farms out with @distributed, tuning.jl).  Every launch of the headline chain carries all K fits (blockIdx.z), so the
 // kernel count per sweep is that of one fit; results are those of K separate mpst_sweep calls, bit for bit.
-int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
+// phase 1: validation and (if the batch is new) capture of its graph; phase 2: replay and read-back; 0: both.  mpst_sweep_batch_multi
+// prepares all its groups on the calling thread before any group runs: a capture in one thread is invalidated by another thread's
+// synchronous copies (the read-back of a group that has finished its sweep) - "operation failed due to a previous error during
+// capture", one run in a dozen when two groups captured side by side.
+static int sweep_batch_impl(void* const* ctxs, int32_t K, mpst_sweep_stats* out, int phase) {
     if (!ctxs || K < 1 || K > 64) return fail(nullptr, MPST_ERR_INVALID, "mpst_sweep_batch: 1..64 contexts");
     Ctx* c0 = (Ctx*)ctxs[0];
     if (!c0) return MPST_ERR_INVALID;
@@ -1800,6 +1821,7 @@ int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
         }
         c0->batch_key = key;
     }
+    if (phase == 1) return 0;
     HIPC(c0, hipEventRecord(c0->ev_start, c0->stream));
     HIPC(c0, hipGraphLaunch(c0->batch_graph, c0->stream));
     HIPC(c0, hipEventRecord(c0->ev_stop, c0->stream));
@@ -1829,6 +1851,8 @@ int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) {
     if (failed >= 0) return fail(c0, MPST_ERR_SVD, "bond-tensor decomposition failed in fit %d of the batch (its svd_status is set; the other fits are intact)", failed);
     return 0;
 }
+
+int mpst_sweep_batch(void* const* ctxs, int32_t K, mpst_sweep_stats* out) { return sweep_batch_impl(ctxs, K, out, 0); }
 
 // K fits dealt over several devices (or several groups on one device): every group is one mpst_sweep_batch on its own host
 // thread - no collective, nothing shared between groups.  What scales on a node: the sharded sweep replicates its eigensolver
@@ -1864,13 +1888,24 @@ int mpst_sweep_batch_multi(void* const* ctxs, int32_t K, const int32_t* group, m
                 return fail((Ctx*)ctxs[0], MPST_ERR_INVALID, "group %d mixes devices %d and %d: a group is one launch chain on one device", keys[g],
                             ((Ctx*)members[g][0])->device, ((Ctx*)m)->device);
     }
+    // a context in two groups would be swept by two host threads at once, on one stream and one set of device scalars
+    for (int k = 0; k < K; ++k)
+        for (int j = 0; j < k; ++j)
+            if (ctxs[j] == ctxs[k]) return fail((Ctx*)ctxs[0], MPST_ERR_INVALID, "context %d appears twice", k);
     std::vector<int> rc(G, 0);
     std::vector<std::vector<mpst_sweep_stats>> st(G);
-    std::vector<std::thread> th;
+    // every group's validation and graph capture here, one after the other; the threads only replay
     for (int g = 0; g < G; ++g) {
         st[g].resize(members[g].size());
-        th.emplace_back([&, g] { rc[g] = mpst_sweep_batch(members[g].data(), (int32_t)members[g].size(), st[g].data()); });
+        if ((rc[g] = sweep_batch_impl(members[g].data(), (int32_t)members[g].size(), st[g].data(), 1))) {
+            Ctx* lead = (Ctx*)members[g][0];
+            if (lead != (Ctx*)ctxs[0]) ((Ctx*)ctxs[0])->err = lead->err;
+            return rc[g];
+        }
     }
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+        th.emplace_back([&, g] { rc[g] = sweep_batch_impl(members[g].data(), (int32_t)members[g].size(), st[g].data(), 2); });
     for (auto& t : th) t.join();
     if (out)
         for (int g = 0; g < G; ++g)
@@ -2477,12 +2512,34 @@ int mpst_get_tail_phases(void* ctx, double* us) {
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
     const unsigned long long* t = sc.eig_stamps;
     const double t0 = (double)t[16];
-    for (int i = 0; i < 48; ++i) us[i] = (t[16 + i] && t[16]) ? 0.01 * ((double)t[16 + i] - t0) : -1.0;
+    // tile workgroup: slots 16..31, chain 32..43, split 44..55
+    for (int i = 0; i < 48; ++i) us[i] = -1.0;
+    for (int i = 0; i < 16; ++i) if (t[16 + i] && t[16]) us[i] = 0.01 * ((double)t[16 + i] - t0);
+    for (int i = 0; i < 12; ++i) if (t[32 + i] && t[16]) us[16 + i] = 0.01 * ((double)t[32 + i] - t0);
+    for (int i = 0; i < 12; ++i) if (t[44 + i] && t[16]) us[32 + i] = 0.01 * ((double)t[44 + i] - t0);
     // slots a launch did not reach keep the stamps of an earlier one: nothing after the first stamp that runs backwards counts
     for (int g = 0; g < 3; ++g)
         for (int i = 1; i < 16; ++i)
             if (us[16 * g + i] < us[16 * g + i - 1] || us[16 * g + i - 1] == -1.0) us[16 * g + i] = -1.0;
-    for (int i = 0; i < 4; ++i) us[48 + i] = (double)t[60 + i];        // bonds by |Z^T Z - I| of their candidates: < 1e-13, < 1e-8, < 3e-5, above
+    for (int i = 0; i < 4; ++i) us[48 + i] = (double)t[56 + i];        // bonds by |Z^T Z - I| of their candidates: < 1e-13, < 1e-8, < 3e-5, above
+    // every workgroup of the stamped launch left (start, end) in the gradient workspace: earliest start, latest end, latest start
+    us[52] = us[53] = us[54] = 0.0;
+    {
+        const size_t ng = (size_t)std::min<unsigned long long>(t[60], 2048ull);
+        if (ng > 0 && c->tail_span) {
+            std::vector<unsigned long long> sp(2 * ng);
+            HIPC(c, hipMemcpy(sp.data(), c->tail_span, sp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            unsigned long long s0 = ~0ull, s1 = 0ull, e1 = 0ull;
+            for (size_t i = 0; i < ng; ++i) {
+                s0 = std::min(s0, sp[2 * i]);
+                s1 = std::max(s1, sp[2 * i]);
+                e1 = std::max(e1, sp[2 * i + 1]);
+            }
+            us[52] = 0.01 * ((double)s0 - t0);
+            us[53] = 0.01 * ((double)e1 - t0);
+            us[54] = 0.01 * ((double)s1 - t0);
+        }
+    }
     return 0;
 }
 

@@ -1284,6 +1284,132 @@ __device__ __forceinline__ double kr_at(const KrSide& k, int row, unsigned z) {
     return k.env[row * BT_ELS + ie] * k.ph[row * BT_PLS + ip];
 }
 
+// =====================================================================================================================
+// k_env_walk (round 6): construct_caches (RealRealHighDimension.jl:45-103) in ONE launch.  The environments of different series never
+// meet: a workgroup takes a tile of 16 series and walks the whole chain with it - T - 1 dependent steps, no grid-wide dependency -
+// where enqueue_caches() issues one k_env launch per site (99 launches of ~7 us at the headline shape, twice per sweep when the
+// reference's cache rebuilds are on: 1.4 ms of a 40 ms sweep).  A step is the product of k_env, bit for bit (the Khatri-Rao entries
+// prev_i[a] * phi_i[s], four MFMA chains over the quarters of the contraction added as (q0 + q1) + (q2 + q3): mpst_internal.h), so the
+// caches it leaves are those of the per-site launches and of the incremental update_caches! of a sweep.  8 waves = (column tile,
+// quarter); the row just computed stays in LDS as the next step's `prev`; the next site's vectors and this wave's share of the next
+// site tensor are requested while the current step computes.  Bond dimensions up to 32, d * chi <= 128.
+// =====================================================================================================================
+constexpr int EW_T = 512;
+constexpr int EW_ZS = 130;                   // row stride of the dense Khatri-Rao tile
+constexpr int EW_PS = 34;                    // row stride of the kept environment rows
+constexpr int EW_TMAX = 1023;                // longest chain (the bond dimensions are staged in LDS)
+__global__ __launch_bounds__(EW_T) void k_env_walk(View v, int left_side, int nstep) {
+    __shared__ __attribute__((aligned(16))) double Zt[16 * EW_ZS];
+    __shared__ __attribute__((aligned(16))) double prevs[16 * EW_PS];
+    __shared__ __attribute__((aligned(16))) double part[8 * 256];
+    __shared__ int chis[EW_TMAX + 1];             // the bond dimensions: a scalar load from memory per step would be a dependent microsecond each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int d = v.d, T = v.T;
+    for (int i = tid; i <= T; i += EW_T) chis[i] = v.chi[i];
+    const Span tl = tile_span_k(v, (int)blockIdx.x);
+    __syncthreads();
+    const int nt = wave & 1, q = wave >> 1;
+    const int col = nt * 16 + i16;
+    const int64_t cs = (int64_t)v.N * v.cap;
+    double* base = left_side ? v.LE : v.RE;
+    // sites in walking order: left 0 .. T-2 (LE[j] from LE[j-1] and site j), right T-1 .. 1 (RE[j] from RE[j+1] and site j); nstep of them
+    auto site_of = [&](int st) { return left_side ? st : T - 1 - st; };
+    // the sites' vectors come from HBM (2+ us away, more than a step takes): they are fetched a CHUNK of sites ahead - thread = (site of
+    // the chunk, row, s) - and parked in LDS, two chunks deep
+    const int per = 16 * d;
+    const int CH = min(8, EW_T / per);              // sites per chunk (d <= 16: at least 2)
+    __shared__ double phs[2][8 * 16 * 17];
+    const int cs_site = tid / per, cs_rem = tid - cs_site * per;
+    const int prow = cs_rem / d, ps = cs_rem - prow * d;
+    auto load_phi_chunk = [&](int c0) -> double {   // this thread's value of the chunk that starts at step c0
+        const int st = c0 + cs_site;
+        const bool ok = cs_site < CH && st < nstep && prow < tl.count;
+        return ok ? v.phi[((int64_t)site_of(st) * v.N + tl.start + prow) * d + ps] : 0.0;
+    };
+    // this wave's share of a site tensor as the B operand of its quarter: M[z][col], z = 4 (q ks4 + u) + kq
+    auto load_b = [&](int st, double (&bv)[8]) {
+        const int j = site_of(st);
+        const int Dp = left_side ? __builtin_amdgcn_readfirstlane(chis[j]) : __builtin_amdgcn_readfirstlane(chis[j + 1]);
+        const int Dout = left_side ? __builtin_amdgcn_readfirstlane(chis[j + 1]) : __builtin_amdgcn_readfirstlane(chis[j]);
+        const int Z = Dp * d, nsteps = ((Z + 3) & ~3) >> 2, ks4 = env_ks4(nsteps);
+        const double* M = v.sites + (int64_t)j * v.site_stride;
+        // left: M[(a,s)][k], row stride chi[j+1];  right: M[k][(s,b)] read transposed, column stride d * chi[j+1]
+        const int64_t sz = left_side ? Dout : 1, sk = left_side ? 1 : (int64_t)d * __builtin_amdgcn_readfirstlane(chis[j + 1]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = 4 * (q * ks4 + u) + kq;
+            bv[u] = (col < Dout && u < ks4 && z < Z) ? M[(int64_t)z * sz + (int64_t)col * sk] : 0.0;
+        }
+    };
+    double bv[8], bvn[8];                           // this step's and the next step's B operand; the one after is requested inside the step
+    double phq = load_phi_chunk(0);                 // chunk 0 ...
+    load_b(0, bv);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) bvn[u] = 0.0;
+    if (nstep > 1) load_b(1, bvn);
+    if (cs_site < CH) phs[0][cs_site * 272 + prow * 17 + ps] = phq;
+    phq = load_phi_chunk(CH);                       // ... and chunk 1 in flight
+    for (int st = 0; st < nstep; ++st) {
+        const int j = site_of(st);
+        const int Dp = st == 0 ? 1 : (left_side ? __builtin_amdgcn_readfirstlane(chis[j]) : __builtin_amdgcn_readfirstlane(chis[j + 1]));
+        const int Dout = left_side ? __builtin_amdgcn_readfirstlane(chis[j + 1]) : __builtin_amdgcn_readfirstlane(chis[j]);
+        const int Z = Dp * d, ZP = (Z + 3) & ~3, nsteps = ZP >> 2, ks4 = env_ks4(nsteps);
+        const int ch = st / CH, cin = st - ch * CH;
+        if (cin == 0 && st > 0) {
+            // a new chunk begins: the one fetched during the last chunk goes to LDS (the buffer of the chunk before the last is free),
+            // the next one is requested
+            if (cs_site < CH) phs[ch & 1][cs_site * 272 + prow * 17 + ps] = phq;
+            phq = load_phi_chunk((ch + 1) * CH);
+        }
+        // (LDS-only barriers: __syncthreads() would also wait for the acknowledgement of the last step's stores and for the operands
+        // requested two steps ahead - the very round trips the walk is built to hide)
+        lds_barrier();                              // (also: the previous step's rows are in prevs, its Zt is consumed)
+        // ---- the Khatri-Rao tile of this step: Zt[i][z] = prev_i[a] phi_i[s], left z = a d + s, right z = s Dp + a ----
+        {
+            const double* ph = phs[ch & 1] + cin * 272;
+            const int row = tid >> 5, a = tid & 31;  // 16 rows x 32 bond entries
+            const double pa = (a < Dp && row < tl.count) ? (st == 0 ? 1.0 : prevs[row * EW_PS + a]) : 0.0;
+            if (a < Dp) {
+                for (int s = 0; s < d; ++s) Zt[row * EW_ZS + (left_side ? a * d + s : s * Dp + a)] = pa * ph[row * 17 + s];
+            }
+            for (int z = Z + a; z < ZP; z += 32) Zt[row * EW_ZS + z] = 0.0;
+        }
+        lds_barrier();
+        double bvnn[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bvnn[u] = 0.0;
+        if (st + 2 < nstep) load_b(st + 2, bvnn);   // two steps ahead: the site tensors come from the L2, about a step away
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (nt * 16 < Dout) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int step = q * ks4 + u;
+                if (u < ks4 && step < nsteps) acc = mfma_f64(Zt[i16 * EW_ZS + 4 * step + kq], bv[u], acc);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(q * 2 + nt) * 256 + r * 64 + lane] = acc[r];
+        lds_barrier();
+        {
+            const int tnt = tid >> 8, e = tid & 255;
+            const double sum = (part[tnt * 256 + e] + part[(2 + tnt) * 256 + e]) + (part[(4 + tnt) * 256 + e] + part[(6 + tnt) * 256 + e]);
+            const int i = ((e >> 4) & 3) + 4 * (e >> 6), c = tnt * 16 + (e & 15);
+            if (i < tl.count && c < Dout) base[(int64_t)j * cs + (int64_t)(tl.start + i) * v.cap + c] = sum;
+            prevs[i * EW_PS + c] = sum;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bv[u] = bvn[u];
+            bvn[u] = bvnn[u];
+        }
+    }
+}
+void launch_env_walk(const View& v, int left_side, int nstep, hipStream_t s) {
+    if (nstep > 0) hipLaunchKernelGGL(k_env_walk, dim3(v.ntiles), dim3(EW_T), 0, s, v, left_side, std::min(nstep, v.T - 1));
+}
+bool env_walk_supported(const View& v) { return v.zw != 2 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.d >= 2 && v.d <= 16 && v.T >= 2 && v.T <= EW_TMAX; }
+
 // ---- the back-split and the next bond's tensor inside k_bond_tail: split_block / chain_bt_block (the same products, the same order
 // of operations: the same bits) cut in two - what does not depend on the eigenvectors is REQUESTED at the head of the kernel and
 // arrives under the polish; what follows the polish is MFMAs and stores.  Capacity <= 32 on this path: the shared bond has at most two
@@ -1523,6 +1649,7 @@ struct TailArgs {
     const double* M;                // bt_new as [c][k = O index][n = S index]: btn going left, btnT going right
     double* out;                    // the new environment rows
     int32_t lid, going_left, nsplit, nchain, flags;     // flags: 1 the next bond's overlaps are wanted, 2 leave phase stamps
+    unsigned long long* span;       // stamped launch: (start, end) of every workgroup, or null
 };
 
 // Verification + re-orthonormalisation of the K candidate vectors Z ([c * BT_ZS + k], zero beyond the live rows / columns), all 8 waves:
@@ -1538,10 +1665,24 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
         // ---- D: wave w owns the 16 x 16 tile (w & 3) over rows [64 (w >> 2), +64) ----
         const int a0 = 16 * ((wave & 3) >> 1), b0 = 16 * (wave & 1), kb = 64 * (wave >> 2);
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int s4 = 0; s4 < 16; ++s4) {
-            const double* zr = Z + (kb + 4 * s4 + q4) * BT_ZS;
-            acc = mfma_f64(zr[a0 + jl], zr[b0 + jl], acc);
+        {
+            // operands a batch of 8 k-steps ahead of the MFMAs that consume them (see k_bond_tail's overlap product)
+            double da[2][8], db[2][8];
+            auto fetch = [&](int bt) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double* zr = Z + (kb + 4 * (8 * bt + u) + q4) * BT_ZS;
+                    da[bt][u] = zr[a0 + jl];
+                    db[bt][u] = zr[b0 + jl];
+                }
+            };
+            fetch(0);
+            fetch(1);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = mfma_f64(da[bt][u], db[bt][u], acc);
         }
         if (wave >= 4) {
 #pragma unroll
@@ -1584,8 +1725,15 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
             // Cm = D - 3/4 D^2 (the update below takes half of it): four tiles, waves 0..3
             if (wave < 4) {
                 d4 c2 = {0.0, 0.0, 0.0, 0.0};
+                double ca_[8], cb_[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) c2 = mfma_f64(D[(a0 + jl) * 32 + 4 * u + q4], D[(4 * u + q4) * 32 + b0 + jl], c2);
+                for (int u = 0; u < 8; ++u) {
+                    ca_[u] = D[(a0 + jl) * 32 + 4 * u + q4];
+                    cb_[u] = D[(4 * u + q4) * 32 + b0 + jl];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 8; ++u) c2 = mfma_f64(ca_[u], cb_[u], c2);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int aa = a0 + q4 + 4 * r, bb = b0 + jl;
@@ -1597,14 +1745,25 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
         }
         // ---- Z <- Z - (Z Cm) / 2: 8 row tiles x 2 column tiles, two per wave ----
         d4 upd[2];
+        {
+            // the two tiles of a wave share the row tile of Z: its operand once, both column tiles of Cm
+            const int c0 = 16 * wave;
+            double ua[8], ub0[8], ub1[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tile = wave * 2 + h;
-            const int c0 = 16 * (tile >> 1), ca = 16 * (tile & 1);
-            d4 a = {0.0, 0.0, 0.0, 0.0};
+            for (int s4 = 0; s4 < 8; ++s4) {
+                ua[s4] = Z[(c0 + jl) * BT_ZS + 4 * s4 + q4];
+                ub0[s4] = Cm[(4 * s4 + q4) * 32 + jl];
+                ub1[s4] = Cm[(4 * s4 + q4) * 32 + 16 + jl];
+            }
+            asm volatile("" ::: "memory");
+            d4 a0_ = {0.0, 0.0, 0.0, 0.0}, a1_ = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int s4 = 0; s4 < 8; ++s4) a = mfma_f64(Z[(c0 + jl) * BT_ZS + 4 * s4 + q4], Cm[(4 * s4 + q4) * 32 + ca + jl], a);
-            upd[h] = a;
+            for (int s4 = 0; s4 < 8; ++s4) {
+                a0_ = mfma_f64(ua[s4], ub0[s4], a0_);
+                a1_ = mfma_f64(ua[s4], ub1[s4], a1_);
+            }
+            upd[0] = a0_;
+            upd[1] = a1_;
         }
         __syncthreads();
 #pragma unroll
@@ -1662,11 +1821,16 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     if (tid == 0 && (ta.flags & 2)) {
         if (bid == nchain + nsplit) stp = v.sc->eig_stamps + 16;
         else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
-        else if (bid == nchain) stp = v.sc->eig_stamps + 48;
+        else if (bid == nchain) stp = v.sc->eig_stamps + 44;
     }
     int sti = 0;
 #define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
     TSTAMP();
+    // ... and every workgroup of a stamped launch leaves its own start and end: the launch's span, and how the workgroups are spread over it
+    unsigned long long* spanp = ((ta.flags & 2) && tid == 0 && ta.span && bid < 2048) ? ta.span + 2 * bid : nullptr;
+    if (spanp) spanp[0] = __builtin_amdgcn_s_memrealtime();
+    if ((ta.flags & 2) && tid == 0 && bid == 0) v.sc->eig_stamps[60] = gridDim.x;
+#define TEND() do { if (spanp) spanp[1] = __builtin_amdgcn_s_memrealtime(); } while (0)
     double* Zl = smem;                             // [128][BT_ZS] candidates, then the kept eigenvectors E (zero beyond the live rows / kept columns)
     double* Dl = Zl + 128 * BT_ZS;                 // [32][32]
     double* Dh = Dl + 1024;                        // [1024]
@@ -1786,20 +1950,33 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     // the candidates came first
     if (role == 0) {
         if (want_next) {
-            // P = O bt_new, this wave's 16 columns (two accumulation chains)
-            if (D4 && ko.left) {
-                const double ph = ko.ph[i16 * BT_PLS + kq];
-                const double* er = ko.env + i16 * BT_ELS;
+            // P = O bt_new, this wave's 16 columns.  A wave issues one MFMA per 64 cycles whatever their dependencies (profiles/ubench/
+            // mfma_rate.hip), so what a product costs is 64 cycles per MFMA PLUS every operand latency the wave waits out in between:
+            // operands are fetched a batch of 8 k-steps ahead (left to itself the compiler reads, waits, multiplies, reads ...).
+            // Whole batches: beyond the live extent the O side is zero.
+            double ab[4][8];
+            auto fetch = [&](int bt) {
+                if (D4 && ko.left) {
+                    const double* er = ko.env + i16 * BT_ELS + 8 * bt;
 #pragma unroll
-                for (int u = 0; u < 32; u += 2) {
-                    if (4 * u < KP) pacc0 = mfma_f64(er[u] * ph, bm[u], pacc0);
-                    if (4 * u + 4 < KP) pacc1 = mfma_f64(er[u + 1] * ph, bm[u + 1], pacc1);
+                    for (int u = 0; u < 8; ++u) ab[bt][u] = er[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ab[bt][u] = kr_at(ko, i16, 4u * (8 * bt + u) + kq);
                 }
-            } else {
+            };
+            const double phf = (D4 && ko.left) ? ko.ph[i16 * BT_PLS + kq] : 1.0;
+            fetch(0);
 #pragma unroll
-                for (int u = 0; u < 32; u += 2) {
-                    if (4 * u < KP) pacc0 = mfma_f64(kr_at(ko, i16, 4u * u + kq), bm[u], pacc0);
-                    if (4 * u + 4 < KP) pacc1 = mfma_f64(kr_at(ko, i16, 4u * u + 4u + kq), bm[u + 1], pacc1);
+            for (int bt = 0; bt < 4; ++bt) {
+                if (bt < 3) fetch(bt + 1);
+                asm volatile("" ::: "memory");
+                if (32 * bt < KP) {
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        pacc0 = mfma_f64(ab[bt][u] * phf, bm[8 * bt + u], pacc0);
+                        pacc1 = mfma_f64(ab[bt][u + 1] * phf, bm[8 * bt + u + 1], pacc1);
+                    }
                 }
             }
         }
@@ -1812,7 +1989,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         if (__ballot(lane < K0 && (!(P == P) || P > 1e300))) bad = true;
         if (lane == 0) {
             // how far from orthonormal the candidates were, by class (diagnostics: mpst_get_tail_phases)
-            v.sc->eig_stamps[60 + (emax0 < 1e-13 ? 0 : emax0 < 1e-8 ? 1 : emax0 < 3e-5 ? 2 : 3)] += 1ull;
+            v.sc->eig_stamps[56 + (emax0 < 1e-13 ? 0 : emax0 < 1e-8 ? 1 : emax0 < 3e-5 ? 2 : 3)] += 1ull;
             v.sc->n_keep = nk;
             v.sc->n_spec = K0;
             v.sc->bt_norm2 = tr;
@@ -1829,6 +2006,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         else tail_split_finish(v, b, lid, going_left, bid - nchain, nsplit, bm, Ef, BT_ZS, nk, inv);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TSTAMP();  // [7] role done, stores drained
+        TEND();
         return;
     }
     // ---- the dense S tile, by all waves (env' then pays one LDS read per MFMA, whichever side S is).  It goes over the polish scratch:
@@ -1852,10 +2030,18 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         const int col = nt * 16 + i16;
         d4 acc = {0.0, 0.0, 0.0, 0.0};
         if (nt * 16 < nk) {
+            double sa[8], sb[8];                    // both operands of the quarter first, then eight MFMAs back to back
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int step = min(q * ks4 + u, nsteps - 1);
+                sa[u] = St[i16 * BT_SS + 4 * step + kq];
+                sb[u] = Ef[(4 * step + kq) * BT_ZS + col];
+            }
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int step = q * ks4 + u;
-                if (u < ks4 && step < nsteps) acc = mfma_f64(St[i16 * BT_SS + 4 * step + kq], Ef[(4 * step + kq) * BT_ZS + col], acc);
+                if (u < ks4 && step < nsteps) acc = mfma_f64(sa[u], sb[u], acc);
             }
         }
 #pragma unroll
@@ -1870,20 +2056,30 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         envs[i * BT_ENVS + col] = sum;
     }
     TSTAMP();      // [8] new environment rows
-    if (!want_next) return;
-    __syncthreads();
+    if (!want_next) {
+        TEND();
+        return;
+    }
+    lds_barrier();                                  // (LDS only: __syncthreads() would wait for the acknowledgement of the rows just stored)
     {
         // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
         d4 zacc = {0.0, 0.0, 0.0, 0.0};
+        double za[8], zb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) zacc = mfma_f64(envs[i16 * BT_ENVS + 4 * u + kq], Ef[(16 * wave + i16) * BT_ZS + 4 * u + kq], zacc);
+        for (int u = 0; u < 8; ++u) {
+            za[u] = envs[i16 * BT_ENVS + 4 * u + kq];
+            zb[u] = Ef[(16 * wave + i16) * BT_ZS + 4 * u + kq];
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) zacc = mfma_f64(za[u], zb[u], zacc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
             if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
         }
     }
-    __syncthreads();
+    lds_barrier();
     TSTAMP();      // [9] z, row dot
     if (tid < 16 && tid < tl.count) {
         const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
@@ -1897,7 +2093,9 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP();      // [10] stores drained
+    TEND();
 #undef TSTAMP
+#undef TEND
 }
 // two register budgets of the same body: 128 VGPRs (two workgroups per CU: the chain / split workgroups find room beside the tile
 // workgroups) or whatever the body wants (one workgroup per CU)
@@ -2057,7 +2255,7 @@ void launch_grad_s(const View& v, int lid, hipStream_t s) {
 bool bond_tail_supported(const View& v) {
     return v.zw != 2 && v.loss == MPST_LOSS_KLD && v.chi_max <= 32 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.svd_alg != MPST_SVD_JACOBI && v.d >= 2 && v.d <= 16;
 }
-void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, hipStream_t s) {
+void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, unsigned long long* span, hipStream_t s) {
     const int dm = v.d * v.cap, rid = lid + 1;
     TailArgs ta;
     ta.lid = lid;
@@ -2065,6 +2263,7 @@ void launch_bond_tail(const View& v, int lid, int going_left, int chain, int wan
     ta.nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
     ta.nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
     ta.flags = want_next ? 1 : 0;
+    ta.span = span;
     const int64_t cs = (int64_t)v.N * v.cap;
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr;
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * cs : nullptr;

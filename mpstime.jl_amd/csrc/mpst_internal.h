@@ -540,8 +540,11 @@ void launch_env_split(const View& v, int lid, int going_left, int site, int left
                       int out_bond, double* out, int chain /* also assemble the next bond's tensor */, hipStream_t s);
 // the four-launch chain's last launch (k_bond_tail): k_eig_fin's verification + polish, environment update, back-split, the next
 // bond's tensor (chain) and the next bond's overlaps (want_next) in one
-void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, hipStream_t s);
+void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, unsigned long long* span /* [2 * 2048] or null */, hipStream_t s);
 bool bond_tail_supported(const View& v);
+// construct_caches in one launch: a workgroup walks the whole chain with its 16 series (k_env_walk); left_side: LE, else RE
+void launch_env_walk(const View& v, int left_side, int nstep /* sites, from the chain end */, hipStream_t s);
+bool env_walk_supported(const View& v);
 // the headline chain for K independent fits of one shape per launch (blockIdx.z selects the fit's View in the device array vs)
 void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);
 void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s);

@@ -390,7 +390,7 @@ class SweepEngine:
     def tail_phases(self):
         """Stamps (us since its first tile workgroup started) of the last stamped k_bond_tail launch: that tile workgroup, the first
         workgroup of the next bond's tensor, the first back-split workgroup."""
-        us = np.zeros(52)
+        us = np.zeros(55)
         self._chk(self.lib.mpst_get_tail_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
         tile = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "factors_in_lds", "truncation",
                 "candidates_in_lds", "polished", "overlap_product_issued", "s_tile_formed", "env_rows", "z_rowdot", "stores_drained")
@@ -398,7 +398,8 @@ class SweepEngine:
                 "polished", "operands_ready", "role_done")
         pick = lambda names, x: {k: round(float(v), 2) for k, v in zip(names, x) if v >= 0 or k == "start"}
         return {"tile": pick(tile, us[:16]), "chain": pick(role, us[16:32]), "split": pick(role, us[32:48]),
-                "bonds_by_candidate_orthogonality": dict(zip(("below_1e-13", "below_1e-8", "below_3e-5", "above"), [int(x) for x in us[48:52]]))}
+                "bonds_by_candidate_orthogonality": dict(zip(("below_1e-13", "below_1e-8", "below_3e-5", "above"), [int(x) for x in us[48:52]])),
+                "all_workgroups": {"first_start": round(float(us[52]), 2), "last_start": round(float(us[54]), 2), "last_end": round(float(us[53]), 2)}}
 
     def selftest_mfma(self, A, B):
         A = np.ascontiguousarray(A, dtype=np.float64)

@@ -21,8 +21,11 @@ eng.set_dataset(0, full.phi, full.label_index, C)
 eng.set_mps(W0)
 eng.build_caches()
 secs = []
-for _ in range(6):
+for _ in range(5):
     secs.append(eng.sweep()["seconds"])
+if eng.info().get("four_launch_chain"):
+    eng.tail_phases()                       # clears the all-workgroups span
+secs.append(eng.sweep()["seconds"])
 out = {"N": N, "chi": chi, "sweep_ms": [round(1e3 * s, 3) for s in secs], "info": eng.info(), "eig_phases_us": eng.eig_phases()}
 if out["info"].get("four_launch_chain"):
     ph = eng.tail_phases()
@@ -30,6 +33,7 @@ if out["info"].get("four_launch_chain"):
     out["tail_chain_us"] = ph["chain"]
     out["tail_split_us"] = ph["split"]
     out["bonds_by_candidate_orthogonality"] = ph["bonds_by_candidate_orthogonality"]
+    out["tail_all_workgroups_us"] = ph["all_workgroups"]
 eng.set_profile(0x7FF)
 eng.sweep()
 out["event_profile_us_per_launch"] = {k: (round(v[0] / max(v[1], 1), 2), v[1]) for k, v in eng.get_profile().items() if v[1]}
