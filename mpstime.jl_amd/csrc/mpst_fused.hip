@@ -1248,7 +1248,8 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
 // DevScalars::redo and leaves the MPS alone; every later tail launch of the sweep leaves at once, and the host redoes the sweep
 // from its snapshot on the six-launch chain (mpst_sweep).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
 // =====================================================================================================================
-constexpr int BT_T = 512;                    // 8 waves
+constexpr int BT_T = 512;                    // 8 tile waves ...
+constexpr int BT_TT = BT_T + 256;            // ... and 4 role waves
 constexpr int BT_ZS = 36;                    // LDS row stride of the candidate / kept eigenvectors: rows 16 apart in 16 different bank pairs
                                              // (with the 32 of k_eig_fin's layout the A operand of Z D is a 16-way conflict: 3 us per polish)
 constexpr int BT_ENVS = 34;                  // LDS row stride of the 16 x 32 tile of new environment rows
@@ -1256,7 +1257,7 @@ constexpr int BT_ELS = 37, BT_PLS = 21;      // LDS row strides of the staged fa
                                              // entries / 16 site states and zeros behind them (the padded K extent reads up to 4 beyond the live ones)
 constexpr int BT_FAC = 16 * (BT_ELS + BT_PLS);
 constexpr int BT_SS = 129;                   // row stride of the dense S tile (over D / Dh / misc once the polish is done)
-constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2048 + 16 * BT_ENVS + 128;     // 76 KB: two workgroups per CU
+constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2048 + 16 * BT_ENVS + 128 + 2048;     // 92 KB
 static_assert(2 * BT_FAC <= 2048, "the factors live where the pieces of env' go later");
 static_assert(16 * BT_SS <= 32 * 32 + 1024 + 128, "the dense S tile lives in the polish scratch");
 
@@ -1419,9 +1420,9 @@ bool env_walk_supported(const View& v) { return v.zw != 2 && v.cap <= 32 && v.d 
 // (operand of the second product); [16, 32) av[j][u], this wave's share of bt_new for the two row blocks of T.
 #define TC_WPRE(it, j, r) R[((it) * 2 + (j)) * 4 + (r)]
 #define TC_AV(j, u) R[16 + (j) * 8 + (u)]
-__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32]) {
+__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32], const int rt) {
     const int d = v.d;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = rt >> 6, lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ktc = (v.cap + 15) >> 4;
     const int s = (job / ktc) % d, c = job / (ktc * d);
@@ -1457,11 +1458,46 @@ __device__ __forceinline__ void tail_chain_request(const View& v, const BondDims
         }
     }
 }
-__device__ __forceinline__ void tail_chain_finish(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
-                                                  double* __restrict__ cpart /* [4][2][256] */, const double* __restrict__ Ev, const int ldE, const int nk,
-                                                  const double inv) {
+// (rt: the thread's index among the 256 of the role - in k_bond_tail they are the workgroup's waves 8..11)
+__device__ __forceinline__ void tail_chain_first(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
+                                                 double* __restrict__ cpart /* [4][2][256] */, const double* __restrict__ Ev, const int ldE, const int nk, const int rt) {
     const int d = v.d;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = rt >> 6, lane = rt & 63;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int ktc = (v.cap + 15) >> 4;
+    const int kt = job % ktc;
+    const int k0 = 16 * kt;
+    if (k0 >= nk) return;
+    const int kcol = k0 + i16;
+    const bool kv = kcol < nk;
+    const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
+    const int nj = (Dc + 15) >> 4;
+    const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
+    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
+    (void)d;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        d4 t = {0, 0, 0, 0};
+        if (j < nj) {
+            double bv[8];                           // the eigenvector operand first, then eight MFMAs back to back
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = kbeg + 4 * u + kq;
+                bv[u] = (kv && q < kend) ? Ev[(int64_t)q * ldE + kcol] : 0.0;
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (kbeg + 4 * u < kend) t = mfma_f64(TC_AV(j, u), bv[u], t);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart[(wave * 2 + j) * 256 + r * 64 + lane] = t[r];
+    }
+}
+__device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
+                                                  const double* __restrict__ cpart, const int nk, const double inv, const int rt) {
+    const int d = v.d;
+    const int wave = rt >> 6, lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ktc = (v.cap + 15) >> 4;
     const int kt = job % ktc, s = (job / ktc) % d, c = job / (ktc * d);
@@ -1469,26 +1505,9 @@ __device__ __forceinline__ void tail_chain_finish(const View& v, const BondDimsF
     if (k0 >= nk) return;
     const int kcol = k0 + i16;
     const bool kv = kcol < nk;
-    const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
+    const int Dc = going_left ? b.Dl : b.Dr;
     const int nj = (Dc + 15) >> 4;
     const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];
-    const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
-    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        d4 t = {0, 0, 0, 0};
-        if (j < nj) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int q = kbeg + 4 * u + kq;
-                const double bv = (kv && q < kend) ? Ev[(int64_t)q * ldE + kcol] : 0.0;
-                if (kbeg + 4 * u < kend) t = mfma_f64(TC_AV(j, u), bv, t);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cpart[(wave * 2 + j) * 256 + r * 64 + lane] = t[r];
-    }
-    __syncthreads();
     d4 T[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1532,7 +1551,7 @@ __device__ __forceinline__ void tail_chain_finish(const View& v, const BondDimsF
             for (int j = 0; j < 2; ++j)
                 if (j < nj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], TC_WPRE(it, j, r), acc);
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], TC_WPRE(it, j, r), acc);    // A[m = k][kk = b] = T^T tile, register r
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1561,8 +1580,8 @@ __device__ __forceinline__ void tail_split_tile(const View& v, const BondDimsF& 
         n0 = (rem % ty) * 16;       // column tile of T (y)
     }
 }
-__device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& b, int going_left, int tile, double (&R)[32]) {
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& b, int going_left, int tile, double (&R)[32], const int rt) {
+    const int lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     int c, m0, n0;
     tail_split_tile(v, b, going_left, tile, c, m0, n0);
@@ -1584,8 +1603,8 @@ __device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& 
     }
 }
 __device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF& b, int lid, int going_left, int blk, int nblk, double (&R)[32],
-                                                  const double* __restrict__ Ev, const int ldE, const int nk, const double inv) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                                                  const double* __restrict__ Ev, const int ldE, const int nk, const double inv, const int rt) {
+    const int wave = rt >> 6, lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     double* Wl = v.sites + (int64_t)lid * v.site_stride;
     double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
@@ -1605,12 +1624,16 @@ __device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF
         for (int w = 0; w < 4; ++w) {
             p[w] = d4{0, 0, 0, 0};
             const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
+            double ev[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int k = kbeg + 4 * u + kq;
-                const double e = (kcol < nk && k < kend) ? Ev[(int64_t)k * ldE + kcol] : 0.0;
-                if (kbeg + 4 * u < kend) p[w] = going_left ? mfma_f64(R[8 * w + u], e, p[w]) : mfma_f64(e, R[8 * w + u], p[w]);
+                ev[u] = (kcol < nk && k < kend) ? Ev[(int64_t)k * ldE + kcol] : 0.0;
             }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (kbeg + 4 * u < kend) p[w] = going_left ? mfma_f64(R[8 * w + u], ev[u], p[w]) : mfma_f64(ev[u], R[8 * w + u], p[w]);
         }
         if (going_left) {
             double* out = Wl + (int64_t)c * b.X * nk;
@@ -1632,13 +1655,13 @@ __device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF
     // (two-dimensional walks: an integer division per element costs more than the copy)
     if (going_left) {
         for (int k = blk; k < nk; k += nblk)
-            for (int y = threadIdx.x; y < b.Y; y += 256) Wr[(int64_t)k * b.Y + y] = Ev[(int64_t)y * ldE + k];
-        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid;
+            for (int y = rt; y < b.Y; y += 256) Wr[(int64_t)k * b.Y + y] = Ev[(int64_t)y * ldE + k];
+        if (blk == 0 && rt == 0) *v.label_site = lid;
     } else {
-        const int k = threadIdx.x & 31;
-        for (int x = blk * 8 + ((int)threadIdx.x >> 5); x < b.X; x += nblk * 8)
+        const int k = rt & 31;
+        for (int x = blk * 8 + (rt >> 5); x < b.X; x += nblk * 8)
             if (k < nk) Wl[(int64_t)x * nk + k] = Ev[(int64_t)x * ldE + k];
-        if (blk == 0 && threadIdx.x == 0) *v.label_site = lid + 1;
+        if (blk == 0 && rt == 0) *v.label_site = lid + 1;
     }
 }
 
@@ -1658,14 +1681,15 @@ struct TailArgs {
 // Else Z <- Z (I - D/2 + 3 D^2 / 8): the deviation becomes 5/8 |D|^3 <= 1.7e-14 for |D| <= 3e-5 - ONE pass over Z where
 // k_eig_fin's verify_and_polish forms D twice (D^2 is a 32^3 product); beyond 3e-5 a second, first-order pass follows.
 __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __restrict__ D, double* __restrict__ Dh, double* __restrict__ misc,
-                                            const int n, const int K, const double rres, double& emax0) {
+                                            const int n, const int K, const double rres, double& emax0, const bool worker) {
+    // worker: one of the 8 waves that do the work; the workgroup's other waves (the role waves of k_bond_tail) only keep the barriers company
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jl = lane & 15, q4 = lane >> 4;
     for (int pass = 0; pass < 2; ++pass) {
         // ---- D: wave w owns the 16 x 16 tile (w & 3) over rows [64 (w >> 2), +64) ----
         const int a0 = 16 * ((wave & 3) >> 1), b0 = 16 * (wave & 1), kb = 64 * (wave >> 2);
         d4 acc = {0.0, 0.0, 0.0, 0.0};
-        {
+        if (worker) {
             // operands a batch of 8 k-steps ahead of the MFMAs that consume them (see k_bond_tail's overlap product)
             double da[2][8], db[2][8];
             auto fetch = [&](int bt) {
@@ -1684,7 +1708,7 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc = mfma_f64(da[bt][u], db[bt][u], acc);
         }
-        if (wave >= 4) {
+        if (worker && wave >= 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Dh[(wave & 3) * 256 + (q4 + 4 * r) * 16 + jl] = acc[r];
         }
@@ -1704,14 +1728,14 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
         }
         err = wave_max(err);
         const double rr = wave_max(rres);
-        if (lane == 0) {
+        if (worker && lane == 0) {
             misc[8 + wave] = err;
             misc[16 + wave] = rr;
         }
         __syncthreads();
         double emax = 0.0, rmax = 0.0;
 #pragma unroll
-        for (int w = 0; w < BT_T / 64; ++w) {
+        for (int w = 0; w < 8; ++w) {
             emax = fmax(emax, misc[8 + w]);
             rmax = fmax(rmax, misc[16 + w]);
         }
@@ -1723,7 +1747,7 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
         const double* Cm = D;
         if (second) {
             // Cm = D - 3/4 D^2 (the update below takes half of it): four tiles, waves 0..3
-            if (wave < 4) {
+            if (wave < 4) {             // (workers)
                 d4 c2 = {0.0, 0.0, 0.0, 0.0};
                 double ca_[8], cb_[8];
 #pragma unroll
@@ -1745,7 +1769,9 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
         }
         // ---- Z <- Z - (Z Cm) / 2: 8 row tiles x 2 column tiles, two per wave ----
         d4 upd[2];
-        {
+        upd[0] = d4{0.0, 0.0, 0.0, 0.0};
+        upd[1] = d4{0.0, 0.0, 0.0, 0.0};
+        if (worker) {
             // the two tiles of a wave share the row tile of Z: its operand once, both column tiles of Cm
             const int c0 = 16 * wave;
             double ua[8], ub0[8], ub1[8];
@@ -1766,14 +1792,16 @@ __device__ __forceinline__ bool tail_polish(double* __restrict__ Z, double* __re
             upd[1] = a1_;
         }
         __syncthreads();
+        if (worker) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int tile = wave * 2 + h;
-            const int c0 = 16 * (tile >> 1), ca = 16 * (tile & 1);
+            for (int h = 0; h < 2; ++h) {
+                const int tile = wave * 2 + h;
+                const int c0 = 16 * (tile >> 1), ca = 16 * (tile & 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = c0 + q4 + 4 * r, aa = ca + jl;
-                if (c < n && aa < K) Z[c * BT_ZS + aa] -= 0.5 * upd[h][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int c = c0 + q4 + 4 * r, aa = ca + jl;
+                    if (c < n && aa < K) Z[c * BT_ZS + aa] -= 0.5 * upd[h][r];
+                }
             }
         }
         __syncthreads();
@@ -1812,16 +1840,22 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     const int lid = ta.lid, going_left = ta.going_left, nsplit = ta.nsplit, nchain = ta.nchain;
     const int want_next = ta.flags & 1;
     const int d = v.d;
-    // blocks [0, nchain): the next bond's tensor (the longest dependent chain: first to be dispatched); [nchain, nchain + nsplit): the
-    // back-split; the rest: one 16-series tile each
+    // Workgroup = 8 tile waves (one 16-series tile: threads [0, BT_T)) + 4 role waves (threads [BT_T, BT_TT)): the role waves of workgroups
+    // [0, nchain) form the next bond's tensor, those of [nchain, nchain + nsplit) the back-split, the others leave at once.  (As
+    // workgroups of their own - 24 of them beside 256 tile workgroups at the headline shape - the roles shared CUs with tiles and the
+    // launch took 22 us instead of 15, stamped; here they also share the workgroup's copy of the polished eigenvectors.)
     const int bid = (int)blockIdx.x;
-    const int role = bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 0);
-    // phase stamps (100 MHz) of one workgroup per role: DevScalars::eig_stamps[16..] first tile workgroup, [32..] chain, [40..] split
+    const bool rolew = tid >= BT_T;
+    const int rt = tid - BT_T;                      // role waves: the thread's index among the role's 256
+    const int role = !rolew ? 0 : (bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 3));
+    if (role == 3) return;                          // (a retired wave no longer counts at the workgroup's barriers)
+    // phase stamps (100 MHz): DevScalars::eig_stamps[16..] the tile waves of workgroup 0, [32..] its role waves (chain), [44..] the role
+    // waves of the first split workgroup
     unsigned long long* stp = nullptr;
-    if (tid == 0 && (ta.flags & 2)) {
-        if (bid == nchain + nsplit) stp = v.sc->eig_stamps + 16;
+    if ((ta.flags & 2) && (tid == 0 || tid == BT_T)) {
+        if (bid == 0 && tid == 0) stp = v.sc->eig_stamps + 16;
         else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
-        else if (bid == nchain) stp = v.sc->eig_stamps + 44;
+        else if (bid == nchain && rolew) stp = v.sc->eig_stamps + 44;
     }
     int sti = 0;
 #define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1840,19 +1874,21 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     double* part = Sf;                             // ... and, once both are consumed, [4 quarters][2 column tiles][256] pieces of env'
     double* envs = part + 2048;                    // [16][BT_ENVS] new environment rows of the tile
     double* redy = envs + 16 * BT_ENVS;            // [8][16] the waves' pieces of yhat
+    double* cpart = redy + 128;                    // [4][2][256] the chain role's partial tiles
     double* St = Dl;                               // [16][BT_SS] the dense S tile, once the polish is done
     const double* __restrict__ ws = v.eig_ws;
     // the loader role of a thread: threads [0, 256) the S side, [256, 512) the O side; 16 threads per series row, two bond entries and
     // one site state each
     const bool lower = tid < 256;
     const int lrow = (tid & 255) >> 4, lj = tid & 15;
+    const bool worker = !rolew;
     // ONE tile per tile workgroup, no loop around any of this: a loop invites the compiler to hoist the address arithmetic of every
     // phase - polish, roles, products - in front of it, and the kernel then lives in scratch memory (400 bytes per lane, measured)
     // ---- requests, first those that need nothing but the kernel arguments: the bond dimensions are a dependent (scalar) load from memory,
     // about a microsecond on a cold start, and everything asked for before their first use is in flight by the time they arrive ----
     double zin[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
+    for (int m = 0; m < 8; ++m) zin[m] = worker ? ws[WS_Z + tid + m * BT_T] : 0.0;
     const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
     double lam_in = lane < 32 ? ws[WS_LAM + lane] : 0.0;                 // every wave: the truncation rule runs in its lanes
     const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
@@ -1861,7 +1897,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     Span tl{0, 0, 0, 0};
     double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
     if (role == 0) {
-        tl = tile_span_k(v, bid - nchain - nsplit);
+        tl = tile_span_k(v, bid);                   // (count 0 beyond the last tile: a workgroup that is there for its role waves only)
         if (lower || want_next) {
             // whole rows (the capacity is a kernel argument); what lies beyond the live bond is dropped when the dimensions are known
             const double* prev = lower ? ta.Sprev : ta.Oprev;
@@ -1896,8 +1932,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
         for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
     }
-    if (role == 2 && lower) tail_chain_request(v, b, lid, going_left, bid, bm);
-    if (role == 1 && lower) tail_split_load(v, b, going_left, (bid - nchain) * 4 + wave, bm);
+    if (role == 2) tail_chain_request(v, b, lid, going_left, bid, bm, rt);
+    if (role == 1) tail_split_load(v, b, going_left, (bid - nchain) * 4 + (rt >> 6), bm, rt);
     const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
     lam_in = lane < K0 ? lam_in : 0.0;
     {
@@ -1917,7 +1953,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     {
         const double trw = wave_sum(gdiag);         // pieces of the trace: they meet at the barrier the factors need anyway
-        if (lane == 0) red[wave] = trw;
+        if (lane == 0 && worker) red[wave] = trw;
     }
     __syncthreads();
     TSTAMP();      // [5] factors in LDS, trace pieces published
@@ -1931,13 +1967,13 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     for (int m = 0; m < 8; ++m) {
         const int i = tid + m * BT_T;
         const int c = i >> 5, kk = i & 31;
-        Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
+        if (worker) Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
     }
     __syncthreads();
     TSTAMP();      // [5] candidates in LDS
     bool ok = triflag == 1.0 && redo_in == 0;
     double emax0 = 0.0;
-    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0);
+    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0, worker);
     TSTAMP();      // [6] verified + polished
     if (!ok) {
         if (bid == 0 && tid == 0 && redo_in == 0) {
@@ -2001,17 +2037,28 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     const double* __restrict__ Ef = Zl;
     if (role != 0) {
-        if (!lower) return;                         // (a retired wave no longer counts at the barriers of the 256-thread bodies)
-        if (role == 2) tail_chain_finish(v, b, lid, going_left, bid, bm, Dl, Ef, BT_ZS, nk, inv);
-        else tail_split_finish(v, b, lid, going_left, bid - nchain, nsplit, bm, Ef, BT_ZS, nk, inv);
+        // ---- role waves: their products beside the tile waves' (the workgroup's barriers from here on: B1 .. B3, with the overlaps B4, B5;
+        // the chain role exchanges its partial tiles across B1, everything else just arrives)
+        const int job = role == 2 ? bid : bid - nchain;
+        if (role == 2) tail_chain_first(v, b, lid, going_left, job, bm, cpart, Ef, BT_ZS, nk, rt);
+        else tail_split_finish(v, b, lid, going_left, job, nsplit, bm, Ef, BT_ZS, nk, inv, rt);
+        lds_barrier();                              // B1
+        if (role == 2) tail_chain_second(v, b, lid, going_left, job, bm, cpart, nk, inv, rt);
+        TSTAMP();  // role done (stores in flight)
+        lds_barrier();                              // B2
+        lds_barrier();                              // B3
+        if (want_next) {
+            lds_barrier();                          // B4
+            lds_barrier();                          // B5
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TSTAMP();  // [7] role done, stores drained
+        TSTAMP();  // stores drained
         TEND();
         return;
     }
     // ---- the dense S tile, by all waves (env' then pays one LDS read per MFMA, whichever side S is).  It goes over the polish scratch:
     // the barrier keeps it off the error pieces a slower wave may still be reading (tail_polish returns without one when nothing is to do)
-    __syncthreads();
+    __syncthreads();                                // B1
     {
         const int row = tid >> 5, z0 = tid & 31;    // 4 entries per thread: z0, z0 + 32, ...
 #pragma unroll
@@ -2020,7 +2067,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             St[row * BT_SS + z] = z < ZS ? kr_at(ks, row, (unsigned)z) : 0.0;
         }
     }
-    __syncthreads();
+    __syncthreads();                                // B2
     TSTAMP();      // [7] S tile formed
     // env' = S E, the sums of k_env / k_env_split (mpst_internal.h: four chains over the quarters of the contraction): wave = (column tile,
     // quarter), the quarters meet in LDS as (q0 + q1) + (q2 + q3).  At most 32 vectors are kept here: two column tiles.
@@ -2047,7 +2094,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(q * 2 + nt) * 256 + r * 64 + lane] = acc[r];      // (both factor sets are consumed: P is issued, S is dense)
     }
-    __syncthreads();
+    __syncthreads();                                // B3
     {
         const int nt = tid >> 8, e = tid & 255;
         const double sum = (part[nt * 256 + e] + part[(2 + nt) * 256 + e]) + (part[(4 + nt) * 256 + e] + part[(6 + nt) * 256 + e]);
@@ -2060,7 +2107,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         TEND();
         return;
     }
-    lds_barrier();                                  // (LDS only: __syncthreads() would wait for the acknowledgement of the rows just stored)
+    lds_barrier();                                  // B4 (LDS only: __syncthreads() would wait for the acknowledgement of the rows just stored)
     {
         // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
         d4 zacc = {0.0, 0.0, 0.0, 0.0};
@@ -2079,7 +2126,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
         }
     }
-    lds_barrier();
+    lds_barrier();                                  // B5
     TSTAMP();      // [9] z, row dot
     if (tid < 16 && tid < tl.count) {
         const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
@@ -2097,14 +2144,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #undef TSTAMP
 #undef TEND
 }
-// two register budgets of the same body: 128 VGPRs (two workgroups per CU: the chain / split workgroups find room beside the tile
-// workgroups) or whatever the body wants (one workgroup per CU)
 template <bool D4>
-__global__ __launch_bounds__(BT_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_bond_tail(View v, TailArgs ta) {
-    bond_tail_body<D4>(v, ta);
-}
-template <bool D4>
-__global__ __launch_bounds__(BT_T) void k_bond_tail_w(View v, TailArgs ta) {
+__global__ __launch_bounds__(BT_TT) void k_bond_tail(View v, TailArgs ta) {
     bond_tail_body<D4>(v, ta);
 }
 
@@ -2192,8 +2233,6 @@ hipError_t b2_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_bond_tail<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_bond_tail<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bond_tail_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bond_tail_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
     if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
     return hipSuccess;
 }
@@ -2275,20 +2314,14 @@ void launch_bond_tail(const View& v, int lid, int going_left, int chain, int wan
     ta.phO = going_left ? phl : phr;
     ta.M = going_left ? v.btn : v.btnT;
     ta.out = going_left ? v.RE + (int64_t)rid * cs : v.LE + (int64_t)lid * cs;
-    static const bool wide = [] { const char* e = getenv("MPST_TAIL_WIDE"); return e && e[0] == '1'; }();
     // which bond's tail leaves its phase stamps (mpst_get_tail_phases): MPST_TAIL_STAMP="lid,going_left", default the middle bond going left
     static const int stamp_lid = [] { const char* e = getenv("MPST_TAIL_STAMP"); return e ? atoi(e) : -1; }();
     static const int stamp_dir = [] { const char* e = getenv("MPST_TAIL_STAMP"); const char* q = e ? strchr(e, ',') : nullptr; return q ? atoi(q + 1) : 1; }();
     if (lid == (stamp_lid >= 0 ? stamp_lid : (v.T - 1) / 2) && (going_left != 0) == (stamp_dir != 0)) ta.flags |= 2;
     const size_t lds = (size_t)BT_LDS_DOUBLES * sizeof(double);
-    const dim3 grid(ta.nchain + ta.nsplit + v.ntiles);          // one 16-series tile per tile workgroup
-    if (wide) {
-        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail_w<true>, grid, dim3(BT_T), lds, s, v, ta);
-        else hipLaunchKernelGGL(k_bond_tail_w<false>, grid, dim3(BT_T), lds, s, v, ta);
-    } else {
-        if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_T), lds, s, v, ta);
-        else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_T), lds, s, v, ta);
-    }
+    const dim3 grid(std::max(v.ntiles, ta.nchain + ta.nsplit));           // one 16-series tile per workgroup; the first ones carry a role as well
+    if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_TT), lds, s, v, ta);
+    else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_TT), lds, s, v, ta);
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);

@@ -395,7 +395,7 @@ class SweepEngine:
         tile = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "factors_in_lds", "truncation",
                 "candidates_in_lds", "polished", "overlap_product_issued", "s_tile_formed", "env_rows", "z_rowdot", "stores_drained")
         role = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "barrier", "truncation", "candidates_in_lds",
-                "polished", "operands_ready", "role_done")
+                "polished", "operands_ready", "role_done", "stores_drained")
         pick = lambda names, x: {k: round(float(v), 2) for k, v in zip(names, x) if v >= 0 or k == "start"}
         return {"tile": pick(tile, us[:16]), "chain": pick(role, us[16:32]), "split": pick(role, us[32:48]),
                 "bonds_by_candidate_orthogonality": dict(zip(("below_1e-13", "below_1e-8", "below_3e-5", "above"), [int(x) for x in us[48:52]])),
