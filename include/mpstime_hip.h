@@ -371,16 +371,16 @@ int  mpst_get_info_n(void* ctx, int32_t* out, int32_t n);
  * tridiagonal eigenvectors, back-transformation, verification+re-orthonormalisation; us[5] = shader
  * cycles (s_memtime) of the tridiagonalisation, for the effective clock */
 int  mpst_get_eig_phases(void* ctx, double* us /*[6]*/);
-/* in-kernel phase stamps (us since its first tile workgroup started; -1: not taken) of the last stamped k_bond_tail launch - the
- * four-launch chain's last launch, which stands for k_eig_fin + update_caches! + the back-split (RealRealHighDimension.jl:107-203)
- * and the next bond's yhat pass (loss_functions.jl:248-262).  Which bond leaves stamps: MPST_TAIL_STAMP="lid,going_left" (default: the
- * middle bond of the backward half-sweep).  us[0..15] the first tile workgroup: start, candidate vectors requested, factors requested,
- * bond dimensions known, everything requested, factors in LDS, overlap product issued, truncation rule, candidates in LDS, verified +
- * polished, dense S tile, new environment rows, z + row dot, stores drained; us[16..31] the first workgroup of the next bond's tensor,
- * us[32..47] the first back-split workgroup: start, the same four request stamps, barrier, truncation rule, candidates in LDS,
- * polished, role done (stores drained); us[48..51] bonds since the context was created by how far from orthonormal their candidate
- * vectors were: |Z^T Z - I| below 1e-13 (nothing to do), below 1e-8 (first-order polish), below 3e-5 (second-order), above (two passes);
- * us[52], us[53], us[54] the earliest start, the latest end and the latest start over ALL workgroups of the stamped launch */
+/* in-kernel phase stamps (us since workgroup 0 started; -1: not taken) of the last stamped k_bond_tail launch - the four-launch chain's
+ * last launch, which stands for k_eig_fin + update_caches! + the back-split (RealRealHighDimension.jl:107-203) and the next bond's
+ * yhat pass (loss_functions.jl:248-262).  Which bond leaves stamps: MPST_TAIL_STAMP="lid,going_left" (default: the middle bond of the
+ * backward half-sweep).  us[0..15] workgroup 0, which also hosts a job of the next bond's tensor when the sweep goes on: start,
+ * candidate vectors requested, factors requested, bond dimensions known, everything requested, factors in LDS, truncation rule,
+ * candidates in LDS, verified + polished, overlap product issued, dense S tile, new environment rows, z + row dot, tile done, role
+ * done, stores drained; us[16..31] the same for the last workgroup (a tile, no role); us[48..51] bonds since the context was created
+ * by how far from orthonormal their candidate vectors were: |Z^T Z - I| below 1e-13 (nothing to do), below 1e-8 (first-order polish),
+ * below 3e-5 (second-order), above (two passes); us[52], us[53], us[54] the earliest start, the latest end and the latest start over
+ * ALL workgroups of the stamped launch */
 int  mpst_get_tail_phases(void* ctx, double* us /*[55]*/);
 
 #ifdef __cplusplus

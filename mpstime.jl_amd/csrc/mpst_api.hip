@@ -2501,8 +2501,8 @@ int mpst_get_eig_phases(void* ctx, double* us) {
     return 0;
 }
 
-// phase stamps of the last stamped k_bond_tail launch (us since its first tile workgroup started; -1: not taken): us[0..15] that workgroup,
-// us[16..31] the first workgroup of the next bond's tensor, us[32..47] the first back-split workgroup (see include/mpstime_hip.h)
+// phase stamps of the last stamped k_bond_tail launch (us since workgroup 0 started; -1: not taken): us[0..15] workgroup 0 (which also
+// hosts a job of the next bond's tensor when the sweep goes on), us[16..31] the last workgroup (no role) (see include/mpstime_hip.h)
 int mpst_get_tail_phases(void* ctx, double* us) {
     Ctx* c = (Ctx*)ctx;
     if (!c || !c->sc || !us) return MPST_ERR_INVALID;
@@ -2512,13 +2512,12 @@ int mpst_get_tail_phases(void* ctx, double* us) {
     HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
     const unsigned long long* t = sc.eig_stamps;
     const double t0 = (double)t[16];
-    // tile workgroup: slots 16..31, chain 32..43, split 44..55
+    // workgroup 0: slots 16..31; the last workgroup: 32..47
     for (int i = 0; i < 48; ++i) us[i] = -1.0;
     for (int i = 0; i < 16; ++i) if (t[16 + i] && t[16]) us[i] = 0.01 * ((double)t[16 + i] - t0);
-    for (int i = 0; i < 12; ++i) if (t[32 + i] && t[16]) us[16 + i] = 0.01 * ((double)t[32 + i] - t0);
-    for (int i = 0; i < 12; ++i) if (t[44 + i] && t[16]) us[32 + i] = 0.01 * ((double)t[44 + i] - t0);
+    for (int i = 0; i < 16; ++i) if (t[32 + i] && t[16]) us[16 + i] = 0.01 * ((double)t[32 + i] - t0);
     // slots a launch did not reach keep the stamps of an earlier one: nothing after the first stamp that runs backwards counts
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 2; ++g)
         for (int i = 1; i < 16; ++i)
             if (us[16 * g + i] < us[16 * g + i - 1] || us[16 * g + i - 1] == -1.0) us[16 * g + i] = -1.0;
     for (int i = 0; i < 4; ++i) us[48 + i] = (double)t[56 + i];        // bonds by |Z^T Z - I| of their candidates: < 1e-13, < 1e-8, < 3e-5, above

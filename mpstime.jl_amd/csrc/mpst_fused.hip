@@ -1248,8 +1248,7 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
 // DevScalars::redo and leaves the MPS alone; every later tail launch of the sweep leaves at once, and the host redoes the sweep
 // from its snapshot on the six-launch chain (mpst_sweep).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
 // =====================================================================================================================
-constexpr int BT_T = 512;                    // 8 tile waves ...
-constexpr int BT_TT = BT_T + 256;            // ... and 4 role waves
+constexpr int BT_T = 512;                    // 8 waves
 constexpr int BT_ZS = 36;                    // LDS row stride of the candidate / kept eigenvectors: rows 16 apart in 16 different bank pairs
                                              // (with the 32 of k_eig_fin's layout the A operand of Z D is a 16-way conflict: 3 us per polish)
 constexpr int BT_ENVS = 34;                  // LDS row stride of the 16 x 32 tile of new environment rows
@@ -1257,7 +1256,7 @@ constexpr int BT_ELS = 37, BT_PLS = 21;      // LDS row strides of the staged fa
                                              // entries / 16 site states and zeros behind them (the padded K extent reads up to 4 beyond the live ones)
 constexpr int BT_FAC = 16 * (BT_ELS + BT_PLS);
 constexpr int BT_SS = 129;                   // row stride of the dense S tile (over D / Dh / misc once the polish is done)
-constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2048 + 16 * BT_ENVS + 128 + 2048;     // 92 KB
+constexpr int BT_LDS_DOUBLES = 128 * BT_ZS + 32 * 32 + 1024 + 128 + 2048 + 16 * BT_ENVS + 128;     // 76 KB
 static_assert(2 * BT_FAC <= 2048, "the factors live where the pieces of env' go later");
 static_assert(16 * BT_SS <= 32 * 32 + 1024 + 128, "the dense S tile lives in the polish scratch");
 
@@ -1420,7 +1419,7 @@ bool env_walk_supported(const View& v) { return v.zw != 2 && v.cap <= 32 && v.d 
 // (operand of the second product); [16, 32) av[j][u], this wave's share of bt_new for the two row blocks of T.
 #define TC_WPRE(it, j, r) R[((it) * 2 + (j)) * 4 + (r)]
 #define TC_AV(j, u) R[16 + (j) * 8 + (u)]
-__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32], const int rt) {
+__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32], const int rt, const int Dnb) {
     const int d = v.d;
     const int wave = rt >> 6, lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -1429,7 +1428,6 @@ __device__ __forceinline__ void tail_chain_request(const View& v, const BondDims
     const double* Bc = v.btn + (int64_t)c * b.L;
     const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
     const int nj = (Dc + 15) >> 4;
-    const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];
     const double* Wn = v.sites + (int64_t)(going_left ? lid - 1 : lid + 2) * v.site_stride;
     const int Xn = Dnb * d;
 #pragma unroll
@@ -1495,7 +1493,7 @@ __device__ __forceinline__ void tail_chain_first(const View& v, const BondDimsF&
     }
 }
 __device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
-                                                  const double* __restrict__ cpart, const int nk, const double inv, const int rt) {
+                                                  const double* __restrict__ cpart, const int nk, const double inv, const int rt, const int Dnb) {
     const int d = v.d;
     const int wave = rt >> 6, lane = rt & 63;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -1507,7 +1505,6 @@ __device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF
     const bool kv = kcol < nk;
     const int Dc = going_left ? b.Dl : b.Dr;
     const int nj = (Dc + 15) >> 4;
-    const int Dnb = going_left ? v.chi[lid - 1] : v.chi[lid + 3];
     d4 T[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1840,22 +1837,20 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     const int lid = ta.lid, going_left = ta.going_left, nsplit = ta.nsplit, nchain = ta.nchain;
     const int want_next = ta.flags & 1;
     const int d = v.d;
-    // Workgroup = 8 tile waves (one 16-series tile: threads [0, BT_T)) + 4 role waves (threads [BT_T, BT_TT)): the role waves of workgroups
-    // [0, nchain) form the next bond's tensor, those of [nchain, nchain + nsplit) the back-split, the others leave at once.  (As
-    // workgroups of their own - 24 of them beside 256 tile workgroups at the headline shape - the roles shared CUs with tiles and the
-    // launch took 22 us instead of 15, stamped; here they also share the workgroup's copy of the polished eigenvectors.)
+    // One 16-series tile per workgroup.  The first nchain workgroups ALSO form the next bond's tensor (one job each), the next nsplit the
+    // back-split (one block each) - after their tile work, with waves 0..3, from operands requested as soon as the overlap product has
+    // released its registers.  (As workgroups of their own - 24 beside 256 tile workgroups at the headline shape - the roles shared CUs with
+    // tiles and the launch took 22 us instead of 15, stamped; as extra waves of the tile workgroups they held their hosts' barriers up: 21 us.)
     const int bid = (int)blockIdx.x;
-    const bool rolew = tid >= BT_T;
-    const int rt = tid - BT_T;                      // role waves: the thread's index among the role's 256
-    const int role = !rolew ? 0 : (bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 3));
-    if (role == 3) return;                          // (a retired wave no longer counts at the workgroup's barriers)
-    // phase stamps (100 MHz): DevScalars::eig_stamps[16..] the tile waves of workgroup 0, [32..] its role waves (chain), [44..] the role
-    // waves of the first split workgroup
+    const int role = bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 0);
+    const int rt = tid;                             // role threads: the workgroup's first 256
+    const bool rolet = role != 0 && tid < 256;
+    // phase stamps (100 MHz): DevScalars::eig_stamps[16..] workgroup 0 (hosts a job of the next bond's tensor when the sweep goes on),
+    // [32..] the last workgroup (no role)
     unsigned long long* stp = nullptr;
-    if ((ta.flags & 2) && (tid == 0 || tid == BT_T)) {
-        if (bid == 0 && tid == 0) stp = v.sc->eig_stamps + 16;
-        else if (bid == 0 && nchain > 0) stp = v.sc->eig_stamps + 32;
-        else if (bid == nchain && rolew) stp = v.sc->eig_stamps + 44;
+    if ((ta.flags & 2) && tid == 0) {
+        if (bid == 0) stp = v.sc->eig_stamps + 16;
+        else if (bid == (int)gridDim.x - 1) stp = v.sc->eig_stamps + 32;
     }
     int sti = 0;
 #define TSTAMP() do { if (stp) stp[sti++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1874,21 +1869,20 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     double* part = Sf;                             // ... and, once both are consumed, [4 quarters][2 column tiles][256] pieces of env'
     double* envs = part + 2048;                    // [16][BT_ENVS] new environment rows of the tile
     double* redy = envs + 16 * BT_ENVS;            // [8][16] the waves' pieces of yhat
-    double* cpart = redy + 128;                    // [4][2][256] the chain role's partial tiles
+    double* cpart = Dl;                            // [4][2][256] the chain role's partial tiles (the polish scratch and the S tile are long consumed)
     double* St = Dl;                               // [16][BT_SS] the dense S tile, once the polish is done
     const double* __restrict__ ws = v.eig_ws;
     // the loader role of a thread: threads [0, 256) the S side, [256, 512) the O side; 16 threads per series row, two bond entries and
     // one site state each
     const bool lower = tid < 256;
     const int lrow = (tid & 255) >> 4, lj = tid & 15;
-    const bool worker = !rolew;
     // ONE tile per tile workgroup, no loop around any of this: a loop invites the compiler to hoist the address arithmetic of every
     // phase - polish, roles, products - in front of it, and the kernel then lives in scratch memory (400 bytes per lane, measured)
     // ---- requests, first those that need nothing but the kernel arguments: the bond dimensions are a dependent (scalar) load from memory,
     // about a microsecond on a cold start, and everything asked for before their first use is in flight by the time they arrive ----
     double zin[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) zin[m] = worker ? ws[WS_Z + tid + m * BT_T] : 0.0;
+    for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
     const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
     double lam_in = lane < 32 ? ws[WS_LAM + lane] : 0.0;                 // every wave: the truncation rule runs in its lanes
     const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
@@ -1896,8 +1890,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     TSTAMP();      // [1] candidates requested
     Span tl{0, 0, 0, 0};
     double fe0 = 0.0, fe1 = 0.0, fp = 0.0;
-    if (role == 0) {
-        tl = tile_span_k(v, bid);                   // (count 0 beyond the last tile: a workgroup that is there for its role waves only)
+    {
+        tl = tile_span_k(v, bid);                   // (count 0 beyond the last tile: a workgroup that is there for its role only)
         if (lower || want_next) {
             // whole rows (the capacity is a kernel argument); what lies beyond the live bond is dropped when the dimensions are known
             const double* prev = lower ? ta.Sprev : ta.Oprev;
@@ -1913,6 +1907,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     // ---- ... then those that need the bond dimensions -----------------------------------------------------------------------
     const EigProblem pb = resolve(v, lid, going_left, nullptr, 0, 0);
     const BondDimsF b = bond_dims_f(v, lid);
+    // (the outer bond of the neighbouring site, for the chain role: asked for with the other dimensions, not a dependent round trip later)
+    const int Dnb = role == 2 ? (going_left ? v.chi[max(lid - 1, 0)] : v.chi[min(lid + 3, v.T)]) : 1;
     const int n = pb.n, K0 = pb.K0, nspec = pb.nspec;
     // S: the side the kept eigenvectors live on (Y going left, X going right); O: the other side
     const int DS = ta.Sprev ? (going_left ? b.Dr : b.Dl) : 1, DO = ta.Oprev ? (going_left ? b.Dl : b.Dr) : 1;
@@ -1923,7 +1919,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     TSTAMP();      // [3] bond dimensions known
     d4 pacc0 = {0.0, 0.0, 0.0, 0.0}, pacc1 = {0.0, 0.0, 0.0, 0.0};
     double bm[32];          // requested operands of the workgroup's role: the tile's slice of bt_new / see tail_chain_request, tail_split_load
-    if (role == 0 && want_next) {
+    if (want_next) {
         // this wave's 16 columns of bt_new, every k-step: no predicates (sixteen exec-masked loads in a row keep the memory
         // pipeline from ever holding a tile's worth of requests).  Rows beyond the live ones meet zeros of the O side, columns
         // beyond them zeros of z: their (finite) values are read from clamped addresses and do not matter.
@@ -1932,8 +1928,6 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
         for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
     }
-    if (role == 2) tail_chain_request(v, b, lid, going_left, bid, bm, rt);
-    if (role == 1) tail_split_load(v, b, going_left, (bid - nchain) * 4 + (rt >> 6), bm, rt);
     const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
     lam_in = lane < K0 ? lam_in : 0.0;
     {
@@ -1943,7 +1937,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         fe1 = (lj + 16 < Dp && !bnd) ? fe1 : 0.0;
     }
     TSTAMP();      // [4] everything requested
-    if (role == 0) {
+    {
         double* fac = lower ? Sf : Of;
         fac[lrow * BT_ELS + lj] = fe0;
         fac[lrow * BT_ELS + lj + 16] = fe1;
@@ -1953,7 +1947,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     {
         const double trw = wave_sum(gdiag);         // pieces of the trace: they meet at the barrier the factors need anyway
-        if (lane == 0 && worker) red[wave] = trw;
+        if (lane == 0) red[wave] = trw;
     }
     __syncthreads();
     TSTAMP();      // [5] factors in LDS, trace pieces published
@@ -1967,13 +1961,13 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     for (int m = 0; m < 8; ++m) {
         const int i = tid + m * BT_T;
         const int c = i >> 5, kk = i & 31;
-        if (worker) Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
+        Zl[c * BT_ZS + kk] = (c < n && kk < nk) ? zin[m] : 0.0;
     }
     __syncthreads();
     TSTAMP();      // [5] candidates in LDS
     bool ok = triflag == 1.0 && redo_in == 0;
     double emax0 = 0.0;
-    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0, worker);
+    if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0, true);
     TSTAMP();      // [6] verified + polished
     if (!ok) {
         if (bid == 0 && tid == 0 && redo_in == 0) {
@@ -1984,7 +1978,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     // P = O bt_new AFTER the polish: its operand (128 KB of bt_new per workgroup: the CU's L1 moves 64 bytes a cycle) has arrived by now,
     // the candidates came first
-    if (role == 0) {
+    {
         if (want_next) {
             // P = O bt_new, this wave's 16 columns.  A wave issues one MFMA per 64 cycles whatever their dependencies (profiles/ubench/
             // mfma_rate.hip), so what a product costs is 64 cycles per MFMA PLUS every operand latency the wave waits out in between:
@@ -2017,7 +2011,12 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             }
         }
     }
-    TSTAMP();      // [10] P issued (tile workgroups)
+    TSTAMP();      // [10] P issued
+    // the role's operands into the registers the overlap product has just released: they arrive under the rest of the tile's work
+    if (rolet) {
+        if (role == 2) tail_chain_request(v, b, lid, going_left, bid, bm, rt, Dnb);
+        else tail_split_load(v, b, going_left, (bid - nchain) * 4 + wave, bm, rt);
+    }
     if (bid == 0 && wave == 0) {                    // publication (fin_body)
         if (lane < K0) v.lam[lane] = lam_in;
         bool bad = !(tr == tr) || tr > 1e300;
@@ -2036,29 +2035,9 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         }
     }
     const double* __restrict__ Ef = Zl;
-    if (role != 0) {
-        // ---- role waves: their products beside the tile waves' (the workgroup's barriers from here on: B1 .. B3, with the overlaps B4, B5;
-        // the chain role exchanges its partial tiles across B1, everything else just arrives)
-        const int job = role == 2 ? bid : bid - nchain;
-        if (role == 2) tail_chain_first(v, b, lid, going_left, job, bm, cpart, Ef, BT_ZS, nk, rt);
-        else tail_split_finish(v, b, lid, going_left, job, nsplit, bm, Ef, BT_ZS, nk, inv, rt);
-        lds_barrier();                              // B1
-        if (role == 2) tail_chain_second(v, b, lid, going_left, job, bm, cpart, nk, inv, rt);
-        TSTAMP();  // role done (stores in flight)
-        lds_barrier();                              // B2
-        lds_barrier();                              // B3
-        if (want_next) {
-            lds_barrier();                          // B4
-            lds_barrier();                          // B5
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        TSTAMP();  // stores drained
-        TEND();
-        return;
-    }
     // ---- the dense S tile, by all waves (env' then pays one LDS read per MFMA, whichever side S is).  It goes over the polish scratch:
     // the barrier keeps it off the error pieces a slower wave may still be reading (tail_polish returns without one when nothing is to do)
-    __syncthreads();                                // B1
+    lds_barrier();                                  // B1 (LDS-only barriers from here on: __syncthreads() would also wait for the role's operands)
     {
         const int row = tid >> 5, z0 = tid & 31;    // 4 entries per thread: z0, z0 + 32, ...
 #pragma unroll
@@ -2067,7 +2046,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             St[row * BT_SS + z] = z < ZS ? kr_at(ks, row, (unsigned)z) : 0.0;
         }
     }
-    __syncthreads();                                // B2
+    lds_barrier();                                  // B2
     TSTAMP();      // [7] S tile formed
     // env' = S E, the sums of k_env / k_env_split (mpst_internal.h: four chains over the quarters of the contraction): wave = (column tile,
     // quarter), the quarters meet in LDS as (q0 + q1) + (q2 + q3).  At most 32 vectors are kept here: two column tiles.
@@ -2094,7 +2073,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(q * 2 + nt) * 256 + r * 64 + lane] = acc[r];      // (both factor sets are consumed: P is issued, S is dense)
     }
-    __syncthreads();                                // B3
+    lds_barrier();                                  // B3
     {
         const int nt = tid >> 8, e = tid & 255;
         const double sum = (part[nt * 256 + e] + part[(2 + nt) * 256 + e]) + (part[(4 + nt) * 256 + e] + part[(6 + nt) * 256 + e]);
@@ -2103,49 +2082,60 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         envs[i * BT_ENVS + col] = sum;
     }
     TSTAMP();      // [8] new environment rows
-    if (!want_next) {
-        TEND();
-        return;
-    }
-    lds_barrier();                                  // B4 (LDS only: __syncthreads() would wait for the acknowledgement of the rows just stored)
-    {
-        // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
-        d4 zacc = {0.0, 0.0, 0.0, 0.0};
-        double za[8], zb[8];
+    if (want_next) {
+        lds_barrier();                              // B4 (LDS only: __syncthreads() would wait for the acknowledgement of the rows just stored)
+        {
+            // z = E env'^T for this wave's 16 columns, in the accumulator layout of P; yhat piece = sum over the columns of P .* z
+            d4 zacc = {0.0, 0.0, 0.0, 0.0};
+            double za[8], zb[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            za[u] = envs[i16 * BT_ENVS + 4 * u + kq];
-            zb[u] = Ef[(16 * wave + i16) * BT_ZS + 4 * u + kq];
+            for (int u = 0; u < 8; ++u) {
+                za[u] = envs[i16 * BT_ENVS + 4 * u + kq];
+                zb[u] = Ef[(16 * wave + i16) * BT_ZS + 4 * u + kq];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 8; ++u) zacc = mfma_f64(za[u], zb[u], zacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
+                if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
+            }
         }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < 8; ++u) zacc = mfma_f64(za[u], zb[u], zacc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double x = sum16((pacc0[r] + pacc1[r]) * zacc[r]);
-            if (i16 == 0) redy[wave * 16 + kq + 4 * r] = x;
+        lds_barrier();                              // B5
+        TSTAMP();  // [9] z, row dot
+        if (tid < 16 && tid < tl.count) {
+            const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
+                              ((redy[64 + tid] + redy[80 + tid]) + (redy[96 + tid] + redy[112 + tid]))) * inv;
+            // the reader (k_grad_s) adds the eight slice slots of a series in order: the overlap in slot 0, zeros behind it
+            double2* yp = (double2*)(v.ypart + (int64_t)(tl.start + tid) * YS_MAXSL);
+            yp[0] = make_double2(y, 0.0);
+            yp[1] = make_double2(0.0, 0.0);
+            yp[2] = make_double2(0.0, 0.0);
+            yp[3] = make_double2(0.0, 0.0);
         }
     }
-    lds_barrier();                                  // B5
-    TSTAMP();      // [9] z, row dot
-    if (tid < 16 && tid < tl.count) {
-        const double y = (((redy[tid] + redy[16 + tid]) + (redy[32 + tid] + redy[48 + tid])) +
-                          ((redy[64 + tid] + redy[80 + tid]) + (redy[96 + tid] + redy[112 + tid]))) * inv;
-        // the reader (k_grad_s) adds the eight slice slots of a series in order: the overlap in slot 0, zeros behind it
-        double2* yp = (double2*)(v.ypart + (int64_t)(tl.start + tid) * YS_MAXSL);
-        yp[0] = make_double2(y, 0.0);
-        yp[1] = make_double2(0.0, 0.0);
-        yp[2] = make_double2(0.0, 0.0);
-        yp[3] = make_double2(0.0, 0.0);
+    TSTAMP();      // [10] tile done
+    // ---- the workgroup's role, if it has one: waves 0..3, operands long in registers, E still in LDS ----------------------------------
+    if (role != 0) {
+        if (!rolet) return;                         // (a retired wave no longer counts at the barrier below)
+        if (role == 2) {
+            tail_chain_first(v, b, lid, going_left, bid, bm, cpart, Ef, BT_ZS, nk, rt);
+            lds_barrier();
+            tail_chain_second(v, b, lid, going_left, bid, bm, cpart, nk, inv, rt, Dnb);
+        } else {
+            tail_split_finish(v, b, lid, going_left, bid - nchain, nsplit, bm, Ef, BT_ZS, nk, inv, rt);
+        }
+        TSTAMP();  // [11] role done (stores in flight)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TSTAMP();      // [10] stores drained
+    TSTAMP();      // [12] stores drained
     TEND();
 #undef TSTAMP
 #undef TEND
 }
 template <bool D4>
-__global__ __launch_bounds__(BT_TT) void k_bond_tail(View v, TailArgs ta) {
+__global__ __launch_bounds__(BT_T) void k_bond_tail(View v, TailArgs ta) {
     bond_tail_body<D4>(v, ta);
 }
 
@@ -2320,8 +2310,8 @@ void launch_bond_tail(const View& v, int lid, int going_left, int chain, int wan
     if (lid == (stamp_lid >= 0 ? stamp_lid : (v.T - 1) / 2) && (going_left != 0) == (stamp_dir != 0)) ta.flags |= 2;
     const size_t lds = (size_t)BT_LDS_DOUBLES * sizeof(double);
     const dim3 grid(std::max(v.ntiles, ta.nchain + ta.nsplit));           // one 16-series tile per workgroup; the first ones carry a role as well
-    if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_TT), lds, s, v, ta);
-    else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_TT), lds, s, v, ta);
+    if (v.d == 4) hipLaunchKernelGGL(k_bond_tail<true>, grid, dim3(BT_T), lds, s, v, ta);
+    else hipLaunchKernelGGL(k_bond_tail<false>, grid, dim3(BT_T), lds, s, v, ta);
 }
 void launch_grad_norm(const View& v, int lid, hipStream_t s) {
     hipLaunchKernelGGL(k_grad_norm, dim3(v.n_norm_part), dim3(64), 0, s, v, lid);

@@ -393,11 +393,12 @@ class SweepEngine:
         us = np.zeros(55)
         self._chk(self.lib.mpst_get_tail_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
         tile = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "factors_in_lds", "truncation",
-                "candidates_in_lds", "polished", "overlap_product_issued", "s_tile_formed", "env_rows", "z_rowdot", "stores_drained")
-        role = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "barrier", "truncation", "candidates_in_lds",
-                "polished", "operands_ready", "role_done", "stores_drained")
+                "candidates_in_lds", "polished", "overlap_product_issued", "s_tile_formed", "env_rows", "z_rowdot", "tile_done", "role_done",
+                "stores_drained")
+        role = tile
         pick = lambda names, x: {k: round(float(v), 2) for k, v in zip(names, x) if v >= 0 or k == "start"}
-        return {"tile": pick(tile, us[:16]), "chain": pick(role, us[16:32]), "split": pick(role, us[32:48]),
+        # workgroup 0 (hosts a job of the next bond's tensor when the sweep goes on), the first back-split host, the last workgroup (no role)
+        return {"host_of_a_chain_job": pick(tile, us[:16]), "plain_tile": pick(role, us[16:32]),
                 "bonds_by_candidate_orthogonality": dict(zip(("below_1e-13", "below_1e-8", "below_3e-5", "above"), [int(x) for x in us[48:52]])),
                 "all_workgroups": {"first_start": round(float(us[52]), 2), "last_start": round(float(us[54]), 2), "last_end": round(float(us[53]), 2)}}
 

@@ -29,9 +29,8 @@ secs.append(eng.sweep()["seconds"])
 out = {"N": N, "chi": chi, "sweep_ms": [round(1e3 * s, 3) for s in secs], "info": eng.info(), "eig_phases_us": eng.eig_phases()}
 if out["info"].get("four_launch_chain"):
     ph = eng.tail_phases()
-    out["tail_tile_us"] = ph["tile"]
-    out["tail_chain_us"] = ph["chain"]
-    out["tail_split_us"] = ph["split"]
+    out["tail_wg0_chain_host_us"] = ph["host_of_a_chain_job"]
+    out["tail_last_wg_plain_tile_us"] = ph["plain_tile"]
     out["bonds_by_candidate_orthogonality"] = ph["bonds_by_candidate_orthogonality"]
     out["tail_all_workgroups_us"] = ph["all_workgroups"]
 eng.set_profile(0x7FF)
