@@ -137,6 +137,7 @@ struct Ctx {
     int ynext_lid = -1;
     uint64_t ynext_epoch = 0, ynext_seq = 0, bond_seq = 0;
     int tail_redos = 0;
+    int tail_force_fail = -1, tail_launches = 0;      // test hook (MPST_TAIL_FORCE_REDO=n): the n-th tail launch of the context reports a failed verification
     // sliced bond GEMMs (k_yhat_s / k_grad_s): slice contributions to yhat, loss pieces, arrival tickets
     double *b2_ypart = nullptr, *b2_lossp = nullptr;
     unsigned int* b2_tick = nullptr;
@@ -487,6 +488,9 @@ int ensure_workspace(Ctx* c) {
         // (a context that is advanced in batches keeps the six-launch chain mpst_sweep_batch runs: its solo and its batched sweeps agree bit for bit)
         c->chain4_ok = c->fused && c->b2 && c->batch_hint <= 1 && !(e4 && e4[0] == '0');
         c->ynext_lid = -1;
+        c->tail_launches = 0;
+        c->tail_force_fail = -1;
+        if (const char* ff = getenv("MPST_TAIL_FORCE_REDO")) c->tail_force_fail = atoi(ff);
         dfree(&c->btnT);
         if (c->chain4_ok && (rc = dalloc(c, &c->btnT, c->C * Lmax))) return rc;
         if (c->chain4_ok && (rc = dalloc(c, &c->tail_span, 2 * 2048))) return rc;
@@ -778,7 +782,7 @@ int enqueue_bond(Ctx* c, const View& v_in, int lid, int going_left, bool have_bt
             ProfScope p(c, K_ENV);                                                // verification, back-split, update_caches!, next yhat
             const int nxt = going_left ? lid - 1 : lid + 1;
             const int want = (nxt >= 0 && nxt <= c->T - 2) ? 1 : 0;
-            launch_bond_tail(v, lid, going_left, chain, want, c->tail_span, s);
+            launch_bond_tail(v, lid, going_left, chain, want | (c->tail_launches++ == c->tail_force_fail ? 4 : 0), c->tail_span, s);
             if (want) {
                 c->ynext_lid = nxt;
                 c->ynext_epoch = c->epoch;

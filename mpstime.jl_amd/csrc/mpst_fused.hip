@@ -1965,7 +1965,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     __syncthreads();
     TSTAMP();      // [5] candidates in LDS
-    bool ok = triflag == 1.0 && redo_in == 0;
+    bool ok = triflag == 1.0 && redo_in == 0 && !(ta.flags & 4);
     double emax0 = 0.0;
     if (ok) ok = tail_polish(Zl, Dl, Dh, misc, n, nk, (tid < nk ? res_in : 0.0) / (tnorm_in > 0.0 ? tnorm_in : 1.0), emax0, true);
     TSTAMP();      // [6] verified + polished
@@ -2284,14 +2284,14 @@ void launch_grad_s(const View& v, int lid, hipStream_t s) {
 bool bond_tail_supported(const View& v) {
     return v.zw != 2 && v.loss == MPST_LOSS_KLD && v.chi_max <= 32 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.svd_alg != MPST_SVD_JACOBI && v.d >= 2 && v.d <= 16;
 }
-void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next, unsigned long long* span, hipStream_t s) {
+void launch_bond_tail(const View& v, int lid, int going_left, int chain, int want_next /* bit 0; bit 2: forced failure (test hook) */, unsigned long long* span, hipStream_t s) {
     const int dm = v.d * v.cap, rid = lid + 1;
     TailArgs ta;
     ta.lid = lid;
     ta.going_left = going_left;
     ta.nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
     ta.nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
-    ta.flags = want_next ? 1 : 0;
+    ta.flags = (want_next & 1) | (want_next & 4);      // bit 2: test hook - this launch reports a failed verification
     ta.span = span;
     const int64_t cs = (int64_t)v.N * v.cap;
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * cs : nullptr;
