@@ -1411,72 +1411,74 @@ void launch_env_walk(const View& v, int left_side, int nstep, hipStream_t s) {
 bool env_walk_supported(const View& v) { return v.zw != 2 && v.cap <= 32 && v.d * v.cap <= MAX_DIM && v.d >= 2 && v.d <= 16 && v.T >= 2 && v.T <= EW_TMAX; }
 
 // ---- the back-split and the next bond's tensor inside k_bond_tail: split_block / chain_bt_block (the same products, the same order
-// of operations: the same bits) cut in two - what does not depend on the eigenvectors is REQUESTED at the head of the kernel and
-// arrives under the polish; what follows the polish is MFMAs and stores.  Capacity <= 32 on this path: the shared bond has at most two
-// 16-row blocks, a wave's share of a contraction is one batch of 8 k-steps.
-// (the three roles' requested operands share ONE array of 32 registers per lane - a workgroup has one role; three arrays would all be
-// live across the polish as far as the register allocator can tell.)  Chain role: [0, 16) wpre[it][j][r], the neighbouring site's tensor
-// (operand of the second product); [16, 32) av[j][u], this wave's share of bt_new for the two row blocks of T.
-#define TC_WPRE(it, j, r) R[((it) * 2 + (j)) * 4 + (r)]
-#define TC_AV(j, u) R[16 + (j) * 8 + (u)]
-__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[32], const int rt, const int Dnb) {
+// of operations: the same bits), done by tile workgroups AFTER their tile work, all 8 waves, a 16-register share of the operands per
+// lane requested as soon as the overlap product has released its registers.  A unit of work is small - 8 MFMAs before and 8 after one
+// exchange through LDS - so that its hosts finish not long after the plain tile workgroups (as 4-wave jobs with 32 operands per lane
+// the hosts ended 6 us after the others; as workgroups of their own, or as extra waves, worse: see k_bond_tail).  Capacity <= 32 on this
+// path: the shared bond has at most two 16-row blocks.
+//
+// Chain job (class c, site state s, 16 kept vectors kt) = workgroup; wave w = (contraction range w & 3, row block j = w >> 2) of
+// T = bt_new_c[.., s, ..] E, then output tile w of bt' = W[neighbour] T.  R[0..7]: bt_new operand, R[8..15]: wpre[j'][r] of tile w.
+__device__ __forceinline__ void tail_chain_request(const View& v, const BondDimsF& b, int lid, int going_left, int job, double (&R)[16], const int Dnb) {
     const int d = v.d;
-    const int wave = rt >> 6, lane = rt & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ktc = (v.cap + 15) >> 4;
     const int s = (job / ktc) % d, c = job / (ktc * d);
     const double* Bc = v.btn + (int64_t)c * b.L;
     const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
     const int nj = (Dc + 15) >> 4;
-    const double* Wn = v.sites + (int64_t)(going_left ? lid - 1 : lid + 2) * v.site_stride;
-    const int Xn = Dnb * d;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int tl = 16 * (wave + 4 * it) + i16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = 16 * j + 4 * r + kq;
-                const bool ok = j < nj && tl < Xn && a < Dc;
-                TC_WPRE(it, j, r) = ok ? (going_left ? Wn[(int64_t)tl * b.Dl + a] : Wn[(int64_t)a * Xn + tl]) : 0.0;
-            }
-    }
     const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
-    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * j + i16;
-        const double* ap = going_left ? Bc + (int64_t)(row * d + s) * b.Y : Bc + s * b.Dr + row;
+    {
+        const int rg = wave & 3, j = wave >> 2;
+        const int kbeg = 4 * ks4 * rg, kend = min(Kc, 4 * ks4 * (rg + 1));
+        // (every load unconditional, from a clamped address, the value dropped afterwards: a load under a lane predicate becomes a branch
+        // around it whose join waits for the data - sixteen such loads were sixteen L2 round trips one after the other, 1.8 us stamped)
+        const int row = 16 * j + i16, rowc = min(row, Dc - 1);
+        const double* ap = going_left ? Bc + (int64_t)(rowc * d + s) * b.Y : Bc + s * b.Dr + rowc;
         const int64_t astr = going_left ? 1 : b.Y;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int q = kbeg + 4 * u + kq;
-            TC_AV(j, u) = (j < nj && row < Dc && q < kend) ? ap[(int64_t)q * astr] : 0.0;
+            const double x = ap[(int64_t)min(q, Kc - 1) * astr];
+            R[u] = (j < nj && row < Dc && q < kend) ? x : 0.0;
         }
     }
+    {
+        const double* Wn = v.sites + (int64_t)(going_left ? lid - 1 : lid + 2) * v.site_stride;
+        const int Xn = Dnb * d;
+        const int tl = 16 * wave + i16, tlc = min(tl, Xn - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = 16 * j + 4 * r + kq, ac = min(a, Dc - 1);
+                const bool ok = j < nj && tl < Xn && a < Dc;
+                const double x = going_left ? Wn[(int64_t)tlc * b.Dl + ac] : Wn[(int64_t)ac * Xn + tlc];
+                R[8 + 4 * j + r] = ok ? x : 0.0;
+            }
+    }
 }
-// (rt: the thread's index among the 256 of the role - in k_bond_tail they are the workgroup's waves 8..11)
-__device__ __forceinline__ void tail_chain_first(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
-                                                 double* __restrict__ cpart /* [4][2][256] */, const double* __restrict__ Ev, const int ldE, const int nk, const int rt) {
+__device__ __forceinline__ void tail_chain_job(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[16],
+                                               double* __restrict__ cpart /* [4 ranges][2 row blocks][256] */, const double* __restrict__ Ev, const int ldE,
+                                               const int nk, const double inv, const int Dnb) {
     const int d = v.d;
-    const int wave = rt >> 6, lane = rt & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     const int ktc = (v.cap + 15) >> 4;
-    const int kt = job % ktc;
+    const int kt = job % ktc, s = (job / ktc) % d, c = job / (ktc * d);
     const int k0 = 16 * kt;
-    if (k0 >= nk) return;
+    const bool live = k0 < nk;                      // (wave-uniform; the barrier below is reached either way)
     const int kcol = k0 + i16;
     const bool kv = kcol < nk;
     const int Kc = going_left ? b.Y : b.X, Dc = going_left ? b.Dl : b.Dr;
     const int nj = (Dc + 15) >> 4;
     const int ks4 = (((Kc + 3) >> 2) + 3) >> 2;
-    const int kbeg = 4 * ks4 * wave, kend = min(Kc, 4 * ks4 * (wave + 1));
-    (void)d;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    {
+        const int rg = wave & 3, j = wave >> 2;
+        const int kbeg = 4 * ks4 * rg, kend = min(Kc, 4 * ks4 * (rg + 1));
         d4 t = {0, 0, 0, 0};
-        if (j < nj) {
+        if (live && j < nj) {
             double bv[8];                           // the eigenvector operand first, then eight MFMAs back to back
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1486,25 +1488,13 @@ __device__ __forceinline__ void tail_chain_first(const View& v, const BondDimsF&
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (kbeg + 4 * u < kend) t = mfma_f64(TC_AV(j, u), bv[u], t);
+                if (kbeg + 4 * u < kend) t = mfma_f64(R[u], bv[u], t);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cpart[(wave * 2 + j) * 256 + r * 64 + lane] = t[r];
+        for (int r = 0; r < 4; ++r) cpart[(rg * 2 + j) * 256 + r * 64 + lane] = t[r];
     }
-}
-__device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF& b, int lid, int going_left, int job, const double (&R)[32],
-                                                  const double* __restrict__ cpart, const int nk, const double inv, const int rt, const int Dnb) {
-    const int d = v.d;
-    const int wave = rt >> 6, lane = rt & 63;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int ktc = (v.cap + 15) >> 4;
-    const int kt = job % ktc, s = (job / ktc) % d, c = job / (ktc * d);
-    const int k0 = 16 * kt;
-    if (k0 >= nk) return;
-    const int kcol = k0 + i16;
-    const bool kv = kcol < nk;
-    const int Dc = going_left ? b.Dl : b.Dr;
-    const int nj = (Dc + 15) >> 4;
+    lds_barrier();
+    if (!live) return;
     d4 T[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -1513,20 +1503,17 @@ __device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF
             const int o = j * 256 + r * 64 + lane;
             T[j][r] = ((cpart[o] + cpart[2 * 256 + o]) + (cpart[4 * 256 + o] + cpart[6 * 256 + o])) * inv;
         }
+    const int mt = wave;                            // this wave's output tile
     if (going_left) {
         const int Xp = Dnb * d, Yp = d * nk;
         double* out = v.bt + (int64_t)c * Xp * Yp;
-        const int ntx = (Xp + 15) >> 4;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int mt = wave + 4 * it;
-            if (mt >= ntx) break;
+        if (16 * mt < Xp) {
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 if (j < nj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma_f64(TC_WPRE(it, j, r), T[j][r], acc);
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(R[8 + 4 * j + r], T[j][r], acc);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1537,18 +1524,14 @@ __device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF
     } else {
         const int Ypp = d * Dnb, Xp = nk * d;
         double* out = v.bt + (int64_t)c * Xp * Ypp;
-        const int nty = (Ypp + 15) >> 4;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int nt = wave + 4 * it;
-            if (nt >= nty) break;
-            const int y = 16 * nt + i16;
+        if (16 * mt < Ypp) {
+            const int y = 16 * mt + i16;
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 if (j < nj) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], TC_WPRE(it, j, r), acc);    // A[m = k][kk = b] = T^T tile, register r
+                    for (int r = 0; r < 4; ++r) acc = mfma_f64(T[j][r], R[8 + 4 * j + r], acc);    // A[m = k][kk = b] = T^T tile, register r
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -1559,8 +1542,8 @@ __device__ __forceinline__ void tail_chain_second(const View& v, const BondDimsF
     }
 }
 // back-split: tile = (class, row / column tile of the site that keeps the label, kept-column tile) laid out for the CAPACITY (how many
-// vectors are kept is not known when the operands are requested); one tile per wave
-// (registers: a[w][u] = R[8 w + u], the bt_new operand of the wave's tile by contraction range)
+// vectors are kept is not known when the operands are requested).  A host takes two tiles: wave w = (tile w >> 2, contraction range
+// w & 3); the ranges meet in LDS as (p0 + p1) + (p2 + p3).  R[0..7]: the bt_new operand of the wave's range.
 __device__ __forceinline__ void tail_split_tile(const View& v, const BondDimsF& b, int going_left, int tile, int& c, int& m0, int& n0) {
     const int tkc = (v.cap + 15) >> 4;
     if (going_left) {
@@ -1577,9 +1560,10 @@ __device__ __forceinline__ void tail_split_tile(const View& v, const BondDimsF& 
         n0 = (rem % ty) * 16;       // column tile of T (y)
     }
 }
-__device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& b, int going_left, int tile, double (&R)[32], const int rt) {
-    const int lane = rt & 63;
+__device__ __forceinline__ void tail_split_request(const View& v, const BondDimsF& b, int going_left, int host, double (&R)[16]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i16 = lane & 15, kq = lane >> 4;
+    const int tile = 2 * host + (wave >> 2), rg = wave & 3;
     int c, m0, n0;
     tail_split_tile(v, b, going_left, tile, c, m0, n0);
     const bool live = c < v.C;
@@ -1587,21 +1571,20 @@ __device__ __forceinline__ void tail_split_load(const View& v, const BondDimsF& 
     // going left  T[x][k] = sum_y bt_new[x][y] E[y][k]: A operand bt_new[m = x][kk = y];  going right T[k][y] = sum_x E[x][k] bt_new[x][y]: B operand bt_new[kk = x][n = y]
     const int K = going_left ? b.Y : b.X;
     const int ks4 = (((K + 3) >> 2) + 3) >> 2;
-    const int mm = (going_left ? m0 : n0) + i16;
+    const int mm = (going_left ? m0 : n0) + i16, mmc = min(mm, (going_left ? b.X : b.Y) - 1);
     const bool mv = live && mm < (going_left ? b.X : b.Y);
+    const int kbeg = 4 * ks4 * rg, kend = min(K, 4 * ks4 * (rg + 1));
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = kbeg + 4 * u + kq;
-            R[8 * w + u] = (mv && k < kend) ? (going_left ? Bc[(int64_t)mm * b.Y + k] : Bc[(int64_t)k * b.Y + mm]) : 0.0;
-        }
+    for (int u = 0; u < 8; ++u) {
+        const int k = kbeg + 4 * u + kq, kc = min(k, K - 1);
+        const double x = going_left ? Bc[(int64_t)mmc * b.Y + kc] : Bc[(int64_t)kc * b.Y + mmc];      // (unconditional: see tail_chain_request)
+        R[u] = (mv && k < kend) ? x : 0.0;
     }
 }
-__device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF& b, int lid, int going_left, int blk, int nblk, double (&R)[32],
-                                                  const double* __restrict__ Ev, const int ldE, const int nk, const double inv, const int rt) {
-    const int wave = rt >> 6, lane = rt & 63;
+__device__ __forceinline__ void tail_split_job(const View& v, const BondDimsF& b, int lid, int going_left, int host, int nhost, const double (&R)[16],
+                                               double* __restrict__ spart /* [8 waves][256] */, const double* __restrict__ Ev, const int ldE, const int nk,
+                                               const double inv) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int i16 = lane & 15, kq = lane >> 4;
     double* Wl = v.sites + (int64_t)lid * v.site_stride;
     double* Wr = v.sites + (int64_t)(lid + 1) * v.site_stride;
@@ -1609,18 +1592,16 @@ __device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF
     const int K = going_left ? b.Y : b.X;
     const int ks4 = (((K + 3) >> 2) + 3) >> 2;
     const int ntile = v.C * tkc * (((going_left ? b.X : b.Y) + 15) >> 4);
-    // (the launcher gives every wave of the split workgroups one tile of the capacity layout: no loop - see k_bond_tail on loops)
-    const int tile = blk * 4 + wave;
+    const int tile = 2 * host + (wave >> 2), rg = wave & 3;
     int c, m0, n0;
     tail_split_tile(v, b, going_left, tile, c, m0, n0);
     const int kn0 = going_left ? n0 : m0;           // first kept vector of the tile
-    if (tile < ntile && kn0 < nk) {
-        const int kcol = kn0 + i16;
-        d4 p[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            p[w] = d4{0, 0, 0, 0};
-            const int kbeg = 4 * ks4 * w, kend = min(K, 4 * ks4 * (w + 1));
+    const bool live = tile < ntile && kn0 < nk;     // (wave-uniform)
+    const int kcol = kn0 + i16;
+    {
+        const int kbeg = 4 * ks4 * rg, kend = min(K, 4 * ks4 * (rg + 1));
+        d4 p = {0, 0, 0, 0};
+        if (live) {
             double ev[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1630,35 +1611,41 @@ __device__ __forceinline__ void tail_split_finish(const View& v, const BondDimsF
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (kbeg + 4 * u < kend) p[w] = going_left ? mfma_f64(R[8 * w + u], ev[u], p[w]) : mfma_f64(ev[u], R[8 * w + u], p[w]);
+                if (kbeg + 4 * u < kend) p = going_left ? mfma_f64(R[u], ev[u], p) : mfma_f64(ev[u], R[u], p);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) spart[wave * 256 + r * 64 + lane] = p[r];
+    }
+    lds_barrier();
+    if (live && rg == 0) {
+        const double* sp = spart + (wave & 4) * 256;
         if (going_left) {
             double* out = Wl + (int64_t)c * b.X * nk;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + kq + 4 * r;
-                if (row < b.X && n0 + i16 < nk) out[(int64_t)row * nk + n0 + i16] = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) * inv;
+                const int row = m0 + kq + 4 * r, o = r * 64 + lane;
+                if (row < b.X && n0 + i16 < nk) out[(int64_t)row * nk + n0 + i16] = ((sp[o] + sp[256 + o]) + (sp[512 + o] + sp[768 + o])) * inv;
             }
         } else {
             double* out = Wr + (int64_t)c * nk * b.Y;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + kq + 4 * r;
-                if (row < nk && n0 + i16 < b.Y) out[(int64_t)row * b.Y + n0 + i16] = ((p[0][r] + p[1][r]) + (p[2][r] + p[3][r])) * inv;
+                const int row = m0 + kq + 4 * r, o = r * 64 + lane;
+                if (row < nk && n0 + i16 < b.Y) out[(int64_t)row * b.Y + n0 + i16] = ((sp[o] + sp[256 + o]) + (sp[512 + o] + sp[768 + o])) * inv;
             }
         }
     }
-    // the other site: the kept eigenvectors themselves
-    // (two-dimensional walks: an integer division per element costs more than the copy)
+    // the other site: the kept eigenvectors themselves, a share per host (two-dimensional walks: an integer division per element costs more
+    // than the copy)
     if (going_left) {
-        for (int k = blk; k < nk; k += nblk)
-            for (int y = rt; y < b.Y; y += 256) Wr[(int64_t)k * b.Y + y] = Ev[(int64_t)y * ldE + k];
-        if (blk == 0 && rt == 0) *v.label_site = lid;
+        for (int k = host; k < nk; k += nhost)
+            for (int y = tid; y < b.Y; y += BT_T) Wr[(int64_t)k * b.Y + y] = Ev[(int64_t)y * ldE + k];
+        if (host == 0 && tid == 0) *v.label_site = lid;
     } else {
-        const int k = rt & 31;
-        for (int x = blk * 8 + (rt >> 5); x < b.X; x += nblk * 8)
+        const int k = tid & 31;
+        for (int x = host * 16 + (tid >> 5); x < b.X; x += nhost * 16)
             if (k < nk) Wl[(int64_t)x * nk + k] = Ev[(int64_t)x * ldE + k];
-        if (blk == 0 && rt == 0) *v.label_site = lid + 1;
+        if (host == 0 && tid == 0) *v.label_site = lid + 1;
     }
 }
 
@@ -1838,13 +1825,11 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     const int want_next = ta.flags & 1;
     const int d = v.d;
     // One 16-series tile per workgroup.  The first nchain workgroups ALSO form the next bond's tensor (one job each), the next nsplit the
-    // back-split (one block each) - after their tile work, with waves 0..3, from operands requested as soon as the overlap product has
-    // released its registers.  (As workgroups of their own - 24 beside 256 tile workgroups at the headline shape - the roles shared CUs with
+    // back-split (two tiles each) - after their tile work, from operands requested as soon as the overlap product has released its
+    // registers.  (As workgroups of their own - 24 beside 256 tile workgroups at the headline shape - the roles shared CUs with
     // tiles and the launch took 22 us instead of 15, stamped; as extra waves of the tile workgroups they held their hosts' barriers up: 21 us.)
     const int bid = (int)blockIdx.x;
     const int role = bid < nchain ? 2 : (bid < nchain + nsplit ? 1 : 0);
-    const int rt = tid;                             // role threads: the workgroup's first 256
-    const bool rolet = role != 0 && tid < 256;
     // phase stamps (100 MHz): DevScalars::eig_stamps[16..] workgroup 0 (hosts a job of the next bond's tensor when the sweep goes on),
     // [32..] the last workgroup (no role)
     unsigned long long* stp = nullptr;
@@ -1884,8 +1869,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
     for (int m = 0; m < 8; ++m) zin[m] = ws[WS_Z + tid + m * BT_T];
     const double triflag = ws[WS_MISC + 3], tnorm_in = ws[WS_MISC + 2];
-    double lam_in = lane < 32 ? ws[WS_LAM + lane] : 0.0;                 // every wave: the truncation rule runs in its lanes
-    const double res_in = tid < 32 ? ws[WS_RES + tid] : 0.0;
+    double lam_in = ws[WS_LAM + (lane & 31)];                            // every wave: the truncation rule runs in its lanes (masked below)
+    const double res_in = ws[WS_RES + (tid & 31)];                       // (used by threads < nk only)
     const int redo_in = v.sc->redo;
     TSTAMP();      // [1] candidates requested
     Span tl{0, 0, 0, 0};
@@ -1897,10 +1882,14 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             const double* prev = lower ? ta.Sprev : ta.Oprev;
             const double* ph = lower ? ta.phS : ta.phO;
             const bool valid = lrow < tl.count;
-            const int64_t smp = tl.start + (valid ? lrow : 0);
-            fe0 = (valid && lj < v.cap) ? (prev ? prev[smp * v.cap + lj] : 1.0) : 0.0;
-            fe1 = (valid && lj + 16 < v.cap) ? (prev ? prev[smp * v.cap + lj + 16] : 1.0) : 0.0;
-            fp = (valid && lj < d) ? ph[smp * d + lj] : 0.0;
+            const int64_t smp = tl.count > 0 ? tl.start + (valid ? lrow : 0) : 0;
+            // (unconditional loads from clamped addresses: see tail_chain_request; a tile beyond the data set has count 0 and start 0)
+            const double x0 = prev ? prev[smp * v.cap + min(lj, v.cap - 1)] : 1.0;
+            const double x1 = prev ? prev[smp * v.cap + min(lj + 16, v.cap - 1)] : 1.0;
+            const double xp = ph[smp * d + min(lj, d - 1)];
+            fe0 = (valid && lj < v.cap) ? x0 : 0.0;
+            fe1 = (valid && lj + 16 < v.cap) ? x1 : 0.0;
+            fp = (valid && lj < d) ? xp : 0.0;
         }
     }
     TSTAMP();      // [2] factors requested
@@ -1928,7 +1917,8 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
 #pragma unroll
         for (int u = 0; u < 32; ++u) bm[u] = M[(unsigned)min(4 * u + kq, KO - 1) * (unsigned)NS + col];
     }
-    const double gdiag = tid < n ? pb.G[(size_t)tid * n + tid] : 0.0;
+    const double gd_ = pb.G[(size_t)min(tid, n - 1) * (n + 1)];
+    const double gdiag = tid < n ? gd_ : 0.0;
     lam_in = lane < K0 ? lam_in : 0.0;
     {
         const int Dp = lower ? DS : DO;
@@ -2013,10 +2003,11 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     }
     TSTAMP();      // [10] P issued
     // the role's operands into the registers the overlap product has just released: they arrive under the rest of the tile's work
-    if (rolet) {
-        if (role == 2) tail_chain_request(v, b, lid, going_left, bid, bm, rt, Dnb);
-        else tail_split_load(v, b, going_left, (bid - nchain) * 4 + wave, bm, rt);
-    }
+    // (registers of their own: the overlap product's MFMAs may still be reading bm)
+    double rr[16];
+    if (role == 2) tail_chain_request(v, b, lid, going_left, bid, rr, Dnb);
+    else if (role == 1) tail_split_request(v, b, going_left, bid - nchain, rr);
+    TSTAMP();      // role operands requested
     if (bid == 0 && wave == 0) {                    // publication (fin_body)
         if (lane < K0) v.lam[lane] = lam_in;
         bool bad = !(tr == tr) || tr > 1e300;
@@ -2038,6 +2029,7 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
     // ---- the dense S tile, by all waves (env' then pays one LDS read per MFMA, whichever side S is).  It goes over the polish scratch:
     // the barrier keeps it off the error pieces a slower wave may still be reading (tail_polish returns without one when nothing is to do)
     lds_barrier();                                  // B1 (LDS-only barriers from here on: __syncthreads() would also wait for the role's operands)
+    TSTAMP();      // B1 passed
     {
         const int row = tid >> 5, z0 = tid & 31;    // 4 entries per thread: z0, z0 + 32, ...
 #pragma unroll
@@ -2116,18 +2108,10 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
         }
     }
     TSTAMP();      // [10] tile done
-    // ---- the workgroup's role, if it has one: waves 0..3, operands long in registers, E still in LDS ----------------------------------
-    if (role != 0) {
-        if (!rolet) return;                         // (a retired wave no longer counts at the barrier below)
-        if (role == 2) {
-            tail_chain_first(v, b, lid, going_left, bid, bm, cpart, Ef, BT_ZS, nk, rt);
-            lds_barrier();
-            tail_chain_second(v, b, lid, going_left, bid, bm, cpart, nk, inv, rt, Dnb);
-        } else {
-            tail_split_finish(v, b, lid, going_left, bid - nchain, nsplit, bm, Ef, BT_ZS, nk, inv, rt);
-        }
-        TSTAMP();  // [11] role done (stores in flight)
-    }
+    // ---- the workgroup's role, if it has one: all waves, operands long in registers, E still in LDS ------------------------------------
+    if (role == 2) tail_chain_job(v, b, lid, going_left, bid, rr, cpart, Ef, BT_ZS, nk, inv, Dnb);
+    else if (role == 1) tail_split_job(v, b, lid, going_left, bid - nchain, nsplit, rr, cpart, Ef, BT_ZS, nk, inv);
+    if (role != 0) TSTAMP();  // [11] role done (stores in flight)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TSTAMP();      // [12] stores drained
     TEND();
@@ -2289,7 +2273,7 @@ void launch_bond_tail(const View& v, int lid, int going_left, int chain, int wan
     TailArgs ta;
     ta.lid = lid;
     ta.going_left = going_left;
-    ta.nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 4);
+    ta.nsplit = cdivf(v.C * cdivf(dm, 16) * cdivf(v.cap, 16), 2);        // hosts of the back-split: two tiles (of the capacity layout) each
     ta.nchain = chain ? v.C * v.d * cdivf(v.cap, 16) : 0;
     ta.flags = (want_next & 1) | (want_next & 4);      // bit 2: test hook - this launch reports a failed verification
     ta.span = span;

@@ -393,7 +393,7 @@ class SweepEngine:
         us = np.zeros(55)
         self._chk(self.lib.mpst_get_tail_phases(self.ctx, us.ctypes.data_as(C.POINTER(C.c_double))))
         tile = ("start", "candidates_requested", "factors_requested", "bond_dims_known", "all_requested", "factors_in_lds", "truncation",
-                "candidates_in_lds", "polished", "overlap_product_issued", "s_tile_formed", "env_rows", "z_rowdot", "tile_done", "role_done",
+                "candidates_in_lds", "polished", "overlap_product_issued", "role_requested", "b1_passed", "s_tile_formed", "env_rows", "z_rowdot", "tile_done", "role_done",
                 "stores_drained")
         role = tile
         pick = lambda names, x: {k: round(float(v), 2) for k, v in zip(names, x) if v >= 0 or k == "start"}
