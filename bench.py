@@ -94,7 +94,7 @@ def kernel_model(N, d, chi, C, info):
         model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n * n * chi)
         model.pop("eig_vec", None)
     if info.get("large_bond"):
-        model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n ** 3)   # rocSOLVER dsyevd: sytrd + stedc + ormtr back-transformation
+        model["eig_tri"] = ("mfma", 4.0 / 3.0 * n ** 3 + 4.0 * n ** 3)   # (dense symmetric eigensolver count: reduction + back-transformation)
     return model
 
 

@@ -399,7 +399,7 @@ int ensure_workspace_typed(Ctx* c) {
         std::string e;
         if ((rc = big_eig_create(&c->big, zw * dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         const char* sel = getenv("MPST_BIG_EIG");
-        if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, zw * dm, &e)))
+        if (!(sel && (strcmp(sel, "jacobi") == 0 || strcmp(sel, "rocsolver") == 0)) && (rc = blocked_eig_create(&c->blk, zw * dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         // real element types: the randomised subspace solver in front of the exact one (complex Gram matrices arrive as embeddings)
         if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, zw * c->C * dm, c->cap, c->C, zw == 2, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
@@ -515,7 +515,7 @@ int ensure_workspace(Ctx* c) {
         std::string e;
         if ((rc = big_eig_create(&c->big, dm, c->stream, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         const char* sel = getenv("MPST_BIG_EIG");
-        if (!(sel && strcmp(sel, "rocsolver") == 0) && (rc = blocked_eig_create(&c->blk, dm, &e)))
+        if (!(sel && (strcmp(sel, "jacobi") == 0 || strcmp(sel, "rocsolver") == 0)) && (rc = blocked_eig_create(&c->blk, dm, &e)))
             return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
         // MPST_BIG_SYNC=1: read the eigensolver's verdict after every bond (one host synchronisation per bond) instead of once per sweep
         if (c->blk && (rc = blocked_eig_enable_subspace(c->blk, c->C * dm, c->cap, c->C, 0, &e))) return fail(c, rc, "large-bond eigensolver: %s", e.c_str());
@@ -634,7 +634,7 @@ int enqueue_big_eig(Ctx* c, const View& v, int lid, int going_left) {
         if (need_lib < 0) return fail(c, MPST_ERR_DEVICE, "blocked eigensolver failed at bond %d: %s", lid, hipGetErrorString(hipGetLastError()));
         if (need_lib) c->big_fallbacks++;
     }
-    if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "rocsolver_dsyevd failed at bond %d", lid);
+    if (need_lib && launch_eig_big(v, lid, going_left, c->big, s)) return fail(c, MPST_ERR_DEVICE, "the large-bond Jacobi fallback could not be launched at bond %d", lid);
     return 0;
 }
 
@@ -2628,7 +2628,7 @@ int mpst_selftest_eig(void* ctx, const double* G, int32_t n, int32_t alg, double
             rc = launch_eig_big_raw(dG, n, dl, dE, ds, be, c->stream);
             (void)hipStreamSynchronize(c->stream);
             big_eig_destroy(be);
-            if (rc) return fail(c, rc, "rocsolver_dsyevd failed");
+            if (rc) return fail(c, rc, "the large-bond Jacobi solver could not be launched");
         }
     } else {
         launch_eig_raw(dG, n, alg, dl, dE, ds, dws, c->stream);

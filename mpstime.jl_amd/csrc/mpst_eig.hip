@@ -25,7 +25,6 @@
 //    unconditionally robust; column k converges to lambda_k v_k.
 #include "mpst_internal.h"
 #include "mpst_eig_common.inl"
-#include <rocsolver/rocsolver.h>
 #include <type_traits>
 
 namespace mpst {
@@ -1391,36 +1390,144 @@ void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int
 
 
 // =====================================================================================
-// Bond tensors beyond 128 x 128 (d*chi_max in (128, DIM_LIMIT]): library slow path
+// Bond tensors beyond 128 x 128 (d*chi_max in (128, DIM_LIMIT]): the robust slow path
 // =====================================================================================
-// The register/LDS-resident solver above holds n <= 128.  Larger Gram matrices (the reference's documented
-// d = 8..12, chi_max = 37..64 runs, docs/src/hyperparameters.md:65,127,241-245) go through rocSOLVER's dsyevd
-// (blocked tridiagonalisation + divide and conquer - the LAPACK routine family the reference's own gesdd belongs to) on
-// the engine's stream.  Bond dimensions live on the device, so the problem is always solved at the CAPACITY size
-// ncap = d*cap with the live n x n Gram matrix zero-padded: the padding adds exact zero eigenvalues below the spectrum
-// of the positive semi-definite G and leaves the eigenvectors of its non-zero eigenvalues untouched.
+// The register/LDS-resident solver above holds n <= 128; larger Gram matrices (the reference's documented d = 8..12, chi_max = 37..64
+// runs, docs/src/hyperparameters.md:65,127,241-245) are solved by the blocked tridiagonal path (mpst_eig_blocked.hip) or the subspace
+// solver in front of it.  What stands BEHIND those - a bond whose on-device verification fails, MPST_BIG_EIG=jacobi - is this: a
+// one-sided (Hestenes) Jacobi iteration on the columns of G, the algorithm of jacobi_core above spread over workgroups: a round of the
+// round-robin tournament is one launch (one workgroup per column pair, columns in global memory), a sweep is np - 1 rounds, and a
+// small kernel after every sweep records whether anything was rotated; later launches leave at once when the matrix has converged.
+// Slow (milliseconds) and unconditionally robust: it is the reference's gesdd -> gesvd -> recursive chain's last resort
+// (RealRealHighDimension.jl:146-203), and the reason no vendor solver is linked.  The problem is always solved at the CAPACITY size
+// ncap = d*cap with the live n x n Gram matrix zero-padded (bond dimensions live on the device): the padding adds exact zero eigenvalues
+// below the spectrum of the positive semi-definite G and leaves the eigenvectors of its non-zero eigenvalues untouched.
+constexpr int BIGJ_MAX_SWEEPS = 160;     // (graded spectra converge slowly: 67 sweeps for the cluster test of tests/test_gpu_bigbond.py)
 struct BigEig {
-    rocblas_handle h = nullptr;
     int ncap = 0;
     hipStream_t stream = nullptr;
-    double *A = nullptr, *D = nullptr, *Ew = nullptr;
-    rocblas_int* info = nullptr;
+    double *W = nullptr;        // [ncap][ncap] working columns (column-major: column p at W + p * ncap)
+    double *A = nullptr;        // [ncap][ncap] eigenvectors, column i = vector of D[i] (ascending), as dsyevd leaves them
+    double *D = nullptr;        // [ncap] eigenvalues, ascending
+    double *nrm = nullptr;      // [ncap] column norms
+    int32_t* info = nullptr;    // [4]: 0 = converged flag (1: stop), 1 = rotations in the current sweep, 2 = sweeps used, 3 = result (0 ok)
 };
 
-__global__ __launch_bounds__(256) void k_big_prep(View v, int lid, int going_left, const double* rawG, int rawn, double* A, int ncap) {
+__global__ __launch_bounds__(256) void k_big_prep(View v, int lid, int going_left, const double* rawG, int rawn, double* A, int ncap, int32_t* info) {
     const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, 0);
     const int n = pb.n;
+    if (blockIdx.x == 0 && threadIdx.x < 4) info[threadIdx.x] = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)ncap * ncap; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / ncap), c = (int)(i - (int64_t)r * ncap);
         A[i] = (r < n && c < n) ? pb.G[(size_t)r * n + c] : 0.0;       // symmetric: row- and column-major coincide
     }
+}
+// deterministic block-wide sums of three values (256 threads)
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red /* [12] */) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[w] = a;
+        red[4 + w] = b;
+        red[8 + w] = c;
+    }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[4] + red[5]) + (red[6] + red[7]);
+    c = (red[8] + red[9]) + (red[10] + red[11]);
+}
+// one round of the tournament: workgroup kk rotates the column pair pair_of(r, kk)
+// (scale: the largest column norm of G.  Two columns that are both below 1e-14 of it hold nothing but the rounding of the large ones - their
+// eigenvalues are beyond what a double-precision G resolves - and are left alone: rotating noise against noise never converges)
+__global__ __launch_bounds__(256) void k_bigjac_round(double* __restrict__ W, int ncap, int r, int32_t* info, const double* __restrict__ scale) {
+    __shared__ double red[12];
+    if (*(const volatile int32_t*)info != 0) return;          // converged in an earlier sweep
+    const double tiny2 = 1e-28 * scale[0] * scale[0];
+    int p, q;
+    pair_of(r, (int)blockIdx.x, ncap, p, q);
+    double* cp = W + (size_t)p * ncap;
+    double* cq = W + (size_t)q * ncap;
+    double vp[4], vq[4];
+    double app = 0.0, aqq = 0.0, apq = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = threadIdx.x + 256 * m;
+        vp[m] = row < ncap ? cp[row] : 0.0;
+        vq[m] = row < ncap ? cq[row] : 0.0;
+        app += vp[m] * vp[m];
+        aqq += vq[m] * vq[m];
+        apq += vp[m] * vq[m];
+    }
+    block_sum3(app, aqq, apq, red);
+    if (fabs(apq) > 2.5e-15 * sqrt(app * aqq) && app * aqq > 0.0 && (app > tiny2 || aqq > tiny2)) {
+        const double zeta = (aqq - app) / (2.0 * apq);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t);
+        const double sn = c * t;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int row = threadIdx.x + 256 * m;
+            if (row < ncap) {
+                cp[row] = c * vp[m] - sn * vq[m];
+                cq[row] = sn * vp[m] + c * vq[m];
+            }
+        }
+        if (threadIdx.x == 0) info[1] = 1;                     // (benign race: every writer writes 1)
+    }
+}
+__global__ __launch_bounds__(256) void k_bigjac_scale(const double* __restrict__ nrm, int ncap, double* __restrict__ scale) {
+    __shared__ double red[4];
+    double m = 0.0;
+    for (int j = threadIdx.x; j < ncap; j += 256) m = fmax(m, nrm[j]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) scale[0] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__global__ void k_bigjac_check(int32_t* info) {
+    if (threadIdx.x == 0 && info[0] == 0) {
+        info[2] += 1;
+        if (info[1] == 0) info[0] = 1;
+        info[1] = 0;
+    }
+}
+// column norms (= eigenvalues), ascending order, normalised vectors: D and A as dsyevd would leave them
+__global__ __launch_bounds__(256) void k_bigjac_norms(const double* __restrict__ W, int ncap, double* __restrict__ nrm) {
+    __shared__ double red[12];
+    const double* cp = W + (size_t)blockIdx.x * ncap;
+    double s = 0.0, z0 = 0.0, z1 = 0.0;
+    for (int row = threadIdx.x; row < ncap; row += 256) s += cp[row] * cp[row];
+    block_sum3(s, z0, z1, red);
+    if (threadIdx.x == 0) nrm[blockIdx.x] = sqrt(s);
+}
+__global__ __launch_bounds__(256) void k_bigjac_sort(const double* __restrict__ W, const double* __restrict__ nrm, int ncap, double* __restrict__ A, double* __restrict__ D,
+                                                     int32_t* info) {
+    const int col = blockIdx.x;
+    const double me = nrm[col];
+    int below = 0;                                  // rank in ASCENDING order (ties by index)
+    for (int j = threadIdx.x; j < ncap; j += 256) {
+        const double o = nrm[j];
+        below += (o < me || (o == me && j < col)) ? 1 : 0;
+    }
+    __shared__ int cnt[4];
+    for (int off = 32; off > 0; off >>= 1) below += __shfl_down(below, off, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = below;
+    __syncthreads();
+    const int rk = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (threadIdx.x == 0) D[rk] = me;
+    const double inv = me > 0.0 ? 1.0 / me : 0.0;
+    for (int row = threadIdx.x; row < ncap; row += 256) A[(size_t)rk * ncap + row] = W[(size_t)col * ncap + row] * inv;
+    if (col == 0 && threadIdx.x == 0) info[3] = info[0] == 1 ? 0 : 1;      // not converged within BIGJ_MAX_SWEEPS: the caller's MPST_ERR_SVD
 }
 
 // eigenvalues D (ascending, ncap of them), eigenvectors in the columns of A (column-major): truncation rule and
 // publication exactly as in k_eig_fin
 __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int going_left, const double* rawG, int rawn,
                                                          const double* __restrict__ A, const double* __restrict__ D,
-                                                         const rocblas_int* info, int ncap, double* rawlam, double* rawE,
+                                                         const int32_t* info, int ncap, double* rawlam, double* rawE,
                                                          int32_t* rawinfo) {
     __shared__ double lam_s[CAP_LIMIT + 2];
     __shared__ double red[16];
@@ -1451,13 +1558,14 @@ __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int go
         const int k = i / n, c = i - k * n;
         Eout[(size_t)c * ldE + k] = A[(size_t)(ncap - 1 - k) * ncap + c];
     }
+    const int failed = info[3];
     if (raw) {
         if (tid < K0) rawlam[tid] = lam_s[tid];
-        if (tid == 0) *rawinfo = *info ? 1000 + *info : -2;
+        if (tid == 0) *rawinfo = failed ? 1000 + failed : -2;
     } else {
         if (tid < K0 / st) v.lam[tid] = lam_s[st * tid];
         if (tid == 0) {
-            bool bad = !(tr == tr) || tr > 1e300 || *info != 0;
+            bool bad = !(tr == tr) || tr > 1e300 || failed != 0;
             for (int i = 0; i < K0; ++i) {
                 const double P = lam_s[i] * inv2;
                 if (!(P == P) || P > 1e300) bad = true;
@@ -1467,7 +1575,7 @@ __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int go
             v.sc->n_spec = K0 / st;
             v.sc->bt_norm2 = tr;
             v.sc->inv_norm = inv;
-            v.sc->eig_sweeps = 0;
+            v.sc->eig_sweeps = info[2];
             if (bad) v.sc->status = MPST_ERR_SVD;
             v.chi[lid + 1] = nk;
         }
@@ -1476,56 +1584,64 @@ __global__ __launch_bounds__(EIG_THREADS) void k_big_fin(View v, int lid, int go
 
 int big_eig_create(BigEig** out, int ncap, hipStream_t s, std::string* err) {
     BigEig* b = new BigEig();
-    b->ncap = ncap;
+    b->ncap = (ncap + 1) & ~1;          // the tournament pairs columns: an even number of them (one more zero column changes nothing)
     auto bail = [&](const char* what) {
         if (err) *err = what;
         big_eig_destroy(b);
         return MPST_ERR_DEVICE;
     };
-    // the rocBLAS handle (seconds of one-off initialisation) is created by the first bond that actually needs the library
     b->stream = s;
-    if (hipMalloc((void**)&b->A, sizeof(double) * (size_t)ncap * ncap) != hipSuccess || hipMalloc((void**)&b->D, sizeof(double) * ncap) != hipSuccess ||
-        hipMalloc((void**)&b->Ew, sizeof(double) * ncap) != hipSuccess || hipMalloc((void**)&b->info, sizeof(rocblas_int)) != hipSuccess)
-        return bail("hipMalloc of the rocSOLVER buffers failed");
+    const size_t nn = (size_t)b->ncap * b->ncap;
+    if (hipMalloc((void**)&b->W, sizeof(double) * nn) != hipSuccess || hipMalloc((void**)&b->A, sizeof(double) * nn) != hipSuccess ||
+        hipMalloc((void**)&b->D, sizeof(double) * b->ncap) != hipSuccess || hipMalloc((void**)&b->nrm, sizeof(double) * b->ncap) != hipSuccess ||
+        hipMalloc((void**)&b->info, sizeof(int32_t) * 4) != hipSuccess)
+        return bail("hipMalloc of the large-bond Jacobi buffers failed");
     *out = b;
     return 0;
 }
 void big_eig_destroy(BigEig* b) {
     if (!b) return;
+    if (b->W) (void)hipFree(b->W);
     if (b->A) (void)hipFree(b->A);
     if (b->D) (void)hipFree(b->D);
-    if (b->Ew) (void)hipFree(b->Ew);
+    if (b->nrm) (void)hipFree(b->nrm);
     if (b->info) (void)hipFree(b->info);
-    if (b->h) rocblas_destroy_handle(b->h);
     delete b;
 }
-static bool big_eig_handle(BigEig* b) {
-    if (b->h) return true;
-    if (rocblas_create_handle(&b->h) != rocblas_status_success) {
-        b->h = nullptr;
-        return false;
+// the iteration proper on b->W (filled by k_big_prep): leaves b->D, b->A, b->info[3]
+static void enqueue_big_jacobi(BigEig* b, hipStream_t s) {
+    const int np = b->ncap;
+    hipLaunchKernelGGL(k_bigjac_norms, dim3(np), dim3(256), 0, s, b->W, np, b->nrm);
+    hipLaunchKernelGGL(k_bigjac_scale, dim3(1), dim3(256), 0, s, b->nrm, np, b->D);        // (D[0] is scratch until the sort writes D)
+    // sweeps in chunks of eight, the verdict read after each chunk: this is the cold path of a bond whose fast solver has failed its check
+    // (the plain stream, never a captured graph), and a converged matrix should not cost the launches of the sweeps it no longer needs
+    for (int sweep = 0; sweep < BIGJ_MAX_SWEEPS; ++sweep) {
+        for (int r = 0; r < np - 1; ++r) hipLaunchKernelGGL(k_bigjac_round, dim3(np / 2), dim3(256), 0, s, b->W, np, r, b->info, b->D);
+        hipLaunchKernelGGL(k_bigjac_check, dim3(1), dim3(64), 0, s, b->info);
+        if ((sweep & 7) == 7) {
+            int32_t done = 0;
+            if (hipMemcpyAsync(&done, b->info, sizeof done, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) break;
+            if (done) break;
+        }
     }
-    return rocblas_set_stream(b->h, b->stream) == rocblas_status_success;
+    hipLaunchKernelGGL(k_bigjac_norms, dim3(np), dim3(256), 0, s, b->W, np, b->nrm);
+    hipLaunchKernelGGL(k_bigjac_sort, dim3(np), dim3(256), 0, s, b->W, b->nrm, np, b->A, b->D, b->info);
 }
 int launch_eig_big(const View& v, int lid, int going_left, BigEig* b, hipStream_t s) {
     const int ncap = b->ncap;
-    if (!big_eig_handle(b)) return MPST_ERR_DEVICE;
-    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->A, ncap);
-    if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, ncap, b->A, ncap, b->D, b->Ew, b->info) != rocblas_status_success)
-        return MPST_ERR_DEVICE;
+    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->W, ncap, b->info);
+    enqueue_big_jacobi(b, s);
     hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(EIG_THREADS), 0, s, v, lid, going_left, (const double*)nullptr, 0, b->A, b->D, b->info, ncap,
                        (double*)nullptr, (double*)nullptr, (int32_t*)nullptr);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : MPST_ERR_DEVICE;
 }
 int launch_eig_big_raw(const double* G, int n, double* lam, double* E, int32_t* info, BigEig* b, hipStream_t s) {
     View v{};
-    if (!big_eig_handle(b)) return MPST_ERR_DEVICE;
     hipLaunchKernelGGL(k_eig_clear, dim3(1), dim3(256), 0, s, lam, E, n);
-    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, 0, 0, G, n, b->A, b->ncap);
-    if (rocsolver_dsyevd(b->h, rocblas_evect_original, rocblas_fill_lower, b->ncap, b->A, b->ncap, b->D, b->Ew, b->info) != rocblas_status_success)
-        return MPST_ERR_DEVICE;
+    hipLaunchKernelGGL(k_big_prep, dim3(256), dim3(256), 0, s, v, 0, 0, G, n, b->W, b->ncap, b->info);
+    enqueue_big_jacobi(b, s);
     hipLaunchKernelGGL(k_big_fin, dim3(1), dim3(EIG_THREADS), 0, s, v, 0, 0, G, n, b->A, b->D, b->info, b->ncap, lam, E, info);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : MPST_ERR_DEVICE;
 }
 
 }  // namespace mpst

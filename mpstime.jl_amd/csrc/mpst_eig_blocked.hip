@@ -2,8 +2,9 @@
 // tridiagonalisation spread over the chip, bisection + twisted factorisation per wanted eigenvalue, reflector
 // back-transformation, verification.  Stand-in for ITensors.svd -> LAPACK gesdd in decomposeBT
 // (src/Training/RealRealHighDimension.jl:166-169,185-188) at the sizes of the reference's documented runs
-// (d = 8..12, chi_max = 37..64: docs/src/hyperparameters.md:65,127,241-245).  rocSOLVER's dsyevd (mpst_eig.hip) stays
-// as the fallback when the on-device verification rejects the result (clustered kept eigenvalues).
+// (d = 8..12, chi_max = 37..64: docs/src/hyperparameters.md:65,127,241-245).  A multi-workgroup one-sided Jacobi
+// iteration (mpst_eig.hip: slow, robust, hand-written like the rest - no vendor solver is linked) stays as the fallback when the on-device
+// verification rejects the result (clustered kept eigenvalues).
 //
 // One dependent launch per Householder step instead of LAPACK's symv / dot / axpy / syr2 sequence (dsytd2):
 //   k_bt_step  (G workgroups) step j.  Every workgroup redundantly finishes the previous step's w (the one global

@@ -668,7 +668,7 @@ bool eig_merged();   // k_eig_trivec instead of k_eig_tri + k_eig_vec (default; 
 void launch_eig_raw(const double* G, int n, int alg, double* lam, double* E, int32_t* info, double* ws, hipStream_t s);
 void launch_eig_raw_gated(const double* G, int n, double* lam, double* E, int32_t* info, double* ws, const int32_t* gate, hipStream_t s);
 size_t eig_workspace_doubles();
-// library slow path for d*chi_max > MAX_DIM (rocSOLVER dsyevd at the capacity size, see mpst_eig.hip)
+// robust slow path for d*chi_max > MAX_DIM (multi-workgroup one-sided Jacobi at the capacity size, see mpst_eig.hip; no vendor solver is linked)
 struct BigEig;
 int big_eig_create(BigEig** out, int ncap, hipStream_t s, std::string* err);
 void big_eig_destroy(BigEig* b);
