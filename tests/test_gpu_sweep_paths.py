@@ -158,3 +158,51 @@ def test_fits_dealt_over_groups_are_bit_identical_and_destroyed_members_do_not_a
     finally:
         for e in solo + bat:
             e.close()
+
+
+def test_three_groups_of_unequal_size_with_a_member_recreated_between_calls():
+    """mpst_sweep_batch_multi with three groups of 4, 3 and 2 fits (three shapes), every group a launch chain on its own host thread
+    (their graphs captured one after the other before any thread runs): the bits of separate sweeps; a member of the middle group
+    destroyed and recreated between two calls; a context named in two groups is refused."""
+    import mpstime_jl_amd as mt
+    from tests.helpers import make_problem
+    sizes = [4, 3, 2]
+    shapes = [(256, 12, 12), (192, 10, 8), (160, 9, 16)]
+    groups, shp = [], []
+    for g, k in enumerate(sizes):
+        groups += [g] * k
+        shp += [shapes[g]] * k
+    K = len(groups)
+    probs = [make_problem(shp[k][0], shp[k][1], 4, 4, 2, seed=90 + k) for k in range(K)]
+
+    def fresh(k):
+        e = mt.SweepEngine(0)
+        e.set_batch_hint(sizes[groups[k]])
+        e.set_options(chi_max=shp[k][2], eta=[0.05, 0.02, 0.1][k % 3])
+        ds, W = probs[k]
+        e.set_dataset(0, ds.phi, ds.label_index, 2)
+        e.set_mps(W)
+        e.build_caches()
+        return e
+
+    solo = [fresh(k) for k in range(K)]
+    bat = [fresh(k) for k in range(K)]
+    try:
+        for call in range(3):
+            if call == 1:                       # member 5 (the middle group's second fit) goes and comes back: same data, same start
+                bat[5].close()
+                solo[5].close()
+                bat[5], solo[5] = fresh(5), fresh(5)
+                for e in (bat[5], solo[5]):     # ... brought to where its group is
+                    e.sweep()
+            for e in solo:
+                e.sweep()
+            st = mt.sweep_batch_multi(bat, groups)
+            assert len(st) == K and all(s["eig_fallbacks"] == 0 for s in st)
+            for k, (a, b) in enumerate(zip(solo, bat)):
+                assert all(np.array_equal(x, y) for x, y in zip(a.get_mps(), b.get_mps())), (call, k)
+        with pytest.raises(mt.MPSTError, match="appears twice"):
+            mt.sweep_batch_multi(bat[:4] + [bat[0]] + bat[5:], groups)
+    finally:
+        for e in solo + bat:
+            e.close()
