@@ -359,10 +359,11 @@ int  mpst_get_profile(void* ctx, double* total_us /*[16]*/, int64_t* count /*[16
  * (csrc/mpst_typed.hip) run the sweep */
 int  mpst_get_info(void* ctx, int32_t* out /*[16]*/);
 /* the same, at most n entries: for callers compiled against another revision of this header.  Entries beyond the 16 of mpst_get_info:
- * out[16] large bonds the randomised subspace eigensolver attempted (real element types, d*chi_max > 128: top-chi_max singular
- * triplets of the bond matrix by five GEMM half-steps + a (chi_max + 32)-dimensional Rayleigh-Ritz problem, certified on the device
- * against the Gram matrix), out[17] those whose result was accepted - the others were solved by the exact Householder path (real and
- * complex bonds), out[18] the bonds of a sweep run FOUR launches (k_grad_s, k_gram_upd, k_eig_trivec, k_bond_tail: verification +
+ * out[16] large bonds the randomised subspace eigensolver attempted (real AND complex element types, d*chi_max > 128: top-chi_max
+ * singular triplets of the bond matrix by five GEMM half-steps + a (chi_max + 32)-dimensional Rayleigh-Ritz problem, certified on
+ * the device against the Gram matrix), out[17] those whose result was accepted - the others were solved by the exact Householder
+ * path.  Both counters are as of the last sweep, batch or bond step that RETURNED (they are read at that call's own synchronisation
+ * point; the query does not wait for the stream), out[18] the bonds of a sweep run FOUR launches (k_grad_s, k_gram_upd, k_eig_trivec, k_bond_tail: verification +
  * polish of the eigenvectors, back-split, update_caches!, the next bond's tensor and the next bond's overlaps in the last one;
  * Float64, KLD, d*chi_max <= 128, chi_max <= 32, one rank, update_iters = 1, no track_cost), out[19] sweeps / bond steps in which a
  * tail launch's verification failed and the rest ran on the six-launch chain (whose k_eig_fin has the Jacobi fallback). */

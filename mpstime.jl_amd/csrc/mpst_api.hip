@@ -137,6 +137,7 @@ struct Ctx {
     int ynext_lid = -1;
     uint64_t ynext_epoch = 0, ynext_seq = 0, bond_seq = 0;
     int tail_redos = 0;
+    int32_t ss_counts[2] = {0, 0};      // subspace eigensolver: bonds attempted / accepted, read where a sweep or a bond step synchronises anyway
     int tail_force_fail = -1, tail_launches = 0;      // test hook (MPST_TAIL_FORCE_REDO=n): the n-th tail launch of the context reports a failed verification
     // sliced bond GEMMs (k_yhat_s / k_grad_s): slice contributions to yhat, loss pieces, arrival tickets
     double *b2_ypart = nullptr, *b2_lossp = nullptr;
@@ -540,6 +541,11 @@ int ensure_workspace(Ctx* c) {
 // clears the sticky error flag and the per-sweep diagnostics (status, eig_sweeps_total, eig_fallbacks are adjacent);
 // enqueued at the head of every sweep / bond step - inside the captured graph too - so that a context recovers
 // after a failed decomposition (the class of failure tune() retries on)
+// The subspace eigensolver's counters, read where the stream has just been synchronised (after a sweep, a bond step, a batch): the info
+// query returns these and never touches the stream.
+static void refresh_ss_counts(Ctx* c) {
+    if (c->blk) (void)blocked_eig_subspace_counts(c->blk, c->stream, &c->ss_counts[0], &c->ss_counts[1]);
+}
 int enqueue_reset_status(Ctx* c) {
     static_assert(offsetof(DevScalars, eig_fallbacks) == offsetof(DevScalars, status) + 8, "status / eig_sweeps_total / eig_fallbacks adjacent");
     HIPC(c, hipMemsetAsync((char*)c->sc + offsetof(DevScalars, status), 0, 12, c->stream));
@@ -1702,6 +1708,7 @@ int mpst_sweep(void* ctx, mpst_sweep_stats* out) {
         HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
         sc.eig_fallbacks += tail_fallbacks;
     }
+    refresh_ss_counts(c);
     std::vector<int32_t> chi(c->T + 1);
     HIPC(c, hipMemcpy(chi.data(), c->chi, chi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (out) {
@@ -1838,6 +1845,7 @@ static int sweep_batch_impl(void* const* ctxs, int32_t K, mpst_sweep_stats* out,
         Ctx* c = (Ctx*)ctxs[k];
         DevScalars sc;
         HIPC(c0, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
+        refresh_ss_counts(c);
         std::vector<int32_t> chi(c->T + 1);
         HIPC(c0, hipMemcpy(chi.data(), c->chi, chi.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (out) {
@@ -1972,6 +1980,7 @@ int mpst_bond_step(void* ctx, int32_t lid, int32_t going_left, mpst_bond_debug* 
         HIPC(c, hipStreamSynchronize(c->stream));
         HIPC(c, hipMemcpy(&sc, c->sc, sizeof sc, hipMemcpyDeviceToHost));
     }
+    refresh_ss_counts(c);
     c->host_label_site = going_left ? lid : lid + 1;
     prof_collect(c);
     if (dbg) {
@@ -2472,7 +2481,6 @@ int mpst_get_info_n(void* ctx, int32_t* out, int32_t n) {
     if (!out || n < 0) return MPST_ERR_INVALID;
     int rc = mpst_get_info(ctx, full);
     if (rc) return rc;
-    full[16] = full[17] = 0;
     {
         Ctx* c4 = (Ctx*)ctx;
         View v4 = make_view(c4, MPST_TRAIN);
@@ -2480,10 +2488,10 @@ int mpst_get_info_n(void* ctx, int32_t* out, int32_t n) {
         full[18] = (c4->chain4_ok && c4->b2 && !multi(c4) && c4->opt.update_iters == 1 && !c4->opt.track_cost && eig_merged() && bond_tail_supported(v4)) ? 1 : 0;
         full[19] = c4->tail_redos;
     }
-    if (n > 16) {       // bonds the subspace eigensolver attempted / whose result was accepted (the rest went to the exact solver)
-        Ctx* c = (Ctx*)ctx;
-        if (c->blk && blocked_eig_subspace_counts(c->blk, c->stream, &full[16], &full[17])) return fail(c, MPST_ERR_DEVICE, "reading the subspace eigensolver's counters failed");
-    }
+    // bonds the subspace eigensolver attempted / whose result was accepted (the rest went to the exact solver), as of the last sweep,
+    // batch or bond step that returned: cached at their synchronisation point, the query itself never waits for the stream
+    full[16] = ((Ctx*)ctx)->ss_counts[0];
+    full[17] = ((Ctx*)ctx)->ss_counts[1];
     for (int i = 0; i < n && i < 20; ++i) out[i] = full[i];
     return 0;
 }

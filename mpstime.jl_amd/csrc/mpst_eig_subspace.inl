@@ -21,7 +21,14 @@
 //     sqrt(sum_k |r_k|^2 / theta_k) <= 1e-9 ||M||_F      (the first-order bound of ||M (P~ - P)||_F: a residual lies outside the
 //     iterated block, where the spectrum is far below theta_k; checked against the true error on every dumped bond),
 // orthonormality |V^H V - I| (k_bt_gram / k_bt_decide, then the Loewdin rounds of k_bt_polish as for the exact solver) and the
-// Frobenius certificate ||G||_F^2 - sum theta^2 (no eigenvalue above the kept ones was missed, down to the resolution of fp64).
+// Frobenius certificate ||G||_F^2 - ||H||_F^2 >= (what the block missed)^2.  RESOLUTION OF THAT CERTIFICATE: the subtraction resolves
+// 64 eps ||G||_F^2, i.e. a missed eigenvalue above ~1.2e-7 lambda_1; the fp64 cutoff keeps values down to 1e-10 of the trace.  For kept
+// values in that window the certificate proves nothing and nothing is claimed: there the residual test says the kept pairs ARE
+// eigenpairs, and that they are the LARGEST ones rests on the iteration itself (a direction of M with a larger singular value than a
+// kept one is amplified MORE than the kept one by every application; to be absent after five it must be orthogonal to the start block
+// to ~1e-16) - an argument, not a check.  The linear deficit tr G - tr H (resolution eps tr) was considered and not used: it sums
+// lambda_j (1 - |Q^H u_j|^2) over ALL directions, so the unconverged oversampling columns and the discarded tail, which are legitimate,
+// exceed a kept value of 1e-9 tr routinely and the bond would be sent to the exact path for no reason.
 // A bond that fails any of them is solved by the exact path, whose launches follow in the same stream and leave at once when
 // the word st[0] says the result stands.  Deterministic: Omega is a hash of (row, column), all sums have a fixed order.
 // Real and complex element types (the complex kernels are at the end of the file); not attempted: d chi <= 128 (measured: no gain,

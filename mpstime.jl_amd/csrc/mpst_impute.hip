@@ -773,7 +773,7 @@ struct ImpArgs {
     const int32_t* ord;         // the instances of this chunk (run_impute orders them by where their missing sites begin)
     double x0, dxu;             // TRIG kernels: the uniform grid x_k = x0 + k dxu
     const double* lin;          // TRIG, real models: [2d-1][d][d] Legendre linearisation table (scaled by the states' norms), else null
-    int dbg;                    // k_imp_leftb: parts switched off for timing (MPST_IMB_DBG, lab use)
+    int dbg;                    // k_imp_leftb: parts switched off for timing (0 outside -DMPST_LAB builds)
 };
 enum { IMP_MEDIAN = 0, IMP_MODE = 1, IMP_QUANTILE = 2, IMP_MEAN = 3, IMP_ITS_REJECT = 4 };
 enum { IMP_BASIS_LEGENDRE = 0, IMP_BASIS_LEGENDRE_NO_NORM = 1, IMP_BASIS_FOURIER = 2, IMP_BASIS_STOUDENMIRE = 3, IMP_BASIS_SAHAND = 4,
@@ -1761,8 +1761,12 @@ static int launch_impute_t(const ImpModel& v, const ImputeParams& q, int64_t i0,
     if (mid) (void)hipEventRecord(mid, s);
     ImpArgs g{q.missing, q.Rbuf, q.grid_x, q.grid_phi, q.u, q.pbuf, q.sbuf, q.x_out, q.err_out, q.max_missing, q.ngrid, q.method,
               q.get_wmad, q.rev, q.ntrial, q.mean_basis, q.reject_thr, q.order + i0, q.x0, q.dxu, q.lin, 0};
+#ifdef MPST_LAB
+    // lab builds only (make EXTRA=-DMPST_LAB): MPST_IMB_DBG switches parts of k_imp_leftb off for timing - results are then
+    // WRONG by construction, so the shipped library never reads the variable
     static const int imb_dbg = [] { const char* e = getenv("MPST_IMB_DBG"); return e ? atoi(e) : 0; }();
     g.dbg = imb_dbg;
+#endif
     // two workgroups per CU (128 VGPRs each, 70-183 of them spilled) against one (256 VGPRs, no spill): the spilling
     // build wins where the density loop is latency-bound - real models and complex ones with d <= 5 - because a second
     // workgroup hides more than the scratch traffic costs (same-box A/B: profiles/r03_impute_occupancy_ab.txt;

@@ -179,19 +179,25 @@ function fitMPS_hip(W::MPS, train::EncodedTimeSeriesSet, test::EncodedTimeSeries
             its > 1 && check(c, ccall((:mpst_set_options, LIB), Cint, (Ptr{Cvoid}, Ref{MpstOptions}), c, sweep_options(its)))
             st = Ref(MpstSweepStats(0, 0, 0, 0, 0))
             check(c, ccall((:mpst_sweep, LIB), Cint, (Ptr{Cvoid}, Ref{MpstSweepStats}), c, st))
-            # both half-sweeps run inside the one call: the reference's mid-sweep lines follow it
-            verbosity > -1 && println("Backward sweep finished.")                                                      # :766
-            verbosity > -1 && println("Starting forward sweep: [$its/$nsweeps]")                                       # :772
+            # both half-sweeps run inside the one call: the reference's mid-sweep lines (:766, :772) go where they fall in its output -
+            # between the two halves' per-bond lines when those are printed, straight after the call otherwise
+            midlines() = if verbosity > -1
+                println("Backward sweep finished.")                                                                    # :766
+                println("Starting forward sweep: [$its/$nsweeps]")                                                     # :772
+            end
             if opts.track_cost && verbosity >= 1
                 # what custGD / TSGO (loss_functions.jl:50-52, :80-82) and apply_update (:181-184) print, bond by bond
                 check(c, ccall((:mpst_get_loss_trace, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), c, trace))
                 for q in 1:2nb
+                    q == nb + 1 && midlines()
                     lid = q <= nb ? nb - q + 1 : q - nb
                     for it in 1:opts.update_iters
                         println("Loss before step $it: $(trace[it, q])")
                     end
                     println("Loss at site $lid*$(lid+1): $(trace[end, q])")
                 end
+            else
+                midlines()
             end
             verbosity > -1 && println("Finished sweep $its. Time for sweep: $(round(st[].seconds, digits=2))s")        # :811
             acc = log!(st[].seconds)

@@ -143,18 +143,23 @@ def fit_encoded(W, training_states_meta: EncodedTimeSeriesSet, testing_states_me
             if its > 0 and (isinstance(opts.loss_grad, tuple) or isinstance(opts.bbopt, tuple)):
                 eng.set_options(rebuild_caches=False, track_cost=opts.track_cost, **engine_options(opts, its))   # :727-728: this sweep's loss / optimiser
             st = eng.sweep()                                                     # :727-808
-            if verbosity > -1:        # both half-sweeps run inside the one call: the reference's mid-sweep lines follow it
-                print("Backward sweep finished.")                                # :766
-                print(f"Starting forward sweep: [{its + 1}/{opts.nsweeps}]")      # :772
+            # both half-sweeps run inside the one call: the reference's mid-sweep lines (:766, :772) are printed where they fall in its
+            # output - between the backward half's and the forward half's per-bond lines when those are printed, straight after otherwise
+            mid = lambda: verbosity > -1 and (print("Backward sweep finished."),
+                                              print(f"Starting forward sweep: [{its + 1}/{opts.nsweeps}]"))
             if opts.track_cost and verbosity >= 1:
                 # what custGD / TSGO (loss_functions.jl:50-52,80-82) and apply_update (:181-184) print, bond by bond
                 trace = eng.loss_trace()
                 nb = len(W) - 1
                 for q in range(2 * nb):
+                    if q == nb:
+                        mid()
                     lid = nb - 1 - q if q < nb else q - nb
                     for it in range(opts.update_iters):
                         print(f"Loss before step {it + 1}: {trace[q, it]}")
                     print(f"Loss at site {lid + 1}*{lid + 2}: {trace[q, opts.update_iters]}")
+            else:
+                mid()
             if verbosity > -1:
                 print(f"Finished sweep {its + 1}. Time for sweep: {round(st['seconds'], 2)}s")
             acc = log(st["seconds"])

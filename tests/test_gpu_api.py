@@ -121,6 +121,12 @@ def test_fitmps_with_per_sweep_loss_and_track_cost(capsys):
     out = capsys.readouterr().out
     assert out.count("Loss before step 1:") == 2 * 11 and out.count("Loss at site") == 2 * 11
     assert "Loss at site 11*12:" in out and "Loss at site 1*2:" in out
+    # the order of the reference's output (RealRealHighDimension.jl:729-811): the backward half's eleven bonds, the two mid-sweep lines,
+    # the forward half's eleven bonds
+    lines = [ln for ln in out.splitlines() if ln.startswith(("Loss at site", "Backward sweep finished", "Starting forward sweep"))]
+    assert lines[0].startswith("Loss at site 11*12:") and lines[10].startswith("Loss at site 1*2:")
+    assert lines[11] == "Backward sweep finished." and lines[12].startswith("Starting forward sweep: [1/1]")
+    assert lines[13].startswith("Loss at site 1*2:") and lines[23].startswith("Loss at site 11*12:") and len(lines) == 24
     # the returned model still carries the encoded training set (not the loss trace), and survives save / load
     assert isinstance(res.train_data, mt.EncodedTimeSeriesSet) and res.train_data.phi.shape[0] == 60
     import tempfile, os
