@@ -123,3 +123,37 @@ def test_weighted_median_matches_definition():
     w2 = np.zeros(5)
     w2[3] = 1.0
     assert I.weighted_median(np.arange(5.0), w2) == 3.0
+
+
+# ---- the committed imputation instance (tests/golden/make_golden_complex_impute.py) and, when a maintainer has written it, the reference's own answer ----
+import os
+
+_IFIX = os.path.join(os.path.dirname(__file__), "golden", "impute_median_c1.npz")
+_IREF = os.path.join(os.path.dirname(__file__), "golden", "juliaref_impute_median_c1.npz")
+
+
+def _instance():
+    g = np.load(_IFIX)
+    T = len(g["x"])
+    return g, [g[f"mps_{j}"] for j in range(T)]
+
+
+def test_imputation_fixture_is_reproduced():
+    g, mps = _instance()
+    for order in ("forwards", "backwards"):
+        x, err = I.impute(mps, g["enc"], g["missing"], g["xs"], g["grid_phi"], "median", order, True)
+        assert np.array_equal(x, g[f"x_{order}"]) and np.allclose(err, g[f"wmad_{order}"], rtol=0, atol=1e-12)
+        assert len(x) == len(g["missing"]) and np.all(np.abs(x) <= 1.0)
+
+
+@pytest.mark.skipif(not os.path.exists(_IREF), reason="no tests/golden/juliaref_impute_median_c1.npz: a maintainer with Julia writes it with "
+                                                      "tests/golden/make_reference_goldens.jl (the reference's impute_median on this instance)")
+def test_imputation_oracle_against_reference_vectors():
+    """impute_median(...; get_wmad = true) of the REFERENCE (MPS_methods.jl:201-230) on the fixture's class MPS, series and grid: the same
+    grid values (exact: they are grid points) and the same weighted median absolute deviations, both imputation orders."""
+    g, mps = _instance()
+    ref = np.load(_IREF)
+    for order in ("forwards", "backwards"):
+        x, err = I.impute(mps, g["enc"], g["missing"], g["xs"], g["grid_phi"], "median", order, True)
+        assert np.allclose(x, ref[f"x_{order}"], rtol=0, atol=1e-12)
+        assert np.allclose(err, ref[f"wmad_{order}"], rtol=0, atol=1e-9)

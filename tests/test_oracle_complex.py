@@ -82,3 +82,50 @@ def test_reduced_precision_problem_keeps_its_element_type():
     assert all(t.dtype == np.complex64 for t in W)
     with pytest.raises(ValueError, match="complex valued encoding"):
         RC.cast_problem(ds, W, np.float32)
+
+
+# ---- the committed complex fixture (tests/golden/make_golden_complex_impute.py) and, when a maintainer has written it, the reference's own run on it ----
+import os
+
+_CFIX = os.path.join(os.path.dirname(__file__), "golden", "complex_kld_c2.npz")
+_CREF = os.path.join(os.path.dirname(__file__), "golden", "juliaref_complex_kld_c2.npz")
+
+
+def _complex_fixture_trajectory():
+    g = np.load(_CFIX)
+    T = g["phi"].shape[1]
+    ds = R.EncodedSet(g["phi"], g["label_index"], g["class_distribution"])
+    W = [g[f"W0_{j}"].copy() for j in range(T)]
+    chimax, iters, nsw, sep = [int(x) for x in g["opts"]]
+    opts = RC.SweepOptions(nsweeps=nsw, chi_max=chimax, eta=float(g["eta"]), update_iters=iters, loss_grad=str(g["loss"]), bbopt=str(g["bbopt"]),
+                           train_classes_separately=bool(sep))
+    bonds, klds = [], [R.mse_loss_acc(W, ds)[1]]
+    for _ in range(nsw):
+        rec = []
+        RC.sweep(W, ds, opts, record=rec)
+        bonds += rec
+        klds.append(R.mse_loss_acc(W, ds)[1])
+    return g, bonds, klds
+
+
+def test_complex_fixture_is_reproduced():
+    g, bonds, klds = _complex_fixture_trajectory()
+    assert np.iscomplexobj(g["phi"]) and np.iscomplexobj(g["W0_0"])
+    assert np.array_equal([b["chi"] for b in bonds], g["bond_chi"])
+    assert np.allclose([b["loss"] for b in bonds], g["bond_loss"], rtol=1e-10)
+    assert np.allclose([b["grad_norm"] for b in bonds], g["bond_grad_norm"], rtol=1e-9)
+    assert np.allclose(klds, g["train_KL_div"], rtol=1e-9)
+
+
+@pytest.mark.skipif(not os.path.exists(_CREF), reason="no tests/golden/juliaref_complex_kld_c2.npz: a maintainer with Julia writes it with "
+                                                      "tests/golden/make_reference_goldens.jl (the reference's legacy ITensor engine on this fixture)")
+def test_complex_oracle_against_reference_vectors():
+    """fitMPS_IT's sweep body (use_legacy_ITensor = true, ComplexF64) on the fixture's inputs: per-bond loss, ||grad||, chi, kept singular values."""
+    g, bonds, klds = _complex_fixture_trajectory()
+    ref = np.load(_CREF)
+    assert np.array_equal([b["chi"] for b in bonds], ref["bond_chi"])
+    assert np.allclose([b["loss"] for b in bonds], ref["bond_loss"], rtol=1e-8, atol=1e-11)
+    assert np.allclose([b["grad_norm"] for b in bonds], ref["bond_grad_norm"], rtol=1e-8)
+    for i, b in enumerate(bonds):
+        assert np.allclose(b["S"], ref["bond_S"][i, :len(b["S"])], rtol=0, atol=1e-8 * b["S"][0])
+    assert np.allclose(klds, ref["train_KL_div"], rtol=1e-6)
