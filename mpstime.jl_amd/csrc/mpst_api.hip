@@ -276,7 +276,7 @@ View make_view(Ctx* c, int which) {
     v.norm_part = c->norm_part; v.n_norm_part = c->n_norm_part; v.btn = c->btn;
     v.btnT = (which == MPST_TRAIN && c->chain4_ok && !c->chain4_hold) ? c->btnT : nullptr;
     v.trace = nullptr; v.trace_it = 0; v.yhat_scaled = 0;
-    v.cls_off = s.cls_off; v.ypart = c->b2_ypart; v.lossp = c->b2_lossp; v.tick = c->b2_tick; v.b2_ksplit = c->b2_ksplit; v.dbg = c->b2_dbg;
+    v.cls_off = s.cls_off; v.ypart = c->b2_ypart; v.lossp = c->b2_lossp; v.tick = c->b2_tick; v.b2_ksplit = c->b2_ksplit; v.b2_nw = (c->batch_hint > 1 && c->d == 4) ? 4 : 8; v.dbg = c->b2_dbg;
     {
         int32_t so = 0, to = 0;
         for (int k = 0; k <= MAX_C; ++k) {
@@ -466,7 +466,10 @@ int ensure_workspace(Ctx* c) {
             c->b2_ksplit = b2_ksplit(gv, max_pass);
             // a context that runs in batches of K fits shares the chip with K - 1 others: fewer, longer shares per gradient block
             // (less hand-over per fit; the share count fixes the order of the partial sums, so it belongs to the context, not to the call)
-            if (c->batch_hint > 1 && getenv("MPST_B2_KSPLIT") == nullptr) c->b2_ksplit = std::max(1, c->b2_ksplit / std::min(c->batch_hint, 8));
+            // (d = 4: the batched launches run k_grad_s with four waves per workgroup, two workgroups per CU - twice the workgroups fill the chip)
+            if (c->batch_hint > 1 && getenv("MPST_B2_KSPLIT") == nullptr)
+                c->b2_ksplit = c->d == 4 ? std::max(1, std::min(c->b2_ksplit, 2 * c->b2_ksplit / std::min(c->batch_hint, 16)))
+                                         : std::max(1, c->b2_ksplit / std::min(c->batch_hint, 8));
             c->b2_norm_parts = c->C * b2_blocks_cap(gv);
             c->partial_elems = std::max(c->partial_elems, b2_partial_elems(gv, max_pass));
             if ((rc = dalloc(c, &c->b2_ypart, (int64_t)8 * c->C * tr.N))) return rc;
@@ -1764,7 +1767,7 @@ static int sweep_batch_impl(void* const* ctxs, int32_t K, mpst_sweep_stats* out,
         const DataSet &a = c0->ds[MPST_TRAIN], &b = c->ds[MPST_TRAIN];
         const bool same = c->device == c0->device && c->T == c0->T && c->d == c0->d && c->C == c0->C && c->cap == c0->cap && a.N == b.N && a.ntiles == b.ntiles &&
                           a.counts == b.counts && c->opt.loss == c0->opt.loss && c->opt.train_classes_separately == c0->opt.train_classes_separately &&
-                          c->opt.chi_max == c0->opt.chi_max && c->b2_ksplit == c0->b2_ksplit && c->b2_norm_parts == c0->b2_norm_parts;
+                          c->opt.chi_max == c0->opt.chi_max && c->b2_ksplit == c0->b2_ksplit && (c->batch_hint > 1) == (c0->batch_hint > 1) && c->b2_norm_parts == c0->b2_norm_parts;
         if (!same) return fail(c0, MPST_ERR_UNSUPPORTED, "context %d differs in shape from context 0 (T, d, C, capacity, chi_max, class counts, loss): batch fits of one shape", k);
         HIPC(c0, hipStreamSynchronize(c->stream));
     }

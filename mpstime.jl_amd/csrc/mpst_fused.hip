@@ -337,6 +337,21 @@ __global__ __launch_bounds__(64) void k_grad_norm(View v, int lid) {
 }
 
 // step of TSGO / GD from the norm pieces: every caller sums them in the same order, so all see the same bits
+// Workgroups are dealt round-robin over the 8 XCDs in launch order (observed, speed only): the p-th workgroup of the launch lands on
+// XCD p % 8.  The blocks of one (fit, class, share) read the SAME series, a different 64-byte piece of every environment row each: dealt
+// in launch order they sit on all 8 XCDs and every XCD's L2 pulls every series from memory (K = 8: 17x the algorithmic bytes).  The
+// batched launch therefore gives XCD x the x-th CONTIGUOUS eighth of the logical order (blocks fastest, then shares, classes, fits): the
+// blocks of a share run side by side on one XCD and meet in its L2.  Which workgroup computes what does not enter any sum.
+__device__ __forceinline__ void xcd_contiguous(int& bx, int& by, int& bz) {
+    const int gx = (int)gridDim.x, gy = (int)gridDim.y, gz = (int)gridDim.z;
+    const int G = gx * gy * gz;
+    if (G & 7) return;
+    const int p = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+    const int l = (p & 7) * (G >> 3) + (p >> 3);
+    bx = l % gx;
+    by = (l / gx) % gy;
+    bz = l / (gx * gy);
+}
 __device__ __forceinline__ double step_from_parts(const View& v, double* red, double* nrm_out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < v.n_norm_part; i += 256) s += v.norm_part[i];
@@ -349,14 +364,13 @@ __device__ __forceinline__ double step_from_parts(const View& v, double* red, do
 // Gram matrix of bt_new = bt - step*grad viewed as the matrix decomposeBT hands to svd, one 16 x 16 tile per
 // workgroup, K split over the 4 waves.  The diagonal tiles see every entry of bt_new exactly once (their A-operand
 // panel) and write it to v.btn - a second buffer, the other tiles are still reading the old one.
-__device__ __forceinline__ void gram_upd_body(const View& v, int lid, int going_left, int first_iter) {
+__device__ __forceinline__ void gram_upd_body(const View& v, int lid, int going_left, int first_iter, const int tile) {
     __shared__ double part[4][256];
     __shared__ double red[4];
     const BondDimsF b = bond_dims_f(v, lid);
     const int n = going_left ? b.Y : b.X;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tn = (n + 15) >> 4;
-    const int tile = blockIdx.x;
     const bool live = tile < tn * tn;
     const int m0 = (tile / tn) * 16, n0 = (tile % tn) * 16;
     const bool diag = m0 == n0;
@@ -696,14 +710,14 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
 // beyond: the next bond's tensor (chain_bt_block)
 __device__ __forceinline__ void env_split_body(const View& v, int lid, int going_left, int site, int left_side,
                                                const double* __restrict__ prev, int prev_bond, int out_bond,
-                                               double* __restrict__ out, int nsplit, int ntb, int tp) {
+                                               double* __restrict__ out, int nsplit, int ntb, int tp, const int bid) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if ((int)blockIdx.x >= ntb + nsplit) {
-        chain_bt_block(v, lid, going_left, (int)blockIdx.x - ntb - nsplit, smem, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
+    if (bid >= ntb + nsplit) {
+        chain_bt_block(v, lid, going_left, bid - ntb - nsplit, smem, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
         return;
     }
-    if ((int)blockIdx.x >= ntb) {
-        split_block(v, lid, going_left, (int)blockIdx.x - ntb, nsplit, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
+    if (bid >= ntb) {
+        split_block(v, lid, going_left, bid - ntb, nsplit, v.E, v.cap, v.sc->n_keep, v.sc->inv_norm);
         return;
     }
     // new environment rows out_i = Z_i E.  A wave owns one 16-column tile of the output; with fewer than four column tiles
@@ -734,8 +748,8 @@ __device__ __forceinline__ void env_split_body(const View& v, int lid, int going
             const int z = 4 * (q * ks4 + u) + kq;
             bv[q][u] = (cv && u < ks4 && z < Z) ? M[(int64_t)z * sz + col] : 0.0;
         }
-    for (int t0 = (int)blockIdx.x * tp; t0 < v.ntiles; t0 += ntb * tp) {
-        if (t0 != (int)blockIdx.x * tp) __syncthreads();          // the previous pass has been consumed
+    for (int t0 = bid * tp; t0 < v.ntiles; t0 += ntb * tp) {
+        if (t0 != bid * tp) __syncthreads();          // the previous pass has been consumed
         for (int sl = 0; sl < tp; ++sl) {
             if (t0 + sl < v.ntiles) {
                 const Span tl = v.tiles[t0 + sl];
@@ -754,7 +768,10 @@ __device__ __forceinline__ void env_split_body(const View& v, int lid, int going
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int step = q * ks4 + u;
-                    if (u < ks4 && step < nsteps) p[q] = mfma_f64(Xs[i16 * FXS + 4 * step + kq], bv[q][u], p[q]);
+                    // (unconditional: the B operand of a step beyond the contraction is zero and its A operand is read from the last live
+                    // step, so the chain gains an exact +0 - a predicated MFMA costs a copy of the accumulator, and the copies of 32 of
+                    // them took the kernel past 256 registers: one workgroup per CU instead of two, 2.7x the time with 32 fits per launch)
+                    p[q] = mfma_f64(Xs[i16 * FXS + 4 * min(step, nsteps - 1) + kq], bv[q][u], p[q]);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -825,20 +842,30 @@ __device__ __forceinline__ Span tile_span_k(const View& v, int t) {
 // grid.x = nslc * ngw (see launch_yhat_s): workgroup id -> (group walker = id % ngw, slice = id / ngw); grid.y = passes (MSE: C)
 // Every wave stages, consumes and stores its own tile: no workgroup barrier, one round trip to memory per group.
 // LM: 16-entry pieces of an environment row a lane group fetches (capacity <= 16 LM); D4: d == 4 (the headline shapes).
-template <int LM, bool D4>
-__device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, int ngw) {
+template <int LM, bool D4, int NS>
+__device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, int ngw, const int bid_x, const int bid_y) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const B2 b = b2_dims(v, lid);
     const int d = v.d, rid = lid + 1;
     const bool mse = v.loss == MPST_LOSS_MSE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int gw = (int)blockIdx.x % ngw, sl = (int)blockIdx.x / ngw;       // consecutive ids (XCDs) walk different series groups
-    if (sl * YS_W >= b.Y) return;
-    const int pass = mse ? (int)blockIdx.y : 0;
-    const int col = sl * YS_W + i16;
-    const bool cv = col < b.Y;
-    const int sp = cv ? col / b.Dr : 0, bb = cv ? col - sp * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
+    const int gw = bid_x % ngw, sl = bid_x / ngw;       // consecutive ids (XCDs) walk different series groups
+    // NS = slices of B_c a workgroup takes for the series it has staged (sl counts groups of NS slices).  1: the single-fit launches
+    // (latency: most workgroups, least work each).  4: the batched launches - the staging of a tile (rows to registers, to LDS, the next
+    // tile's loads: 3.4 us of the 6.3 a group takes with one slice, the matrix pipe idle meanwhile; profiles/r06_b2_stamps.txt) is paid
+    // once per four slices, and the rows are fetched a quarter as often.  The sums per (series, slice) are the same either way.
+    if (sl * NS * YS_W >= b.Y) return;
+    const int pass = mse ? bid_y : 0;
+    int col[NS], sp[NS], bb[NS];
+    bool cv[NS];
+#pragma unroll
+    for (int ss = 0; ss < NS; ++ss) {
+        col[ss] = (sl * NS + ss) * YS_W + i16;
+        cv[ss] = col[ss] < b.Y;
+        sp[ss] = cv[ss] ? col[ss] / b.Dr : 0;
+        bb[ss] = cv[ss] ? col[ss] - sp[ss] * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
+    }
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
     const double* phl = v.phi + (int64_t)lid * v.N * d;
@@ -868,18 +895,18 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
     // persistent workgroup) reads its fragment from global memory instead.  The first group's own rows are requested in the
     // same breath: one round trip to memory before the first MFMA, not two.
     const int cls0 = mse ? pass : tile_span_k(v, 8 * gw).cls;
-    double* Bsh = smem + 128 * (ls + ps);                  // [128][17]
-    double t4[4];
+    double* Bsh = smem + 128 * (ls + ps);                  // [NS][128][17]
+    double t4[4 * NS];
     {
         const double* Bc = v.bt + (int64_t)cls0 * b.L;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = tid + YS_T * k, x = idx >> 4, cc = sl * YS_W + (idx & 15);
+        for (int k = 0; k < 4 * NS; ++k) {
+            const int idx = tid + YS_T * (k & 3), x = idx >> 4, cc = (sl * NS + (k >> 2)) * YS_W + (idx & 15);
             t4[k] = (x < b.X && cc < b.Y) ? Bc[(int64_t)x * b.Y + cc] : 0.0;
         }
     }
     // this wave's tile of a group: 4 rows x 16 consecutive bond entries per load instruction, and the 4 Y values per lane
-    double lev[4][LM], phv[4], yv[4];
+    double lev[4][LM], phv[4], yv[NS][4];
     Span tl{0, 0, 0, 0};
     auto load_tile = [&](int g) {
         tl = tile_span_k(v, 8 * g + wave);
@@ -887,7 +914,9 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
         for (int r = 0; r < 4; ++r) {
             const int i = kq + 4 * r;
             const int64_t smp = tl.start + (i < tl.count ? i : 0);
-            yv[r] = (cv && i < tl.count) ? phr[smp * d + sp] * (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
+#pragma unroll
+            for (int ss = 0; ss < NS; ++ss)
+                yv[ss][r] = (cv[ss] && i < tl.count) ? phr[smp * d + sp[ss]] * (REn ? REn[smp * v.cap + bb[ss]] : 1.0) : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -904,9 +933,9 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
     };
     if (gw < ngroups) load_tile(gw);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = tid + YS_T * k;
-        Bsh[(idx >> 4) * 17 + (idx & 15)] = t4[k];
+    for (int k = 0; k < 4 * NS; ++k) {
+        const int idx = tid + YS_T * (k & 3);
+        Bsh[(k >> 2) * 128 * 17 + (idx >> 4) * 17 + (idx & 15)] = t4[k];
     }
     __syncthreads();
     for (int g = gw; g < ngroups; g += ngw) {
@@ -928,16 +957,23 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
                 if (i16 < d) PHs[row * ps + i16] = phv[q];
             }
         }
-        double yc[4] = {yv[0], yv[1], yv[2], yv[3]};
+        double yc[NS][4];
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yc[ss][r] = yv[ss][r];
         if (g + ngw < ngroups) load_tile(g + ngw);         // the next group's rows fly during this group's matrix work
         if (tc.count <= 0) continue;                       // (wave-uniform; nothing below synchronises across waves)
         const int cls = mse ? pass : tc.cls;
-        if (cls != cur_cls) {                              // B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
+#pragma unroll
+        for (int ss = 0; ss < NS; ++ss) {
+        if ((sl * NS + ss) * YS_W >= b.Y) break;
+        if (cls != cur_cls || NS > 1) {                    // B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
             if (cls == cls0) {
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bq[mt][r] = Bsh[(16 * mt + kq + 4 * r) * 17 + i16];
+                    for (int r = 0; r < 4; ++r) bq[mt][r] = Bsh[ss * 128 * 17 + (16 * mt + kq + 4 * r) * 17 + i16];
             } else {
                 const double* Bc = v.bt + (int64_t)cls * b.L;
 #pragma unroll
@@ -945,7 +981,7 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int x = 16 * mt + kq + 4 * r;
-                        bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
+                        bq[mt][r] = (cv[ss] && x < b.X) ? Bc[(int64_t)x * b.Y + col[ss]] : 0.0;
                     }
             }
             cur_cls = cls;
@@ -981,10 +1017,11 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double x = sum16((acc0[r] + acc1[r]) * yc[r]);
+                const double x = sum16((acc0[r] + acc1[r]) * yc[ss][r]);
                 const int i = kq + 4 * r;
-                if (i16 == 0 && i < tc.count) ypart[(int64_t)(tc.start + i) * YS_MAXSL + sl] = x;
+                if (i16 == 0 && i < tc.count) ypart[(int64_t)(tc.start + i) * YS_MAXSL + sl * NS + ss] = x;
             }
+        }
         }
         YSTAMP();
     }
@@ -996,8 +1033,8 @@ constexpr int GS_MAXKS = 64;
 
 // grid.x = ksplit * nbc * nbc (capacity), grid.y = C.  Workgroup id -> (ks = id % ksplit, block = id / ksplit).
 // AW2: compile-time bound of ceil(aw / 8), D2 of ceil(d / 8) (register arrays of the loader role).
-template <int AW2, int D2>
-__device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, int nbc) {
+template <int AW2, int D2, int FS, int KC, int NW>
+__device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, int nbc, const int bid_x, const int bid_y) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double redl[8];
     __shared__ int last_s;
@@ -1006,8 +1043,8 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
     const bool mse = v.loss == MPST_LOSS_MSE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int c = blockIdx.y;
-    const int ks = (int)blockIdx.x % ksplit, blk = (int)blockIdx.x / ksplit;
+    const int c = bid_y;
+    const int ks = bid_x % ksplit, blk = bid_x / ksplit;
     const int bx = blk / nbc, by = blk % nbc;
     const int grp = c * nbc * nbc + blk;                    // ticket / norm-piece slot (capacity layout)
     if (bx >= b.nbx || by >= b.nby) {
@@ -1028,19 +1065,20 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
     const double2* ypart2 = (const double2*)(v.ypart + (int64_t)(mse ? c : 0) * v.N * YS_MAXSL);
     // record of a series in LDS: [LE slice (aw) | phi_l (d) | RE slice (bw) | phi_r (d) | 0], stride fs (odd); then the weights
     const int o_pl = b.aw, o_re = b.aw + d, o_pr = b.aw + d + b.bw, zc = 2 * b.aw + 2 * d;
-    const int fs = (zc + 1) | 1;
-    double* wv = smem + GS_KC * fs;                         // [GS_KC] w_i of the stage's series (0 beyond the share)
+    const int fs = FS > 0 ? FS : ((zc + 1) | 1);            // FS: the stride at compile time (d = 4: 25) - every LDS address of the matrix loop an immediate
+    double* wv = smem + KC * fs;                         // [KC] w_i of the stage's series (0 beyond the share)
     // loader role 1: 8 lanes per series (entries j, j + 8 of every factor), 4 passes of 64 series per stage
     const int lsm = tid >> 3, j = tid & 7;
-    double r_le[4][AW2], r_re[4][AW2], r_pl[4][D2], r_pr[4][D2];
-    // loader role 2 (threads < GS_KC): the slices' contributions to yhat of series base + tid, 64 contiguous bytes
+    constexpr int NP = KC / (8 * NW);    // passes of 8 NW series per stage (8 lanes per series)
+    double r_le[NP][AW2], r_re[NP][AW2], r_pl[NP][D2], r_pr[NP][D2];
+    // loader role 2 (threads < KC): the slices' contributions to yhat of series base + tid, 64 contiguous bytes
     double2 r_y[4];
     double r_dl = 0.0;
     bool r_ok = false;
     auto load_stage = [&](int base) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int smp = base + 64 * p + lsm;
+        for (int p = 0; p < NP; ++p) {
+            const int smp = base + 8 * NW * p + lsm;
             const bool ok = smp < s1;
             const int64_t sm = ok ? smp : s0;
 #pragma unroll
@@ -1056,7 +1094,7 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
                 r_pr[p][h] = (ok && jj < d) ? phr[sm * d + jj] : 0.0;
             }
         }
-        if (tid < GS_KC) {
+        if (tid < KC) {
             const int smp = base + tid;
             r_ok = smp < s1;
             const int64_t sm = r_ok ? smp : s0;
@@ -1065,16 +1103,28 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
             r_dl = (mse && r_ok && v.label[sm] == c) ? 1.0 : 0.0;
         }
     };
-    // consumer role: tile (tx, ty) of the block, series 4 u + kq of the wave's half of the stage
-    const int tile = wave & 3, kh = wave >> 2;
+    // consumer role (round 6): wave w takes the series [32 w, 32 w + 32) of a stage - an eighth of the contraction - and ALL four 16 x 16
+    // tiles of the block: two row operands and two column operands per k-step feed four MFMAs (9 LDS reads and 6 products per four
+    // MFMAs; one tile per wave cost 5 reads and 3 products per MFMA and the LDS pipe, not the matrix pipe, set the pace).  The eight
+    // partial blocks meet in LDS after the last stage, in wave order.
+    const int tile = wave & 3, kh = wave >> 2;              // epilogue: waves 0..3 own tile (tx, ty) of the finished block
     const int tx = tile >> 1, ty = tile & 1;
-    const int xr = 16 * tx + i16, yc = 16 * ty + i16;           // block-local row / column this lane feeds
-    const int al = xr / d, slx = xr - al * d;                   // X_i[row] = LE_i[a0 + al] * phi_l[i][slx]
-    const int spl = yc / b.bw, bl = yc - spl * b.bw;            // Y_i[col] = phi_r[i][spl] * RE_i[b0 + bl]
-    const bool xv = al < b.aw && a0 + al < b.Dl, yvld = spl < d && b0 + bl < b.Dr;
-    // operands of lanes outside the live block come from the record's zero cell: no select in the loop
-    const int ia = xv ? al : zc, ipl = xv ? o_pl + slx : zc, ib = yvld ? o_re + bl : zc, ipr = yvld ? o_pr + spl : zc;
-    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    int ia[2], ipl[2], ib[2], ipr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int xr = 16 * h + i16, yc = 16 * h + i16;         // block-local row / column this lane feeds
+        const int al = xr / d, slx = xr - al * d;               // X_i[row] = LE_i[a0 + al] * phi_l[i][slx]
+        const int spl = yc / b.bw, bl = yc - spl * b.bw;        // Y_i[col] = phi_r[i][spl] * RE_i[b0 + bl]
+        const bool xv = al < b.aw && a0 + al < b.Dl, yvld = spl < d && b0 + bl < b.Dr;
+        // operands of lanes outside the live block come from the record's zero cell: no select in the loop
+        ia[h] = xv ? al : zc;
+        ipl[h] = xv ? o_pl + slx : zc;
+        ib[h] = yvld ? o_re + bl : zc;
+        ipr[h] = yvld ? o_pr + spl : zc;
+    }
+    d4 acc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) acc[h][0] = acc[h][1] = d4{0.0, 0.0, 0.0, 0.0};
     double loss = 0.0;
     const bool do_loss = bx == 0 && by == 0;
 #ifdef MPST_B2_DEBUG
@@ -1088,9 +1138,17 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
     GSTAMP(0);
     if (s0 < s1) load_stage(s0);
     GWAITSTAMP(6);
-    for (int base = s0; base < s1; base += GS_KC) {
+#ifdef MPST_B2_DEBUG
+    unsigned long long g_wait = 0, g_stage = 0, g_n = 0;
+#endif
+    for (int base = s0; base < s1; base += KC) {
+#ifdef MPST_B2_DEBUG
+        const unsigned long long g_t0 = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_wait += __builtin_amdgcn_s_memrealtime() - g_t0;
+#endif
         __syncthreads();                                   // the previous stage is consumed
-        if (tid < GS_KC) {
+        if (tid < KC) {
             double w = 0.0;
             if (r_ok) {
                 const double ys[8] = {r_y[0].x, r_y[0].y, r_y[1].x, r_y[1].y, r_y[2].x, r_y[2].y, r_y[3].x, r_y[3].y};
@@ -1104,8 +1162,8 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
             wv[tid] = w;
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            double* rec = smem + (64 * p + lsm) * fs;
+        for (int p = 0; p < NP; ++p) {
+            double* rec = smem + (8 * NW * p + lsm) * fs;
 #pragma unroll
             for (int h = 0; h < AW2; ++h) {
                 const int jj = j + 8 * h;
@@ -1125,31 +1183,37 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
             if (j == 0) rec[zc] = 0.0;
         }
         __syncthreads();
-        GSTAMP(7);
-        if (base + GS_KC < s1) load_stage(base + GS_KC);   // the next stage's loads fly during the matrix work
-        const double* rbase = smem + (kh * (GS_KC / 2) + kq) * fs;
-        const double *pa = rbase + ia, *pp = rbase + ipl, *pb = rbase + ib, *pq = rbase + ipr;
-        const double* wb = wv + kh * (GS_KC / 2) + kq;
-        const int fs4 = 4 * fs;
-#pragma unroll 8
-        for (int u = 0; u < GS_KC / 8; ++u) {               // series beyond the share are zero records with zero weight
-            const double a = *pa * *pp;
-            const double bbv = *pb * *pq * wb[4 * u];
-            acc = mfma_f64(a, bbv, acc);
-            pa += fs4;
-            pp += fs4;
-            pb += fs4;
-            pq += fs4;
+#ifdef MPST_B2_DEBUG
+        g_stage += __builtin_amdgcn_s_memrealtime() - g_t0;
+        g_n += 1;
+        if (dbg) { dbg[7] = g_wait; dbg[5] = g_stage | (g_n << 48); }
+#endif
+        if (base + KC < s1) load_stage(base + KC);   // the next stage's loads fly during the matrix work
+        const double* rbase = smem + (wave * (KC / NW) + kq) * fs;
+        const double* wb = wv + wave * (KC / NW) + kq;
+#pragma unroll
+        for (int u = 0; u < KC / (4 * NW); ++u) {         // series beyond the share are zero records with zero weight
+            const double* rec = rbase + 4 * u * fs;
+            const double w = wb[4 * u];
+            const double x0 = rec[ia[0]] * rec[ipl[0]], x1 = rec[ia[1]] * rec[ipl[1]];
+            const double y0 = rec[ib[0]] * rec[ipr[0]] * w, y1 = rec[ib[1]] * rec[ipr[1]] * w;
+            acc[0][0] = mfma_f64(x0, y0, acc[0][0]);
+            acc[0][1] = mfma_f64(x0, y1, acc[0][1]);
+            acc[1][0] = mfma_f64(x1, y0, acc[1][0]);
+            acc[1][1] = mfma_f64(x1, y1, acc[1][1]);
+            if (u & 1) asm volatile("" ::: "memory");       // operands of at most two k-steps ahead of the matrix pipe
         }
     }
     GSTAMP(1);
-    // the two halves of every tile meet in LDS: (half 0) + (half 1)
+    // the eight partial blocks meet in LDS (64 KB, over the stage records): tile t of wave w at [(w * 4 + t) * 256]
     __syncthreads();
-    if (kh == 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) smem[tile * 256 + r * 64 + lane] = acc[r];
-    }
-    if (do_loss) {                                          // threads < GS_KC carry the terms
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) smem[(wave * 4 + 2 * h + g) * 256 + r * 64 + lane] = acc[h][g][r];
+    if (do_loss) {                                          // threads < KC carry the terms
         loss = wave_sum(loss);
         if (lane == 0) redl[wave] = loss;
     }
@@ -1165,7 +1229,11 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
         const int aa = row / d, sx = row - aa * d, sy = colb / b.bw, bb2 = colb - sy * b.bw;
         ev[r] = kh == 0 && aa < b.aw && a0 + aa < b.Dl && sy < d && b0 + bb2 < b.Dr;
         gidx[r] = 2 + (int64_t)c * b.L + (int64_t)((a0 + aa) * d + sx) * b.Y + sy * b.Dr + b0 + bb2;
-        if (kh == 0) tot[r] = acc[r] + smem[tile * 256 + r * 64 + lane];
+        if (kh == 0) {                                      // wave order, pairwise: ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7))
+            const double* q = smem + tile * 256 + r * 64 + lane;
+            tot[r] = (q[0] + q[1024]) + (q[2048] + q[3072]);
+            if (NW == 8) tot[r] += (q[4096] + q[5120]) + (q[6144] + q[7168]);
+        }
     }
     if (do_loss && tid == 0) v.lossp[c * ksplit + ks] = (redl[0] + redl[1]) + (redl[2] + redl[3]);    // waves 4..7 carry none
     double n2 = 0.0;
@@ -2127,31 +2195,58 @@ __global__ __launch_bounds__(BT_T) void k_bond_tail(View v, TailArgs ta) {
 // launch (blockIdx.z picks the fit's View from a device array - mpst_sweep_batch): the command processor dispatches about
 // 70 k kernels a second however many queues feed it, which caps K concurrent single-fit chains at 2.3x one chain; one
 // chain of K-fold launches keeps the kernel count of ONE fit.
-__global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_left, int first_iter) { gram_upd_body(v, lid, going_left, first_iter); }
+__global__ __launch_bounds__(256) void k_gram_upd(View v, int lid, int going_left, int first_iter) { gram_upd_body(v, lid, going_left, first_iter, (int)blockIdx.x); }
 __global__ __launch_bounds__(256) void k_gram_upd_b(const View* __restrict__ vs, int lid, int going_left, int first_iter) {
-    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
-    gram_upd_body(v, lid, going_left, first_iter);
+    // the tiles of one fit read the same two matrices (bt, the gradient): side by side on one XCD, they meet in its L2 (xcd_contiguous)
+    int bx = (int)blockIdx.x, by = 0, bz = (int)blockIdx.z;
+    xcd_contiguous(bx, by, bz);
+    const View& v = vs[bz];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    gram_upd_body(v, lid, going_left, first_iter, bx);
 }
-__global__ __launch_bounds__(256) void k_env_split(View v, int lid, int going_left, int site, int left_side, const double* __restrict__ prev,
+__global__ __launch_bounds__(256, 2) void k_env_split(View v, int lid, int going_left, int site, int left_side, const double* __restrict__ prev,
                                                    int prev_bond, int out_bond, double* __restrict__ out, int nsplit, int ntb, int tp) {
-    env_split_body(v, lid, going_left, site, left_side, prev, prev_bond, out_bond, out, nsplit, ntb, tp);
+    env_split_body(v, lid, going_left, site, left_side, prev, prev_bond, out_bond, out, nsplit, ntb, tp, (int)blockIdx.x);
 }
 // batched: the environment rows are addressed by element offsets into the fit's own LE / RE (prev_off < 0: boundary)
-__global__ __launch_bounds__(256) void k_env_split_b(const View* __restrict__ vs, int lid, int going_left, int site, int left_side, int64_t prev_off,
+__global__ __launch_bounds__(256, 2) void k_env_split_b(const View* __restrict__ vs, int lid, int going_left, int site, int left_side, int64_t prev_off,
                                                      int prev_bond, int out_bond, int64_t out_off, int nsplit, int ntb, int tp) {
-    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    // a fit's workgroups all read its eigenvectors E (32 KB each) and, the split / chain ones, bt_new: one XCD per fit (xcd_contiguous)
+    int bx = (int)blockIdx.x, by = 0, bz = (int)blockIdx.z;
+    xcd_contiguous(bx, by, bz);
+    const View& v = vs[bz];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
     double* base = left_side ? v.LE : v.RE;
-    env_split_body(v, lid, going_left, site, left_side, prev_off >= 0 ? base + prev_off : nullptr, prev_bond, out_bond, base + out_off, nsplit, ntb, tp);
+    env_split_body(v, lid, going_left, site, left_side, prev_off >= 0 ? base + prev_off : nullptr, prev_bond, out_bond, base + out_off, nsplit, ntb, tp, bx);
 }
-template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) { yhat_s_body<LM, D4>(v, lid, nslc, ngw); }
-template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s_b(const View* __restrict__ vs, int lid, int nslc, int ngw) {
-    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
-    yhat_s_body<LM, D4>(v, lid, nslc, ngw);
+template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) {
+    yhat_s_body<LM, D4, 1>(v, lid, nslc, ngw, (int)blockIdx.x, (int)blockIdx.y);
 }
-template <int AW2, int D2> __global__ __launch_bounds__(GS_T) void k_grad_s(View v, int lid, int ksplit, int nbc) { grad_s_body<AW2, D2>(v, lid, ksplit, nbc); }
-template <int AW2, int D2> __global__ __launch_bounds__(GS_T) void k_grad_s_b(const View* __restrict__ vs, int lid, int ksplit, int nbc) {
-    const View& v = vs[blockIdx.z];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
-    grad_s_body<AW2, D2>(v, lid, ksplit, nbc);
+template <int LM, bool D4, int NS> __global__ __launch_bounds__(YS_T) void k_yhat_s_b(const View* __restrict__ vs, int lid, int nslc, int ngw) {
+    // the slices of one group walker read the same series (a full environment row each): side by side on one XCD (xcd_contiguous)
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    xcd_contiguous(bx, by, bz);
+    const View& v = vs[bz];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    const int sl = bx % nslc, gw = bx / nslc;           // logical x: slices fastest (the body wants gw = x % ngw)
+    yhat_s_body<LM, D4, NS>(v, lid, nslc, ngw, sl * ngw + gw, by);
+}
+// KC = series per stage.  Measured with KC = 128 under __launch_bounds__(GS_T, 4) (128 VGPRs, 38 spilled; two workgroups per CU so that one
+// stages while the other multiplies - with one workgroup per CU the staging of a stage, 1.3 us of 4.2, leaves the matrix pipe idle): it
+// LOSES, 40.5 -> 63.9 us with 8 fits per launch, 140 -> 161 us with 32 (profiles/r06_batched_gemm_ab.txt); 256 everywhere.
+// NW = waves per workgroup.  8 (512 threads, one workgroup per CU at 174+ registers) where a launch has about one workgroup per CU and
+// latency counts (a single fit); 4 (256 threads, two workgroups per CU, each wave a quarter of a stage) for contexts advanced in batches:
+// one workgroup stages its next 256 series (1.3 us of the 4.2 a stage takes, all eight waves idle on the matrix pipe meanwhile -
+// profiles/r06_b2_stamps.txt) while the other multiplies.  The wave count fixes which wave sums which series, so it belongs to the
+// context (View::b2_nw): its solo and its batched sweeps agree bit for bit.
+template <int AW2, int D2, int FS, int KC, int NW> __global__ __launch_bounds__(64 * NW, 2) void k_grad_s(View v, int lid, int ksplit, int nbc) {
+    grad_s_body<AW2, D2, FS, KC, NW>(v, lid, ksplit, nbc, (int)blockIdx.x, (int)blockIdx.y);
+}
+template <int AW2, int D2, int FS, int KC, int NW> __global__ __launch_bounds__(64 * NW, 2) void k_grad_s_b(const View* __restrict__ vs, int lid, int ksplit, int nbc) {
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
+    xcd_contiguous(bx, by, bz);
+    const View& v = vs[bz];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
+    // logical x: blocks fastest, then shares (the body wants ks = x % ksplit)
+    const int nblk = nbc * nbc;
+    const int blk = bx % nblk, ks = bx / nblk;
+    grad_s_body<AW2, D2, FS, KC, NW>(v, lid, ksplit, nbc, blk * ksplit + ks, by);
 }
 
 // the loss of the bond from the pieces of k_grad_s (same order wherever it is formed): gradbuf[0..1] for the all-reduce
@@ -2188,7 +2283,7 @@ int b2_ksplit(const View& v, int64_t max_pass) {
 }
 int64_t b2_partial_elems(const View& v, int64_t max_pass) { return (int64_t)v.C * b2_blocks_cap(v) * b2_ksplit(v, max_pass) * 1024; }
 static size_t yhat_s_lds(const View& v) { return (size_t)128 * (v.cap + 1 + v.d + 1 + 17) * sizeof(double); }
-static size_t grad_s_lds(const View& v) { return std::max((size_t)GS_KC * (((2 * b2_aw(v) + 2 * v.d + 1) | 1) + 1), (size_t)4 * 256) * sizeof(double); }
+static size_t grad_s_lds(const View& v) { return std::max((size_t)GS_KC * (((2 * b2_aw(v) + 2 * v.d + 1) | 1) + 1), (size_t)32 * 256) * sizeof(double); }
 hipError_t b2_init_attrs(int device) {
     static std::atomic<unsigned long long> done{0};
     if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
@@ -2196,15 +2291,20 @@ hipError_t b2_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_yhat_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 25, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 25, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<2, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 2, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 25, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 25, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<2, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 2, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_bond_tail<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_bond_tail<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BT_LDS_DOUBLES * (int)sizeof(double))) != hipSuccess) return e;
     if (device >= 0 && device < 64) done.fetch_or(1ull << device, std::memory_order_release);
@@ -2224,20 +2324,33 @@ void launch_loss_sum(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_loss_s
 void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
     const int nslc = cdivf(v.d * v.cap, YS_W);
     const int ngroups = cdivf(v.ntiles, 8);
+    static const bool ns4 = getenv("MPST_YS_NS4") != nullptr;
+    if (ns4 && v.cap <= 32 && v.d == 4 && K >= 4) {
+        // A/B switch (MPST_YS_NS4=1): four slices per workgroup - the staged rows of a tile are used for four slices of B_c, a quarter of the
+        // row fetches.  It LOSES as built (K = 32: 257 against 190 us; its 64 KB of B_c per workgroup arrive after 10 us, and the per-slice
+        // reload of the B fragment from LDS costs what the shared staging saves: profiles/r06_batched_gemm_ab.txt); not the default.
+        const int nslg = cdivf(nslc, 4);
+        const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / (nslg * K))));
+        const dim3 grid(nslg * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1, K);
+        hipLaunchKernelGGL((k_yhat_s_b<2, true, 4>), grid, dim3(YS_T), yhat_s_lds(v) + (size_t)3 * 128 * 17 * sizeof(double), s, vs, lid, nslg, ngw);
+        return;
+    }
     // group walkers per slice: about 512 workgroups over the whole batch - fewer, longer walks per fit amortise a workgroup's
     // start-up and its slice of B_c over more series (the series a walker takes do not change any sum)
     const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / (nslc * K))));
     const dim3 grid(nslc * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1, K);
-    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s_b<2, true>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
-    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s_b<2, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
-    else hipLaunchKernelGGL((k_yhat_s_b<4, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s_b<2, true, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s_b<2, false, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else hipLaunchKernelGGL((k_yhat_s_b<4, false, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
 }
 void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
     const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);
     const dim3 grid(v.b2_ksplit * nbc * nbc, v.C, K);
-    if (aw > 8) hipLaunchKernelGGL((k_grad_s_b<2, 1>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
-    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s_b<1, 2>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
-    else hipLaunchKernelGGL((k_grad_s_b<1, 1>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    if (aw > 8) hipLaunchKernelGGL((k_grad_s_b<2, 1, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s_b<1, 2, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else if (v.d == 4 && v.b2_nw == 4) hipLaunchKernelGGL((k_grad_s_b<1, 1, 25, 256, 4>), grid, dim3(256), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else if (v.d == 4) hipLaunchKernelGGL((k_grad_s_b<1, 1, 25, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
+    else hipLaunchKernelGGL((k_grad_s_b<1, 1, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, vs, lid, v.b2_ksplit, nbc);
 }
 void launch_gram_upd_b(const View& v, const View* vs, int K, int lid, int going_left, int first_iter, hipStream_t s) {
     const int dm = v.d * v.cap;
@@ -2260,9 +2373,11 @@ void launch_env_split_b(const View& v, const View* vs, int K, int lid, int going
 void launch_grad_s(const View& v, int lid, hipStream_t s) {
     const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);
     const dim3 grid(v.b2_ksplit * nbc * nbc, v.C);
-    if (aw > 8) hipLaunchKernelGGL((k_grad_s<2, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);         // d = 2, 3
-    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s<1, 2>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);   // d = 9..16
-    else hipLaunchKernelGGL((k_grad_s<1, 1>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
+    if (aw > 8) hipLaunchKernelGGL((k_grad_s<2, 1, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);         // d = 2, 3
+    else if (v.d > 8) hipLaunchKernelGGL((k_grad_s<1, 2, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);   // d = 9..16
+    else if (v.d == 4 && v.b2_nw == 4) hipLaunchKernelGGL((k_grad_s<1, 1, 25, 256, 4>), grid, dim3(256), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
+    else if (v.d == 4) hipLaunchKernelGGL((k_grad_s<1, 1, 25, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
+    else hipLaunchKernelGGL((k_grad_s<1, 1, 0, 256, 8>), grid, dim3(GS_T), grad_s_lds(v), s, v, lid, v.b2_ksplit, nbc);
 }
 // the four-launch chain: real fp64, KLD, at most 32 kept vectors (the 32-column layout of the eigenvector block), tridiagonal solver
 bool bond_tail_supported(const View& v) {

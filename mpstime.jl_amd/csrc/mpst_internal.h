@@ -392,6 +392,7 @@ struct View {
     double* lossp;      // [C][ksplit] loss pieces
     unsigned int* tick; // [C * blocks_cap + 1] arrival tickets of the gradient blocks, + the launch-wide one
     int32_t b2_ksplit;  // shares the series of a pass are split into
+    int32_t b2_nw;      // waves per workgroup of k_grad_s: 8, or 4 for a context that is advanced in batches (mpst_fused.hip: k_grad_s)
     int32_t n_lossp;    // > 0: the bond's loss is still in lossp's pieces ([C][n_lossp]); 0: it is gradbuf[0]
     unsigned long long* dbg;   // bring-up stamps (-DMPST_B2_DEBUG), else null
     double* trace;      // track_cost: this bond's row of the loss trace ([update_iters + 1]) or null

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256) void k_split(View v, int lid, int going_left) 
 // Blocks [ntiles, gridDim.x) do not belong to the environment update: they assemble the bond tensor of
 // the NEXT bond (bt_lid >= 0), which depends on the same inputs (the site tensors k_split just wrote) -
 // one dependent kernel hand-over (~5 us) less per bond.
-__global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, const double* __restrict__ prev,
+__global__ __launch_bounds__(256, 2) void k_env(View v, int site, int left_side, const double* __restrict__ prev,
                                              int prev_bond, int mode, int out_bond, double* __restrict__ out,
                                              int bt_lid, int bt_bx) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -790,7 +790,9 @@ __global__ __launch_bounds__(256) void k_env(View v, int site, int left_side, co
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int step = q * ks4 + s0 + u;
-                    if (s0 + u < ks4 && step < nsteps) p[q] = mfma_f64(smem[i16 * ZS + 4 * step + kq], bv[q][u], p[q]);
+                    // (unconditional: beyond the contraction the B operand is zero and the A operand is read from the last live step - an
+                    // exact +0; predicated MFMAs cost accumulator copies and a workgroup per CU)
+                    p[q] = mfma_f64(smem[i16 * ZS + 4 * min(step, nsteps - 1) + kq], bv[q][u], p[q]);
                 }
         }
 #pragma unroll
