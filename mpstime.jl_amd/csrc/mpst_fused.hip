@@ -842,7 +842,12 @@ __device__ __forceinline__ Span tile_span_k(const View& v, int t) {
 // grid.x = nslc * ngw (see launch_yhat_s): workgroup id -> (group walker = id % ngw, slice = id / ngw); grid.y = passes (MSE: C)
 // Every wave stages, consumes and stores its own tile: no workgroup barrier, one round trip to memory per group.
 // LM: 16-entry pieces of an environment row a lane group fetches (capacity <= 16 LM); D4: d == 4 (the headline shapes).
-template <int LM, bool D4, int NS>
+// V2 (d == 4, even capacity <= 32): the rows of a tile are fetched with 16-byte loads - 10 load instructions per lane and group instead
+// of 20.  Measured (profiles/r06_batched_gemm_ab.txt): of the 6.3 us a group takes, 2.7 are spent ISSUING the next group's 20 loads (about
+// 40 cycles of the CU's address path per wave-wide 8-byte load, 160 of them per group and CU), 0.25 writing the rows to LDS, 2.9 on the
+// 32 MFMAs, the row dots and the stores.  The right-hand factors (RE row, phi_r) then go through LDS like the left-hand ones: the
+// 16-byte loads fetch whole rows, the lane that needs Y_i[col] = phi_r[i][sp] RE_i[bb] picks its two numbers there.
+template <int LM, bool D4, bool V2>
 __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, int ngw, const int bid_x, const int bid_y) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const B2 b = b2_dims(v, lid);
@@ -851,29 +856,22 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const int gw = bid_x % ngw, sl = bid_x / ngw;       // consecutive ids (XCDs) walk different series groups
-    // NS = slices of B_c a workgroup takes for the series it has staged (sl counts groups of NS slices).  1: the single-fit launches
-    // (latency: most workgroups, least work each).  4: the batched launches - the staging of a tile (rows to registers, to LDS, the next
-    // tile's loads: 3.4 us of the 6.3 a group takes with one slice, the matrix pipe idle meanwhile; profiles/r06_b2_stamps.txt) is paid
-    // once per four slices, and the rows are fetched a quarter as often.  The sums per (series, slice) are the same either way.
-    if (sl * NS * YS_W >= b.Y) return;
+    if (sl * YS_W >= b.Y) return;
     const int pass = mse ? bid_y : 0;
-    int col[NS], sp[NS], bb[NS];
-    bool cv[NS];
-#pragma unroll
-    for (int ss = 0; ss < NS; ++ss) {
-        col[ss] = (sl * NS + ss) * YS_W + i16;
-        cv[ss] = col[ss] < b.Y;
-        sp[ss] = cv[ss] ? col[ss] / b.Dr : 0;
-        bb[ss] = cv[ss] ? col[ss] - sp[ss] * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
-    }
+    const int col = sl * YS_W + i16;
+    const bool cv = col < b.Y;
+    const int sp = cv ? col / b.Dr : 0, bb = cv ? col - sp * b.Dr : 0;       // Y_i[col] = phi_r[i][sp] * RE_i[bb]
     const double* LEp = lid > 0 ? v.LE + (int64_t)(lid - 1) * v.N * v.cap : nullptr;
     const double* REn = rid < v.T - 1 ? v.RE + (int64_t)(rid + 1) * v.N * v.cap : nullptr;
     const double* phl = v.phi + (int64_t)lid * v.N * d;
     const double* phr = v.phi + (int64_t)rid * v.N * d;
     const int ngroups = (v.ntiles + 7) >> 3;
     const int ls = v.cap + 1, ps = d + 1;                  // LDS row strides (odd: the 16 rows a wave reads hit 16 banks)
-    double* LEs = smem + wave * 16 * (ls + ps);            // [16][ls] this wave's environment rows, zero beyond Dl
+    const int wstride = (V2 ? 2 : 1) * 16 * (ls + ps);     // V2: [LE rows | phi_l | RE rows | phi_r] per wave
+    double* LEs = smem + wave * wstride;                   // [16][ls] this wave's environment rows, zero beyond Dl
     double* PHs = LEs + 16 * ls;                           // [16][ps] site vectors
+    double* REs = PHs + 16 * ps;                           // V2: [16][ls] right environment rows, zero beyond Dr
+    double* PRs = REs + 16 * ls;                           // V2: [16][ps]
     const int XP = (b.X + 3) & ~3;
     const unsigned magic = (65536u + (unsigned)d - 1u) / (unsigned)d;        // x / d = (x * magic) >> 16 for x < 1024
     double* ypart = v.ypart + (int64_t)pass * v.N * YS_MAXSL;
@@ -895,47 +893,75 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
     // persistent workgroup) reads its fragment from global memory instead.  The first group's own rows are requested in the
     // same breath: one round trip to memory before the first MFMA, not two.
     const int cls0 = mse ? pass : tile_span_k(v, 8 * gw).cls;
-    double* Bsh = smem + 128 * (ls + ps);                  // [NS][128][17]
-    double t4[4 * NS];
+    double* Bsh = smem + 8 * wstride;                      // [128][17]
+    double t4[4];
     {
         const double* Bc = v.bt + (int64_t)cls0 * b.L;
 #pragma unroll
-        for (int k = 0; k < 4 * NS; ++k) {
-            const int idx = tid + YS_T * (k & 3), x = idx >> 4, cc = (sl * NS + (k >> 2)) * YS_W + (idx & 15);
+        for (int k = 0; k < 4; ++k) {
+            const int idx = tid + YS_T * k, x = idx >> 4, cc = sl * YS_W + (idx & 15);
             t4[k] = (x < b.X && cc < b.Y) ? Bc[(int64_t)x * b.Y + cc] : 0.0;
         }
     }
-    // this wave's tile of a group: 4 rows x 16 consecutive bond entries per load instruction, and the 4 Y values per lane
-    double lev[4][LM], phv[4], yv[NS][4];
+    // this wave's tile of a group.  Scalar form: 4 rows x 16 consecutive bond entries per load instruction, and the 4 Y values per lane.
+    // V2: lane (kq, i16) fetches entries 2 i16, 2 i16 + 1 of rows kq + 4 q of both environments (4 + 4 loads), lanes < 32 the site
+    // vectors of row lane / 2 (two entries each: 1 + 1 loads)
+    double lev[4][LM], phv[4], yv[4];
+    double2 le2[4], re2[4], pl2 = make_double2(0.0, 0.0), pr2 = make_double2(0.0, 0.0);
     Span tl{0, 0, 0, 0};
     auto load_tile = [&](int g) {
         tl = tile_span_k(v, 8 * g + wave);
+        if constexpr (V2) {
+            const int a = 2 * i16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = kq + 4 * r;
-            const int64_t smp = tl.start + (i < tl.count ? i : 0);
-#pragma unroll
-            for (int ss = 0; ss < NS; ++ss)
-                yv[ss][r] = (cv[ss] && i < tl.count) ? phr[smp * d + sp[ss]] * (REn ? REn[smp * v.cap + bb[ss]] : 1.0) : 0.0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 4 * q + kq;
-            const bool valid = row < tl.count;
-            const int64_t smp = tl.start + (valid ? row : 0);
-#pragma unroll
-            for (int m = 0; m < LM; ++m) {
-                const int a = i16 + 16 * m;
-                lev[q][m] = (valid && a < b.Dl) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * q + kq;
+                const bool valid = row < tl.count;
+                const int64_t smp = tl.start + (valid ? row : 0);
+                le2[q] = make_double2(0.0, 0.0);
+                re2[q] = make_double2(0.0, 0.0);
+                if (valid && a < v.cap) {
+                    if (LEp) le2[q] = *(const double2*)(LEp + smp * v.cap + a);
+                    else le2[q] = make_double2(1.0, 1.0);
+                    if (REn) re2[q] = *(const double2*)(REn + smp * v.cap + a);
+                    else re2[q] = make_double2(1.0, 1.0);
+                }
+                if (a >= b.Dl) le2[q].x = 0.0;
+                if (a + 1 >= b.Dl) le2[q].y = 0.0;
+                if (a >= b.Dr) re2[q].x = 0.0;
+                if (a + 1 >= b.Dr) re2[q].y = 0.0;
             }
-            phv[q] = (valid && i16 < d) ? phl[smp * d + i16] : 0.0;
+            const int prow = lane >> 1, half = lane & 1;
+            const bool pvalid = lane < 32 && prow < tl.count;
+            const int64_t psmp = tl.start + (pvalid ? prow : 0);
+            pl2 = pvalid ? *(const double2*)(phl + psmp * 4 + 2 * half) : make_double2(0.0, 0.0);
+            pr2 = pvalid ? *(const double2*)(phr + psmp * 4 + 2 * half) : make_double2(0.0, 0.0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = kq + 4 * r;
+                const int64_t smp = tl.start + (i < tl.count ? i : 0);
+                yv[r] = (cv && i < tl.count) ? phr[smp * d + sp] * (REn ? REn[smp * v.cap + bb] : 1.0) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * q + kq;
+                const bool valid = row < tl.count;
+                const int64_t smp = tl.start + (valid ? row : 0);
+#pragma unroll
+                for (int m = 0; m < LM; ++m) {
+                    const int a = i16 + 16 * m;
+                    lev[q][m] = (valid && a < b.Dl) ? (LEp ? LEp[smp * v.cap + a] : 1.0) : 0.0;
+                }
+                phv[q] = (valid && i16 < d) ? phl[smp * d + i16] : 0.0;
+            }
         }
     };
     if (gw < ngroups) load_tile(gw);
 #pragma unroll
-    for (int k = 0; k < 4 * NS; ++k) {
-        const int idx = tid + YS_T * (k & 3);
-        Bsh[(k >> 2) * 128 * 17 + (idx >> 4) * 17 + (idx & 15)] = t4[k];
+    for (int k = 0; k < 4; ++k) {
+        const int idx = tid + YS_T * k;
+        Bsh[(idx >> 4) * 17 + (idx & 15)] = t4[k];
     }
     __syncthreads();
     for (int g = gw; g < ngroups; g += ngw) {
@@ -944,36 +970,60 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         YSTAMP();
+        double yc[4];
         if (tc.count > 0) {
+            if constexpr (V2) {
+                const int a = 2 * i16;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = 4 * q + kq;
-#pragma unroll
-                for (int m = 0; m < LM; ++m) {
-                    const int a = i16 + 16 * m;
-                    if (a < v.cap) LEs[row * ls + a] = lev[q][m];
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 4 * q + kq;
+                    if (a < v.cap) {
+                        LEs[row * ls + a] = le2[q].x;
+                        LEs[row * ls + a + 1] = le2[q].y;
+                        REs[row * ls + a] = re2[q].x;
+                        REs[row * ls + a + 1] = re2[q].y;
+                    }
+                    if (i16 == 0) LEs[row * ls + v.cap] = 0.0;      // the entry a = Dl = capacity the padded K extent can touch
                 }
-                if (i16 == 0) LEs[row * ls + v.cap] = 0.0;          // the entry a = Dl = capacity the padded K extent can touch
-                if (i16 < d) PHs[row * ps + i16] = phv[q];
+                if (lane < 32) {
+                    const int prow = lane >> 1, half = lane & 1;
+                    PHs[prow * ps + 2 * half] = pl2.x;
+                    PHs[prow * ps + 2 * half + 1] = pl2.y;
+                    PRs[prow * ps + 2 * half] = pr2.x;
+                    PRs[prow * ps + 2 * half + 1] = pr2.y;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                       // (same wave wrote them: program order, no barrier)
+                    const int i = kq + 4 * r;
+                    yc[r] = cv ? PRs[i * ps + sp] * REs[i * ls + bb] : 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = 4 * q + kq;
+#pragma unroll
+                    for (int m = 0; m < LM; ++m) {
+                        const int a = i16 + 16 * m;
+                        if (a < v.cap) LEs[row * ls + a] = lev[q][m];
+                    }
+                    if (i16 == 0) LEs[row * ls + v.cap] = 0.0;      // the entry a = Dl = capacity the padded K extent can touch
+                    if (i16 < d) PHs[row * ps + i16] = phv[q];
+                }
             }
         }
-        double yc[NS][4];
+        if constexpr (!V2) {
 #pragma unroll
-        for (int ss = 0; ss < NS; ++ss)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yc[ss][r] = yv[ss][r];
+            for (int r = 0; r < 4; ++r) yc[r] = yv[r];
+        }
         if (g + ngw < ngroups) load_tile(g + ngw);         // the next group's rows fly during this group's matrix work
         if (tc.count <= 0) continue;                       // (wave-uniform; nothing below synchronises across waves)
         const int cls = mse ? pass : tc.cls;
-#pragma unroll
-        for (int ss = 0; ss < NS; ++ss) {
-        if ((sl * NS + ss) * YS_W >= b.Y) break;
-        if (cls != cur_cls || NS > 1) {                    // B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
+        if (cls != cur_cls) {                              // B_c fragment: bq[mt][r] = B_c[16 mt + kq + 4 r][col]
             if (cls == cls0) {
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bq[mt][r] = Bsh[ss * 128 * 17 + (16 * mt + kq + 4 * r) * 17 + i16];
+                    for (int r = 0; r < 4; ++r) bq[mt][r] = Bsh[(16 * mt + kq + 4 * r) * 17 + i16];
             } else {
                 const double* Bc = v.bt + (int64_t)cls * b.L;
 #pragma unroll
@@ -981,7 +1031,7 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int x = 16 * mt + kq + 4 * r;
-                        bq[mt][r] = (cv[ss] && x < b.X) ? Bc[(int64_t)x * b.Y + col[ss]] : 0.0;
+                        bq[mt][r] = (cv && x < b.X) ? Bc[(int64_t)x * b.Y + col] : 0.0;
                     }
             }
             cur_cls = cls;
@@ -1017,11 +1067,10 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double x = sum16((acc0[r] + acc1[r]) * yc[ss][r]);
+                const double x = sum16((acc0[r] + acc1[r]) * yc[r]);
                 const int i = kq + 4 * r;
-                if (i16 == 0 && i < tc.count) ypart[(int64_t)(tc.start + i) * YS_MAXSL + sl * NS + ss] = x;
+                if (i16 == 0 && i < tc.count) ypart[(int64_t)(tc.start + i) * YS_MAXSL + sl] = x;
             }
-        }
         }
         YSTAMP();
     }
@@ -2217,16 +2266,16 @@ __global__ __launch_bounds__(256, 2) void k_env_split_b(const View* __restrict__
     double* base = left_side ? v.LE : v.RE;
     env_split_body(v, lid, going_left, site, left_side, prev_off >= 0 ? base + prev_off : nullptr, prev_bond, out_bond, base + out_off, nsplit, ntb, tp, bx);
 }
-template <int LM, bool D4> __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) {
-    yhat_s_body<LM, D4, 1>(v, lid, nslc, ngw, (int)blockIdx.x, (int)blockIdx.y);
+template <int LM, bool D4, bool V2> __global__ __launch_bounds__(YS_T) void k_yhat_s(View v, int lid, int nslc, int ngw) {
+    yhat_s_body<LM, D4, V2>(v, lid, nslc, ngw, (int)blockIdx.x, (int)blockIdx.y);
 }
-template <int LM, bool D4, int NS> __global__ __launch_bounds__(YS_T) void k_yhat_s_b(const View* __restrict__ vs, int lid, int nslc, int ngw) {
+template <int LM, bool D4, bool V2> __global__ __launch_bounds__(YS_T) void k_yhat_s_b(const View* __restrict__ vs, int lid, int nslc, int ngw) {
     // the slices of one group walker read the same series (a full environment row each): side by side on one XCD (xcd_contiguous)
     int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z;
     xcd_contiguous(bx, by, bz);
     const View& v = vs[bz];       // by reference: a local copy would live in per-lane scratch (the class tables are indexed dynamically)
     const int sl = bx % nslc, gw = bx / nslc;           // logical x: slices fastest (the body wants gw = x % ngw)
-    yhat_s_body<LM, D4, NS>(v, lid, nslc, ngw, sl * ngw + gw, by);
+    yhat_s_body<LM, D4, V2>(v, lid, nslc, ngw, sl * ngw + gw, by);
 }
 // KC = series per stage.  Measured with KC = 128 under __launch_bounds__(GS_T, 4) (128 VGPRs, 38 spilled; two workgroups per CU so that one
 // stages while the other multiplies - with one workgroup per CU the staging of a stage, 1.3 us of 4.2, leaves the matrix pipe idle): it
@@ -2282,24 +2331,26 @@ int b2_ksplit(const View& v, int64_t max_pass) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(ks, GS_MAXKS));
 }
 int64_t b2_partial_elems(const View& v, int64_t max_pass) { return (int64_t)v.C * b2_blocks_cap(v) * b2_ksplit(v, max_pass) * 1024; }
-static size_t yhat_s_lds(const View& v) { return (size_t)128 * (v.cap + 1 + v.d + 1 + 17) * sizeof(double); }
+static bool yhat_s_v2(const View& v) { return v.d == 4 && v.cap <= 32 && !(v.cap & 1) && getenv("MPST_YS_V1") == nullptr; }      // 16-byte row loads
+static size_t yhat_s_lds(const View& v) { return (size_t)128 * ((yhat_s_v2(v) ? 2 : 1) * (v.cap + 1 + v.d + 1) + 17) * sizeof(double); }
 static size_t grad_s_lds(const View& v) { return std::max((size_t)GS_KC * (((2 * b2_aw(v) + 2 * v.d + 1) | 1) + 1), (size_t)32 * 256) * sizeof(double); }
 hipError_t b2_init_attrs(int device) {
     static std::atomic<unsigned long long> done{0};
     if (device >= 0 && device < 64 && (done.load(std::memory_order_acquire) >> device) & 1ull) return hipSuccess;
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 25, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 1, 25, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<2, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s<1, 2, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_yhat_s_b<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 0, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 25, 256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_grad_s_b<1, 1, 25, 256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) != hipSuccess) return e;
@@ -2315,33 +2366,25 @@ void launch_yhat_s(const View& v, int lid, hipStream_t s) {
     const int ngroups = cdivf(v.ntiles, 8);
     const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / nslc)));      // group walkers per slice
     const dim3 grid(nslc * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1);
-    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s<2, true>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
-    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s<2, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
-    else hipLaunchKernelGGL((k_yhat_s<4, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    if (yhat_s_v2(v)) hipLaunchKernelGGL((k_yhat_s<2, true, true>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    else if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s<2, true, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s<2, false, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
+    else hipLaunchKernelGGL((k_yhat_s<4, false, false>), grid, dim3(YS_T), yhat_s_lds(v), s, v, lid, nslc, ngw);
 }
 void launch_loss_sum(const View& v, hipStream_t s) { hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, s, v); }
+
 // ---- batched launchers: v = the shape every fit of the batch shares, vs = the K Views on the device ----
 void launch_yhat_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
     const int nslc = cdivf(v.d * v.cap, YS_W);
     const int ngroups = cdivf(v.ntiles, 8);
-    static const bool ns4 = getenv("MPST_YS_NS4") != nullptr;
-    if (ns4 && v.cap <= 32 && v.d == 4 && K >= 4) {
-        // A/B switch (MPST_YS_NS4=1): four slices per workgroup - the staged rows of a tile are used for four slices of B_c, a quarter of the
-        // row fetches.  It LOSES as built (K = 32: 257 against 190 us; its 64 KB of B_c per workgroup arrive after 10 us, and the per-slice
-        // reload of the B fragment from LDS costs what the shared staging saves: profiles/r06_batched_gemm_ab.txt); not the default.
-        const int nslg = cdivf(nslc, 4);
-        const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / (nslg * K))));
-        const dim3 grid(nslg * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1, K);
-        hipLaunchKernelGGL((k_yhat_s_b<2, true, 4>), grid, dim3(YS_T), yhat_s_lds(v) + (size_t)3 * 128 * 17 * sizeof(double), s, vs, lid, nslg, ngw);
-        return;
-    }
     // group walkers per slice: about 512 workgroups over the whole batch - fewer, longer walks per fit amortise a workgroup's
     // start-up and its slice of B_c over more series (the series a walker takes do not change any sum)
     const int ngw = std::max(1, std::min(ngroups, std::max(1, 512 / (nslc * K))));
     const dim3 grid(nslc * ngw, v.loss == MPST_LOSS_MSE ? v.C : 1, K);
-    if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s_b<2, true, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
-    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s_b<2, false, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
-    else hipLaunchKernelGGL((k_yhat_s_b<4, false, 1>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    if (yhat_s_v2(v)) hipLaunchKernelGGL((k_yhat_s_b<2, true, true>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else if (v.cap <= 32 && v.d == 4) hipLaunchKernelGGL((k_yhat_s_b<2, true, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else if (v.cap <= 32) hipLaunchKernelGGL((k_yhat_s_b<2, false, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
+    else hipLaunchKernelGGL((k_yhat_s_b<4, false, false>), grid, dim3(YS_T), yhat_s_lds(v), s, vs, lid, nslc, ngw);
 }
 void launch_grad_s_b(const View& v, const View* vs, int K, int lid, hipStream_t s) {
     const int aw = b2_aw(v), nbc = cdivf(v.cap, aw);

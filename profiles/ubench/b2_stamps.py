@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import mpstime_jl_amd._lib as L  # noqa: E402
 
-L.LIB_PATH = os.path.join(ROOT, "profiles", "ubench", "b2dbg", "libmpstime_hip_b2dbg.so")
+L.LIB_PATH = os.path.join(ROOT, "profiles", "ubench", "b2dbg" + os.environ.get("B2DBG_TAG", ""), "libmpstime_hip_b2dbg.so")
 import mpstime_jl_amd as mt  # noqa: E402
 from bench import make_inputs  # noqa: E402
 
