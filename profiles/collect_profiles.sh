@@ -1,12 +1,12 @@
 #!/bin/bash
 # On the GPU box, from the repo root:  profiles/collect_profiles.sh <tag> <pmc: 0|1> <program + args ...>
-# Writes gpurun_out/${ROUND:-r05}/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of the command), the command's own
+# Writes gpurun_out/${ROUND:-r06}/<tag>/: kernel_stats.csv (rocprofv3 --kernel-trace --stats of the command), the command's own
 # output, and - with pmc=1 - three separate counter passes aggregated by profiles/aggregate_pmc.py into pmc_counters.json.
 set -euo pipefail
 tag=$1; pmc=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 prog=$root/$1; shift      # the program is given relative to the repo root; the profiler runs from /tmp
-out=$root/gpurun_out/${ROUND:-r05}/$tag
+out=$root/gpurun_out/${ROUND:-r06}/$tag
 rm -rf $out            # never leave an earlier run's kernel_stats.csv / pmc_counters.json behind a failed pass
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp

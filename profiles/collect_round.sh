@@ -1,10 +1,10 @@
 #!/bin/bash
-# On the GPU box, from the repo root:  profiles/collect_round.sh [round-tag]   (default r05)
+# On the GPU box, from the repo root:  profiles/collect_round.sh [round-tag]   (default r06)
 # Re-takes every profile and bench line profiles/README.md lists for the round on the sources of this tree and leaves them under
 # gpurun_out/<round>/final/ with the names they carry in profiles/ (copy them over and commit).  The counter file is taken first:
 # bench.py quotes it (roofline.traffic) only while its csrc digest matches the tree.
 set -euo pipefail
-R=${1:-r05}
+R=${1:-r06}
 export ROUND=$R
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
@@ -20,10 +20,27 @@ python bench.py --steps 20 --warmup 3 --pmc-file $out/${R}_pmc_counters.json > $
 MPST_B2=0 profiles/collect_profiles.sh headline_fused 0 bench.py --steps 3 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/collect_fused.log 2>&1
 cp gpurun_out/$R/headline_fused/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_bond_fused_ab.csv
 grep -v "^$" gpurun_out/$R/headline_fused/stdout_under_rocprof.txt | tail -1 > $out/${R}_bench_n1_bond_fused_ab_under_rocprofv3.json
-# the same kernels when the chip is fed: 8 independent fits per launch (mpst_sweep_batch) - per-kernel durations and MFMA utilisation of the _b variants
-profiles/collect_profiles.sh batched 1 bench.py --steps 2 --warmup 2 --no-cpu-baseline --concurrent 8 > $out/collect_batched.log 2>&1
-cp gpurun_out/$R/batched/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_batched8.csv
-cp gpurun_out/$R/batched/pmc_counters.json $out/${R}_pmc_counters_batched8.json
+# same-box A/B of the four-launch chain (k_bond_tail) against the six-launch chain it replaces, with and without the cache rebuilds
+profiles/r06_ab_chain4.sh > $out/${R}_ab_chain4.txt 2>&1 || true
+python profiles/r06_tail_phases.py > $out/${R}_tail_phases.json 2> $out/tail_phases.err || true
+# the same kernels when the chip is fed: 8 and 32 independent fits per launch (mpst_sweep_batch) - per-kernel durations, HBM bytes and MFMA
+# utilisation of the _b variants, each batch size on its own (profiles/r06_batched_probe.py runs nothing but the batched chain)
+for K in 8 32; do
+  profiles/collect_profiles.sh batched$K 1 profiles/r06_batched_probe.py $K 4096 2 > $out/collect_batched$K.log 2>&1
+  cp gpurun_out/$R/batched$K/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_batched$K.csv
+  cp gpurun_out/$R/batched$K/pmc_counters.json $out/${R}_pmc_counters_batched$K.json
+  python profiles/r06_batched_probe.py $K 4096 5 > $out/${R}_batched_rate_$K.json 2> $out/batched_rate_$K.err
+done
+if [ -f profiles/ubench/b2dbg/libmpstime_hip_b2dbg.so ]; then
+  for K in 8 32; do python profiles/ubench/b2_stamps.py $K > $out/${R}_b2_stamps_k$K.json 2> $out/b2_stamps_$K.err || true; done
+fi
+# BASELINE configs[3]'s size on one GPU (the persistent k_bond_fused pair): kernel stats, counters, bench line; and the sliced pair at that size
+profiles/collect_profiles.sh n32768 1 bench.py --N 32768 --steps 3 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/collect_n32768.log 2>&1
+cp gpurun_out/$R/n32768/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_n32768.csv
+cp gpurun_out/$R/n32768/pmc_counters.json $out/${R}_pmc_counters_n32768.json
+MPST_B2=1 MPST_CHAIN4=0 python bench.py --N 32768 --steps 5 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/${R}_bench_n32768_sliced_ab.json 2> $out/bench_n32768_sliced.err || true
+# two ranks sharing the one GPU of the box (one-shot all-reduce; RCCL refuses two ranks on a device): the N > 1 line with its multi_gpu keys
+MPST_BENCH_SHARE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 --fits-per-gpu 8 > $out/${R}_bench_gpus2_shared_gpu.json 2> $out/bench_gpus2.err || true
 profiles/collect_profiles.sh impute 1 bench.py --workload impute --steps 1 --warmup 1 --no-cpu-baseline > $out/collect_impute.log 2>&1
 cp gpurun_out/$R/impute/kernel_stats.csv $out/${R}_rocprofv3_kernel_stats_impute.csv
 cp gpurun_out/$R/impute/pmc_counters.json $out/${R}_pmc_counters_impute.json
