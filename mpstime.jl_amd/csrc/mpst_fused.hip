@@ -205,8 +205,10 @@ __global__ __launch_bounds__(FUSED_T) void k_bond_fused(View v, int lid, int ass
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int u = 0; u < 32; u += 2) {
-            if (4 * u < XP) acc0 = mfma_f64(Xs[i16 * FXS + 4 * u + kq], bq[u >> 2][u & 3], acc0);
-            if (4 * u + 4 < XP) acc1 = mfma_f64(Xs[i16 * FXS + 4 * u + 4 + kq], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+            // (unconditional: the staged rows are zero beyond the live extent - an exact +0; a predicate per MFMA costs a copy of the
+            // accumulator or a branch that keeps the operand reads from being batched)
+            acc0 = mfma_f64(Xs[i16 * FXS + 4 * u + kq], bq[u >> 2][u & 3], acc0);
+            acc1 = mfma_f64(Xs[i16 * FXS + 4 * u + 4 + kq], bq[(u + 1) >> 2][(u + 1) & 3], acc1);
             // at most 8 operand reads ahead of the matrix pipe: the whole tile's worth (64 VGPRs) would spill
             if ((u & 7) == 6) asm volatile("" ::: "memory");
         }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(FUSED_T) void k_bond_fused(View v, int lid, int ass
             const double bop = wi * Ys[i * FXS + col];
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt)
-                if (mt < nmt) gacc[mt] = mfma_f64(Xs[i * FXS + 16 * mt + i16], bop, gacc[mt]);
+                gacc[mt] = mfma_f64(Xs[i * FXS + 16 * mt + i16], bop, gacc[mt]);      // (rows beyond the live tiles are zero)
             asm volatile("" ::: "memory");
         }
         FSTAMP();
@@ -441,7 +443,7 @@ __device__ __forceinline__ void gram_upd_body(const View& v, int lid, int going_
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u)
-                if (k0 + 4 * u < kend) acc = mfma_f64(a[u], bb[u], acc);
+                acc = mfma_f64(a[u], bb[u], acc);           // (operands beyond the contraction are zero: an exact +0, no predicate)
         }
     }
 #pragma unroll
@@ -480,7 +482,7 @@ __device__ __forceinline__ d4 gemm_tile_g(const double* __restrict__ A, int64_t 
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < K) acc = mfma_f64(a[u], b[u], acc);
+            acc = mfma_f64(a[u], b[u], acc);
     }
     return acc;
 }
@@ -514,7 +516,7 @@ __device__ __forceinline__ d4 gemm_tile_g4(const double* __restrict__ A, int64_t
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (q0 + 4 * u < kend) p[w] = mfma_f64(a[u], b[u], p[w]);
+                p[w] = mfma_f64(a[u], b[u], p[w]);
         }
     }
     d4 acc;
@@ -643,7 +645,7 @@ __device__ __forceinline__ void chain_bt_block(const View& v, int lid, int going
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (q0 + 4 * u < kend) t = mfma_f64(av[u], bv[u], t);
+                    t = mfma_f64(av[u], bv[u], t);
             }
         }
 #pragma unroll
@@ -1045,11 +1047,22 @@ __device__ __forceinline__ void yhat_s_body(const View& v, int lid, int nslc, in
                 // x = 4 u + kq = a d + s with a = u, s = kq: the site factor is one register, the row entries sit at
                 // immediate offsets
                 const double ph = phx[kq];
+                if (v.cap == 32) {
+                    // every row has its 32 entries (+ the zero behind them) and is zero beyond the live bond: all 32 k-steps, no predicate
+                    // (a predicate per MFMA is a branch that keeps the compiler from batching the operand reads)
 #pragma unroll
-                for (int u = 0; u < 32; u += 2) {
-                    if (4 * u < XP) acc0 = mfma_f64(ler[u] * ph, bq[u >> 2][u & 3], acc0);
-                    if (4 * u + 4 < XP) acc1 = mfma_f64(ler[u + 1] * ph, bq[(u + 1) >> 2][(u + 1) & 3], acc1);
-                    if ((u & 7) == 6) asm volatile("" ::: "memory");      // at most 8 operands ahead of the matrix pipe
+                    for (int u = 0; u < 32; u += 2) {
+                        acc0 = mfma_f64(ler[u] * ph, bq[u >> 2][u & 3], acc0);
+                        acc1 = mfma_f64(ler[u + 1] * ph, bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+                        if ((u & 7) == 6) asm volatile("" ::: "memory");  // at most 8 operands ahead of the matrix pipe
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 32; u += 2) {
+                        if (4 * u < XP) acc0 = mfma_f64(ler[u] * ph, bq[u >> 2][u & 3], acc0);
+                        if (4 * u + 4 < XP) acc1 = mfma_f64(ler[u + 1] * ph, bq[(u + 1) >> 2][(u + 1) & 3], acc1);
+                        if ((u & 7) == 6) asm volatile("" ::: "memory");  // at most 8 operands ahead of the matrix pipe
+                    }
                 }
             } else {
 #pragma unroll
@@ -1502,7 +1515,7 @@ __global__ __launch_bounds__(EW_T) void k_env_walk(View v, int left_side, int ns
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int step = q * ks4 + u;
-                if (u < ks4 && step < nsteps) acc = mfma_f64(Zt[i16 * EW_ZS + 4 * step + kq], bv[u], acc);
+                acc = mfma_f64(Zt[i16 * EW_ZS + 4 * min(step, nsteps - 1) + kq], bv[u], acc);      // (bv is zero beyond the contraction)
             }
         }
 #pragma unroll
@@ -1605,7 +1618,7 @@ __device__ __forceinline__ void tail_chain_job(const View& v, const BondDimsF& b
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (kbeg + 4 * u < kend) t = mfma_f64(R[u], bv[u], t);
+                t = mfma_f64(R[u], bv[u], t);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) cpart[(rg * 2 + j) * 256 + r * 64 + lane] = t[r];
@@ -2168,16 +2181,14 @@ __device__ __forceinline__ void bond_tail_body(const View& v, const TailArgs& ta
             double sa[8], sb[8];                    // both operands of the quarter first, then eight MFMAs back to back
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int step = min(q * ks4 + u, nsteps - 1);
+                const int st0 = q * ks4 + u, step = min(st0, nsteps - 1);
                 sa[u] = St[i16 * BT_SS + 4 * step + kq];
-                sb[u] = Ef[(4 * step + kq) * BT_ZS + col];
+                const double e = Ef[(4 * step + kq) * BT_ZS + col];
+                sb[u] = (u < ks4 && st0 < nsteps) ? e : 0.0;        // (a step beyond the quarter adds an exact +0: no predicate on the MFMA)
             }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int step = q * ks4 + u;
-                if (u < ks4 && step < nsteps) acc = mfma_f64(sa[u], sb[u], acc);
-            }
+            for (int u = 0; u < 8; ++u) acc = mfma_f64(sa[u], sb[u], acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[(q * 2 + nt) * 256 + r * 64 + lane] = acc[r];      // (both factor sets are consumed: P is issued, S is dense)

@@ -70,7 +70,7 @@ __device__ __forceinline__ d4 wave_gemm_tile(const double* __restrict__ A, int64
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < kend) acc = mfma_f64(a[u], b[u], acc);
+            acc = mfma_f64(a[u], b[u], acc);        // (operands beyond the contraction are zero: an exact +0, no predicate)
     }
     return acc;
 }
