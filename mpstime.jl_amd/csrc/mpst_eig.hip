@@ -560,25 +560,35 @@ __global__ __launch_bounds__(TRI_T) void k_eig_tri(View v, int lid, int going_le
 // =====================================================================================
 // Everything k_eig_vec does for eigenvalue k.  MERGED = false: T and the reflectors come from the global workspace
 // (written by k_eig_tri); MERGED = true: they are already in this workgroup's LDS (tri_core<true>, rotated rows).
-template <bool MERGED>
-__device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, double* smem, int* cnt_s, double* red_s, int* arg_s,
+// HALVES (k_eig_trivec_bm): TWO eigenpairs at a time, threads [0, 256) one, [256, 512) the other - the same code on a scratch set each
+// (T, the reflectors and their compact-WY factors are shared and read-only; what both halves write there they write with the same
+// values), every barrier workgroup-wide and met by both halves in step (no barrier sits under a data-dependent branch).  Each pair's
+// arithmetic is exactly that of the one-pair kernels: the same bits.
+constexpr int VEC_SCRATCH = 128 * 4 + 8 + 128 + 8 + 24 + 24;      // Dm .. Bb
+constexpr int VEC_LDS_DOUBLES = 16384 + 272 + 128 * 6 + 144 + 48 + 2048 + 16;
+template <bool MERGED, bool HALVES = false>
+__device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, double* smem, int* cnt_s_, double* red_s_, int* arg_s_,
                                          double* __restrict__ ws, unsigned long long* stamps, const double lo_in,
                                          const double hi_in, const double tnorm_in) {
     auto vix = [](int c, int j) { return MERGED ? vsw(c, j) : c * 16 + j; };
     const int n = pb.n;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = HALVES ? ((int)threadIdx.x >> 8) : 0;
+    const int tid = HALVES ? ((int)threadIdx.x & (VEC_THREADS - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* cnt_s = cnt_s_ + 8 * half;
+    double* red_s = red_s_ + 8 * half;
+    int* arg_s = arg_s_ + 8 * half;
     double* Vd = smem;              // [8][128][16] reflectors (dense blocks of 16)
     double* de = Vd + 16384;        // [272]: 128 (d, e^2) pairs + padding pairs for the 8-step Sturm groups
     double* es = de + 272;          // [128]
     double* taus = es + 128;        // [128]
-    double* Dm = taus + 128;        // [128] D^-_i  (bottom-up pivots)
+    double* Dm = half ? smem + VEC_LDS_DOUBLES : taus + 128;        // [128] D^-_i  (bottom-up pivots)
     double* Ub = Dm + 128;          // [128] U_i
     double* Dp = Ub + 128;          // [128] D_i    (top-down pivots)
     double* Lb = Dp + 128;          // [128] L_i
     double* z = Lb + 128 + 8;       // [128] with 8 slack entries before and after
     double* Fb = z + 128 + 8;       // [24] rescaled group-boundary minors, top-down
     double* Bb = Fb + 24;           // [24] bottom-up
-    double* Tb = Bb + 24;           // [8][16][16] triangular factors of the blocked reflectors
+    double* Tb = taus + 128 + VEC_SCRATCH;      // [8][16][16] triangular factors of the blocked reflectors (behind the first scratch set)
     const bool st = stamps && k == 0 && tid == 0;
 #ifdef MPST_TRI_DEBUG
 #define VDBG(j) do { if (st) stamps[40 + (j)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -757,7 +767,8 @@ __device__ __forceinline__ void vec_core(const EigProblem& pb, const int k, doub
                     Bb[b] = qc;                       // Q_{j-7} on the scale of the next group
                 }
             }
-        } else {
+        } else if (half == 0) {
+            // (HALVES: the factors are shared and formed IN PLACE - Gram matrix, then its triangular inverse over it - so one half forms them)
             // Waves 2, 3 (idle otherwise): compact-WY factors of the reflector blocks for the
             // back-transformation.  Q_b = H(16b) ... H(16b+15) = I - V_b T_b V_b^T with
             // T_b^-1 = diag(1/tau) + striu(V_b^T V_b); the Gram matrix comes from the fp64 MFMA
@@ -1067,18 +1078,19 @@ __global__ __launch_bounds__(TRI_T) void k_eig_trivec(View v, int lid, int going
 }
 __device__ __noinline__ void vec_core_call(const EigProblem& pb, const int k, double* smem, int* cnt_s, double* red_s, int* arg_s,
                                            double* __restrict__ ws, unsigned long long* stamps, const double lo, const double hi, const double tnorm) {
-    vec_core<true>(pb, k, smem, cnt_s, red_s, arg_s, ws, stamps, lo, hi, tnorm);
+    vec_core<true, true>(pb, k, smem, cnt_s, red_s, arg_s, ws, stamps, lo, hi, tnorm);
 }
 // The same for SEVERAL eigenpairs per workgroup: blockIdx.x, + gridDim.x, ... - one reduction, then the vector phase once per pair
 // (30 us each).  For mpst_sweep_batch beyond 8 fits: 32 workgroups per fit repeat the 114 us reduction 32 times, K x 32 > 256
 // workgroups run in rounds; 16 (8) workgroups per fit with 2 (4) pairs each keep 16 (32) fits in one round.  A body of its own:
-// the single-fit kernels keep their register allocation.
+// the single-fit kernels keep their register allocation.  Round 6: the vector phase runs for TWO pairs at a time, on the two halves
+// of the 512 threads that stay (vec_core<.., HALVES>): 4 pairs cost two vector phases, not four (32 fits: 247 -> 190 us per bond).
 __device__ __forceinline__ void trivec_body_multi(const View& v, int lid, int going_left, const double* rawG, int rawn, int rawalg,
                                                   double* __restrict__ ws, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int cnt_s[8];
-    __shared__ double red_s[8];
-    __shared__ int arg_s[8];
+    __shared__ int cnt_s[16];
+    __shared__ double red_s[16];
+    __shared__ int arg_s[16];
     const EigProblem pb = resolve(v, lid, going_left, rawG, rawn, rawalg);
     const int k = blockIdx.x, tid = threadIdx.x;
     if (!pb.tri) {
@@ -1107,10 +1119,13 @@ __device__ __forceinline__ void trivec_body_multi(const View& v, int lid, int go
         ws[WS_MISC + 2] = tnorm;
         ws[WS_MISC + 3] = 1.0;
     }
-    if (tid >= VEC_THREADS) return;
-    for (int kk = k; kk < nvec; kk += (int)gridDim.x) {
-        vec_core_call(pb, kk, smem, cnt_s, red_s, arg_s, ws, kk == 0 ? st : nullptr, lo, hi, tnorm);
-        lds_barrier();                  // (the scratch of the vector phase is reused by the next pair)
+    if (tid >= 2 * VEC_THREADS) return;
+    const int half = tid >> 8;
+    for (int kk = k; kk < nvec; kk += 2 * (int)gridDim.x) {
+        // this half's pair; a half without one repeats its partner's (the same values to the same places) and keeps the barriers in step
+        const int mine = kk + half * (int)gridDim.x < nvec ? kk + half * (int)gridDim.x : kk;
+        vec_core_call(pb, mine, smem, cnt_s, red_s, arg_s, ws, mine == 0 && half == 0 ? st : nullptr, lo, hi, tnorm);
+        lds_barrier();                  // (the scratch of the vector phase is reused by the next pairs)
     }
 }
 // raw problem behind a gate word (v.label_site, 0 = leave at once): the Rayleigh-Ritz problem of the subspace solver
@@ -1293,7 +1308,7 @@ __global__ void k_eig_clear(double* lam, double* E, int n) {
 
 static size_t eig_lds_bytes() { return (size_t)EIG_LDS_DOUBLES * sizeof(double); }
 static size_t tri_lds_bytes() { return (size_t)(8128 + 256 * 3 + 128 * 2 + 32 + 192 + 64) * sizeof(double); }
-static size_t vec_lds_bytes() { return (size_t)(16384 + 272 + 128 * 6 + 144 + 48 + 2048 + 16) * sizeof(double); }
+static size_t vec_lds_bytes() { return (size_t)VEC_LDS_DOUBLES * sizeof(double); }
 
 size_t eig_workspace_doubles() { return WS_TOTAL; }
 hipError_t eig_init_attrs(int device) {
@@ -1306,7 +1321,7 @@ hipError_t eig_init_attrs(int device) {
     if ((e = hipFuncSetAttribute((const void*)k_eig_vec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_bm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_bm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(vec_lds_bytes() + VEC_SCRATCH * sizeof(double)))) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_trivec_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vec_lds_bytes())) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_eig_fin_g, hipFuncAttributeMaxDynamicSharedMemorySize, (int)eig_lds_bytes())) != hipSuccess) return e;
@@ -1349,7 +1364,7 @@ void launch_eig_b(const View& v, const View* vs, int K, int lid, int going_left,
     const int rounds = ((int)gvec.x * K + 255) / 256;
     if (stage == 0 && bm_on && rounds > 1) {
         const int nb = std::max(8, ((int)gvec.x + rounds - 1) / rounds);
-        hipLaunchKernelGGL(k_eig_trivec_bm, dim3(nb, 1, K), dim3(TRI_T), vec_lds_bytes(), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
+        hipLaunchKernelGGL(k_eig_trivec_bm, dim3(nb, 1, K), dim3(TRI_T), vec_lds_bytes() + VEC_SCRATCH * sizeof(double), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
         return;
     }
     if (stage == 0) hipLaunchKernelGGL(k_eig_trivec_b, gvec, dim3(TRI_T), vec_lds_bytes(), s, vs, lid, going_left, (const double*)nullptr, 0, 0);
