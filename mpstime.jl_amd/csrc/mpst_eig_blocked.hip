@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_larft(View v, int lid, int going_le
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if (u0 + u < (wave + 1) * ks) acc = mfma_f64(x[u], x[u], acc);
+            acc = mfma_f64(x[u], x[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_gram(View v, int lid, int going_lef
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (r0 + 4 * u < rend) acc = mfma_f64(x[u], y[u], acc);
+            acc = mfma_f64(x[u], y[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(BT_T) void k_bt_polish(View v, int lid, int going_l
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    if (q0 + 4 * u < kout) acc = mfma_f64(x[u], y[u], acc);
+                    acc = mfma_f64(x[u], y[u], acc);
             }
         }
 #pragma unroll

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_ss_mm(View v, int lid, int going_left, 
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < kend) acc = mfma_f64(a[u], b[u], acc);
+            acc = mfma_f64(a[u], b[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void k_ss_gram(View v, int lid, int going_left
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < kend) acc = mfma_f64(a[u], b[u], acc);
+            acc = mfma_f64(a[u], b[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r * 64 + lane] = acc[r];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_ss_apply(View v, int lid, int going_lef
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < p) acc = mfma_f64(a[u], b[u], acc);
+            acc = mfma_f64(a[u], b[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_ss_ritz(View v, int lid, int going_left
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < p) acc = mfma_f64(a[u], bb[u], acc);
+            acc = mfma_f64(a[u], bb[u], acc);
     }
     const double th = kc < K0 ? s.lamH[kc] : 0.0;
     const double sc = th > 1e-13 * s.lamH[0] ? 1.0 / sqrt(th) : 0.0;      // below: the small solver delivered no vector (and nobody keeps one)
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_ss_resid(View v, int lid, int going_lef
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-            if (k0 + 4 * u < kend) acc = mfma_f64(a[u], bb[u], acc);
+            acc = mfma_f64(a[u], bb[u], acc);
     }
     f2 = wave_sum(f2);
 #pragma unroll
