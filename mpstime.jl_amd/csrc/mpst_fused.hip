@@ -1410,7 +1410,9 @@ __device__ __forceinline__ KrSide kr_side(const double* fac, int Dp, int d, bool
 }
 __device__ __forceinline__ double kr_at(const KrSide& k, int row, unsigned z) {
     const unsigned q = (z * k.magic) >> 16, r = z - q * k.div;
-    const unsigned ie = k.left ? q : r, ip = k.left ? r : q;
+    // (entries the padded extent of a product asks for beyond the live ones: on the right the site index reaches 21 at d = 11 .. 16 with a
+    // bond of 3 and 31 with a bond of 1 - tests/fuzz_chain4.py found the first; it is clamped onto the row's zero pad, as is the bond index on the left)
+    const unsigned ie = min(k.left ? q : r, (unsigned)(BT_ELS - 1)), ip = min(k.left ? r : q, (unsigned)(BT_PLS - 1));
     return k.env[row * BT_ELS + ie] * k.ph[row * BT_PLS + ip];
 }
 
