@@ -190,3 +190,18 @@ def test_env_walk_builds_the_caches_of_the_per_site_launches(T, d, chi, C):
     (Wa, ea), (Wb, eb) = res[0], res[None]
     assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(Wa, Wb))
     assert ea == eb
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fuzz_random_shapes_four_against_six_launches(seed):
+    """tests/fuzz_chain4.py as seeded, bounded cases: random (N, T, d, chi, C) - bonds of 1, 2 and 3, d up to 16 - through both chains bond by
+    bond from a common state (the shape that found kr_at's padded index, d >= 11 with a bond of 3, came out of it)."""
+    from tests import fuzz_chain4
+    assert fuzz_chain4.main(seed, 8) == 0
+
+
+def test_fuzz_random_shapes_against_the_oracle():
+    """tests/fuzz_sweep_oracle.py as seeded, bounded cases: random shapes, KLD / MSE / classes trained separately, either chain, every bond
+    of a sweep against the NumPy oracle from the oracle's state."""
+    from tests import fuzz_sweep_oracle
+    assert fuzz_sweep_oracle.main(0, 10) == 0
