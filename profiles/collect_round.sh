@@ -56,4 +56,5 @@ python bench.py --dtype f32 --classes 2 > $out/${R}_bench_typed_f32_two_classes.
 python bench.py --N 8192 --T 200 --chi 64 --d 8 --steps 3 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/${R}_bench_chi64_d8_N8192_T200.json 2> $out/bench_big.err
 python bench.py --N 32768 --steps 5 --warmup 2 --no-cpu-baseline --concurrent 1 > $out/${R}_bench_n32768.json 2> $out/bench_n32768.err
 for t in c64 f32; do python bench.py --dtype $t --study > $out/${R}_tolerance_study_$t.json 2> $out/study_$t.err; done
+python profiles/r06_determinism.py 10 2>/dev/null | grep -v amdgpu.ids > $out/${R}_determinism_soak.log || true
 ls -la $out
