@@ -1375,8 +1375,8 @@ __device__ __forceinline__ void grad_s_body(const View& v, int lid, int ksplit, 
 //    columns of it and forms z = E env' for the same 16 columns in the accumulator layout, so the row dot needs no exchange;
 //  * split / chain workgroups: the back-split and the next bond's tensor as in k_env_split, with E from LDS.
 // A failed verification (genuinely clustered kept eigenvalues: k_eig_fin would fall through to its Jacobi solver) sets the sticky
-// DevScalars::redo and leaves the MPS alone; every later tail launch of the sweep leaves at once, and the host redoes the sweep
-// from its snapshot on the six-launch chain (mpst_sweep).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
+// DevScalars::redo (= 1 + the bond's position in the sweep) and leaves the MPS, the caches and the chained tensor alone; every later tail
+// launch of the sweep leaves at once, and the host finishes the sweep FROM THAT BOND on the six-launch chain (mpst_sweep; no snapshot).  loss_functions.jl:248-262 (yhat), RealRealHighDimension.jl:107-203.
 // =====================================================================================================================
 constexpr int BT_T = 512;                    // 8 waves
 constexpr int BT_ZS = 36;                    // LDS row stride of the candidate / kept eigenvectors: rows 16 apart in 16 different bank pairs
@@ -2296,7 +2296,7 @@ template <int LM, bool D4, bool V2> __global__ __launch_bounds__(YS_T) void k_yh
 // NW = waves per workgroup.  8 (512 threads, one workgroup per CU at 174+ registers) where a launch has about one workgroup per CU and
 // latency counts (a single fit); 4 (256 threads, two workgroups per CU, each wave a quarter of a stage) for contexts advanced in batches:
 // one workgroup stages its next 256 series (1.3 us of the 4.2 a stage takes, all eight waves idle on the matrix pipe meanwhile -
-// profiles/r06_b2_stamps.txt) while the other multiplies.  The wave count fixes which wave sums which series, so it belongs to the
+// profiles/r06_batched_gemm_ab.txt) while the other multiplies.  The wave count fixes which wave sums which series, so it belongs to the
 // context (View::b2_nw): its solo and its batched sweeps agree bit for bit.
 template <int AW2, int D2, int FS, int KC, int NW> __global__ __launch_bounds__(64 * NW, 2) void k_grad_s(View v, int lid, int ksplit, int nbc) {
     grad_s_body<AW2, D2, FS, KC, NW>(v, lid, ksplit, nbc, (int)blockIdx.x, (int)blockIdx.y);

@@ -330,8 +330,9 @@ struct DevScalars {
     int32_t eig_fallbacks;      // bonds on which the tridiagonal path failed its check (Jacobi used)
     int32_t pad[2];             // one-shot all-reduce: time-out diagnostics (OneShotParams.dbg)
     int32_t xref;               // typed MSE: largest overlap exponent of the bond's series (k_tbt_assemble resets, k_tyhat raises)
-    int32_t redo;               // k_bond_tail: a bond's on-device verification failed - every later tail launch of the sweep leaves at once and the
-                                // host redoes the sweep from its snapshot on the chain that has the Jacobi fallback (sticky until the host clears it)
+    int32_t redo;               // k_bond_tail: 1 + the position in the sweep of a bond whose on-device verification failed - every later tail launch of the
+                                // sweep leaves at once and the host finishes the sweep from that bond on the chain that has the Jacobi fallback (sticky
+                                // until the host clears it)
     unsigned long long eig_stamps[64];  // s_memrealtime (100 MHz) at the phase boundaries of the last eigensolve
 };
 
